@@ -1,0 +1,246 @@
+/*
+ * rsx.h — C-ABI of librsx, the MI355X (gfx950) ray/primitive intersection, KD-tree traversal
+ * and spectral-accumulation library that sits under Raysect's Python API.
+ *
+ * Everything here is plain C: pointers, sizes, POD structs. No torch / C++ types cross the boundary.
+ * Ownership: the caller owns every buffer it passes; the library owns what hides behind the opaque
+ * handles (rsx_ctx, rsx_scene, rsx_kd) and frees it in the matching *_free call.
+ * Errors: every call returns RSX_OK (0) or a negative RSX_E* code; rsx_last_error() gives the text
+ * (thread-local). No exceptions cross the ABI. One rsx_ctx per GPU; calls on one ctx are serialised
+ * by the caller (mirrors the reference's one-process-one-world model).
+ *
+ * Each entry point names the reference interface (file:line under raysect/source) it replaces.
+ */
+#ifndef RSX_H
+#define RSX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RSX_OK            0
+#define RSX_EINVAL       -1   /* bad argument */
+#define RSX_ENODEV       -2   /* no usable gfx950 device / HIP failure at init */
+#define RSX_EHIP         -3   /* HIP runtime error (text in rsx_last_error) */
+#define RSX_ENOMEM       -4
+#define RSX_EUNSUPPORTED -5   /* scene uses something outside the device path (e.g. CSG nesting too deep) */
+
+/* ---- primitive and material enumerations ------------------------------------------------------ */
+enum {
+    RSX_PRIM_SPHERE = 0,    /* raysect/primitive/sphere.pyx   params[0]=radius                       */
+    RSX_PRIM_BOX = 1,       /* raysect/primitive/box.pyx      params[0..2]=lower, params[3..5]=upper */
+    RSX_PRIM_CYLINDER = 2,  /* raysect/primitive/cylinder.pyx params[0]=radius, params[1]=height     */
+    RSX_PRIM_MESH = 3,      /* raysect/primitive/mesh/mesh.pyx  mesh = index into rsx_scene_desc.meshes */
+    RSX_PRIM_UNION = 4,     /* raysect/primitive/csg.pyx:262-383 */
+    RSX_PRIM_INTERSECT = 5, /* raysect/primitive/csg.pyx:386-468 */
+    RSX_PRIM_SUBTRACT = 6,  /* raysect/primitive/csg.pyx:471-599 */
+    RSX_PRIM_NULL = 7       /* csg.pyx NullPrimitive: never hit, contains nothing */
+};
+
+enum {
+    RSX_MAT_ABSORBER = 0,        /* optical/material/absorber.pyx:37-55  -> zero spectrum                     */
+    RSX_MAT_UNIFORM_EMITTER = 1, /* optical/material/emitter/uniform.pyx:36-88 -> table[bin] * scale         */
+    RSX_MAT_DEBUG_LIGHT = 2      /* optical/material/debug.pyx:41-79 -> scale*max(0,-L_local.n) * table[bin] */
+};
+
+/* ---- flattened KD-tree (raysect/core/math/spatial/kdtree3d.pxd:38-43 `kdnode`, 32 B -> 16 B) -- */
+typedef struct rsx_kdnode {
+    int32_t type;   /* -1 = leaf, 0/1/2 = split axis                      */
+    int32_t count;  /* leaf: item count; branch: index of the upper child (lower child is id+1) */
+    union {
+        double split;                                   /* branch: split plane coordinate */
+        struct { int32_t first_item; int32_t pad; } leaf; /* leaf: offset of its ids in items[] */
+    } u;
+} rsx_kdnode;
+
+typedef struct rsx_kdtree {
+    const rsx_kdnode *nodes;
+    const int32_t *items;
+    int32_t n_nodes;
+    int32_t n_items;
+    int32_t max_depth;      /* depth cap the tree was built with (bounds the traversal stack) */
+    int32_t pad;
+    double lower[3];        /* KDTree3DCore.bounds */
+    double upper[3];
+} rsx_kdtree;
+
+/* ---- mesh data (raysect/primitive/mesh/mesh.pxd:43-60 MeshData), shared by instances ----------- */
+typedef struct rsx_meshdata {
+    const float *vertices;        /* [n_vertices,3] f32 */
+    const int32_t *triangles;     /* [n_triangles,tri_stride] (after the degenerate filter) */
+    const float *vertex_normals;  /* [n_normals,3] or NULL */
+    const float *face_normals;    /* [n_triangles,3] f32 (mesh.pyx:428-462) */
+    int32_t n_vertices;
+    int32_t n_triangles;
+    int32_t n_normals;
+    int32_t tri_stride;           /* 3, or 6 when vertex-normal indices follow */
+    int32_t smoothing;
+    int32_t closed;
+    rsx_kdtree kd;                /* over triangle AABBs (mesh.pyx:464-504) */
+} rsx_meshdata;
+
+/* ---- primitive table --------------------------------------------------------------------------
+ * primitives[0 .. n_world) are World.primitives in registration order: that index is the
+ * "primitive id" reported by hits (world KD item id, core/acceleration/kdtree.pyx:52-55).
+ * CSG operands follow; their transforms/boxes are relative to the owning CSG node (CSGRoot). */
+typedef struct rsx_primitive {
+    int32_t type;
+    int32_t material;     /* index into the render call's material table (world primitives only) */
+    int32_t mesh;         /* RSX_PRIM_MESH: index into meshes[] */
+    int32_t child_a;      /* CSG: primitive indices of operands A and B */
+    int32_t child_b;
+    int32_t pad;
+    double params[6];
+    double to_local[16];  /* Node.to_local(): root -> primitive space, row-major 4x4 */
+    double to_root[16];   /* Node.to_root()  */
+    double box_lower[3];  /* BoundPrimitive.box = primitive.bounding_box() in root space */
+    double box_upper[3];
+} rsx_primitive;
+
+typedef struct rsx_scene_desc {
+    const rsx_primitive *primitives;
+    const rsx_meshdata *meshes;
+    int32_t n_primitives;
+    int32_t n_world;
+    int32_t n_meshes;
+    int32_t pad;
+    rsx_kdtree world_kd;  /* _PrimitiveKDTree over the n_world primitive boxes */
+} rsx_scene_desc;
+
+/* ---- render inputs ---------------------------------------------------------------------------- */
+typedef struct rsx_camera {   /* optical/observer/imaging/pinhole.pyx:148-204 */
+    int32_t nx, ny;
+    double image_delta, image_start_x, image_start_y;
+    double to_root[16];
+    double sensitivity;       /* _pixel_sensitivity(); used only by the power pipeline */
+} rsx_camera;
+
+typedef struct rsx_material {
+    int32_t type;
+    int32_t table;            /* row of tables[] holding SpectralFunction.sample(min,max,bins) */
+    double scale;             /* emitter scale / light intensity */
+    double light_dir[3];      /* RSX_MAT_DEBUG_LIGHT: normalised world-space light direction */
+} rsx_material;
+
+#define RSX_RNG_STREAM 0  /* uniforms[] supplied by caller: 2 per sample in task order (reference MT19937-64 parity) */
+#define RSX_RNG_PHILOX 1  /* on-device Philox4x32-10 keyed by (seed; pixel, sample): order/shard independent      */
+
+typedef struct rsx_render_desc {
+    rsx_camera camera;
+    const rsx_material *materials;  /* one per world primitive material id */
+    const double *tables;           /* [n_tables, bins] f64, this slice's bins */
+    const int32_t *tasks;           /* [n_tasks,2] (ix,iy) or NULL -> rect tile in iy-outer/ix-inner order */
+    const double *uniforms;         /* RSX_RNG_STREAM: [n_tasks*spp*2] */
+    int64_t n_tasks;
+    int32_t rect[4];                /* x0,y0,x1,y1 when tasks == NULL */
+    int32_t n_materials;
+    int32_t n_tables;
+    int32_t bins;                   /* bins in this spectral slice */
+    int32_t spp;                    /* pixel_samples */
+    int32_t power;                  /* 1: SpectralPower (sample*sensitivity), 0: SpectralRadiance */
+    int32_t rng_mode;
+    uint64_t seed;
+} rsx_render_desc;
+
+typedef struct rsx_ctx rsx_ctx;
+typedef struct rsx_scene rsx_scene;
+typedef struct rsx_kd rsx_kd;
+
+/* ---- library / device ------------------------------------------------------------------------- */
+/* Opens HIP device `device_ordinal` (must be gfx950). No reference analogue (the reference is CPU-only). */
+int rsx_init(int device_ordinal, rsx_ctx **out);
+void rsx_free(rsx_ctx *ctx);
+const char *rsx_last_error(void);
+const char *rsx_version(void);
+/* Launch all kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL = own stream. */
+int rsx_set_stream(rsx_ctx *ctx, void *hip_stream);
+int rsx_synchronize(rsx_ctx *ctx);
+/* Duration (ms, HIP events on the launch stream) of the most recent kernel launched through this ctx. */
+int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms);
+/* Device allocation helpers so non-torch callers can keep frames resident in HBM. */
+int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr);
+int rsx_dev_free(rsx_ctx *ctx, void *dptr);
+int rsx_dev_upload(rsx_ctx *ctx, void *dptr, const void *host, size_t bytes);
+int rsx_dev_download(rsx_ctx *ctx, void *host, const void *dptr, size_t bytes);
+int rsx_dev_memset(rsx_ctx *ctx, void *dptr, int value, size_t bytes);
+
+/* ---- host-side builders (CPU in the reference too) --------------------------------------------- */
+/* SAH KD-tree build, node-for-node identical to KDTree3DCore.__init__/_build/_split
+ * (raysect/core/math/spatial/kdtree3d.pyx:126-486). aabbs = [n,6] (lower xyz, upper xyz); item id = row. */
+int rsx_kd_build(const double *aabbs, int32_t n, int32_t max_depth, int32_t min_items,
+                 double hit_cost, double empty_bonus, rsx_kd **out);
+int rsx_kd_info(const rsx_kd *kd, rsx_kdtree *view);   /* view points into kd-owned memory */
+void rsx_kd_free(rsx_kd *kd);
+/* Serialise exactly like KDTree3DCore.save() (kdtree3d.pyx:864-912); returns bytes written or needed. */
+int64_t rsx_kd_serialise(const rsx_kd *kd, int32_t min_items, double hit_cost, double empty_bonus,
+                         uint8_t *out, int64_t capacity);
+
+/* MeshData.__init__ preprocessing (raysect/primitive/mesh/mesh.pyx:363-504):
+ * filter degenerate triangles in place (returns the new count), face normals, padded triangle AABBs. */
+int32_t rsx_mesh_filter_triangles(const float *vertices, int32_t *triangles, int32_t n_triangles, int32_t stride);
+int rsx_mesh_face_normals(const float *vertices, const int32_t *triangles, int32_t n_triangles, int32_t stride, float *out);
+int rsx_mesh_triangle_aabbs(const float *vertices, const int32_t *triangles, int32_t n_triangles, int32_t stride, double *out);
+/* MeshData.bounding_box(to_world) (mesh.pyx:835-859): out = lower xyz, upper xyz */
+int rsx_mesh_world_bbox(const float *vertices, int32_t n_vertices, const double *to_world, double *out);
+
+/* MT19937-64 exactly as raysect/core/math/random.pyx:99-265 (seed() -> init_by_array64 of 312 words). */
+typedef struct rsx_mt { uint64_t mt[312]; int32_t mti; int32_t pad; } rsx_mt;
+void rsx_mt_seed_words(rsx_mt *st, const uint64_t *key, uint64_t key_length);
+void rsx_mt_uniform(rsx_mt *st, int64_t n, double *out);
+
+/* ---- scene ------------------------------------------------------------------------------------ */
+/* Uploads the flattened scenegraph; replaces Accelerator.build (core/acceleration/accelerator.pxd:37-41,
+ * kdtree.pyx:166-168) + the per-primitive state the reference keeps in Python objects. */
+int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_scene **out);
+void rsx_scene_free(rsx_scene *scene);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* World.hit for a batch of rays (core/scenegraph/world.pyx:125-146 -> kdtree.pyx:170-175).
+ * Host buffers. prim[i] = -1 on a miss. Optional outputs may be NULL.
+ *   tri/uvw: MeshIntersection extras (mesh.pyx:85-135), -1 / 0 for non-mesh hits
+ *   geom[n,12]: hit_point, inside_point, outside_point, normal in primitive-local space
+ *               (core/intersection.pyx:47-54) */
+int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, const double *direction,
+                  const double *max_distance, int32_t *prim, double *t, uint8_t *exiting,
+                  int32_t *tri, float *uvw, double *geom);
+/* Same with every pointer a device pointer; asynchronous on the ctx stream. */
+int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *origin, const double *direction,
+                      const double *max_distance, int32_t *prim, double *t, uint8_t *exiting,
+                      int32_t *tri, float *uvw, double *geom);
+
+/* Primitive.hit + repeated next_intersection() on ONE primitive (sphere.pyx:115-168, box.pyx:157-232,
+ * cylinder.pyx:148-285, csg.pyx:132-179, mesh.pyx:1178-1238): up to max_roots ordered roots per ray.
+ * counts[n]; t[n,max_roots]; exiting[n,max_roots]. Host buffers. */
+int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double *origin, const double *direction,
+                    const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting);
+
+/* World.contains for a batch of points (world.pyx:149-168 -> kdtree.pyx:126-162):
+ * inside[n, n_world] = 1 where world primitive j contains point i. Host buffers. */
+int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *points, uint8_t *inside);
+
+/* One spectral slice of Observer.observe(): _render_pixel for every task (observer.pyx:363-419) —
+ * pinhole ray generation, Ray.trace (optical/ray.pyx:338-401) with closed-form materials, per-pixel
+ * Welford accumulation (statsarray.pyx:743-776). Outputs per task: mean[n_tasks,bins], variance[n_tasks,bins]
+ * (the tuple _render_pixel returns). Host buffers unless *_dev. ray_count may be NULL. */
+int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *mean, double *variance,
+                       uint64_t *ray_count);
+/* Fused form: results are merged straight into a device-resident frame with the combine_samples law
+ * (Pipeline2D.update, optical/observer/pipeline/spectral/power.pyx:424-437; statsarray.pyx:623-668,780-859).
+ * frame_* are device pointers to [nx,ny,frame_bins] (x-major, as StatsArray3D); the slice occupies
+ * bins [slice_offset, slice_offset+desc->bins). desc->tasks/uniforms/materials/tables are host pointers. */
+int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, double *frame_mean,
+                             double *frame_variance, int32_t *frame_samples, int32_t frame_bins,
+                             int32_t slice_offset, uint64_t *ray_count);
+
+/* StatsArray3D.combine_samples applied elementwise to two frames resident on the device
+ * (statsarray.pyx:780-859): a <- combine(a, b). Used to merge passes / sample-sharded ranks. */
+int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, double *var_a, int32_t *n_a,
+                          const double *mean_b, const double *var_b, const int32_t *n_b);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RSX_H */

@@ -1,0 +1,9 @@
+"""Flat namespace with Raysect's class names: what source_amd.scenes builders take as ``ns``."""
+from .core import (AffineMatrix3D, Normal3D, Point3D, Vector3D, rotate, rotate_vector, rotate_x, rotate_y, rotate_z, translate,  # noqa: F401
+                   Node, Intersection, BoundingBox3D)
+from .core.scenegraph import Ray as CoreRay  # noqa: F401
+from .optical import World, Ray, Spectrum, ConstantSF, InterpolatedSF  # noqa: F401
+from .optical.material import AbsorbingSurface, UniformSurfaceEmitter, Light  # noqa: F401
+from .optical.observer import (PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D,  # noqa: F401
+                               HipEngine, RenderEngine)
+from .primitive import Sphere, Box, Cylinder, Mesh, Union, Intersect, Subtract  # noqa: F401

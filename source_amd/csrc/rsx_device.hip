@@ -1,0 +1,1378 @@
+// rsx_device.hip — gfx950 (MI355X / CDNA4) device side of librsx: KD-tree traversal, ray/primitive
+// intersection, pinhole ray generation, closed-form shading and spectral accumulation.
+//
+// Design:
+//  * one ray per lane, 64-wide wavefronts, persistent workgroups pulling 64-ray batches from a global
+//    ticket counter (dynamic load balance across the 256 CUs; per-XCD L2 keeps the flattened trees hot);
+//  * explicit per-lane traversal stacks in LDS, laid out [level][lane] so that every ds_read/ds_write of a
+//    wave is bank-conflict free whatever level each lane is at; an entry is (far node id, far tmax): the
+//    far range's tmin is the tmax of the leaf that was just exhausted, so it is never stored;
+//  * KD nodes are 16 B (one dwordx4 load), triangles are pre-gathered into 48 B records
+//    (9 vertex floats + face normal = three dwordx4 loads, no index indirection);
+//  * arithmetic follows the reference operation for operation (f64 traversal and analytic primitives,
+//    f32 watertight triangle test with its f64 casts): compiled with -ffp-contract=off, IEEE div/sqrt,
+//    so hit ids and distances are bit-identical to the reference's;
+//  * no MFMA: the path is branchy traversal, bound by memory latency/bandwidth, not by a contraction.
+//
+// Reference lines each device function restates are cited at the function.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/rsx.h"
+#include "rsx_internal.h"
+
+#define WAVE 64
+#define WG_WAVES 4
+#define WG_THREADS (WAVE * WG_WAVES)
+
+// ---------------------------------------------------------------------------------------------------
+// error plumbing
+// ---------------------------------------------------------------------------------------------------
+static thread_local std::string g_error;
+
+int rsx_fail(int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+extern "C" const char *rsx_last_error(void) { return g_error.c_str(); }
+extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return rsx_fail(RSX_EHIP, "%s: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// device-resident scene
+// ---------------------------------------------------------------------------------------------------
+struct DMesh {
+    const rsx_kdnode *nodes;
+    const int32_t *items;
+    const float4 *tris;        // 3 x float4 per triangle: v1.xyz v2.x | v2.yz v3.xy | v3.z fn.xyz
+    const float *vnormals;     // [nn,3] or null
+    const int32_t *nidx;       // [nt,3] vertex-normal indices or null
+    double lower[3], upper[3];
+    int32_t smoothing, closed, n_tris, pad;
+};
+
+struct DScene {
+    const rsx_primitive *prims;
+    const DMesh *meshes;
+    const rsx_kdnode *wnodes;
+    const int32_t *witems;
+    double wlower[3], wupper[3];
+    int32_t n_prims, n_world, n_meshes;
+    int32_t wdepth, mdepth;    // stack levels reserved for the world tree / the deepest mesh tree
+};
+
+struct Ray {
+    double ox, oy, oz, dx, dy, dz, maxd;
+};
+
+// candidate kept while searching; full geometry is regenerated once at the end (finalise)
+struct Hit {
+    double t;
+    int32_t prim;              // -1 = none
+    int32_t a0, a1;            // mesh: triangle, - ; box: face, axis ; cylinder: face, type
+    float u, v, w;
+};
+
+struct Stack {                 // per-lane view of the wave's LDS stack region
+    double *t;                 // t[level * WAVE]
+    int32_t *id;               // id[level * WAVE]
+};
+
+__device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
+__device__ __forceinline__ float sel3f(int i, float x, float y, float z) { return i == 0 ? x : (i == 1 ? y : z); }
+
+// Point3D.transform / Vector3D.transform — core/math/point.pyx:253-284, vector.pyx:339-369
+__device__ __forceinline__ void xform_point(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
+    double w = m[12] * x + m[13] * y + m[14] * z + m[15];
+    w = 1.0 / w;
+    ox = (m[0] * x + m[1] * y + m[2] * z + m[3]) * w;
+    oy = (m[4] * x + m[5] * y + m[6] * z + m[7]) * w;
+    oz = (m[8] * x + m[9] * y + m[10] * z + m[11]) * w;
+}
+
+__device__ __forceinline__ void xform_vector(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
+    ox = m[0] * x + m[1] * y + m[2] * z;
+    oy = m[4] * x + m[5] * y + m[6] * z;
+    oz = m[8] * x + m[9] * y + m[10] * z;
+}
+
+__device__ __forceinline__ Ray to_local(const rsx_primitive &p, const Ray &r) {
+    Ray l;
+    xform_point(p.to_local, r.ox, r.oy, r.oz, l.ox, l.oy, l.oz);
+    xform_vector(p.to_local, r.dx, r.dy, r.dz, l.dx, l.dy, l.dz);
+    l.maxd = r.maxd;
+    return l;
+}
+
+// BoundingBox3D._slab / intersect — core/boundingbox.pyx:180-245
+__device__ __forceinline__ void slab(double o, double d, double lo, double hi, double &front, double &back) {
+    double tmin, tmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        const double rcp = 1.0 / d;
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+    }
+    if (tmin > front) front = tmin;
+    if (tmax < back) back = tmax;
+}
+
+__device__ __forceinline__ bool aabb(const double *lo, const double *hi, const Ray &r, double &front, double &back) {
+    front = -INFINITY;
+    back = INFINITY;
+    slab(r.ox, r.dx, lo[0], hi[0], front, back);
+    slab(r.oy, r.dy, lo[1], hi[1], front, back);
+    slab(r.oz, r.dz, lo[2], hi[2], front, back);
+    if (front > back) return false;
+    if (front < 0.0 && back < 0.0) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool aabb_contains(const double *lo, const double *hi, double x, double y, double z) {
+    if (x < lo[0] || x > hi[0]) return false;
+    if (y < lo[1] || y > hi[1]) return false;
+    if (z < lo[2] || z > hi[2]) return false;
+    return true;
+}
+
+__device__ __forceinline__ rsx_kdnode load_node(const rsx_kdnode *nodes, int32_t id) {
+    const int4 raw = *reinterpret_cast<const int4 *>(nodes + id);   // one 16-B load
+    rsx_kdnode nd;
+    nd.type = raw.x;
+    nd.count = raw.y;
+    nd.u.leaf.first_item = raw.z;
+    nd.u.leaf.pad = raw.w;
+    return nd;
+}
+
+// One KD branch step — KDTree3DCore._trace_branch, core/math/spatial/kdtree3d.pyx:626-700.
+// Returns the next node; pushes (far, tmax) when both children are crossed.
+__device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t node, double o, double d, double tmin, double &tmax,
+                                               Stack st, int32_t &sp) {
+    const double split = nd.u.split;
+    const int32_t lower = node + 1, upper = nd.count;
+    if (d == 0) return o < split ? lower : upper;
+    const double plane = (split - o) / d;
+    const bool below = o < split || (o == split && d < 0);
+    const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
+    if (plane > tmax || plane <= 0) return near_id;
+    if (plane < tmin) return far_id;
+    st.t[sp * WAVE] = tmax;
+    st.id[sp * WAVE] = far_id;
+    ++sp;
+    tmax = plane;
+    return near_id;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Mesh — raysect/primitive/mesh/mesh.pyx:506-713 (MeshData.trace / _trace_leaf / _hit_triangle)
+// ---------------------------------------------------------------------------------------------------
+struct MeshHit {
+    float u, v, w, t;
+    int32_t tri;
+};
+
+__device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
+    double tmin, tmax;
+    if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
+
+    // _calc_rayspace_transform, mesh.pyx:566-610
+    int ix, iy, iz;
+    const double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+    if (ax > ay && ax > az) { ix = 1; iy = 2; iz = 0; }
+    else if (ay > ax && ay > az) { ix = 2; iy = 0; iz = 1; }
+    else { ix = 0; iy = 1; iz = 2; }
+    const float rdz = (float)sel3(iz, r.dx, r.dy, r.dz);
+    if (rdz < 0.0f) { const int tmp = ix; ix = iy; iy = tmp; }
+    const float sz = (float)(1.0 / (double)rdz);
+    const float sx = (float)(sel3(ix, r.dx, r.dy, r.dz) * (double)sz);
+    const float sy = (float)(sel3(iy, r.dx, r.dy, r.dz) * (double)sz);
+
+    int32_t node = 0, sp = 0;
+    for (;;) {
+        rsx_kdnode nd = load_node(m.nodes, node);
+        while (nd.type >= 0) {
+            const int axis = nd.type;
+            node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+            nd = load_node(m.nodes, node);
+        }
+        // _trace_leaf, mesh.pyx:520-563
+        double distance = r.maxd < tmax ? r.maxd : tmax;
+        int32_t closest = -1;
+        float bu = 0, bv = 0, bw = 0;
+        const int32_t *items = m.items + nd.u.leaf.first_item;
+        for (int32_t k = 0; k < nd.count; ++k) {
+            const int32_t tri = items[k];
+            const float4 q0 = m.tris[3 * (size_t)tri], q1 = m.tris[3 * (size_t)tri + 1], q2 = m.tris[3 * (size_t)tri + 2];
+            // _hit_triangle, mesh.pyx:616-713: f32 vertex minus f64 origin, rounded to f32
+            const float v1x = (float)((double)q0.x - r.ox), v1y = (float)((double)q0.y - r.oy), v1z = (float)((double)q0.z - r.oz);
+            const float v2x = (float)((double)q0.w - r.ox), v2y = (float)((double)q1.x - r.oy), v2z = (float)((double)q1.y - r.oz);
+            const float v3x = (float)((double)q1.z - r.ox), v3y = (float)((double)q1.w - r.oy), v3z = (float)((double)q2.x - r.oz);
+            const float a1 = sel3f(ix, v1x, v1y, v1z), b1 = sel3f(iy, v1x, v1y, v1z), c1 = sel3f(iz, v1x, v1y, v1z);
+            const float a2 = sel3f(ix, v2x, v2y, v2z), b2 = sel3f(iy, v2x, v2y, v2z), c2 = sel3f(iz, v2x, v2y, v2z);
+            const float a3 = sel3f(ix, v3x, v3y, v3z), b3 = sel3f(iy, v3x, v3y, v3z), c3 = sel3f(iz, v3x, v3y, v3z);
+            const float x1 = a1 - sx * c1, x2 = a2 - sx * c2, x3 = a3 - sx * c3;
+            const float y1 = b1 - sy * c1, y2 = b2 - sy * c2, y3 = b3 - sy * c3;
+            float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
+            if (u == 0.0f || v == 0.0f || w == 0.0f) {
+                u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
+                v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
+                w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+            }
+            if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) continue;
+            const float det = u + v + w;
+            if (det == 0.0f) continue;
+            const float z1 = sz * c1, z2 = sz * c2, z3 = sz * c3;
+            const float t = u * z1 + v * z2 + w * z3;
+            if (det > 0.0f) { if (t < 0.0f || (double)t > r.maxd * (double)det) continue; }
+            else            { if (t > 0.0f || (double)t < r.maxd * (double)det) continue; }
+            const float rdet = (float)(1.0 / (double)det);
+            const float ht = t * rdet;
+            if ((double)ht < distance) { distance = (double)ht; closest = tri; bu = u * rdet; bv = v * rdet; bw = w * rdet; }
+        }
+        if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; return true; }
+        if (sp == 0) return false;
+        --sp;
+        tmin = tmax;                    // far range starts where the exhausted near range ended
+        tmax = st.t[sp * WAVE];
+        node = st.id[sp * WAVE];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// analytic primitives: ordered roots inside [0, max_distance]
+//   sphere.pyx:115-159, box.pyx:157-294, cylinder.pyx:148-276, utility.pyx:376-419 (solve_quadratic)
+// Each returns 0..2 roots: t[k] plus (a0, a1) = (face, axis|type) needed to rebuild the intersection.
+// ---------------------------------------------------------------------------------------------------
+#define NO_FACE (-1)
+#define LOWER_FACE 0
+#define UPPER_FACE 1
+#define T_CYLINDER 0
+#define T_SLAB 1
+
+struct Roots {
+    int n;
+    double t[2];
+    int32_t a0[2], a1[2];
+};
+
+__device__ __forceinline__ bool solve_quadratic(double a, double b, double c, double &t0, double &t1) {
+    const double d = b * b - 4 * a * c;
+    if (d < 0) return false;
+    double q;
+    if (b < 0) q = -0.5 * (b - sqrt(d)); else q = -0.5 * (b + sqrt(d));
+    t0 = q / a;
+    t1 = c / q;
+    return true;
+}
+
+// shared tail of Sphere/Box/Cylinder.hit: choose closest root and whether a cached further root exists
+__device__ __forceinline__ void pick_roots(double near_t, double far_t, int nf, int na, int ff, int fa, double maxd, Roots &out) {
+    out.n = 0;
+    if (near_t > far_t) return;                                              // (never true for the sphere's sorted roots)
+    if (near_t > maxd || far_t < 0.0) return;
+    if (near_t >= 0.0) {
+        out.t[0] = near_t; out.a0[0] = nf; out.a1[0] = na; out.n = 1;
+        if (far_t <= maxd) { out.t[1] = far_t; out.a0[1] = ff; out.a1[1] = fa; out.n = 2; }
+    } else if (far_t <= maxd) {
+        out.t[0] = far_t; out.a0[0] = ff; out.a1[0] = fa; out.n = 1;
+    }
+}
+
+__device__ void sphere_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
+    out.n = 0;
+    const double radius = p.params[0];
+    const double a = l.dx * l.dx + l.dy * l.dy + l.dz * l.dz;
+    const double b = 2 * (l.dx * l.ox + l.dy * l.oy + l.dz * l.oz);
+    const double c = l.ox * l.ox + l.oy * l.oy + l.oz * l.oz - radius * radius;
+    double t0, t1;
+    if (!solve_quadratic(a, b, c, t0, t1)) return;
+    if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+    pick_roots(t0, t1, 0, 0, 0, 0, l.maxd, out);
+}
+
+__device__ __forceinline__ void box_slab(int axis, double o, double d, double lo, double hi, double &near_t, double &far_t,
+                                         int &nf, int &ff, int &na, int &fa) {
+    double tmin, tmax;
+    int fmin, fmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        const double rcp = 1.0 / d;
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; fmin = LOWER_FACE; fmax = UPPER_FACE; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; fmin = UPPER_FACE; fmax = LOWER_FACE; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+        fmin = NO_FACE; fmax = NO_FACE;
+    }
+    if (tmin > near_t) { near_t = tmin; nf = fmin; na = axis; }
+    if (tmax < far_t)  { far_t = tmax;  ff = fmax; fa = axis; }
+}
+
+__device__ void box_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
+    double near_t = -INFINITY, far_t = INFINITY;
+    int nf = NO_FACE, ff = NO_FACE, na = -1, fa = -1;
+    box_slab(0, l.ox, l.dx, p.params[0], p.params[3], near_t, far_t, nf, ff, na, fa);
+    box_slab(1, l.oy, l.dy, p.params[1], p.params[4], near_t, far_t, nf, ff, na, fa);
+    box_slab(2, l.oz, l.dz, p.params[2], p.params[5], near_t, far_t, nf, ff, na, fa);
+    pick_roots(near_t, far_t, nf, na, ff, fa, l.maxd, out);
+}
+
+__device__ void cylinder_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
+    out.n = 0;
+    const double radius = p.params[0], height = p.params[1];
+    double near_t, far_t, t0, t1;
+    int nf = NO_FACE, ff = NO_FACE, nt, ft, f0, f1;
+    if (l.dx == 0 && l.dy == 0) {
+        if ((l.ox * l.ox + l.oy * l.oy) <= (radius * radius)) { near_t = -INFINITY; far_t = INFINITY; nt = -1; ft = -1; }
+        else return;
+    } else {
+        const double a = l.dx * l.dx + l.dy * l.dy;
+        const double b = 2.0 * (l.dx * l.ox + l.dy * l.oy);
+        const double c = l.ox * l.ox + l.oy * l.oy - radius * radius;
+        if (!solve_quadratic(a, b, c, t0, t1)) return;
+        if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+        near_t = t0; far_t = t1; nt = T_CYLINDER; ft = T_CYLINDER;
+    }
+    if (l.dz != 0.0) {
+        const double temp = 1.0 / l.dz;
+        if (l.dz > 0) { t0 = -l.oz * temp; t1 = (height - l.oz) * temp; f0 = LOWER_FACE; f1 = UPPER_FACE; }
+        else          { t0 = (height - l.oz) * temp; t1 = -l.oz * temp; f0 = UPPER_FACE; f1 = LOWER_FACE; }
+        if (t0 > near_t) { near_t = t0; nf = f0; nt = T_SLAB; }
+        if (t1 < far_t)  { far_t = t1;  ff = f1; ft = T_SLAB; }
+    }
+    pick_roots(near_t, far_t, nf, nt, ff, ft, l.maxd, out);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// intersection records (Intersection / MeshIntersection) rebuilt from a Hit
+//   sphere.pyx:170-200, box.pyx:296-342, cylinder.pyx:287-354, mesh.pyx:718-800
+// geom = hit_point, inside_point, outside_point, normal (primitive-local space)
+// ---------------------------------------------------------------------------------------------------
+#define PRIM_EPS 1e-9
+#define MESH_EPS 1e-6
+
+__device__ __forceinline__ void normalise3(double &x, double &y, double &z) {
+    double t = x * x + y * y + z * z;
+    t = 1.0 / sqrt(t);
+    x *= t; y *= t; z *= t;
+}
+
+__device__ __forceinline__ double box_interior_offset(double hit, double lo, double hi) {
+    if (fabs(hit - lo) < PRIM_EPS) return PRIM_EPS;
+    if (fabs(hit - hi) < PRIM_EPS) return -PRIM_EPS;
+    return 0.0;
+}
+
+struct Geom {
+    double hit[3], inside[3], outside[3], normal[3];
+    bool exiting;
+};
+
+__device__ void analytic_geom(const rsx_primitive &p, const Ray &l, double t, int a0, int a1, Geom &g) {
+    g.hit[0] = l.ox + t * l.dx; g.hit[1] = l.oy + t * l.dy; g.hit[2] = l.oz + t * l.dz;
+    if (p.type == RSX_PRIM_SPHERE) {
+        g.normal[0] = g.hit[0]; g.normal[1] = g.hit[1]; g.normal[2] = g.hit[2];
+        normalise3(g.normal[0], g.normal[1], g.normal[2]);
+        for (int k = 0; k < 3; ++k) {
+            const double delta = PRIM_EPS * g.normal[k];
+            g.inside[k] = g.hit[k] - delta; g.outside[k] = g.hit[k] + delta;
+        }
+    } else if (p.type == RSX_PRIM_BOX) {
+        g.normal[0] = 0; g.normal[1] = 0; g.normal[2] = 0;
+        const double s = a0 == LOWER_FACE ? -1.0 : 1.0;
+        if (a1 == 0) g.normal[0] = s; else if (a1 == 1) g.normal[1] = s; else if (a1 == 2) g.normal[2] = s;
+        for (int k = 0; k < 3; ++k) {
+            g.inside[k] = g.hit[k] + box_interior_offset(g.hit[k], p.params[k], p.params[3 + k]);
+            g.outside[k] = g.hit[k] + PRIM_EPS * g.normal[k];
+        }
+    } else {  // cylinder
+        const double radius = p.params[0], height = p.params[1];
+        double off[3];
+        if (a1 == T_CYLINDER) {
+            g.normal[0] = g.hit[0]; g.normal[1] = g.hit[1]; g.normal[2] = 0;
+            normalise3(g.normal[0], g.normal[1], g.normal[2]);
+            off[0] = -PRIM_EPS * g.normal[0]; off[1] = -PRIM_EPS * g.normal[1];
+        } else {
+            g.normal[0] = 0; g.normal[1] = 0; g.normal[2] = a0 == LOWER_FACE ? -1.0 : 1.0;
+            off[0] = 0; off[1] = 0;
+            if (g.hit[0] != 0.0 && g.hit[1] != 0.0) {
+                double length = sqrt(g.hit[0] * g.hit[0] + g.hit[1] * g.hit[1]);
+                if ((length - radius) < PRIM_EPS) {
+                    length = 1.0 / length;
+                    off[0] = -PRIM_EPS * length * g.hit[0]; off[1] = -PRIM_EPS * length * g.hit[1];
+                }
+            }
+        }
+        if (fabs(g.hit[2]) < PRIM_EPS) off[2] = PRIM_EPS;
+        else if (fabs(g.hit[2] - height) < PRIM_EPS) off[2] = -PRIM_EPS;
+        else off[2] = 0;
+        for (int k = 0; k < 3; ++k) { g.inside[k] = g.hit[k] + off[k]; g.outside[k] = g.hit[k] + PRIM_EPS * g.normal[k]; }
+    }
+    g.exiting = (l.dx * g.normal[0] + l.dy * g.normal[1] + l.dz * g.normal[2]) >= 0.0;
+}
+
+// MeshData.calc_intersection / _intersection_normal. `t` is the LOCAL distance from l's origin.
+__device__ void mesh_geom(const DMesh &m, const Ray &l, double t, int32_t tri, float u, float v, float w, Geom &g) {
+    const float4 q2 = m.tris[3 * (size_t)tri + 2];
+    const double fx = (double)q2.y, fy = (double)q2.z, fz = (double)q2.w;
+    g.hit[0] = l.ox + l.dx * t; g.hit[1] = l.oy + l.dy * t; g.hit[2] = l.oz + l.dz * t;
+    g.inside[0] = g.hit[0] - fx * MESH_EPS; g.inside[1] = g.hit[1] - fy * MESH_EPS; g.inside[2] = g.hit[2] - fz * MESH_EPS;
+    g.outside[0] = g.hit[0] + fx * MESH_EPS; g.outside[1] = g.hit[1] + fy * MESH_EPS; g.outside[2] = g.hit[2] + fz * MESH_EPS;
+    if (m.smoothing && m.vnormals) {
+        const int32_t n1 = m.nidx[3 * (size_t)tri], n2 = m.nidx[3 * (size_t)tri + 1], n3 = m.nidx[3 * (size_t)tri + 2];
+        for (int k = 0; k < 3; ++k) {   // f32 arithmetic, then widened (mesh.pyx:783-787)
+            const float nk = u * m.vnormals[3 * (size_t)n1 + k] + v * m.vnormals[3 * (size_t)n2 + k] + w * m.vnormals[3 * (size_t)n3 + k];
+            g.normal[k] = (double)nk;
+        }
+    } else {
+        g.normal[0] = fx; g.normal[1] = fy; g.normal[2] = fz;
+    }
+    normalise3(g.normal[0], g.normal[1], g.normal[2]);
+    g.exiting = (l.dx * fx + l.dy * fy + l.dz * fz) > 0.0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// World.hit — core/scenegraph/world.pyx:125-146, core/acceleration/kdtree.pyx:73-122,170-175,
+//             boundprimitive.pyx:42-51
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t idx, const rsx_primitive &p, const Ray &r, Stack mesh_stack, Hit &cand) {
+    cand.prim = -1;
+    const Ray l = to_local(p, r);
+    if (p.type == RSX_PRIM_MESH) {
+        MeshHit mh;
+        if (mesh_trace(sc.meshes[p.mesh], l, mesh_stack, mh)) {
+            cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
+        }
+        return;
+    }
+    Roots roots;
+    roots.n = 0;
+    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
+    if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
+}
+
+__device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, Hit &best) {
+    best.prim = -1;
+    double tmin, tmax;
+    if (!aabb(sc.wlower, sc.wupper, r, tmin, tmax)) return false;
+    Stack mesh_stack;
+    mesh_stack.t = st.t + sc.wdepth * WAVE;
+    mesh_stack.id = st.id + sc.wdepth * WAVE;
+    int32_t node = 0, sp = 0;
+    for (;;) {
+        rsx_kdnode nd = load_node(sc.wnodes, node);
+        while (nd.type >= 0) {
+            const int axis = nd.type;
+            node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+            nd = load_node(sc.wnodes, node);
+        }
+        double distance = r.maxd < tmax ? r.maxd : tmax;
+        const int32_t *items = sc.witems + nd.u.leaf.first_item;
+        for (int32_t k = 0; k < nd.count; ++k) {
+            const int32_t idx = items[k];
+            const rsx_primitive &p = sc.prims[idx];
+            double f, b;
+            if (!aabb(p.box_lower, p.box_upper, r, f, b)) continue;          // BoundPrimitive.hit gate
+            Hit cand;
+            primitive_first_hit(sc, idx, p, r, mesh_stack, cand);
+            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
+        }
+        if (best.prim >= 0) return true;
+        if (sp == 0) return false;
+        --sp;
+        tmin = tmax;
+        tmax = st.t[sp * WAVE];
+        node = st.id[sp * WAVE];
+    }
+}
+
+__device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
+    const rsx_primitive &p = sc.prims[h.prim];
+    const Ray l = to_local(p, r);
+    if (p.type == RSX_PRIM_MESH) mesh_geom(sc.meshes[p.mesh], l, h.t, h.a0, h.u, h.v, h.w, g);
+    else analytic_geom(p, l, h.t, h.a0, h.a1, g);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+__device__ __forceinline__ Stack lane_stack(int levels) {
+    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    char *base = smem + (size_t)wave * levels * WAVE * 12;
+    Stack st;
+    st.t = reinterpret_cast<double *>(base) + lane;
+    st.id = reinterpret_cast<int32_t *>(base + (size_t)levels * WAVE * 8) + lane;
+    return st;
+}
+
+// wave-level ticket: lane 0 takes the next batch of 64 work items
+__device__ __forceinline__ long long next_batch(unsigned long long *ticket) {
+    long long base = 0;
+    if (threadIdx.x % WAVE == 0) base = (long long)atomicAdd(ticket, 64ULL);
+    return __shfl(base, 0, WAVE);
+}
+
+struct HitOut {
+    int32_t *prim; double *t; uint8_t *exiting; int32_t *tri; float *uvw; double *geom;
+};
+
+__global__ __launch_bounds__(WG_THREADS) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
+                                                          const double *maxd, HitOut out, unsigned long long *ticket) {
+    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    const int lane = threadIdx.x % WAVE;
+    for (;;) {
+        const long long base = next_batch(ticket);
+        if (base >= n) break;
+        const long long i = base + lane;
+        if (i >= n) continue;
+        Ray r;
+        r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
+        r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
+        r.maxd = maxd[i];
+        Hit h;
+        const bool hit = world_trace(sc, r, st, h);
+        out.prim[i] = hit ? h.prim : -1;
+        if (out.t) out.t[i] = hit ? h.t : NAN;
+        const bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
+        if (out.tri) out.tri[i] = mesh ? h.a0 : -1;
+        if (out.uvw) { out.uvw[3 * i] = mesh ? h.u : 0.0f; out.uvw[3 * i + 1] = mesh ? h.v : 0.0f; out.uvw[3 * i + 2] = mesh ? h.w : 0.0f; }
+        if (out.exiting || out.geom) {
+            Geom g;
+            if (hit) finalise(sc, r, h, g);
+            if (out.exiting) out.exiting[i] = hit ? (g.exiting ? 1 : 0) : 0;
+            if (out.geom) {
+                double *o = out.geom + 12 * i;
+                for (int k = 0; k < 3; ++k) {
+                    o[k] = hit ? g.hit[k] : NAN; o[3 + k] = hit ? g.inside[k] : NAN;
+                    o[6 + k] = hit ? g.outside[k] : NAN; o[9 + k] = hit ? g.normal[k] : NAN;
+                }
+            }
+        }
+    }
+}
+
+// Primitive.hit + next_intersection() sequence on one primitive (tests / Primitive API parity).
+// Mesh.next_intersection re-traces from hit + d*1e-6 with max - t - 1e-6 (mesh.pyx:1240-1275).
+__global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, long long n, const double *origin, const double *direction,
+                                                      const double *maxd, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
+                                                      unsigned long long *ticket) {
+    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    const int lane = threadIdx.x % WAVE;
+    const rsx_primitive &p = sc.prims[pidx];
+    for (;;) {
+        const long long base = next_batch(ticket);
+        if (base >= n) break;
+        const long long i = base + lane;
+        if (i >= n) continue;
+        Ray r;
+        r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
+        r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
+        r.maxd = maxd[i];
+        Ray l = to_local(p, r);
+        int32_t c = 0;
+        if (p.type == RSX_PRIM_MESH) {
+            const DMesh &m = sc.meshes[p.mesh];
+            double accumulated = 0;
+            MeshHit mh;
+            Stack ms;
+            ms.t = st.t + sc.wdepth * WAVE;
+            ms.id = st.id + sc.wdepth * WAVE;
+            while (c < max_roots && mesh_trace(m, l, ms, mh)) {
+                Geom g;
+                mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
+                const double dist = (double)mh.t + accumulated;
+                t[i * max_roots + c] = dist;
+                exiting[i * max_roots + c] = g.exiting ? 1 : 0;
+                ++c;
+                l.ox = g.hit[0] + l.dx * MESH_EPS; l.oy = g.hit[1] + l.dy * MESH_EPS; l.oz = g.hit[2] + l.dz * MESH_EPS;
+                l.maxd = l.maxd - (double)mh.t - MESH_EPS;
+                accumulated = dist + MESH_EPS;
+            }
+        } else if (p.type <= RSX_PRIM_CYLINDER) {
+            Roots roots;
+            roots.n = 0;
+            if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
+            else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
+            else cylinder_roots(p, l, roots);
+            for (int k = 0; k < roots.n && c < max_roots; ++k) {
+                Geom g;
+                analytic_geom(p, l, roots.t[k], roots.a0[k], roots.a1[k], g);
+                t[i * max_roots + c] = roots.t[k];
+                exiting[i * max_roots + c] = g.exiting ? 1 : 0;
+                ++c;
+            }
+        }
+        counts[i] = c;
+    }
+}
+
+// World.contains — kdtree3d.pyx:736-792, kdtree.pyx:126-162, primitive contains():
+//   sphere.pyx:202-214, box.pyx:344-361, cylinder.pyx:356-372, mesh.pyx:1277-1297 (+802-830)
+__global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n, const double *points, uint8_t *inside,
+                                                         unsigned long long *ticket) {
+    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    const int lane = threadIdx.x % WAVE;
+    for (;;) {
+        const long long base = next_batch(ticket);
+        if (base >= n) break;
+        const long long i = base + lane;
+        if (i >= n) continue;
+        const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
+        for (int j = 0; j < sc.n_world; ++j) inside[i * sc.n_world + j] = 0;
+        if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) continue;
+        int32_t node = 0;
+        rsx_kdnode nd = load_node(sc.wnodes, node);
+        while (nd.type >= 0) {
+            node = sel3(nd.type, px, py, pz) < nd.u.split ? node + 1 : nd.count;
+            nd = load_node(sc.wnodes, node);
+        }
+        for (int32_t k = 0; k < nd.count; ++k) {
+            const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
+            const rsx_primitive &p = sc.prims[idx];
+            if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) continue;
+            double qx, qy, qz;
+            xform_point(p.to_local, px, py, pz, qx, qy, qz);
+            bool in = false;
+            if (p.type == RSX_PRIM_SPHERE) in = (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
+            else if (p.type == RSX_PRIM_BOX) in = aabb_contains(p.params, p.params + 3, qx, qy, qz);
+            else if (p.type == RSX_PRIM_CYLINDER) in = (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
+            else if (p.type == RSX_PRIM_MESH) {
+                const DMesh &m = sc.meshes[p.mesh];
+                if (m.closed) {
+                    Ray zr;
+                    zr.ox = qx; zr.oy = qy; zr.oz = qz; zr.dx = 0; zr.dy = 0; zr.dz = 1; zr.maxd = INFINITY;
+                    MeshHit mh;
+                    Stack ms;
+                    ms.t = st.t + sc.wdepth * WAVE;
+                    ms.id = st.id + sc.wdepth * WAVE;
+                    if (mesh_trace(m, zr, ms, mh)) in = m.tris[3 * (size_t)mh.tri + 2].w > 0.0f;
+                }
+            }
+            inside[i * sc.n_world + idx] = in ? 1 : 0;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// observe(): sample generation + trace + shading  ->  per-sample records; then per-(pixel,bin) Welford
+// ---------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011): counter = (pixel, sample), key = seed
+__device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t sample, double &u1, double &u2) {
+    uint32_t c0 = (uint32_t)pixel, c1 = (uint32_t)(pixel >> 32), c2 = (uint32_t)sample, c3 = (uint32_t)(sample >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t a = ((uint64_t)c1 << 32) | c0, b = ((uint64_t)c3 << 32) | c2;
+    u1 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+    u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+struct RenderParams {
+    rsx_camera cam;
+    const rsx_material *materials;
+    const int32_t *tasks;      // device [n_tasks,2] or null
+    const double *uniforms;    // device or null
+    long long n_tasks;
+    int32_t rect[4];
+    int32_t spp, rng_mode;
+    uint64_t seed;
+};
+
+// per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
+struct Sample {
+    double a, weight;
+    int32_t table, pad;
+};
+
+__device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, int &ix, int &iy) {
+    if (rp.tasks) { ix = rp.tasks[2 * k]; iy = rp.tasks[2 * k + 1]; }
+    else { const int w = rp.rect[2] - rp.rect[0]; ix = rp.rect[0] + (int)(k % w); iy = rp.rect[1] + (int)(k / w); }
+}
+
+// Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
+// 64 rays stay coherent; in task-list mode 64 consecutive tasks.
+__global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    const int lane = threadIdx.x % WAVE;
+    const long long total = rp.n_tasks * rp.spp;
+    const int w = rp.rect[2] - rp.rect[0], h = rp.rect[3] - rp.rect[1];
+    const int tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8;
+    const long long n_units = rp.tasks ? ((rp.n_tasks + 63) / 64) * rp.spp : (long long)tiles_x * tiles_y * rp.spp;
+    for (;;) {
+        const long long unit = next_batch(ticket) / 64;
+        if (unit >= n_units) break;
+        const int s = (int)(unit % rp.spp);
+        const long long chunk = unit / rp.spp;
+        long long k;
+        int ix, iy;
+        if (rp.tasks) {
+            k = chunk * 64 + lane;
+            if (k >= rp.n_tasks) continue;
+            task_pixel(rp, k, ix, iy);
+        } else {
+            const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
+            const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+            if (lx >= w || ly >= h) continue;
+            ix = rp.rect[0] + lx; iy = rp.rect[1] + ly;
+            k = (long long)ly * w + lx;
+        }
+        (void)total;
+        // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
+        double u1, u2;
+        if (rp.rng_mode == RSX_RNG_STREAM) { u1 = rp.uniforms[2 * (k * rp.spp + s)]; u2 = rp.uniforms[2 * (k * rp.spp + s) + 1]; }
+        else philox2(rp.seed, (uint64_t)ix * (uint64_t)rp.cam.ny + (uint64_t)iy, (uint64_t)s, u1, u2);
+        const double delta = rp.cam.image_delta, half = 0.5 * delta;
+        const double pixel_x = rp.cam.image_start_x - delta * ((double)ix + 0.5);
+        const double pixel_y = rp.cam.image_start_y - delta * ((double)iy + 0.5);
+        double dx = (u1 * delta - half) + pixel_x, dy = (u2 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+        normalise3(dx, dy, dz);
+        const double weight = dz;
+        Ray r;
+        xform_point(rp.cam.to_root, 0.0, 0.0, 0.0, r.ox, r.oy, r.oz);         // observer.pyx:403-404
+        xform_vector(rp.cam.to_root, dx, dy, dz, r.dx, r.dy, r.dz);
+        r.maxd = INFINITY;
+        Hit hit;
+        Sample smp;
+        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
+        if (world_trace(sc, r, st, hit)) {                                    // optical/ray.pyx:391-393
+            const rsx_primitive &p = sc.prims[hit.prim];
+            const rsx_material mat = rp.materials[p.material];
+            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
+            else if (mat.type == RSX_MAT_DEBUG_LIGHT) {                      // debug.pyx:67-79
+                if (mat.scale != 0.0) {
+                    Geom g;
+                    finalise(sc, r, hit, g);
+                    double lx, ly, lz;
+                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                    smp.a = mat.scale * (dot > 0 ? dot : 0.0);
+                    smp.table = mat.table;
+                }
+            }
+        }
+        samples[k * rp.spp + s] = smp;
+    }
+}
+
+// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859
+__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n) {
+    if (n == 0) { n = 1; m = x; v = 0; return; }
+    const double pm = m, pv = v;
+    const int pn = n > 1 ? n : 2;
+    n += 1;
+    m = pm + (x - pm) / n;
+    v = (pv * (pn - 1) + (x - pm) * (x - m)) / (n - 1);
+}
+
+__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
+    if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
+    if (nx > 1 && ny > 1) {
+        nt = nx + ny;
+        mt = (nx * mx + ny * my) / (double)nt;
+        vx = (nx - 1) * vx / (double)nx;
+        vy = (ny - 1) * vy / (double)ny;
+        vt = (nx * (mx * mx + vx) + ny * (my * my + vy)) / (double)nt - mt * mt;
+        vt = nt * vt / (double)(nt - 1);
+        return;
+    }
+    if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
+    else if (nx == 1) {
+        if (ny == 0) { nt = 1; mt = mx; vt = 0; }
+        else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
+    } else if (nx > 1) {
+        nt = nx; mt = mx; vt = vx;
+        if (ny == 1) add_sample(my, mt, vt, nt);
+    } else { nt = 0; mt = 0; vt = 0; }
+}
+
+// One thread per (task, bin): sequential Welford over the task's spp samples in sample order
+// (SpectralRadiance/PowerPixelProcessor.add_sample, pipeline/spectral/power.pyx:468-486, radiance.pyx:245-263).
+// frame == null: write per-task (mean, variance) like _render_pixel packs them; else merge into the
+// device-resident frame with the combine_samples law (Pipeline2D.update, power.pyx:424-437).
+struct AccumParams {
+    const Sample *samples;
+    const double *tables;
+    const int32_t *tasks;
+    long long n_tasks;
+    int32_t rect[4];
+    int32_t ny, bins, spp, power;
+    double sensitivity;
+    double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
+    double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
+    int32_t frame_bins, slice_offset;
+};
+
+__global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = ap.n_tasks * ap.bins;
+    if (gid >= total) return;
+    const long long k = gid / ap.bins;
+    const int b = (int)(gid % ap.bins);
+    double m = 0, v = 0;
+    int n = 0;
+    const Sample *s = ap.samples + k * ap.spp;
+    for (int i = 0; i < ap.spp; ++i) {
+        const Sample smp = s[i];
+        double x = smp.table < 0 ? 0.0 : smp.a * ap.tables[(size_t)smp.table * ap.bins + b];
+        x = x * smp.weight;                                                   // observer.pyx:408
+        if (ap.power) x = x * ap.sensitivity;
+        add_sample(x, m, v, n);
+    }
+    if (ap.mean) { ap.mean[gid] = m; ap.variance[gid] = v; }
+    if (ap.fmean) {
+        int ix, iy;
+        if (ap.tasks) { ix = ap.tasks[2 * k]; iy = ap.tasks[2 * k + 1]; }
+        else { const int w = ap.rect[2] - ap.rect[0]; ix = ap.rect[0] + (int)(k % w); iy = ap.rect[1] + (int)(k / w); }
+        const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+        if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
+        double mt, vt;
+        int nt;
+        combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
+        ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, double *va, int32_t *na, const double *mb,
+                                                       const double *vb, const int32_t *nb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (nb[i] < 1) return;
+    double v = vb[i];
+    if (v < 0) v = 0;
+    double mt, vt;
+    int nt;
+    combine_samples(ma[i], va[i], na[i], mb[i], v, nb[i], mt, vt, nt);
+    ma[i] = mt; va[i] = vt; na[i] = nt;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host API
+// ---------------------------------------------------------------------------------------------------
+struct rsx_ctx {
+    int device;
+    hipStream_t stream;        // launch stream (own or external)
+    hipStream_t own_stream;
+    hipEvent_t ev0, ev1;
+    unsigned long long *ticket;
+    int n_cus;
+    float last_ms;
+};
+
+struct rsx_scene {
+    rsx_ctx *ctx;
+    DScene d;
+    std::vector<void *> allocs;
+    int32_t n_world;
+};
+
+extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
+    if (!out) return rsx_fail(RSX_EINVAL, "rsx_init: null out");
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return rsx_fail(RSX_ENODEV, "no HIP device visible");
+    if (device_ordinal < 0 || device_ordinal >= count) return rsx_fail(RSX_ENODEV, "device ordinal %d out of range (0..%d)", device_ordinal, count - 1);
+    HIP_TRY(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_ordinal));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return rsx_fail(RSX_ENODEV, "device %d is %s; librsx is built for gfx950 only", device_ordinal, prop.gcnArchName);
+    rsx_ctx *ctx = new (std::nothrow) rsx_ctx();
+    if (!ctx) return rsx_fail(RSX_ENOMEM, "out of host memory");
+    ctx->device = device_ordinal;
+    ctx->n_cus = prop.multiProcessorCount;
+    ctx->last_ms = 0.f;
+    HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    HIP_TRY(hipEventCreate(&ctx->ev0));
+    HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(hipMalloc(&ctx->ticket, sizeof(unsigned long long)));
+    *out = ctx;
+    return RSX_OK;
+}
+
+extern "C" void rsx_free(rsx_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipFree(ctx->ticket);
+    hipEventDestroy(ctx->ev0);
+    hipEventDestroy(ctx->ev1);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" int rsx_set_stream(rsx_ctx *ctx, void *hip_stream) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return RSX_OK;
+}
+
+extern "C" int rsx_synchronize(rsx_ctx *ctx) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return rsx_fail(RSX_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    ctx->last_ms = *ms;
+    return RSX_OK;
+}
+
+extern "C" int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr) {
+    if (!ctx || !dptr) return rsx_fail(RSX_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
+    return RSX_OK;
+}
+
+extern "C" int rsx_dev_free(rsx_ctx *ctx, void *dptr) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(dptr));
+    return RSX_OK;
+}
+
+extern "C" int rsx_dev_upload(rsx_ctx *ctx, void *dptr, const void *host, size_t bytes) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_dev_download(rsx_ctx *ctx, void *host, const void *dptr, size_t bytes) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_dev_memset(rsx_ctx *ctx, void *dptr, int value, size_t bytes) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(dptr, value, bytes, ctx->stream));
+    return RSX_OK;
+}
+
+// -- scene upload -----------------------------------------------------------------------------------
+namespace {
+
+template <typename T>
+int upload(rsx_scene *sc, const T *host, size_t count, const T **dev) {
+    void *d = nullptr;
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    HIP_TRY(hipMalloc(&d, bytes));
+    sc->allocs.push_back(d);
+    if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    *dev = static_cast<const T *>(d);
+    return RSX_OK;
+}
+
+int tree_depth(const rsx_kdtree &kd) {
+    // deepest chain of branch nodes = stack levels a traversal can need; iterative over the pre-order layout
+    if (kd.n_nodes <= 0) return 0;
+    std::vector<int32_t> depth((size_t)kd.n_nodes, 0);
+    int best = 0;
+    for (int32_t i = 0; i < kd.n_nodes; ++i) {
+        const rsx_kdnode &nd = kd.nodes[i];
+        if (nd.type >= 0) {
+            const int d = depth[i] + 1;
+            if (i + 1 < kd.n_nodes) depth[i + 1] = d;
+            if (nd.count > 0 && nd.count < kd.n_nodes) depth[nd.count] = d;
+            if (d > best) best = d;
+        }
+    }
+    return best;
+}
+
+int validate_tree(const rsx_kdtree &kd, int32_t n_ids, const char *what) {
+    if (kd.n_nodes < 1 || !kd.nodes) return rsx_fail(RSX_EINVAL, "%s: empty KD-tree", what);
+    for (int32_t i = 0; i < kd.n_nodes; ++i) {
+        const rsx_kdnode &nd = kd.nodes[i];
+        if (nd.type >= 0) {
+            if (nd.type > 2 || nd.count <= i || nd.count >= kd.n_nodes || i + 1 >= kd.n_nodes)
+                return rsx_fail(RSX_EINVAL, "%s: malformed branch node %d", what, i);
+        } else {
+            if (nd.count < 0 || nd.u.leaf.first_item < 0 || (int64_t)nd.u.leaf.first_item + nd.count > kd.n_items)
+                return rsx_fail(RSX_EINVAL, "%s: malformed leaf node %d", what, i);
+            for (int32_t k = 0; k < nd.count; ++k) {
+                const int32_t id = kd.items[nd.u.leaf.first_item + k];
+                if (id < 0 || id >= n_ids) return rsx_fail(RSX_EINVAL, "%s: item id %d out of range", what, id);
+            }
+        }
+    }
+    return RSX_OK;
+}
+
+}  // namespace
+
+extern "C" void rsx_scene_free(rsx_scene *scene) {
+    if (!scene) return;
+    hipSetDevice(scene->ctx->device);
+    hipStreamSynchronize(scene->ctx->stream);
+    for (void *p : scene->allocs) hipFree(p);
+    delete scene;
+}
+
+extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_scene **out) {
+    if (!ctx || !desc || !out) return rsx_fail(RSX_EINVAL, "rsx_scene_create: null argument");
+    if (desc->n_world < 0 || desc->n_world > desc->n_primitives) return rsx_fail(RSX_EINVAL, "n_world out of range");
+    for (int32_t i = 0; i < desc->n_primitives; ++i) {
+        const rsx_primitive &p = desc->primitives[i];
+        if (p.type == RSX_PRIM_UNION || p.type == RSX_PRIM_INTERSECT || p.type == RSX_PRIM_SUBTRACT)
+            return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG is not yet on the device path", i);
+        if (p.type == RSX_PRIM_MESH && (p.mesh < 0 || p.mesh >= desc->n_meshes)) return rsx_fail(RSX_EINVAL, "primitive %d: bad mesh index", i);
+        if (p.type < 0 || p.type > RSX_PRIM_NULL) return rsx_fail(RSX_EINVAL, "primitive %d: unknown type %d", i, p.type);
+    }
+    int rc = validate_tree(desc->world_kd, desc->n_world, "world tree");
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    rsx_scene *sc = new (std::nothrow) rsx_scene();
+    if (!sc) return rsx_fail(RSX_ENOMEM, "out of host memory");
+    sc->ctx = ctx;
+    sc->n_world = desc->n_world;
+    DScene &d = sc->d;
+    std::memset(&d, 0, sizeof(d));
+#define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
+    UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
+    UP(upload(sc, desc->world_kd.nodes, (size_t)desc->world_kd.n_nodes, &d.wnodes));
+    UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
+    std::memcpy(d.wlower, desc->world_kd.lower, 24);
+    std::memcpy(d.wupper, desc->world_kd.upper, 24);
+    d.n_prims = desc->n_primitives;
+    d.n_world = desc->n_world;
+    d.n_meshes = desc->n_meshes;
+    d.wdepth = tree_depth(desc->world_kd) + 1;
+    d.mdepth = 1;
+    std::vector<DMesh> meshes((size_t)desc->n_meshes);
+    for (int32_t i = 0; i < desc->n_meshes; ++i) {
+        const rsx_meshdata &m = desc->meshes[i];
+        rc = validate_tree(m.kd, m.n_triangles, "mesh tree");
+        if (rc) { rsx_scene_free(sc); return rc; }
+        DMesh &dm = meshes[(size_t)i];
+        std::memset(&dm, 0, sizeof(dm));
+        // pre-gather: 48-byte triangle records (vertices + face normal) -> no index indirection on the device
+        std::vector<float4> tris((size_t)m.n_triangles * 3);
+        std::vector<int32_t> nidx;
+        if (m.vertex_normals && m.tri_stride >= 6) nidx.resize((size_t)m.n_triangles * 3);
+        for (int32_t t = 0; t < m.n_triangles; ++t) {
+            const int32_t *tr = m.triangles + (size_t)t * m.tri_stride;
+            for (int k = 0; k < 3; ++k)
+                if (tr[k] < 0 || tr[k] >= m.n_vertices) { rsx_scene_free(sc); return rsx_fail(RSX_EINVAL, "mesh %d triangle %d: vertex index out of range", i, t); }
+            const float *a = m.vertices + 3 * (size_t)tr[0], *b = m.vertices + 3 * (size_t)tr[1], *c = m.vertices + 3 * (size_t)tr[2];
+            const float *fn = m.face_normals + 3 * (size_t)t;
+            tris[3 * (size_t)t] = make_float4(a[0], a[1], a[2], b[0]);
+            tris[3 * (size_t)t + 1] = make_float4(b[1], b[2], c[0], c[1]);
+            tris[3 * (size_t)t + 2] = make_float4(c[2], fn[0], fn[1], fn[2]);
+            if (!nidx.empty()) for (int k = 0; k < 3; ++k) {
+                if (tr[3 + k] < 0 || tr[3 + k] >= m.n_normals) { rsx_scene_free(sc); return rsx_fail(RSX_EINVAL, "mesh %d triangle %d: normal index out of range", i, t); }
+                nidx[3 * (size_t)t + k] = tr[3 + k];
+            }
+        }
+        UP(upload(sc, tris.data(), tris.size(), &dm.tris));
+        UP(upload(sc, m.kd.nodes, (size_t)m.kd.n_nodes, &dm.nodes));
+        UP(upload(sc, m.kd.items, (size_t)m.kd.n_items, &dm.items));
+        if (!nidx.empty()) {
+            UP(upload(sc, m.vertex_normals, (size_t)m.n_normals * 3, &dm.vnormals));
+            UP(upload(sc, nidx.data(), nidx.size(), &dm.nidx));
+        }
+        std::memcpy(dm.lower, m.kd.lower, 24);
+        std::memcpy(dm.upper, m.kd.upper, 24);
+        dm.smoothing = m.smoothing; dm.closed = m.closed; dm.n_tris = m.n_triangles;
+        d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1);
+    }
+    UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
+#undef UP
+    *out = sc;
+    return RSX_OK;
+}
+
+// -- launches ---------------------------------------------------------------------------------------
+namespace {
+
+struct Launch {
+    dim3 grid;
+    size_t lds;
+};
+
+// persistent grid: enough workgroups to fill every CU at the occupancy the LDS stacks allow
+int plan(const rsx_scene *sc, long long work_items, Launch &l) {
+    const int levels = sc->d.wdepth + sc->d.mdepth;
+    l.lds = (size_t)WG_WAVES * levels * WAVE * 12;
+    if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "KD-tree too deep for the LDS traversal stack (%d levels)", levels);
+    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l.lds, 1));
+    if (per_cu < 1) per_cu = 1;
+    long long wgs = (long long)sc->ctx->n_cus * per_cu;
+    const long long needed = (work_items + WG_THREADS - 1) / WG_THREADS;
+    if (wgs > needed) wgs = needed;
+    if (wgs < 1) wgs = 1;
+    l.grid = dim3((unsigned)wgs);
+    return RSX_OK;
+}
+
+int reset_ticket(rsx_ctx *ctx) {
+    HIP_TRY(hipMemsetAsync(ctx->ticket, 0, sizeof(unsigned long long), ctx->stream));
+    return RSX_OK;
+}
+
+// scratch device buffer that frees itself
+struct Scratch {
+    void *p = nullptr;
+    ~Scratch() { if (p) hipFree(p); }
+    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return RSX_OK; }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+
+}  // namespace
+
+extern "C" int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *origin, const double *direction, const double *max_distance,
+                                 int32_t *prim, double *t, uint8_t *exiting, int32_t *tri, float *uvw, double *geom) {
+    if (!scene || n < 0 || !origin || !direction || !max_distance || !prim) return rsx_fail(RSX_EINVAL, "rsx_hit_batch_dev: bad arguments");
+    if (n == 0) return RSX_OK;
+    rsx_ctx *ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    Launch l;
+    int rc = plan(scene, n, l);
+    if (rc) return rc;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    rc = reset_ticket(ctx);
+    if (rc) return rc;
+    HitOut out = {prim, t, exiting, tri, uvw, geom};
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_hit_batch, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, const double *direction, const double *max_distance,
+                             int32_t *prim, double *t, uint8_t *exiting, int32_t *tri, float *uvw, double *geom) {
+    if (!scene || n < 0 || !origin || !direction || !max_distance || !prim) return rsx_fail(RSX_EINVAL, "rsx_hit_batch: bad arguments");
+    if (n == 0) return RSX_OK;
+    rsx_ctx *ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    Scratch d_o, d_d, d_m, d_prim, d_t, d_ex, d_tri, d_uvw, d_geom;
+    int rc;
+#define A(s, bytes) do { rc = (s).alloc(bytes); if (rc) return rc; } while (0)
+    A(d_o, N * 24); A(d_d, N * 24); A(d_m, N * 8); A(d_prim, N * 4);
+    if (t) A(d_t, N * 8);
+    if (exiting) A(d_ex, N);
+    if (tri) A(d_tri, N * 4);
+    if (uvw) A(d_uvw, N * 12);
+    if (geom) A(d_geom, N * 96);
+#undef A
+    HIP_TRY(hipMemcpyAsync(d_o.p, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_d.p, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_m.p, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = rsx_hit_batch_dev(scene, n, d_o.as<double>(), d_d.as<double>(), d_m.as<double>(), d_prim.as<int32_t>(), d_t.as<double>(),
+                           d_ex.as<uint8_t>(), d_tri.as<int32_t>(), d_uvw.as<float>(), d_geom.as<double>());
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(prim, d_prim.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) HIP_TRY(hipMemcpyAsync(t, d_t.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (exiting) HIP_TRY(hipMemcpyAsync(exiting, d_ex.p, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (tri) HIP_TRY(hipMemcpyAsync(tri, d_tri.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw.p, N * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (geom) HIP_TRY(hipMemcpyAsync(geom, d_geom.p, N * 96, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double *origin, const double *direction,
+                               const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting) {
+    if (!scene || n < 0 || !origin || !direction || !max_distance || !counts || !t || !exiting || max_roots < 1)
+        return rsx_fail(RSX_EINVAL, "rsx_roots_batch: bad arguments");
+    if (primitive < 0 || primitive >= scene->d.n_prims) return rsx_fail(RSX_EINVAL, "rsx_roots_batch: primitive index out of range");
+    if (n == 0) return RSX_OK;
+    rsx_ctx *ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n, R = (size_t)max_roots;
+    Scratch d_o, d_d, d_m, d_c, d_t, d_ex;
+    int rc;
+    if ((rc = d_o.alloc(N * 24)) || (rc = d_d.alloc(N * 24)) || (rc = d_m.alloc(N * 8)) || (rc = d_c.alloc(N * 4)) ||
+        (rc = d_t.alloc(N * R * 8)) || (rc = d_ex.alloc(N * R))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_o.p, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_d.p, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_m.p, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_t.p, 0, N * R * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_ex.p, 0, N * R, ctx->stream));
+    Launch l;
+    if ((rc = plan(scene, n, l))) return rc;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_roots), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    if ((rc = reset_ticket(ctx))) return rc;
+    hipLaunchKernelGGL(k_roots, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->ticket);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(counts, d_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(t, d_t.p, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(exiting, d_ex.p, N * R, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *points, uint8_t *inside) {
+    if (!scene || n < 0 || !points || !inside) return rsx_fail(RSX_EINVAL, "rsx_contains_batch: bad arguments");
+    if (n == 0) return RSX_OK;
+    rsx_ctx *ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n, W = (size_t)std::max(1, scene->d.n_world);
+    Scratch d_p, d_in;
+    int rc;
+    if ((rc = d_p.alloc(N * 24)) || (rc = d_in.alloc(N * W))) return rc;
+    HIP_TRY(hipMemcpyAsync(d_p.p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    Launch l;
+    if ((rc = plan(scene, n, l))) return rc;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contains), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    if ((rc = reset_ticket(ctx))) return rc;
+    hipLaunchKernelGGL(k_contains, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(inside, d_in.p, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+namespace {
+
+// shared body of rsx_render_pinhole / rsx_render_pinhole_frame
+int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double *h_var, double *fmean, double *fvar, int32_t *fn,
+           int32_t frame_bins, int32_t slice_offset, uint64_t *ray_count) {
+    if (!scene || !desc) return rsx_fail(RSX_EINVAL, "render: null argument");
+    if (desc->n_tasks < 0 || desc->spp < 1 || desc->bins < 1) return rsx_fail(RSX_EINVAL, "render: n_tasks/spp/bins out of range");
+    if (desc->rng_mode == RSX_RNG_STREAM && !desc->uniforms) return rsx_fail(RSX_EINVAL, "render: RSX_RNG_STREAM needs uniforms");
+    if (!desc->tasks) {
+        const long long w = desc->rect[2] - desc->rect[0], h = desc->rect[3] - desc->rect[1];
+        if (w <= 0 || h <= 0 || w * h != desc->n_tasks) return rsx_fail(RSX_EINVAL, "render: rect does not match n_tasks");
+    }
+    for (int32_t i = 0; i < desc->n_materials; ++i)
+        if (desc->materials[i].type != RSX_MAT_ABSORBER && (desc->materials[i].table < 0 || desc->materials[i].table >= desc->n_tables))
+            return rsx_fail(RSX_EINVAL, "render: material %d references table %d of %d", i, desc->materials[i].table, desc->n_tables);
+    if (ray_count) *ray_count = (uint64_t)desc->n_tasks * (uint64_t)desc->spp;
+    if (desc->n_tasks == 0) return RSX_OK;
+    rsx_ctx *ctx = scene->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t T = (size_t)desc->n_tasks, S = T * (size_t)desc->spp, B = (size_t)desc->bins;
+    Scratch d_mat, d_tab, d_tasks, d_uni, d_samples, d_mean, d_var;
+    int rc;
+    if ((rc = d_mat.alloc(sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials))) || (rc = d_tab.alloc(8 * B * (size_t)std::max(1, desc->n_tables))) ||
+        (rc = d_samples.alloc(S * sizeof(Sample)))) return rc;
+    if (desc->n_materials) HIP_TRY(hipMemcpyAsync(d_mat.p, desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials, hipMemcpyHostToDevice, ctx->stream));
+    if (desc->n_tables) HIP_TRY(hipMemcpyAsync(d_tab.p, desc->tables, 8 * B * (size_t)desc->n_tables, hipMemcpyHostToDevice, ctx->stream));
+    if (desc->tasks) {
+        if ((rc = d_tasks.alloc(T * 8))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_tasks.p, desc->tasks, T * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (desc->rng_mode == RSX_RNG_STREAM) {
+        if ((rc = d_uni.alloc(S * 16))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_uni.p, desc->uniforms, S * 16, hipMemcpyHostToDevice, ctx->stream));
+    }
+    if (h_mean) {
+        if ((rc = d_mean.alloc(T * B * 8)) || (rc = d_var.alloc(T * B * 8))) return rc;
+    }
+    // a camera pixel index must exist in the scene's primitive/material tables
+    RenderParams rp;
+    rp.cam = desc->camera;
+    rp.materials = d_mat.as<rsx_material>();
+    rp.tasks = desc->tasks ? d_tasks.as<int32_t>() : nullptr;
+    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? d_uni.as<double>() : nullptr;
+    rp.n_tasks = desc->n_tasks;
+    std::memcpy(rp.rect, desc->rect, sizeof(rp.rect));
+    rp.spp = desc->spp;
+    rp.rng_mode = desc->rng_mode;
+    rp.seed = desc->seed;
+
+    Launch l;
+    if ((rc = plan(scene, (long long)S, l))) return rc;
+    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    if ((rc = reset_ticket(ctx))) return rc;
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_render_trace, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, d_samples.as<Sample>(), ctx->ticket);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+
+    AccumParams ap;
+    ap.samples = d_samples.as<Sample>();
+    ap.tables = d_tab.as<double>();
+    ap.tasks = rp.tasks;
+    ap.n_tasks = desc->n_tasks;
+    std::memcpy(ap.rect, desc->rect, sizeof(ap.rect));
+    ap.ny = desc->camera.ny; ap.bins = desc->bins; ap.spp = desc->spp; ap.power = desc->power;
+    ap.sensitivity = desc->camera.sensitivity;
+    ap.mean = h_mean ? d_mean.as<double>() : nullptr;
+    ap.variance = h_mean ? d_var.as<double>() : nullptr;
+    ap.fmean = fmean; ap.fvar = fvar; ap.fn = fn;
+    ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
+    const long long total = (long long)T * (long long)B;
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
+    HIP_TRY(hipGetLastError());
+    if (h_mean) {
+        HIP_TRY(hipMemcpyAsync(h_mean, d_mean.p, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_var, d_var.p, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));   // scratch buffers die with this scope
+    return RSX_OK;
+}
+
+}  // namespace
+
+extern "C" int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *mean, double *variance, uint64_t *ray_count) {
+    if (!mean || !variance) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole: null output");
+    return render(scene, desc, mean, variance, nullptr, nullptr, nullptr, 0, 0, ray_count);
+}
+
+extern "C" int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, double *frame_mean, double *frame_variance,
+                                        int32_t *frame_samples, int32_t frame_bins, int32_t slice_offset, uint64_t *ray_count) {
+    if (!frame_mean || !frame_variance || !frame_samples) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole_frame: null frame");
+    if (!desc || slice_offset < 0 || slice_offset + desc->bins > frame_bins) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole_frame: slice outside frame");
+    return render(scene, desc, nullptr, nullptr, frame_mean, frame_variance, frame_samples, frame_bins, slice_offset, ray_count);
+}
+
+extern "C" int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, double *var_a, int32_t *n_a, const double *mean_b,
+                                     const double *var_b, const int32_t *n_b) {
+    if (!ctx || n < 0 || !mean_a || !var_a || !n_a || !mean_b || !var_b || !n_b) return rsx_fail(RSX_EINVAL, "rsx_frame_combine_dev: bad arguments");
+    if (n == 0) return RSX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL(k_frame_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, mean_a, var_a, n_a, mean_b, var_b, n_b);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    return RSX_OK;
+}

@@ -1,0 +1,209 @@
+"""
+Device-side handles: one rsx_ctx per process/GPU and the uploaded scenes. Everything here calls librsx through
+ctypes (include/rsx.h); if the library or a gfx950 device is missing these calls raise — there is no CPU path.
+"""
+import ctypes as C
+import os
+import weakref
+
+import numpy as np
+
+from . import _lib
+from .core.math import Normal3D, Point3D
+from .core.scenegraph import Intersection, MeshIntersection
+
+_contexts = {}
+
+
+class DeviceContext:
+    """rsx_ctx wrapper: device memory helpers + kernel timing."""
+
+    def __init__(self, ordinal):
+        self.ordinal = ordinal
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rsx_init(int(ordinal), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def alloc(self, nbytes):
+        p = C.c_void_p()
+        _lib.check(_lib.lib().rsx_dev_alloc(self._h, int(nbytes), C.byref(p)))
+        return p
+
+    def free(self, p):
+        _lib.lib().rsx_dev_free(self._h, p)
+
+    def upload(self, p, array):
+        a = np.ascontiguousarray(array)
+        _lib.check(_lib.lib().rsx_dev_upload(self._h, p, _lib.ptr(a), a.nbytes))
+
+    def download(self, array, p):
+        assert array.flags["C_CONTIGUOUS"]
+        _lib.check(_lib.lib().rsx_dev_download(self._h, _lib.ptr(array), p, array.nbytes))
+
+    def memset(self, p, value, nbytes):
+        _lib.check(_lib.lib().rsx_dev_memset(self._h, p, int(value), int(nbytes)))
+
+    def set_stream(self, hip_stream):
+        _lib.check(_lib.lib().rsx_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
+
+    def synchronize(self):
+        _lib.check(_lib.lib().rsx_synchronize(self._h))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        _lib.check(_lib.lib().rsx_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)
+
+
+def get_context(ordinal=None):
+    """One context per GPU per process; default ordinal = LOCAL_RANK (one process per GPU) or 0."""
+    if ordinal is None:
+        ordinal = int(os.environ.get("RSX_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    if ordinal not in _contexts:
+        _contexts[ordinal] = DeviceContext(ordinal)
+    return _contexts[ordinal]
+
+
+def _f64(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a.reshape(shape) if shape is not None else a
+
+
+class DeviceScene:
+    """An uploaded FlatScene (rsx_scene)."""
+
+    def __init__(self, flat, context=None):
+        self.flat = flat
+        self.context = context or get_context()
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rsx_scene_create(self.context.handle, C.byref(flat.desc), C.byref(self._h)))
+
+    @property
+    def handle(self):
+        return self._h
+
+    def close(self):
+        if self._h:
+            _lib.lib().rsx_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- World.hit ---------------------------------------------------------------------------------
+    def hit_batch(self, origin, direction, max_distance=None, geometry=False):
+        o, d = _f64(origin).reshape(-1, 3), _f64(direction).reshape(-1, 3)
+        n = o.shape[0]
+        m = np.full(n, np.inf) if max_distance is None else _f64(np.broadcast_to(max_distance, (n,)))
+        out = dict(prim=np.empty(n, dtype=np.int32), t=np.empty(n), exiting=np.empty(n, dtype=np.uint8),
+                   tri=np.empty(n, dtype=np.int32), uvw=np.empty((n, 3), dtype=np.float32),
+                   geom=np.empty((n, 12)) if geometry else None)
+        _lib.check(_lib.lib().rsx_hit_batch(self._h, n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(m), _lib.ptr(out["prim"]), _lib.ptr(out["t"]),
+                                            _lib.ptr(out["exiting"]), _lib.ptr(out["tri"]), _lib.ptr(out["uvw"]), _lib.ptr(out["geom"])))
+        return out
+
+    def _intersection(self, ray, prim_obj, t, exiting, tri, uvw, g):
+        args = (ray, float(t), prim_obj, Point3D(*g[0:3]), Point3D(*g[3:6]), Point3D(*g[6:9]), Normal3D(*g[9:12]), bool(exiting),
+                prim_obj.to_local(), prim_obj.to_root())
+        if tri >= 0:
+            i = MeshIntersection(*args)
+            i.triangle, i.u, i.v, i.w = int(tri), float(uvw[0]), float(uvw[1]), float(uvw[2])
+            return i
+        return Intersection(*args)
+
+    def hit_single(self, ray):
+        r = self.hit_batch([[ray.origin.x, ray.origin.y, ray.origin.z]], [[ray.direction.x, ray.direction.y, ray.direction.z]],
+                           [ray.max_distance], geometry=True)
+        if r["prim"][0] < 0:
+            return None
+        obj = self.flat.records[int(r["prim"][0])]["obj"]
+        return self._intersection(ray, obj, r["t"][0], r["exiting"][0], r["tri"][0], r["uvw"][0], r["geom"][0])
+
+    # -- Primitive.hit / next_intersection ------------------------------------------------------
+    def roots_batch(self, index, origin, direction, max_distance=None, max_roots=8):
+        o, d = _f64(origin).reshape(-1, 3), _f64(direction).reshape(-1, 3)
+        n = o.shape[0]
+        m = np.full(n, np.inf) if max_distance is None else _f64(np.broadcast_to(max_distance, (n,)))
+        counts = np.zeros(n, dtype=np.int32)
+        t = np.zeros((n, max_roots))
+        ex = np.zeros((n, max_roots), dtype=np.uint8)
+        _lib.check(_lib.lib().rsx_roots_batch(self._h, int(index), n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(m), int(max_roots),
+                                              _lib.ptr(counts), _lib.ptr(t), _lib.ptr(ex)))
+        return counts, t, ex
+
+    def roots_single(self, index, ray, prim_obj, max_roots=64):
+        counts, t, ex = self.roots_batch(index, [[ray.origin.x, ray.origin.y, ray.origin.z]],
+                                         [[ray.direction.x, ray.direction.y, ray.direction.z]], [ray.max_distance], max_roots)
+        out = []
+        for k in range(int(counts[0])):
+            tk = float(t[0, k])
+            local = ray.origin.transform(prim_obj.to_local())
+            ld = ray.direction.transform(prim_obj.to_local())
+            hit = Point3D(local.x + tk * ld.x, local.y + tk * ld.y, local.z + tk * ld.z)
+            out.append(Intersection(ray, tk, prim_obj, hit, hit, hit, Normal3D(0, 0, 1), bool(ex[0, k]), prim_obj.to_local(), prim_obj.to_root()))
+        return out
+
+    # -- World.contains ----------------------------------------------------------------------------
+    def contains_batch(self, points):
+        p = _f64(points).reshape(-1, 3)
+        inside = np.zeros((p.shape[0], max(1, self.flat.n_world)), dtype=np.uint8)
+        _lib.check(_lib.lib().rsx_contains_batch(self._h, p.shape[0], _lib.ptr(p), _lib.ptr(inside)))
+        return inside[:, :self.flat.n_world]
+
+    def prim_contains(self, index, point):
+        return self.contains_batch([[point.x, point.y, point.z]])[0][index]
+
+
+_private_scenes = weakref.WeakKeyDictionary()
+
+
+def scene_for_primitive(prim):
+    """Device scene able to answer Primitive.hit()/contains() for `prim`: the owning world's scene when the primitive
+    is registered with a World, otherwise a private one-primitive scene (its own scenegraph root)."""
+    from .core.scenegraph import World
+    from ._flatten import FlatScene
+    root = prim.root
+    if isinstance(root, World) and prim in root._primitives:
+        scene = root.build_accelerator()
+        return scene, scene.flat.index_of[id(prim)]
+    cached = _private_scenes.get(prim)
+    key = (tuple(prim.to_root().m), id(root))
+    if cached is None or cached[0] != key:
+        cached = (key, DeviceScene(FlatScene([prim])))
+        _private_scenes[prim] = cached
+    return cached[1], 0
+
+
+def combine_scalar(mx, vx, nx, my, vy, ny):
+    """Host restatement of _combine_samples (core/math/statsarray.pyx:780-859) for the non-fused engine path."""
+    if nx < ny:
+        mx, vx, nx, my, vy, ny = my, vy, ny, mx, vx, nx
+    if nx > 1 and ny > 1:
+        nt = nx + ny
+        mt = (nx * mx + ny * my) / nt
+        vx = (nx - 1) * vx / nx
+        vy = (ny - 1) * vy / ny
+        vt = (nx * (mx * mx + vx) + ny * (my * my + vy)) / nt - mt * mt
+        vt = nt * vt / (nt - 1)
+        return mt, vt, nt
+    if nx == 0 and ny == 0:
+        return 0.0, 0.0, 0
+    if nx == 1:
+        if ny == 0:
+            return mx, 0.0, 1
+        mt = 0.5 * (mx + my)
+        temp = mx - mt
+        return mt, 2 * temp * temp, 2
+    if ny == 1:
+        pm, pv, pn = mx, vx, nx
+        n = nx + 1
+        m = pm + (my - pm) / n
+        v = (pv * (pn - 1) + (my - pm) * (my - m)) / (n - 1)
+        return m, v, n
+    return mx, vx, nx

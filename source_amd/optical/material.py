@@ -1,0 +1,111 @@
+"""
+Materials. The material plugin API (evaluate_surface / evaluate_volume, raysect/optical/material/material.pxd:36-47)
+is kept as the host-side interface. Three closed-form materials are lowered to the device render kernel
+(SURVEY.md §8 a23): AbsorbingSurface, UniformSurfaceEmitter and the debug Light — none of them spawns daughter
+rays, so Ray.trace() is one world.hit() plus a bins-wide multiply. Any other material raises when an
+observer tries to render it on the device (there is no CPU fallback).
+
+Mirrors raysect/optical/material/{material,absorber,debug}.pyx and emitter/uniform.pyx.
+"""
+from ..core.scenegraph import Material as CoreMaterial
+from .. import _lib
+from .spectral import ConstantSF
+
+
+class Material(CoreMaterial):
+    """raysect/optical/material/material.pyx — base of the surface/volume plugin API."""
+
+    def __init__(self):
+        super().__init__()
+        self.importance = 0.0
+
+    def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal,
+                         world_to_primitive, primitive_to_world, intersection):
+        raise NotImplementedError("Material virtual method evaluate_surface() has not been implemented.")
+
+    def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, world_to_primitive, primitive_to_world):
+        raise NotImplementedError("Material virtual method evaluate_volume() has not been implemented.")
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        """Returns the rsx_material record for the device kernel, appending any spectral table it needs to
+        ``tables`` (list of f64[bins] arrays). Materials that cannot run on the device raise."""
+        raise NotImplementedError(
+            "%s has no device lowering: only AbsorbingSurface, UniformSurfaceEmitter and debug Light render on the "
+            "MI355X path in this version (secondary-ray materials are the next scope row, SURVEY.md §8f)." % type(self).__name__)
+
+
+class NullVolume(Material):
+    """material.pyx:150-165 — volume that contributes nothing."""
+
+    def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, world_to_primitive, primitive_to_world):
+        return spectrum
+
+
+def _record(kind, table, scale, light=(0.0, 0.0, 0.0)):
+    m = _lib.Material()
+    m.type, m.table, m.scale = kind, table, float(scale)
+    m.light_dir[0], m.light_dir[1], m.light_dir[2] = light
+    return m
+
+
+class AbsorbingSurface(NullVolume):
+    """absorber.pyx:37-55 — zero spectrum."""
+
+    def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal,
+                         world_to_primitive, primitive_to_world, intersection):
+        return ray.new_spectrum()
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        return _record(_lib.MAT_ABSORBER, 0, 0.0)
+
+
+class UniformSurfaceEmitter(NullVolume):
+    """emitter/uniform.pyx:36-88 — emission_spectrum.sample(bins) * scale."""
+
+    def __init__(self, emission_spectrum, scale=1.0):
+        super().__init__()
+        self.emission_spectrum = emission_spectrum
+        self.scale = float(scale)
+        self.importance = 1.0
+
+    def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal,
+                         world_to_primitive, primitive_to_world, intersection):
+        spectrum = ray.new_spectrum()
+        emission = self.emission_spectrum.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins)
+        spectrum.samples[:] = emission * self.scale
+        return spectrum
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        tables.append(self.emission_spectrum.sample(min_wavelength, max_wavelength, bins))
+        return _record(_lib.MAT_UNIFORM_EMITTER, len(tables) - 1, self.scale)
+
+
+class Light(NullVolume):
+    """debug.pyx:41-79 — Lambertian surface lit by a distant light: intensity * max(0, -L_local . n) * spectrum."""
+
+    def __init__(self, light_direction, intensity=1.0, spectrum=None):
+        super().__init__()
+        self.light_direction = light_direction.normalise()
+        self.intensity = max(0, intensity)
+        if spectrum is None:
+            raise ValueError("source_amd's debug Light needs an explicit spectrum (the reference defaults to its "
+                             "d65_white library table, which is not part of this hot-path build).")
+        self.spectrum = spectrum
+
+    def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal,
+                         world_to_primitive, primitive_to_world, intersection):
+        spectrum = ray.new_spectrum()
+        if self.intensity != 0.0:
+            diffuse = self.intensity * max(0, -(self.light_direction.transform(world_to_primitive).dot(normal)))
+            spectrum.samples[:] = diffuse * self.spectrum.sample(ray.min_wavelength, ray.max_wavelength, ray.bins)
+        return spectrum
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        tables.append(self.spectrum.sample(min_wavelength, max_wavelength, bins))
+        d = self.light_direction
+        return _record(_lib.MAT_DEBUG_LIGHT, len(tables) - 1, float(self.intensity), (d.x, d.y, d.z))
+
+
+# convenience used by scene builders
+def default_white():
+    return ConstantSF(1.0)

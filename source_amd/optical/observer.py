@@ -1,0 +1,535 @@
+"""
+Observer.observe() — the drop-in top of the hot path.
+
+The structure of the reference's driver is kept (raysect/optical/observer/base/observer.pyx:265-446):
+slice the spectrum, build one ray template per slice, initialise the pipelines, ask the frame sampler for
+tasks, then hand each slice's full task list to ``render_engine.run(...)`` — the reference's plug-point #2
+(raysect/core/workflow.py:78-91). Where the reference's engines farm pixels over CPU processes, HipEngine
+submits the whole slice to the MI355X: rsx_render_pinhole_frame traces every (pixel, sample) and merges the
+per-pixel statistics straight into the pipeline's device-resident frame (combine_samples law).
+
+Mirrors: observer/base/observer.pyx, base/slice.pyx, sampler2d.pyx:42-102, imaging/pinhole.pyx:42-207,
+pipeline/spectral/power.pyx:335-486, radiance.pyx:182-263, core/math/statsarray.pyx:513-565, core/workflow.py.
+"""
+import ctypes as C
+import math
+import random as pyrandom
+
+import numpy as np
+
+from .. import _lib
+from ..core import random as rsrandom
+from ..core.scenegraph import Observer, World
+from .ray import Ray
+
+
+class SpectralSlice:
+    """base/slice.pyx:32-69"""
+
+    def __init__(self, min_wavelength, max_wavelength, total_bins, bins, offset):
+        self.total_bins, self.bins, self.offset = total_bins, bins, offset
+        delta = (max_wavelength - min_wavelength) / total_bins
+        self.min_wavelength = min_wavelength + delta * offset
+        self.max_wavelength = min_wavelength + delta * (offset + bins)
+
+
+# ---------------------------------------------------------------------------------------------------
+# render engines — raysect/core/workflow.py
+# ---------------------------------------------------------------------------------------------------
+class RenderEngine:
+    """workflow.py:35-97"""
+
+    def run(self, tasks, render, update, render_args=(), render_kwargs={}, update_args=(), update_kwargs={}):
+        raise NotImplementedError("Virtual method must be implemented in sub-class.")
+
+    def worker_count(self):
+        raise NotImplementedError("Virtual method must be implemented in sub-class.")
+
+
+class HipEngine(RenderEngine):
+    """
+    MI355X render engine. ``rng="philox"`` (default): on-device counter-based RNG keyed by (seed; pixel, sample),
+    independent of task order and of how pixels are sharded over GPUs. ``rng="stream"``: the jitter samples are
+    drawn from the host MT19937-64 stream (source_amd.core.random, same generator and consumption order as the
+    reference's SerialEngine: 2 uniforms per sample in task order) — bit-parity mode for primary-ray scenes.
+    ``fused=True`` merges results into the pipelines' device frames; ``fused=False`` follows the RenderEngine
+    contract literally (update(packed_result) per task), which is what a stock raysect pipeline needs.
+    """
+
+    def __init__(self, rng="philox", seed=0, fused=True):
+        if rng not in ("philox", "stream"):
+            raise ValueError("rng must be 'philox' or 'stream'")
+        self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
+        self.last_kernel_ms = None
+
+    def worker_count(self):
+        return 1
+
+    def run(self, tasks, render, update, render_args=(), render_kwargs={}, update_args=(), update_kwargs={}):
+        observer = render.__self__
+        slice_id, template = render_args
+        observer._render_slice_device(tasks, slice_id, template, self, update, update_args, update_kwargs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# frame sampler / pipelines
+# ---------------------------------------------------------------------------------------------------
+class FrameSampler2D:
+    def generate_tasks(self, pixels):
+        raise NotImplementedError
+
+
+class FullFrameSampler2D(FrameSampler2D):
+    """sampler2d.pyx:42-102: every unmasked pixel, iy-outer / ix-inner, then Python random.shuffle."""
+
+    def __init__(self, mask=None):
+        self.mask = None if mask is None else np.asarray(mask, dtype=bool)
+
+    def generate_tasks(self, pixels):
+        nx, ny = pixels
+        if self.mask is None or (self.mask.shape != tuple(pixels) and self.mask.all()):
+            self.mask = np.ones(pixels, dtype=bool)
+        elif self.mask.shape != tuple(pixels):
+            raise ValueError("The pixel geometry passed to the frame sampler is inconsistent with the mask shape.")
+        tasks = [(ix, iy) for iy in range(ny) for ix in range(nx) if self.mask[ix, iy]]
+        pyrandom.shuffle(tasks)
+        return tasks
+
+
+class StatsArray3D:
+    """
+    core/math/statsarray.pyx:513-565 — (mean f64, variance f64, samples i32)[nx, ny, nz], x-major. The arrays
+    live in HBM while rendering; .mean/.variance/.samples download (and cache) host copies on access.
+    """
+
+    def __init__(self, nx, ny, nz):
+        self.nx, self.ny, self.nz = int(nx), int(ny), int(nz)
+        self._host = [np.zeros((nx, ny, nz)), np.zeros((nx, ny, nz)), np.zeros((nx, ny, nz), dtype=np.int32)]
+        self._dev = None          # (ctx wrapper, mean ptr, var ptr, n ptr)
+        self._dev_dirty = False
+
+    @property
+    def shape(self):
+        return (self.nx, self.ny, self.nz)
+
+    @property
+    def length(self):
+        return self.nx * self.ny * self.nz
+
+    def _device(self, context):
+        """Device pointers of the frame (allocated and uploaded on first use)."""
+        if self._dev is None or self._dev[0] is not context:
+            self._sync_host()
+            ptrs = [context.alloc(a.nbytes) for a in self._host]
+            for p, a in zip(ptrs, self._host):
+                context.upload(p, a)
+            self._dev = (context, *ptrs)
+        return self._dev[1:]
+
+    def _sync_host(self):
+        if self._dev is not None and self._dev_dirty:
+            ctx = self._dev[0]
+            for p, a in zip(self._dev[1:], self._host):
+                ctx.download(a, p)
+            self._dev_dirty = False
+
+    def _mark_device_written(self):
+        self._dev_dirty = True
+
+    @property
+    def mean(self):
+        self._sync_host()
+        return self._host[0]
+
+    @property
+    def variance(self):
+        self._sync_host()
+        return self._host[1]
+
+    @property
+    def samples(self):
+        self._sync_host()
+        return self._host[2]
+
+    def error(self, x, y, z):                               # statsarray.pyx:728-739
+        n, v = self.samples[x, y, z], self.variance[x, y, z]
+        return 0.0 if n <= 0 or v <= 0 else math.sqrt(v / n)
+
+    def errors(self):
+        n, v = self.samples, self.variance
+        with np.errstate(divide="ignore", invalid="ignore"):
+            return np.where((n > 0) & (v > 0), np.sqrt(v / np.maximum(n, 1)), 0.0)
+
+    def release(self):
+        if self._dev is not None:
+            self._sync_host()
+            ctx = self._dev[0]
+            for p in self._dev[1:]:
+                ctx.free(p)
+            self._dev = None
+
+    def __del__(self):
+        try:
+            if self._dev is not None:
+                ctx = self._dev[0]
+                for p in self._dev[1:]:
+                    ctx.free(p)
+        except Exception:
+            pass
+
+
+class Pipeline2D:
+    """base/pipeline.pyx:187-266"""
+    power = False
+
+    def initialise(self, pixels, pixel_samples, min_wavelength, max_wavelength, spectral_bins, spectral_slices, quiet):
+        raise NotImplementedError
+
+    def update(self, x, y, slice_id, packed_result):
+        raise NotImplementedError
+
+    def finalise(self):
+        raise NotImplementedError
+
+
+class SpectralPowerPipeline2D(Pipeline2D):
+    """pipeline/spectral/power.pyx:335-437 — spectral power per pixel (W/nm): samples are scaled by pixel sensitivity."""
+    power = True
+
+    def __init__(self, accumulate=True, name=None):
+        self.name = name or "Spectral Pipeline 2D"
+        self.accumulate = accumulate
+        self.frame = None
+        self._pixels = None
+        self._samples = 0
+        self._spectral_slices = None
+        self.min_wavelength = self.max_wavelength = self.delta_wavelength = 0
+        self.bins = 0
+        self.wavelengths = None
+
+    def initialise(self, pixels, pixel_samples, min_wavelength, max_wavelength, spectral_bins, spectral_slices, quiet):
+        nx, ny = pixels
+        self._pixels, self._samples, self._spectral_slices = pixels, pixel_samples, spectral_slices
+        self.min_wavelength, self.max_wavelength = min_wavelength, max_wavelength
+        self.delta_wavelength = (max_wavelength - min_wavelength) / spectral_bins
+        self.bins = spectral_bins
+        self.wavelengths = np.array([min_wavelength + (0.5 + i) * self.delta_wavelength for i in range(spectral_bins)])
+        if not self.accumulate or self.frame is None or self.frame.shape != (nx, ny, spectral_bins):
+            if self.frame is not None:
+                self.frame.release()
+            self.frame = StatsArray3D(nx, ny, spectral_bins)
+
+    def update(self, x, y, slice_id, packed_result):        # power.pyx:424-437 (host path of the RenderEngine contract)
+        mean, variance = packed_result
+        sl = self._spectral_slices[slice_id]
+        f = self.frame
+        f._sync_host()
+        from ..device import combine_scalar
+        for i in range(sl.bins):
+            z = sl.offset + i
+            m, v, n = combine_scalar(f._host[0][x, y, z], f._host[1][x, y, z], int(f._host[2][x, y, z]),
+                                     float(mean[i]), max(0.0, float(variance[i])), int(self._samples))
+            f._host[0][x, y, z], f._host[1][x, y, z], f._host[2][x, y, z] = m, v, n
+
+    def finalise(self):
+        pass
+
+
+class SpectralRadiancePipeline2D(SpectralPowerPipeline2D):
+    """pipeline/spectral/radiance.pyx:182-263 — spectral radiance per pixel (W/str/m^2/nm)."""
+    power = False
+
+
+# ---------------------------------------------------------------------------------------------------
+# observers
+# ---------------------------------------------------------------------------------------------------
+class _ObserverBase(Observer):
+    """observer/base/observer.pyx:45-511"""
+
+    def __init__(self, parent=None, transform=None, name=None, render_engine=None, spectral_rays=None, spectral_bins=None,
+                 min_wavelength=None, max_wavelength=None, ray_extinction_prob=None, ray_extinction_min_depth=None,
+                 ray_max_depth=None, ray_importance_sampling=None, ray_important_path_weight=None, quiet=None):
+        super().__init__(parent, transform, name)
+        self.render_engine = render_engine or HipEngine()       # reference default: MulticoreEngine()
+        # `x or default`, as the reference
+        self._min_wavelength = min_wavelength or 375.0
+        self._max_wavelength = max_wavelength or 740.0
+        self.spectral_bins = spectral_bins or 15
+        self.spectral_rays = spectral_rays or 1
+        self.ray_extinction_prob = ray_extinction_prob or 0.01
+        self.ray_extinction_min_depth = ray_extinction_min_depth or 3
+        self.ray_max_depth = ray_max_depth or 500
+        self.ray_importance_sampling = ray_importance_sampling or True
+        self.ray_important_path_weight = ray_important_path_weight or 0.2
+        self.quiet = quiet or False
+        self.render_complete = False
+        self.stats = {}
+
+    @property
+    def min_wavelength(self):
+        return self._min_wavelength
+
+    @min_wavelength.setter
+    def min_wavelength(self, value):
+        if value <= 0:
+            raise ValueError("The minimum wavelength must be greater than 0.")
+        if value >= self._max_wavelength:
+            raise ValueError("The minimum wavelength must be less than the maximum wavelength.")
+        self._min_wavelength = value
+
+    @property
+    def max_wavelength(self):
+        return self._max_wavelength
+
+    @max_wavelength.setter
+    def max_wavelength(self, value):
+        if value <= 0:
+            raise ValueError("The maximum wavelength must be greater than 0.")
+        if self._min_wavelength >= value:
+            raise ValueError("The maximum wavelength must be greater than the minimum wavelength.")
+        self._max_wavelength = value
+
+    def observe(self):                                      # observer.pyx:265-309
+        self.render_complete = False
+        if not isinstance(self.root, World):
+            raise TypeError("Observer is not connected to a scene graph containing a World object.")
+        slices = self._slice_spectrum()
+        templates = self._generate_templates(slices)
+        self._initialise_pipelines(self._min_wavelength, self._max_wavelength, self.spectral_bins, slices, self.quiet)
+        tasks = self._generate_tasks()
+        if not tasks:
+            self.render_complete = True
+            return
+        self._slices = slices
+        self.stats = {"rays": 0, "kernel_ms": 0.0}
+        for slice_id, template in enumerate(templates):
+            self.render_engine.run(tasks, self._render_pixel, self._update_state,
+                                   render_args=(slice_id, template), update_args=(slice_id,))
+        self._finalise_pipelines()
+        self.render_complete = True
+
+    def _slice_spectrum(self):                              # observer.pyx:311-340
+        current, start, ranges = 0, 0, []
+        while start < self.spectral_bins:
+            current += self.spectral_bins / self.spectral_rays
+            end = round(current)
+            ranges.append((start, end))
+            start = end
+        return [SpectralSlice(self._min_wavelength, self._max_wavelength, self.spectral_bins, end - start, start) for start, end in ranges]
+
+    def _generate_templates(self, slices):                  # observer.pyx:342-355
+        return [Ray(min_wavelength=s.min_wavelength, max_wavelength=s.max_wavelength, bins=s.bins,
+                    extinction_prob=self.ray_extinction_prob, extinction_min_depth=self.ray_extinction_min_depth,
+                    max_depth=self.ray_max_depth, importance_sampling=self.ray_importance_sampling,
+                    important_path_weight=self.ray_important_path_weight) for s in slices]
+
+    def _render_pixel(self, task, slice_id, template):
+        raise RuntimeError("source_amd observers render whole slices on the device (HipEngine); the per-pixel CPU "
+                           "worker of the reference (observer.pyx:363-419) is intentionally not provided.")
+
+    def _update_state(self, packed_result, slice_id):       # observer.pyx:425-446
+        task, results, ray_count = packed_result
+        self._update_pipelines(task, results, slice_id)
+        self.stats["rays"] = self.stats.get("rays", 0) + ray_count
+
+
+class Observer2D(_ObserverBase):
+    """observer/base/observer.pyx:896-1079"""
+
+    def __init__(self, pixels, frame_sampler, pipelines, parent=None, transform=None, name=None, render_engine=None,
+                 pixel_samples=None, **kw):
+        self.pixel_samples = pixel_samples or 100
+        self.pixels = pixels
+        self.frame_sampler = frame_sampler
+        self.pipelines = pipelines
+        super().__init__(parent, transform, name, render_engine, **kw)
+
+    @property
+    def pixel_samples(self):
+        return self._pixel_samples
+
+    @pixel_samples.setter
+    def pixel_samples(self, value):
+        if value <= 0:
+            raise ValueError("The number of pixel samples must be greater than 0.")
+        self._pixel_samples = int(value)
+
+    @property
+    def pixels(self):
+        return self._pixels
+
+    @pixels.setter
+    def pixels(self, value):
+        pixels = tuple(value)
+        if len(pixels) != 2:
+            raise ValueError("Pixels must be a 2 element tuple defining the x and y resolution.")
+        if pixels[0] <= 0:
+            raise ValueError("Number of x pixels must be greater than 0.")
+        if pixels[1] <= 0:
+            raise ValueError("Number of y pixels must be greater than 0.")
+        self._pixels = pixels
+
+    @property
+    def frame_sampler(self):
+        return self._frame_sampler
+
+    @frame_sampler.setter
+    def frame_sampler(self, value):
+        if not isinstance(value, FrameSampler2D):
+            raise TypeError("The frame sampler for a 2d observer must be a subclass of FrameSampler2D.")
+        self._frame_sampler = value
+
+    @property
+    def pipelines(self):
+        return self._pipelines
+
+    @pipelines.setter
+    def pipelines(self, value):
+        pipelines = tuple(value)
+        if len(pipelines) < 1:
+            raise ValueError("At least one processing pipeline must be provided.")
+        for p in pipelines:
+            if not isinstance(p, Pipeline2D):
+                raise TypeError("Processing pipelines for a 2d observer must be a subclass of Pipeline2D.")
+        self._pipelines = pipelines
+
+    def _generate_tasks(self):
+        return self._frame_sampler.generate_tasks(self._pixels)
+
+    def _initialise_pipelines(self, min_wavelength, max_wavelength, spectral_bins, slices, quiet):
+        for p in self._pipelines:
+            p.initialise(self._pixels, self._pixel_samples, min_wavelength, max_wavelength, spectral_bins, slices, quiet)
+
+    def _update_pipelines(self, task, results, slice_id):
+        x, y = task
+        for result, p in zip(results, self._pipelines):
+            p.update(x, y, slice_id, result)
+
+    def _finalise_pipelines(self):
+        for p in self._pipelines:
+            p.finalise()
+
+
+class PinholeCamera(Observer2D):
+    """optical/observer/imaging/pinhole.pyx:42-207"""
+
+    def __init__(self, pixels, fov=None, sensitivity=None, frame_sampler=None, pipelines=None, parent=None, transform=None, name=None):
+        pipelines = pipelines or [SpectralRadiancePipeline2D()]     # reference default is the (out-of-scope) RGB pipeline
+        frame_sampler = frame_sampler or FullFrameSampler2D()
+        self._fov = 45
+        super().__init__(pixels, frame_sampler, pipelines, parent=parent, transform=transform, name=name)
+        self.fov = fov or 45
+        self.sensitivity = sensitivity or 1.0
+
+    @property
+    def fov(self):
+        return self._fov
+
+    @fov.setter
+    def fov(self, value):
+        if value <= 0 or value >= 180:
+            raise ValueError("The field-of-view angle must lie in the range (0, 180).")
+        self._fov = value
+        self._update_image_geometry()
+
+    @property
+    def pixels(self):
+        return self._pixels
+
+    @pixels.setter
+    def pixels(self, value):
+        Observer2D.pixels.fset(self, value)
+        self._update_image_geometry()
+
+    @property
+    def sensitivity(self):
+        return self._sensitivity
+
+    @sensitivity.setter
+    def sensitivity(self, value):
+        if value <= 0:
+            raise ValueError("Sensitivity must be greater than zero.")
+        self._sensitivity = value
+
+    def _update_image_geometry(self):                       # pinhole.pyx:148-167
+        max_pixels = max(self._pixels)
+        if max_pixels > 1:
+            image_max_width = 2 * math.tan(math.pi / 180 * 0.5 * self._fov)
+            self.image_delta = image_max_width / max_pixels
+            self.image_start_x = 0.5 * self._pixels[0] * self.image_delta
+            self.image_start_y = 0.5 * self._pixels[1] * self.image_delta
+        else:
+            raise RuntimeError("Number of Pinhole camera Pixels must be > 1.")
+
+    def _pixel_sensitivity(self, x, y):
+        return self._sensitivity
+
+    def device_camera(self):
+        cam = _lib.Camera()
+        cam.nx, cam.ny = self._pixels
+        cam.image_delta, cam.image_start_x, cam.image_start_y = self.image_delta, self.image_start_x, self.image_start_y
+        for i, v in enumerate(self.to_root().m):
+            cam.to_root[i] = v
+        cam.sensitivity = float(self._sensitivity)
+        return cam
+
+    # -- the device path --------------------------------------------------------------------------
+    def render_desc(self, world, tasks, slice_, engine, keep, rect=None):
+        """Builds the rsx_render_desc for one spectral slice. ``keep`` collects arrays that must outlive the call."""
+        tables = []
+        mats = [p.material.device_material(tables, slice_.min_wavelength, slice_.max_wavelength, slice_.bins) for p in world._primitives]
+        desc = _lib.RenderDesc()
+        desc.camera = self.device_camera()
+        mat_arr = (_lib.Material * max(1, len(mats)))(*mats)
+        tab = np.ascontiguousarray(np.array(tables, dtype=np.float64).reshape(len(tables), slice_.bins)) if tables else np.zeros((0, slice_.bins))
+        keep.extend([mat_arr, tab])
+        desc.materials, desc.n_materials = mat_arr, len(mats)
+        desc.tables, desc.n_tables = _lib.ptr(tab) if len(tables) else None, len(tables)
+        desc.bins, desc.spp = slice_.bins, self._pixel_samples
+        if rect is not None:
+            desc.tasks = None
+            for i in range(4):
+                desc.rect[i] = rect[i]
+            desc.n_tasks = (rect[2] - rect[0]) * (rect[3] - rect[1])
+        else:
+            t = np.ascontiguousarray(np.array(tasks, dtype=np.int32).reshape(-1, 2))
+            keep.append(t)
+            desc.tasks, desc.n_tasks = _lib.ptr(t), len(t)
+        if engine.rng == "stream":
+            if rect is not None:
+                raise ValueError("rng='stream' needs an explicit task list (the MT stream is consumed in task order)")
+            u = rsrandom.uniform_block(2 * desc.n_tasks * self._pixel_samples)
+            keep.append(u)
+            desc.uniforms, desc.rng_mode = _lib.ptr(u), _lib.RNG_STREAM
+        else:
+            desc.uniforms, desc.rng_mode, desc.seed = None, _lib.RNG_PHILOX, engine.seed
+        return desc
+
+    def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
+        world = self.root
+        scene = world.build_accelerator()
+        sl = self._slices[slice_id]
+        keep = []
+        desc = self.render_desc(world, tasks, sl, engine, keep)
+        L = _lib.lib()
+        rays = C.c_uint64(0)
+        if engine.fused:
+            for pipe in self._pipelines:
+                desc.power = 1 if pipe.power else 0
+                fm, fv, fn = pipe.frame._device(scene.context)
+                _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
+                pipe.frame._mark_device_written()
+                engine.last_kernel_ms = scene.context.last_kernel_ms()
+                self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + engine.last_kernel_ms
+            self.stats["rays"] = self.stats.get("rays", 0) + rays.value
+        else:
+            n = desc.n_tasks
+            results = []
+            for pipe in self._pipelines:
+                desc.power = 1 if pipe.power else 0
+                mean, var = np.zeros((n, sl.bins)), np.zeros((n, sl.bins))
+                _lib.check(L.rsx_render_pinhole(scene.handle, C.byref(desc), _lib.ptr(mean), _lib.ptr(var), C.byref(rays)))
+                results.append((mean, var))
+            for k, task in enumerate(tasks):
+                packed = (tuple(task), [(m[k], v[k]) for m, v in results], self._pixel_samples)
+                update(packed, *update_args, **update_kwargs)

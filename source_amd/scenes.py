@@ -1,0 +1,240 @@
+"""
+Deterministic synthetic geometry and scene builders for the benchmark configs.
+
+The Stanford bunny assets are not shipped with the reference snapshot
+(/root/reference/.MISSING_LARGE_BLOBS) and there is no network, so every config
+of BASELINE.json is rendered on a seeded stand-in mesh generated here (numpy
+only, no reference code involved).
+
+The scene builders take a *namespace* argument ``ns`` exposing the Raysect class
+names (World, Mesh, Box, Sphere, ..., translate, rotate, Point3D, ...).  Passing
+the real ``raysect`` modules builds the scene in the reference (golden fixture
+generation, tests/golden/make_golden.py); passing ``source_amd.api`` builds the
+identical scene in this framework.  That is the parity harness: one scene
+description, two frameworks.
+"""
+import numpy as np
+
+
+def displaced_sphere(n=132, radius=0.08, amplitude=0.25, seed=20250905, modes=6):
+    """
+    Closed UV-sphere with (n+1) latitude rows x 2n longitude columns whose radius
+    is displaced by a seeded low-frequency field (stand-in for the ~70k-triangle
+    Stanford bunny: n=132 -> 35 112 vertices, 69 696 triangles of which the pole
+    fans are degenerate and are removed by the Mesh 'tolerant' filter).
+
+    Returns (vertices float32[nv,3], triangles int32[nt,3]). Face winding gives
+    outward normals (right-hand rule), as Mesh(closed=True) requires.
+    """
+    rng = np.random.RandomState(seed)
+    a = rng.uniform(-1.0, 1.0, modes)
+    p = rng.randint(1, 5, modes)
+    q = rng.randint(0, 5, modes)
+    ph = rng.uniform(0, 2 * np.pi, modes)
+    ps = rng.uniform(0, 2 * np.pi, modes)
+
+    rows, cols = n + 1, 2 * n
+    theta = np.linspace(0.0, np.pi, rows)[:, None]            # polar angle
+    phi = (np.arange(cols) * (2.0 * np.pi / cols))[None, :]   # azimuth
+    field = np.zeros((rows, cols))
+    for k in range(modes):
+        # sin(theta) weighting makes the field azimuth-independent at the poles
+        az = np.cos(q[k] * phi + ps[k]) if q[k] else np.ones_like(phi)
+        w = np.sin(theta) if q[k] else 1.0
+        field += a[k] * np.sin(p[k] * theta + ph[k]) * az * w
+    field /= modes
+    r = radius * (1.0 + amplitude * field)
+
+    x = r * np.sin(theta) * np.cos(phi)
+    y = r * np.cos(theta) * np.ones_like(phi)
+    z = r * np.sin(theta) * np.sin(phi)
+    vertices = np.stack([x, y, z], axis=-1).reshape(-1, 3).astype(np.float32)
+
+    i = np.arange(rows - 1)[:, None]
+    j = np.arange(cols)[None, :]
+    j1 = (j + 1) % cols
+    v00 = (i * cols + j).ravel()
+    v01 = (i * cols + j1).ravel()
+    v10 = ((i + 1) * cols + j).ravel()
+    v11 = ((i + 1) * cols + j1).ravel()
+    t1 = np.stack([v00, v01, v11], axis=-1)
+    t2 = np.stack([v00, v11, v10], axis=-1)
+    triangles = np.empty((2 * t1.shape[0], 3), dtype=np.int32)
+    triangles[0::2] = t1
+    triangles[1::2] = t2
+    return vertices, triangles
+
+
+def vertex_normals(vertices, triangles):
+    """Area-weighted per-vertex normals (float32), for the smoothing path."""
+    v = vertices.astype(np.float64)
+    n = np.zeros_like(v)
+    e1 = v[triangles[:, 1]] - v[triangles[:, 0]]
+    e2 = v[triangles[:, 2]] - v[triangles[:, 0]]
+    fn = np.cross(e1, e2)
+    for k in range(3):
+        np.add.at(n, triangles[:, k], fn)
+    ln = np.linalg.norm(n, axis=1)
+    ln[ln == 0] = 1.0
+    return (n / ln[:, None]).astype(np.float32)
+
+
+def cube_mesh(h=0.5):
+    """12-triangle cube, outward winding."""
+    v = np.array([[-h, -h, -h], [h, -h, -h], [h, h, -h], [-h, h, -h],
+                  [-h, -h, h], [h, -h, h], [h, h, h], [-h, h, h]], dtype=np.float32)
+    t = np.array([[0, 2, 1], [0, 3, 2], [4, 5, 6], [4, 6, 7],
+                  [0, 1, 5], [0, 5, 4], [2, 3, 7], [2, 7, 6],
+                  [1, 2, 6], [1, 6, 5], [0, 4, 7], [0, 7, 3]], dtype=np.int32)
+    return v, t
+
+
+def fan_mesh(n=500, seed=3):
+    """Open fan of n triangles sharing one apex: a single high-valence vertex, so
+    many triangles land in the same KD leaves (stress for leaf-order tie-breaks)."""
+    rng = np.random.RandomState(seed)
+    ang = np.linspace(0, 2 * np.pi, n + 1)
+    rim = np.stack([np.cos(ang), np.sin(ang), 0.2 * rng.uniform(-1, 1, n + 1)], axis=-1)
+    v = np.concatenate([[[0.0, 0.0, 0.5]], rim]).astype(np.float32)
+    t = np.stack([np.zeros(n, dtype=np.int32), np.arange(1, n + 1), np.arange(2, n + 2)], axis=-1).astype(np.int32)
+    return v, t
+
+
+# ----------------------------------------------------------------------------------------------
+# scene builders shared by reference (golden generation) and this framework
+# ----------------------------------------------------------------------------------------------
+
+def build_c2(ns, n=132, smoothing=False, with_normals=False):
+    """
+    BASELINE.json configs[1]: one ~70k-triangle mesh, pinhole camera, primary rays only.
+    Materials are closed-form (no daughter rays): debug Light on the mesh, a uniform
+    emitter on the enclosing box. Camera placement follows demos/materials/bunny.py:30,74.
+    Returns (world, mesh, box).
+    """
+    verts, tris = displaced_sphere(n)
+    world = ns.World()
+    normals = None
+    if with_normals:
+        normals = vertex_normals(verts, tris)
+        tris = np.concatenate([tris, tris], axis=1)
+    mesh = ns.Mesh(verts, tris, normals, smoothing=smoothing, closed=True, parent=world,
+                   transform=ns.translate(0, 0.08, 0) * ns.rotate(165, 0, 0),
+                   material=ns.Light(ns.Vector3D(-1, -1, 1), 1.0, ns.ConstantSF(1.0)))
+    box = ns.Box(ns.Point3D(-2, -2, -2), ns.Point3D(2, 2, 2), world,
+                 material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.1))
+    return world, mesh, box
+
+
+def c2_camera(ns, world, pixels=(1024, 1024), spp=1, bins=15):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=45, parent=world, pipelines=[pipe],
+                           frame_sampler=ns.FullFrameSampler2D(),
+                           transform=ns.translate(0, 0.16, -0.4) * ns.rotate(0, -12, 0))
+    cam.pixel_samples = spp
+    cam.spectral_bins = bins
+    cam.spectral_rays = 1
+    cam.quiet = True
+    return cam, pipe
+
+
+def build_c3(ns, n=132, grid=(5, 3)):
+    """configs[2]: instanced ~1M-triangle scene: grid of Mesh.instance() copies + floor box."""
+    verts, tris = displaced_sphere(n)
+    world = ns.World()
+    base = None
+    meshes = []
+    k = 0
+    for gx in range(grid[0]):
+        for gy in range(grid[1]):
+            tr = ns.translate(0.22 * (gx - (grid[0] - 1) / 2), 0.09 + 0.2 * gy, 0.25 * gy) * ns.rotate(23.0 * k, 0, 0)
+            mat = ns.Light(ns.Vector3D(-1, -1, 1), 1.0, ns.ConstantSF(1.0))
+            if base is None:
+                base = ns.Mesh(verts, tris, smoothing=False, closed=True, parent=world, transform=tr, material=mat)
+                meshes.append(base)
+            else:
+                meshes.append(base.instance(parent=world, transform=tr, material=mat))
+            k += 1
+    floor = ns.Box(ns.Point3D(-3, -0.1, -3), ns.Point3D(3, 0.0, 3), world,
+                   material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.3))
+    sky = ns.Box(ns.Point3D(-10, -10, -10), ns.Point3D(10, 10, 10), world,
+                 material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.05))
+    return world, meshes, floor, sky
+
+
+def c3_camera(ns, world, pixels=(2048, 2048), spp=64, bins=15):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=60, parent=world, pipelines=[pipe],
+                           frame_sampler=ns.FullFrameSampler2D(),
+                           transform=ns.translate(0, 0.35, -0.9) * ns.rotate(0, -8, 0))
+    cam.pixel_samples = spp
+    cam.spectral_bins = bins
+    cam.spectral_rays = 1
+    cam.quiet = True
+    return cam, pipe
+
+
+def build_csg_demo(ns, emitter=True):
+    """configs[3]: the CSG tree of demos/csg.py:24-40 with closed-form materials
+    (primary-ray parity; the demo's Dielectric glass is a 'next' row)."""
+    world = ns.World()
+
+    def obj():
+        cyl_x = ns.Cylinder(1, 4.2, transform=ns.rotate(90, 0, 0) * ns.translate(0, 0, -2.1))
+        cyl_y = ns.Cylinder(1, 4.2, transform=ns.rotate(0, 90, 0) * ns.translate(0, 0, -2.1))
+        cyl_z = ns.Cylinder(1, 4.2, transform=ns.rotate(0, 0, 0) * ns.translate(0, 0, -2.1))
+        cube = ns.Box(ns.Point3D(-1.5, -1.5, -1.5), ns.Point3D(1.5, 1.5, 1.5))
+        sphere = ns.Sphere(2.0)
+        return sphere, ns.Subtract(cube, ns.Union(ns.Union(cyl_x, cyl_y), cyl_z))
+
+    def light():
+        return ns.Light(ns.Vector3D(-1, -1, 1), 1.0, ns.ConstantSF(1.0))
+
+    prims = []
+    for tx, ty, yaw, pitch in [(-2.1, 2.1, 30, -20), (2.1, 2.1, -30, -20), (2.1, -2.1, -30, 20), (-2.1, -2.1, 30, 20)]:
+        s, sub = obj()
+        prims.append(ns.Intersect(s, sub, world, ns.translate(tx, ty, 2.5) * ns.rotate(yaw, pitch, 0), light()))
+    s1 = ns.Sphere(1.0, transform=ns.translate(0, 0, 1.0 - 0.01))
+    s2 = ns.Sphere(0.5, transform=ns.translate(0, 0, -0.5 + 0.01))
+    prims.append(ns.Intersect(s1, s2, world, ns.translate(0, 0, -3.6) * ns.rotate(50, 50, 0), light()))
+    prims.append(ns.Box(ns.Point3D(-50, -50, 50), ns.Point3D(50, 50, 50.1), world,
+                        material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.6)))
+    prims.append(ns.Box(ns.Point3D(-100, -100, -100), ns.Point3D(100, 100, 100), world,
+                        material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.1)))
+    return world, prims
+
+
+def csg_camera(ns, world, pixels=(1024, 1024), spp=16, bins=15):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=75, parent=world, pipelines=[pipe],
+                           frame_sampler=ns.FullFrameSampler2D(),
+                           transform=ns.translate(0, 0, -4) * ns.rotate(0, 0, 0))
+    cam.pixel_samples = spp
+    cam.spectral_bins = bins
+    cam.spectral_rays = 1
+    cam.quiet = True
+    return cam, pipe
+
+
+def build_mixed(ns):
+    """World-level stress scene (fixture F7): instanced meshes + analytic + CSG with
+    overlapping AABBs and three coincident spheres (last-in-leaf tie rule)."""
+    verts, tris = displaced_sphere(24, radius=0.5)
+    world = ns.World()
+    prims = []
+    absorb = ns.AbsorbingSurface
+    m0 = ns.Mesh(verts, tris, smoothing=False, parent=world, transform=ns.translate(-1.0, 0.2, 0.3) * ns.rotate(20, 30, 10), material=absorb())
+    prims.append(m0)
+    prims.append(m0.instance(parent=world, transform=ns.translate(0.4, -0.3, 0.9) * ns.rotate(-40, 10, 70), material=absorb()))
+    prims.append(ns.Sphere(0.45, world, ns.translate(0.5, 0.5, -0.2), absorb()))
+    prims.append(ns.Sphere(0.45, world, ns.translate(0.5, 0.5, -0.2), absorb()))
+    prims.append(ns.Sphere(0.45, world, ns.translate(0.5, 0.5, -0.2), absorb()))
+    prims.append(ns.Box(ns.Point3D(-0.3, -0.4, -0.5), ns.Point3D(0.3, 0.4, 0.5), world, ns.translate(-0.2, -0.9, 0.1) * ns.rotate(15, 25, 35), absorb()))
+    prims.append(ns.Cylinder(0.3, 1.1, world, ns.translate(1.2, -0.5, 0.0) * ns.rotate(70, 20, 0), absorb()))
+    a = ns.Sphere(0.5, transform=ns.translate(0.0, 0.0, 0.2))
+    b = ns.Box(ns.Point3D(-0.3, -0.3, -0.3), ns.Point3D(0.3, 0.3, 0.3))
+    prims.append(ns.Subtract(a, b, world, ns.translate(-0.5, 1.0, -0.6) * ns.rotate(10, 20, 30), absorb()))
+    c = ns.Cylinder(0.25, 0.9, transform=ns.translate(0, 0, -0.45))
+    d = ns.Sphere(0.4)
+    prims.append(ns.Union(c, d, world, ns.translate(1.3, 0.9, 0.7) * ns.rotate(-30, 45, 0), absorb()))
+    prims.append(ns.Box(ns.Point3D(-4, -4, -4), ns.Point3D(4, 4, 4), world, material=absorb()))
+    return world, prims
