@@ -143,6 +143,7 @@ typedef struct rsx_render_desc {
     int32_t power;                  /* 1: SpectralPower (sample*sensitivity), 0: SpectralRadiance */
     int32_t rng_mode;
     uint64_t seed;
+    uint64_t sample_offset;         /* RSX_RNG_PHILOX: first sample counter (sample-sharded ranks use rank*spp) */
 } rsx_render_desc;
 
 typedef struct rsx_ctx rsx_ctx;
@@ -160,6 +161,11 @@ int rsx_set_stream(rsx_ctx *ctx, void *hip_stream);
 int rsx_synchronize(rsx_ctx *ctx);
 /* Duration (ms, HIP events on the launch stream) of the most recent kernel launched through this ctx. */
 int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms);
+/* Durations (ms) of the two kernels of the most recent render call: sample trace and per-bin accumulation. */
+int rsx_last_render_ms(rsx_ctx *ctx, float *trace_ms, float *accumulate_ms);
+/* Per-call kernel durations of the last n render calls (oldest first). The library keeps a ring of HIP event
+ * triples, so K asynchronous renders can be timed individually with a single synchronisation at the end. */
+int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumulate_ms);
 /* Device allocation helpers so non-torch callers can keep frames resident in HBM. */
 int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr);
 int rsx_dev_free(rsx_ctx *ctx, void *dptr);
@@ -230,7 +236,8 @@ int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *me
 /* Fused form: results are merged straight into a device-resident frame with the combine_samples law
  * (Pipeline2D.update, optical/observer/pipeline/spectral/power.pyx:424-437; statsarray.pyx:623-668,780-859).
  * frame_* are device pointers to [nx,ny,frame_bins] (x-major, as StatsArray3D); the slice occupies
- * bins [slice_offset, slice_offset+desc->bins). desc->tasks/uniforms/materials/tables are host pointers. */
+ * bins [slice_offset, slice_offset+desc->bins). desc->tasks/uniforms/materials/tables are host pointers.
+ * Asynchronous on the ctx stream: the frame is complete after rsx_synchronize() (or any later call on the ctx). */
 int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, double *frame_mean,
                              double *frame_variance, int32_t *frame_samples, int32_t frame_bins,
                              int32_t slice_offset, uint64_t *ray_count);

@@ -70,7 +70,7 @@ class RenderDesc(C.Structure):
     _fields_ = [("camera", Camera), ("materials", C.POINTER(Material)), ("tables", C.c_void_p), ("tasks", C.c_void_p),
                 ("uniforms", C.c_void_p), ("n_tasks", C.c_int64), ("rect", C.c_int32 * 4), ("n_materials", C.c_int32),
                 ("n_tables", C.c_int32), ("bins", C.c_int32), ("spp", C.c_int32), ("power", C.c_int32),
-                ("rng_mode", C.c_int32), ("seed", C.c_uint64)]
+                ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("sample_offset", C.c_uint64)]
 
 
 class MT(C.Structure):
@@ -91,6 +91,8 @@ SYMBOLS = [
     ("rsx_set_stream", C.c_int, [_vp, _vp]),
     ("rsx_synchronize", C.c_int, [_vp]),
     ("rsx_last_kernel_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
+    ("rsx_last_render_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    ("rsx_render_history", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("rsx_dev_alloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("rsx_dev_free", C.c_int, [_vp, _vp]),
     ("rsx_dev_upload", C.c_int, [_vp, _vp, _vp, C.c_size_t]),

@@ -708,7 +708,7 @@ struct RenderParams {
     long long n_tasks;
     int32_t rect[4];
     int32_t spp, rng_mode;
-    uint64_t seed;
+    uint64_t seed, sample_offset;
 };
 
 // per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
@@ -753,11 +753,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderPa
         // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
         double u1, u2;
         if (rp.rng_mode == RSX_RNG_STREAM) { u1 = rp.uniforms[2 * (k * rp.spp + s)]; u2 = rp.uniforms[2 * (k * rp.spp + s) + 1]; }
-        else philox2(rp.seed, (uint64_t)ix * (uint64_t)rp.cam.ny + (uint64_t)iy, (uint64_t)s, u1, u2);
+        else philox2(rp.seed, (uint64_t)ix * (uint64_t)rp.cam.ny + (uint64_t)iy, rp.sample_offset + (uint64_t)s, u1, u2);
         const double delta = rp.cam.image_delta, half = 0.5 * delta;
         const double pixel_x = rp.cam.image_start_x - delta * ((double)ix + 0.5);
         const double pixel_y = rp.cam.image_start_y - delta * ((double)iy + 0.5);
-        double dx = (u1 * delta - half) + pixel_x, dy = (u2 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+        // the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc)
+        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
         normalise3(dx, dy, dz);
         const double weight = dz;
         Ray r;
@@ -881,15 +882,36 @@ __global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, 
 // ---------------------------------------------------------------------------------------------------
 // host API
 // ---------------------------------------------------------------------------------------------------
+#define RING_SLOTS 512
+enum { POOL_MATERIALS, POOL_TABLES, POOL_TASKS, POOL_UNIFORMS, POOL_SAMPLES, POOL_MEAN, POOL_VAR, POOL_SLOTS };
+
 struct rsx_ctx {
     int device;
     hipStream_t stream;        // launch stream (own or external)
     hipStream_t own_stream;
-    hipEvent_t ev0, ev1;
+    hipEvent_t ev0, ev1, ev2;  // ev0..ev1 = last traversal kernel, ev1..ev2 = last accumulate kernel
     unsigned long long *ticket;
     int n_cus;
     float last_ms;
+    bool have_accum;
+    // ring of per-render-call event triples so a caller can time K back-to-back async renders without syncing
+    std::vector<hipEvent_t> ring;      // 3 events per slot
+    long long render_calls;
+    // grow-only device workspace so steady-state render calls never hipMalloc
+    void *pool[POOL_SLOTS];
+    size_t pool_bytes[POOL_SLOTS];
 };
+
+static int pool_get(rsx_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes > ctx->pool_bytes[slot]) {
+        if (ctx->pool[slot]) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->pool[slot])); ctx->pool[slot] = nullptr; ctx->pool_bytes[slot] = 0; }
+        const size_t want = bytes + bytes / 8 + 256;
+        HIP_TRY(hipMalloc(&ctx->pool[slot], want));
+        ctx->pool_bytes[slot] = want;
+    }
+    *out = ctx->pool[slot];
+    return RSX_OK;
+}
 
 struct rsx_scene {
     rsx_ctx *ctx;
@@ -913,10 +935,14 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->last_ms = 0.f;
+    ctx->have_accum = false;
+    ctx->render_calls = 0;
+    for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
+    HIP_TRY(hipEventCreate(&ctx->ev2));
     HIP_TRY(hipMalloc(&ctx->ticket, sizeof(unsigned long long)));
     *out = ctx;
     return RSX_OK;
@@ -924,12 +950,15 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
 
 extern "C" void rsx_free(rsx_ctx *ctx) {
     if (!ctx) return;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipFree(ctx->ticket);
-    hipEventDestroy(ctx->ev0);
-    hipEventDestroy(ctx->ev1);
-    hipStreamDestroy(ctx->own_stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(ctx->ticket);
+    for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
+    (void)hipEventDestroy(ctx->ev0);
+    (void)hipEventDestroy(ctx->ev1);
+    (void)hipEventDestroy(ctx->ev2);
+    for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
 
@@ -952,6 +981,30 @@ extern "C" int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms) {
     HIP_TRY(hipEventSynchronize(ctx->ev1));
     HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
     ctx->last_ms = *ms;
+    return RSX_OK;
+}
+
+extern "C" int rsx_last_render_ms(rsx_ctx *ctx, float *trace_ms, float *accumulate_ms) {
+    if (!ctx || !trace_ms || !accumulate_ms) return rsx_fail(RSX_EINVAL, "null argument");
+    if (!ctx->have_accum) return rsx_fail(RSX_EINVAL, "no render call has been issued on this context");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev2));
+    HIP_TRY(hipEventElapsedTime(trace_ms, ctx->ev0, ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(accumulate_ms, ctx->ev1, ctx->ev2));
+    return RSX_OK;
+}
+
+extern "C" int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumulate_ms) {
+    if (!ctx || n < 1 || !trace_ms || !accumulate_ms) return rsx_fail(RSX_EINVAL, "rsx_render_history: bad arguments");
+    if (n > ctx->render_calls || n > RING_SLOTS) return rsx_fail(RSX_EINVAL, "rsx_render_history: only %lld calls recorded (ring of %d)", ctx->render_calls, RING_SLOTS);
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (int32_t i = 0; i < n; ++i) {
+        const long long call = ctx->render_calls - n + i;
+        hipEvent_t *re = &ctx->ring[(size_t)(call % RING_SLOTS) * 3];
+        HIP_TRY(hipEventElapsedTime(&trace_ms[i], re[0], re[1]));
+        HIP_TRY(hipEventElapsedTime(&accumulate_ms[i], re[1], re[2]));
+    }
     return RSX_OK;
 }
 
@@ -1047,9 +1100,9 @@ int validate_tree(const rsx_kdtree &kd, int32_t n_ids, const char *what) {
 
 extern "C" void rsx_scene_free(rsx_scene *scene) {
     if (!scene) return;
-    hipSetDevice(scene->ctx->device);
-    hipStreamSynchronize(scene->ctx->stream);
-    for (void *p : scene->allocs) hipFree(p);
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    for (void *p : scene->allocs) (void)hipFree(p);
     delete scene;
 }
 
@@ -1157,7 +1210,7 @@ int reset_ticket(rsx_ctx *ctx) {
 // scratch device buffer that frees itself
 struct Scratch {
     void *p = nullptr;
-    ~Scratch() { if (p) hipFree(p); }
+    ~Scratch() { if (p) (void)hipFree(p); }
     int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return RSX_OK; }
     template <typename T> T *as() { return static_cast<T *>(p); }
 };
@@ -1290,64 +1343,76 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t T = (size_t)desc->n_tasks, S = T * (size_t)desc->spp, B = (size_t)desc->bins;
-    Scratch d_mat, d_tab, d_tasks, d_uni, d_samples, d_mean, d_var;
+    void *d_mat = nullptr, *d_tab = nullptr, *d_tasks = nullptr, *d_uni = nullptr, *d_samples = nullptr, *d_mean = nullptr, *d_var = nullptr;
     int rc;
-    if ((rc = d_mat.alloc(sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials))) || (rc = d_tab.alloc(8 * B * (size_t)std::max(1, desc->n_tables))) ||
-        (rc = d_samples.alloc(S * sizeof(Sample)))) return rc;
-    if (desc->n_materials) HIP_TRY(hipMemcpyAsync(d_mat.p, desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials, hipMemcpyHostToDevice, ctx->stream));
-    if (desc->n_tables) HIP_TRY(hipMemcpyAsync(d_tab.p, desc->tables, 8 * B * (size_t)desc->n_tables, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = pool_get(ctx, POOL_MATERIALS, sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials), &d_mat)) ||
+        (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)std::max(1, desc->n_tables), &d_tab)) ||
+        (rc = pool_get(ctx, POOL_SAMPLES, S * sizeof(Sample), &d_samples))) return rc;
+    if (desc->n_materials) HIP_TRY(hipMemcpyAsync(d_mat, desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials, hipMemcpyHostToDevice, ctx->stream));
+    if (desc->n_tables) HIP_TRY(hipMemcpyAsync(d_tab, desc->tables, 8 * B * (size_t)desc->n_tables, hipMemcpyHostToDevice, ctx->stream));
     if (desc->tasks) {
-        if ((rc = d_tasks.alloc(T * 8))) return rc;
-        HIP_TRY(hipMemcpyAsync(d_tasks.p, desc->tasks, T * 8, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = pool_get(ctx, POOL_TASKS, T * 8, &d_tasks))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_tasks, desc->tasks, T * 8, hipMemcpyHostToDevice, ctx->stream));
     }
     if (desc->rng_mode == RSX_RNG_STREAM) {
-        if ((rc = d_uni.alloc(S * 16))) return rc;
-        HIP_TRY(hipMemcpyAsync(d_uni.p, desc->uniforms, S * 16, hipMemcpyHostToDevice, ctx->stream));
+        if ((rc = pool_get(ctx, POOL_UNIFORMS, S * 16, &d_uni))) return rc;
+        HIP_TRY(hipMemcpyAsync(d_uni, desc->uniforms, S * 16, hipMemcpyHostToDevice, ctx->stream));
     }
     if (h_mean) {
-        if ((rc = d_mean.alloc(T * B * 8)) || (rc = d_var.alloc(T * B * 8))) return rc;
+        if ((rc = pool_get(ctx, POOL_MEAN, T * B * 8, &d_mean)) || (rc = pool_get(ctx, POOL_VAR, T * B * 8, &d_var))) return rc;
     }
     // a camera pixel index must exist in the scene's primitive/material tables
     RenderParams rp;
     rp.cam = desc->camera;
-    rp.materials = d_mat.as<rsx_material>();
-    rp.tasks = desc->tasks ? d_tasks.as<int32_t>() : nullptr;
-    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? d_uni.as<double>() : nullptr;
+    rp.materials = static_cast<const rsx_material *>(d_mat);
+    rp.tasks = desc->tasks ? static_cast<const int32_t *>(d_tasks) : nullptr;
+    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? static_cast<const double *>(d_uni) : nullptr;
     rp.n_tasks = desc->n_tasks;
     std::memcpy(rp.rect, desc->rect, sizeof(rp.rect));
     rp.spp = desc->spp;
     rp.rng_mode = desc->rng_mode;
     rp.seed = desc->seed;
+    rp.sample_offset = desc->sample_offset;
 
     Launch l;
     if ((rc = plan(scene, (long long)S, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx))) return rc;
+    const int slot = (int)(ctx->render_calls % RING_SLOTS);
+    while (ctx->ring.size() < (size_t)(slot + 1) * 3) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
+    hipEvent_t *re = &ctx->ring[(size_t)slot * 3];
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_render_trace, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, d_samples.as<Sample>(), ctx->ticket);
+    HIP_TRY(hipEventRecord(re[0], ctx->stream));
+    hipLaunchKernelGGL(k_render_trace, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(hipEventRecord(re[1], ctx->stream));
 
     AccumParams ap;
-    ap.samples = d_samples.as<Sample>();
-    ap.tables = d_tab.as<double>();
+    ap.samples = static_cast<const Sample *>(d_samples);
+    ap.tables = static_cast<const double *>(d_tab);
     ap.tasks = rp.tasks;
     ap.n_tasks = desc->n_tasks;
     std::memcpy(ap.rect, desc->rect, sizeof(ap.rect));
     ap.ny = desc->camera.ny; ap.bins = desc->bins; ap.spp = desc->spp; ap.power = desc->power;
     ap.sensitivity = desc->camera.sensitivity;
-    ap.mean = h_mean ? d_mean.as<double>() : nullptr;
-    ap.variance = h_mean ? d_var.as<double>() : nullptr;
+    ap.mean = h_mean ? static_cast<double *>(d_mean) : nullptr;
+    ap.variance = h_mean ? static_cast<double *>(d_var) : nullptr;
     ap.fmean = fmean; ap.fvar = fvar; ap.fn = fn;
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
     const long long total = (long long)T * (long long)B;
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
+    HIP_TRY(hipEventRecord(re[2], ctx->stream));
+    ctx->render_calls++;
+    ctx->have_accum = true;
     if (h_mean) {
-        HIP_TRY(hipMemcpyAsync(h_mean, d_mean.p, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_var, d_var.p, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_mean, d_mean, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_var, d_var, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
-    HIP_TRY(hipStreamSynchronize(ctx->stream));   // scratch buffers die with this scope
+    // frame form: asynchronous — the pooled workspace stays alive in the ctx, stream order protects reuse
     return RSX_OK;
 }
 

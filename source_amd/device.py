@@ -52,6 +52,18 @@ class DeviceContext:
     def synchronize(self):
         _lib.check(_lib.lib().rsx_synchronize(self._h))
 
+    def last_render_ms(self):
+        """(trace_ms, accumulate_ms) of the most recent render call (HIP events on the launch stream)."""
+        a, b = C.c_float(0), C.c_float(0)
+        _lib.check(_lib.lib().rsx_last_render_ms(self._h, C.byref(a), C.byref(b)))
+        return float(a.value), float(b.value)
+
+    def render_history(self, n):
+        """Per-call (trace_ms[n], accumulate_ms[n]) of the last n render calls; synchronises once."""
+        a, b = np.zeros(n, dtype=np.float32), np.zeros(n, dtype=np.float32)
+        _lib.check(_lib.lib().rsx_render_history(self._h, int(n), _lib.ptr(a), _lib.ptr(b)))
+        return a, b
+
     def last_kernel_ms(self):
         ms = C.c_float(0)
         _lib.check(_lib.lib().rsx_last_kernel_ms(self._h, C.byref(ms)))

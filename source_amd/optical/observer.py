@@ -56,10 +56,12 @@ class HipEngine(RenderEngine):
     contract literally (update(packed_result) per task), which is what a stock raysect pipeline needs.
     """
 
-    def __init__(self, rng="philox", seed=0, fused=True):
+    def __init__(self, rng="philox", seed=0, fused=True, timing=True, sample_offset=0):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
         self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
+        self.timing = bool(timing)          # read back HIP-event kernel times after each slice (forces a sync)
+        self.sample_offset = int(sample_offset)
         self.last_kernel_ms = None
 
     def worker_count(self):
@@ -77,6 +79,31 @@ class HipEngine(RenderEngine):
 class FrameSampler2D:
     def generate_tasks(self, pixels):
         raise NotImplementedError
+
+
+class RectTasks:
+    """A rectangular block of pixels [x0,x1) x [y0,y1) in natural order, handed to the device as four integers instead
+    of a Python list of tuples (1024^2 tuples cost more host time than the GPU needs to render them)."""
+
+    def __init__(self, x0, y0, x1, y1):
+        self.rect = (int(x0), int(y0), int(x1), int(y1))
+
+    def __len__(self):
+        return max(0, self.rect[2] - self.rect[0]) * max(0, self.rect[3] - self.rect[1])
+
+    def __iter__(self):
+        x0, y0, x1, y1 = self.rect
+        return ((ix, iy) for iy in range(y0, y1) for ix in range(x0, x1))
+
+
+class RectFrameSampler2D(FrameSampler2D):
+    """Whole frame (or one tile of it: the multi-GPU tile shard) as a single RectTasks block; needs rng='philox'."""
+
+    def __init__(self, rect=None):
+        self.rect = rect
+
+    def generate_tasks(self, pixels):
+        return RectTasks(*(self.rect or (0, 0, pixels[0], pixels[1])))
 
 
 class FullFrameSampler2D(FrameSampler2D):
@@ -126,6 +153,12 @@ class StatsArray3D:
             self._dev = (context, *ptrs)
         return self._dev[1:]
 
+    def bind_device(self, context, mean_ptr, var_ptr, n_ptr):
+        """Use caller-owned device memory (e.g. torch tensors' data_ptr()) as the frame storage. The caller zeroes it."""
+        self._dev = (context, C.c_void_p(mean_ptr), C.c_void_p(var_ptr), C.c_void_p(n_ptr))
+        self._external = True
+        self._dev_dirty = True
+
     def _sync_host(self):
         if self._dev is not None and self._dev_dirty:
             ctx = self._dev[0]
@@ -161,7 +194,7 @@ class StatsArray3D:
             return np.where((n > 0) & (v > 0), np.sqrt(v / np.maximum(n, 1)), 0.0)
 
     def release(self):
-        if self._dev is not None:
+        if self._dev is not None and not getattr(self, "_external", False):
             self._sync_host()
             ctx = self._dev[0]
             for p in self._dev[1:]:
@@ -170,7 +203,7 @@ class StatsArray3D:
 
     def __del__(self):
         try:
-            if self._dev is not None:
+            if self._dev is not None and not getattr(self, "_external", False):
                 ctx = self._dev[0]
                 for p in self._dev[1:]:
                     ctx.free(p)
@@ -297,7 +330,7 @@ class _ObserverBase(Observer):
         templates = self._generate_templates(slices)
         self._initialise_pipelines(self._min_wavelength, self._max_wavelength, self.spectral_bins, slices, self.quiet)
         tasks = self._generate_tasks()
-        if not tasks:
+        if not len(tasks):
             self.render_complete = True
             return
         self._slices = slices
@@ -503,6 +536,7 @@ class PinholeCamera(Observer2D):
             desc.uniforms, desc.rng_mode = _lib.ptr(u), _lib.RNG_STREAM
         else:
             desc.uniforms, desc.rng_mode, desc.seed = None, _lib.RNG_PHILOX, engine.seed
+            desc.sample_offset = engine.sample_offset
         return desc
 
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
@@ -510,7 +544,10 @@ class PinholeCamera(Observer2D):
         scene = world.build_accelerator()
         sl = self._slices[slice_id]
         keep = []
-        desc = self.render_desc(world, tasks, sl, engine, keep)
+        if isinstance(tasks, RectTasks):
+            desc = self.render_desc(world, None, sl, engine, keep, rect=tasks.rect)
+        else:
+            desc = self.render_desc(world, tasks, sl, engine, keep)
         L = _lib.lib()
         rays = C.c_uint64(0)
         if engine.fused:
@@ -519,8 +556,11 @@ class PinholeCamera(Observer2D):
                 fm, fv, fn = pipe.frame._device(scene.context)
                 _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
                 pipe.frame._mark_device_written()
-                engine.last_kernel_ms = scene.context.last_kernel_ms()
-                self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + engine.last_kernel_ms
+                if engine.timing:
+                    tr, ac = scene.context.last_render_ms()
+                    engine.last_kernel_ms = tr
+                    self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + tr
+                    self.stats["accumulate_ms"] = self.stats.get("accumulate_ms", 0.0) + ac
             self.stats["rays"] = self.stats.get("rays", 0) + rays.value
         else:
             n = desc.n_tasks

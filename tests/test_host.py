@@ -1,0 +1,108 @@
+"""Host-side product logic (no GPU): math vs the reference's matrices, the C-ABI surface, MT stream, scenegraph behaviour."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from source_amd import _lib
+
+
+def eq(a, b):
+    return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
+
+
+def test_library_exports_every_declared_symbol():
+    """Every function include/rsx.h declares must be exported by the built librsx.so (and bound in _lib.SYMBOLS)."""
+    header = open(os.path.join(os.path.dirname(_lib._HERE), "include", "rsx.h")).read()
+    declared = set(re.findall(r"\b(rsx_[a-z0-9_]+)\s*\(", header))
+    bound = {name for name, _, _ in _lib.SYMBOLS}
+    assert declared == bound, declared ^ bound
+    handle = C.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(handle, name), name
+    assert b"gfx950" in _lib.lib().rsx_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.KDNode) == 16
+    assert C.sizeof(_lib.Primitive) == 24 + 8 * (6 + 16 + 16 + 6)
+    assert C.sizeof(_lib.MT) == 313 * 8
+    assert C.sizeof(_lib.Material) == 8 + 8 + 24
+
+
+def test_no_device_means_loud_failure():
+    """On a box without a GPU rsx_init must fail with an error, never fall back."""
+    import subprocess, sys
+    code = ("import ctypes as C; from source_amd import _lib; h=C.c_void_p(); rc=_lib.lib().rsx_init(0, C.byref(h)); "
+            "print(rc, _lib.lib().rsx_last_error())")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(_lib._HERE),
+                         env={**os.environ, "HIP_VISIBLE_DEVICES": "-1", "ROCR_VISIBLE_DEVICES": "-1"})
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split()[0] in ("-2", "-3"), out.stdout
+
+
+def test_affine_math_matches_reference(ns, golden):
+    g = golden("f00_math")
+    p = g["params"]
+    for k in range(len(p)):
+        m = ns.translate(*p[k, 0:3]) * ns.rotate(*p[k, 3:6])
+        assert eq(np.array(m.m).reshape(4, 4), g["tr"][k])
+        assert eq(np.array(m.inverse().m).reshape(4, 4), g["inv"][k])
+        c = m * ns.rotate_x(p[k, 6] * 30) * ns.translate(*p[k, 6:9]) * ns.rotate_z(p[k, 7] * 50) * ns.rotate_y(p[k, 8] * 70)
+        assert eq(np.array(c.m).reshape(4, 4), g["chain"][k])
+        assert eq(np.array(c.inverse().m).reshape(4, 4), g["chain_inv"][k])
+        assert eq(np.array(ns.rotate_vector(p[k, 3], ns.Vector3D(*p[k, 0:3])).m).reshape(4, 4), g["rvec"][k])
+        q = ns.Point3D(*p[k, 6:9]).transform(c.inverse())
+        v = ns.Vector3D(*p[k, 0:3]).transform(c)
+        vn = ns.Vector3D(*p[k, 0:3]).normalise()
+        assert eq([q.x, q.y, q.z], g["pts"][k])
+        assert eq([v.x, v.y, v.z, vn.x, vn.y, vn.z], g["vecs"][k])
+
+
+def test_mt_stream_product(golden):
+    from source_amd.core import random as rsrandom
+    g = golden("f01_mt")
+    for s, ref in zip(g["seeds"], g["uniforms"]):
+        rsrandom.seed(int(s))
+        assert eq(rsrandom.uniform_block(600), ref[:600])
+        assert eq([rsrandom.uniform() for _ in range(400)], ref[600:])
+
+
+def test_scenegraph_bookkeeping(ns):
+    world = ns.World()
+    s = ns.Sphere(1.0, world, ns.translate(1, 2, 3))
+    assert world.primitives == [s] and world._rebuild_accelerator
+    node = ns.Node(parent=world, transform=ns.translate(0, 0, 1))
+    b = ns.Box(parent=node)
+    assert world.primitives == [s, b]
+    assert b.to_root().m[11] == 1.0 and b.to_local().m[11] == -1.0
+    world._rebuild_accelerator = False
+    node.transform = ns.translate(0, 0, 2)                    # GEOMETRY change propagates to the world (world.pyx:220-238)
+    assert world._rebuild_accelerator and b.to_root().m[11] == 2.0
+    b.parent = None
+    assert world.primitives == [s]
+    with pytest.raises(ValueError):
+        node.parent = node
+    csg = ns.Union(ns.Sphere(0.5), ns.Box(), world)
+    assert world.primitives == [s, csg]                       # operands live under the private CSGRoot, not the world
+    flat = world.flatten()
+    assert flat.n_world == 2 and len(flat.records) == 4
+    with pytest.raises(ValueError):
+        ns.Sphere(-1)
+    with pytest.raises(ValueError):
+        ns.Box(ns.Point3D(1, 0, 0), ns.Point3D(0, 1, 1))
+
+
+def test_observer_defaults_and_slicing(ns):
+    world = ns.World()
+    cam = ns.PinholeCamera((64, 32), parent=world)
+    assert (cam.spectral_bins, cam.spectral_rays, cam.min_wavelength, cam.max_wavelength) == (15, 1, 375.0, 740.0)
+    assert cam.pixel_samples == 100 and cam.ray_max_depth == 500
+    cam.spectral_bins, cam.spectral_rays = 7, 3
+    assert [(s.offset, s.bins) for s in cam._slice_spectrum()] == [(0, 2), (2, 3), (5, 2)]
+    with pytest.raises(ValueError):
+        cam.fov = 180
+    tasks = ns.FullFrameSampler2D().generate_tasks((3, 2))
+    assert sorted(tasks) == [(x, y) for x in range(3) for y in range(2)]
