@@ -1,0 +1,84 @@
+"""world_size-2 gloo tests of the multi-GPU merge path (CPU): sample-sharded frames merged with the combine_samples law in rank
+order, and tile-sharded frames assembled by all_gather. The per-rank frames come from the oracle (no GPU here)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world_size, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world_size))
+    import torch
+    import torch.distributed as dist
+    from oracle import oracle as orc
+    from source_amd import api as ns, scenes
+    from source_amd import distributed as D
+    dist.init_process_group("gloo", rank=rank, world_size=world_size)
+    world, mesh, box = scenes.build_c2(ns, n=24)
+    nx, ny, spp, bins = 24, 16, 3, 5
+    cam, pipe = scenes.c2_camera(ns, world, (nx, ny), spp=spp, bins=bins)
+    flat = world.flatten()
+    sl = cam._slice_spectrum()[0]
+    # --- sample sharding ---------------------------------------------------------------------------------
+    eng = ns.HipEngine(rng="philox", seed=5, sample_offset=D.rank_sample_offset(0, rank, world_size, spp))
+    keep = []
+    desc = cam.render_desc(world, None, sl, eng, keep, rect=(0, 0, nx, ny))
+    m, v, rays = orc.render_pinhole(flat, desc)
+    to_frame = lambda a: np.ascontiguousarray(a.reshape(ny, nx, bins).transpose(1, 0, 2))   # rect tasks are iy-outer
+    fm, fv = to_frame(m), to_frame(v)
+    fn = np.full((nx, ny, bins), spp, dtype=np.int32)
+    M, V, N = D.merge_sample_sharded(torch.from_numpy(fm), torch.from_numpy(fv), torch.from_numpy(fn), dist)
+    # --- tile sharding -------------------------------------------------------------------------------------
+    rect = D.tile_rect(rank, world_size, nx, ny)
+    eng2 = ns.HipEngine(rng="philox", seed=5)
+    desc2 = cam.render_desc(world, None, sl, eng2, keep, rect=rect)
+    tm, tv, _ = orc.render_pinhole(flat, desc2)
+    w = rect[2] - rect[0]
+    tile = np.ascontiguousarray(tm.reshape(ny, w, bins).transpose(1, 0, 2))
+    full = D.gather_tiles(torch.from_numpy(tile), dist)
+    np.savez(out % rank, M=M.numpy(), V=V.numpy(), N=N.numpy(), fm=fm, fv=fv, full=full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gloo_world2_merge(tmp_path, orc, ns):
+    import torch.multiprocessing as mp
+    from source_amd import scenes
+    from source_amd import distributed as D
+    out = str(tmp_path / "rank%d.npz")
+    mp.spawn(_worker, args=(2, 29517 + os.getpid() % 500, out), nprocs=2, join=True)
+    r0, r1 = np.load(out % 0), np.load(out % 1)
+    for k in ("M", "V", "N", "full"):
+        assert np.array_equal(r0[k], r1[k]), k                      # every rank ends with the same frame
+    # merged frame == reference law applied to (rank0, rank1) in rank order (oracle's combine)
+    spp = 3
+    n = np.full(r0["fm"].shape, spp, dtype=np.int32)
+    m, v, nn = orc.frame_combine(r0["fm"], r0["fv"], n, r1["fm"], np.maximum(r1["fv"], 0), n)
+    assert np.array_equal(r0["M"], m) and np.array_equal(r0["V"], v) and np.array_equal(r0["N"], nn)
+    assert (r0["N"] == 2 * spp).all()
+    # ... and agrees with a single-process render of all 2*spp samples to rounding (different summation order)
+    world, mesh, box = scenes.build_c2(ns, n=24)
+    cam, pipe = scenes.c2_camera(ns, world, (24, 16), spp=2 * spp, bins=5)
+    keep = []
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], ns.HipEngine(rng="philox", seed=5), keep, rect=(0, 0, 24, 16))
+    sm, sv, _ = orc.render_pinhole(world.flatten(), desc)
+    sm = sm.reshape(16, 24, 5).transpose(1, 0, 2)
+    sv = sv.reshape(16, 24, 5).transpose(1, 0, 2)
+    assert np.allclose(r0["M"], sm, rtol=1e-12, atol=0) and np.allclose(r0["V"], sv, rtol=1e-9, atol=1e-300)
+    # tile sharding: assembling rank tiles reproduces the single-process frame bit for bit (Philox counters are per pixel)
+    desc1 = cam.render_desc(world, None, cam._slice_spectrum()[0], ns.HipEngine(rng="philox", seed=5), keep, rect=(0, 0, 24, 16))
+    cam.pixel_samples = spp
+    desc1 = cam.render_desc(world, None, cam._slice_spectrum()[0], ns.HipEngine(rng="philox", seed=5), keep, rect=(0, 0, 24, 16))
+    fm1, _, _ = orc.render_pinhole(world.flatten(), desc1)
+    assert np.array_equal(r0["full"], fm1.reshape(16, 24, 5).transpose(1, 0, 2))
+
+
+def test_combine_arrays_matches_reference(golden):
+    from source_amd import distributed as D
+    g = golden("f09_stats")
+    m, v, n = D.combine_arrays(g["ma"], g["va"], g["na"], g["mb"], np.maximum(g["vb"], 0), g["nb"])
+    assert np.array_equal(np.stack([m, v, n.astype(float)], axis=1), g["comb"])

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Runs on the GPU box (via gpurun): rocprofv3 kernel trace + PMC passes of the bench command, outputs under gpurun_out/.
+# PMC counters are collected in their own runs (one counter group per run, never combined with sys/hip tracing).
+set -u
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_${1:-r01}
+mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o c2 --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
+for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
+    tag=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
+    timeout 300 rocprofv3 --pmc $grp -d "$OUT/pmc_$tag" -o c2 --output-format csv -- $CMD > "$OUT/pmc_$tag.log" 2>&1
+done
+ls -R "$OUT" | head -50
