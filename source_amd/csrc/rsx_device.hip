@@ -77,6 +77,11 @@ struct DScene {
     double wlower[3], wupper[3];
     int32_t n_prims, n_world, n_meshes;
     int32_t wdepth, mdepth;    // stack levels reserved for the world tree / the deepest mesh tree
+    const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
+};
+
+struct CsgInfo {
+    int32_t parent, slot, is_b, top;
 };
 
 struct Ray {
@@ -89,6 +94,10 @@ struct Hit {
     int32_t prim;              // -1 = none
     int32_t a0, a1;            // mesh: triangle, - ; box: face, axis ; cylinder: face, type
     float u, v, w;
+    // CSG hits only: the operand leaf that produced the root, Subtract flip parity / exiting, mesh-leaf hit point
+    int32_t leaf;
+    uint32_t flags;
+    double hx, hy, hz;
 };
 
 struct Stack {                 // per-lane view of the wave's LDS stack region
@@ -456,11 +465,299 @@ __device__ void mesh_geom(const DMesh &m, const Ray &l, double t, int32_t tri, f
 }
 
 // ---------------------------------------------------------------------------------------------------
+// CSG — raysect/primitive/csg.pyx:132-234 (hit / next_intersection / _identify_intersection / _closest_intersection),
+//       :326-348 Union, :421-446 Intersect, :523-568 Subtract (+_modify_intersection)
+//
+// The reference merges two lazily evaluated, ordered root streams per CSG node and keeps the stream heads cached on the
+// node object. Here the same state machine runs per lane with the per-node state in private (scratch) memory, and the
+// recursion over nested CSG nodes is unrolled by a depth template (CSG_MAX_DEPTH nested levels below the top node; deeper
+// trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
+// ---------------------------------------------------------------------------------------------------
+#define CSG_MAX_SLOTS 16
+#define CSG_MAX_DEPTH 4
+#define F_VALID 1u
+#define F_EXIT 2u
+#define F_FLIP 4u
+
+struct Rec {                       // one root of a stream
+    double t, hx, hy, hz;          // distance along the (shared) ray parameter; mesh leaves: hit point in leaf space
+    int32_t leaf, a0, a1;
+    uint32_t flags;
+    float u, v, w, pad;
+};
+
+struct NodeSt {
+    Rec a, b;                      // CSG node: cached stream heads (_cache_intersection_a/_b)
+    double maxd;                   // CSG node: max_distance of the ray hit() was called with
+    int32_t last_is_a, invalid;    // _cache_last_intersection is a / _cache_invalid
+    int32_t tested;                // BoundPrimitive._primitive_tested
+    int32_t further;               // analytic leaf: cached second root
+    double next_t;
+    int32_t next_a0, next_a1;
+    uint32_t next_flags;
+    int32_t seek;                  // mesh leaf: _seek_next_intersection
+    double nox, noy, noz, ndx, ndy, ndz, nmaxd, acc;   // mesh leaf: _next_local_ray, _ray_distance
+};
+
+struct CsgEval {
+    const DScene *sc;
+    NodeSt *st;
+    Stack mesh_stack;
+};
+
+__device__ __forceinline__ bool is_csg(int type) { return type == RSX_PRIM_UNION || type == RSX_PRIM_INTERSECT || type == RSX_PRIM_SUBTRACT; }
+
+// Mesh.hit / next_intersection as a stream (mesh.pyx:1178-1275)
+__device__ __noinline__ void mesh_stream_step(CsgEval &e, int32_t idx, NodeSt &st, const Ray &l, Rec &out) {
+    const DMesh &m = e.sc->meshes[e.sc->prims[idx].mesh];
+    MeshHit mh;
+    out.flags = 0;
+    if (!mesh_trace(m, l, e.mesh_stack, mh)) { st.seek = 0; return; }
+    Geom g;
+    mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
+    out.t = (double)mh.t + st.acc;
+    out.hx = g.hit[0]; out.hy = g.hit[1]; out.hz = g.hit[2];
+    out.leaf = idx; out.a0 = mh.tri; out.a1 = 0; out.u = mh.u; out.v = mh.v; out.w = mh.w;
+    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    st.seek = 1;
+    st.nox = g.hit[0] + l.dx * MESH_EPS; st.noy = g.hit[1] + l.dy * MESH_EPS; st.noz = g.hit[2] + l.dz * MESH_EPS;
+    st.ndx = l.dx; st.ndy = l.dy; st.ndz = l.dz;
+    st.nmaxd = l.maxd - (double)mh.t - MESH_EPS;
+    st.acc = out.t + MESH_EPS;
+}
+
+__device__ __noinline__ void leaf_first(CsgEval &e, int32_t idx, NodeSt &st, const Ray &pr, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    const Ray l = to_local(p, pr);
+    out.flags = 0;
+    st.further = 0;
+    st.seek = 0;
+    if (p.type == RSX_PRIM_MESH) { st.acc = 0; mesh_stream_step(e, idx, st, l, out); return; }
+    Roots roots;
+    roots.n = 0;
+    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
+    if (roots.n == 0) return;
+    Geom g;
+    analytic_geom(p, l, roots.t[0], roots.a0[0], roots.a1[0], g);
+    out.t = roots.t[0]; out.leaf = idx; out.a0 = roots.a0[0]; out.a1 = roots.a1[0]; out.u = out.v = out.w = 0.0f;
+    out.hx = out.hy = out.hz = 0.0;
+    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    if (roots.n == 2) {
+        analytic_geom(p, l, roots.t[1], roots.a0[1], roots.a1[1], g);
+        st.further = 1; st.next_t = roots.t[1]; st.next_a0 = roots.a0[1]; st.next_a1 = roots.a1[1];
+        st.next_flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    }
+}
+
+__device__ __noinline__ void leaf_next(CsgEval &e, int32_t idx, NodeSt &st, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    out.flags = 0;
+    if (p.type == RSX_PRIM_MESH) {
+        if (!st.seek) return;
+        Ray l;
+        l.ox = st.nox; l.oy = st.noy; l.oz = st.noz; l.dx = st.ndx; l.dy = st.ndy; l.dz = st.ndz; l.maxd = st.nmaxd;
+        mesh_stream_step(e, idx, st, l, out);
+        return;
+    }
+    if (!st.further) return;
+    st.further = 0;
+    out.t = st.next_t; out.leaf = idx; out.a0 = st.next_a0; out.a1 = st.next_a1; out.u = out.v = out.w = 0.0f;
+    out.hx = out.hy = out.hz = 0.0;
+    out.flags = st.next_flags;
+}
+
+// operator truth tables on (inside_a, inside_b, which stream supplied the closest root)
+__device__ __forceinline__ bool csg_valid(int type, const Rec &a, const Rec &b, bool closest_is_a) {
+    const bool ia = (a.flags & F_VALID) && (a.flags & F_EXIT), ib = (b.flags & F_VALID) && (b.flags & F_EXIT);
+    if (type == RSX_PRIM_UNION) return (!ia && !ib) || (ia && !ib && closest_is_a) || (!ia && ib && !closest_is_a);
+    if (type == RSX_PRIM_INTERSECT) return (ia && ib) || (ia && !ib && !closest_is_a) || (!ia && ib && closest_is_a);
+    return (!ia && !ib && closest_is_a) || (ia && !ib) || (ia && ib && !closest_is_a);
+}
+
+// _closest_intersection: 1 = a, 0 = b, -1 = none (a wins only when strictly closer)
+__device__ __forceinline__ int csg_closest(const Rec &a, const Rec &b) {
+    if (!(a.flags & F_VALID)) return (b.flags & F_VALID) ? 0 : -1;
+    if (!(b.flags & F_VALID) || a.t < b.t) return 1;
+    return 0;
+}
+
+template <int D> __device__ void node_next(CsgEval &e, int32_t idx, Rec &out);
+
+template <int D>
+__device__ void csg_identify(CsgEval &e, int32_t idx, NodeSt &st, Rec &a, Rec &b, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    out.flags = 0;
+    int closest = csg_closest(a, b);
+    while (closest >= 0) {
+        const Rec &c = closest ? a : b;
+        if (csg_valid(p.type, a, b, closest != 0)) {
+            if (c.t <= st.maxd) {
+                st.a = a; st.b = b; st.last_is_a = closest; st.invalid = 0;
+                out = c;
+                if (p.type == RSX_PRIM_SUBTRACT && !closest) out.flags ^= (F_EXIT | F_FLIP);   // _modify_intersection
+            }
+            return;
+        }
+        if (closest) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
+        closest = csg_closest(a, b);
+    }
+}
+
+template <int D> __device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out);
+
+template <int D>
+__device__ void csg_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {                     // CSGPrimitive.hit
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    st.invalid = 1;
+    st.maxd = pr.maxd;
+    Ray l = to_local(p, pr);
+    l.maxd = INFINITY;
+    Rec a, b;
+    node_first<D>(e, p.child_a, l, a);
+    if (p.type != RSX_PRIM_UNION && !(a.flags & F_VALID)) return;                                  // terminate_early
+    node_first<D>(e, p.child_b, l, b);
+    csg_identify<D>(e, idx, st, a, b, out);
+}
+
+template <int D>
+__device__ void csg_next(CsgEval &e, int32_t idx, Rec &out) {                                      // CSGPrimitive.next_intersection
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    if (st.invalid) return;
+    Rec a = st.a, b = st.b;
+    if (st.last_is_a) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
+    csg_identify<D>(e, idx, st, a, b, out);
+}
+
+// BoundPrimitive.hit / next_intersection over an operand (boundprimitive.pyx:42-60)
+template <int D>
+__device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    double f, b;
+    out.flags = 0;
+    if (!aabb(p.box_lower, p.box_upper, pr, f, b)) { st.tested = 0; return; }
+    st.tested = 1;
+    if (is_csg(p.type)) {
+        if constexpr (D > 0) csg_first<D - 1>(e, idx, pr, out);
+    } else if (p.type != RSX_PRIM_NULL) {
+        leaf_first(e, idx, st, pr, out);
+    }
+}
+
+template <int D>
+__device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    if (!st.tested) return;
+    if (is_csg(p.type)) {
+        if constexpr (D > 0) csg_next<D - 1>(e, idx, out);
+    } else if (p.type != RSX_PRIM_NULL) {
+        leaf_next(e, idx, st, out);
+    }
+}
+
+// contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
+__device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
+    double qx, qy, qz;
+    xform_point(p.to_local, px, py, pz, qx, qy, qz);
+    if (p.type == RSX_PRIM_SPHERE) return (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
+    if (p.type == RSX_PRIM_BOX) return aabb_contains(p.params, p.params + 3, qx, qy, qz);
+    if (p.type == RSX_PRIM_CYLINDER) return (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
+    if (p.type == RSX_PRIM_MESH) {
+        const DMesh &m = sc.meshes[p.mesh];
+        if (!m.closed) return false;
+        Ray zr;
+        zr.ox = qx; zr.oy = qy; zr.oz = qz; zr.dx = 0; zr.dy = 0; zr.dz = 1; zr.maxd = INFINITY;
+        MeshHit mh;
+        if (mesh_trace(m, zr, mesh_stack, mh)) return m.tris[3 * (size_t)mh.tri + 2].w > 0.0f;
+    }
+    return false;
+}
+
+template <int D>
+__device__ bool node_contains(const DScene &sc, int32_t idx, double px, double py, double pz, Stack mesh_stack) {
+    const rsx_primitive &p = sc.prims[idx];
+    if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) return false;
+    if (!is_csg(p.type)) return leaf_contains(sc, p, px, py, pz, mesh_stack);
+    if constexpr (D > 0) {
+        double qx, qy, qz;
+        xform_point(p.to_local, px, py, pz, qx, qy, qz);
+        const bool a = node_contains<D - 1>(sc, p.child_a, qx, qy, qz, mesh_stack);
+        if (p.type == RSX_PRIM_UNION) return a || node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+        if (p.type == RSX_PRIM_INTERSECT) return a && node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+        return a && !node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+    }
+    return false;
+}
+
+// Rebuild the Intersection a CSG node returns for a root: leaf geometry in the leaf's space, lifted operand by operand into
+// the top node's space (csg.pyx:198-208), Subtract's swap/negate applied by parity (it commutes with the affine lifts).
+__device__ void csg_geom(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
+    int32_t chain[CSG_MAX_DEPTH + 3];
+    int n = 0;
+    for (int32_t i = h.leaf; i != h.prim && n < CSG_MAX_DEPTH + 2; i = sc.csg[i].parent) chain[n++] = i;
+    Ray l = to_local(sc.prims[h.prim], r);
+    for (int k = n - 1; k >= 0; --k) l = to_local(sc.prims[chain[k]], l);
+    const rsx_primitive &leaf = sc.prims[h.leaf];
+    if (leaf.type == RSX_PRIM_MESH) {
+        const DMesh &m = sc.meshes[leaf.mesh];
+        Ray at = l;                                     // mesh_geom recomputes hit = o + d*t; feed the stored hit point instead
+        at.ox = h.hx; at.oy = h.hy; at.oz = h.hz;
+        mesh_geom(m, at, 0.0, h.a0, h.u, h.v, h.w, g);
+        g.hit[0] = h.hx; g.hit[1] = h.hy; g.hit[2] = h.hz;
+        const float4 q2 = m.tris[3 * (size_t)h.a0 + 2];
+        const double fx = (double)q2.y, fy = (double)q2.z, fz = (double)q2.w;
+        g.inside[0] = h.hx - fx * MESH_EPS; g.inside[1] = h.hy - fy * MESH_EPS; g.inside[2] = h.hz - fz * MESH_EPS;
+        g.outside[0] = h.hx + fx * MESH_EPS; g.outside[1] = h.hy + fy * MESH_EPS; g.outside[2] = h.hz + fz * MESH_EPS;
+    } else {
+        analytic_geom(leaf, l, h.t, h.a0, h.a1, g);
+    }
+    for (int k = 0; k < n; ++k) {
+        const rsx_primitive &c = sc.prims[chain[k]];
+        double x, y, z;
+        xform_point(c.to_root, g.hit[0], g.hit[1], g.hit[2], x, y, z); g.hit[0] = x; g.hit[1] = y; g.hit[2] = z;
+        xform_point(c.to_root, g.inside[0], g.inside[1], g.inside[2], x, y, z); g.inside[0] = x; g.inside[1] = y; g.inside[2] = z;
+        xform_point(c.to_root, g.outside[0], g.outside[1], g.outside[2], x, y, z); g.outside[0] = x; g.outside[1] = y; g.outside[2] = z;
+        const double *mi = c.to_local;                  // Normal3D.transform(to_root) = multiply by inverse transpose
+        x = mi[0] * g.normal[0] + mi[4] * g.normal[1] + mi[8] * g.normal[2];
+        y = mi[1] * g.normal[0] + mi[5] * g.normal[1] + mi[9] * g.normal[2];
+        z = mi[2] * g.normal[0] + mi[6] * g.normal[1] + mi[10] * g.normal[2];
+        g.normal[0] = x; g.normal[1] = y; g.normal[2] = z;
+    }
+    if (h.flags & F_FLIP) {
+        for (int k = 0; k < 3; ++k) { const double tmp = g.inside[k]; g.inside[k] = g.outside[k]; g.outside[k] = tmp; g.normal[k] = -g.normal[k]; }
+    }
+    g.exiting = (h.flags & F_EXIT) != 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
 // World.hit — core/scenegraph/world.pyx:125-146, core/acceleration/kdtree.pyx:73-122,170-175,
 //             boundprimitive.pyx:42-51
 // ---------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t idx, const rsx_primitive &p, const Ray &r, Stack mesh_stack, Hit &cand) {
+template <bool CSG>
+__device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t idx, const rsx_primitive &p, const Ray &r, Stack mesh_stack,
+                                                    NodeSt *csg_state, Hit &cand) {
     cand.prim = -1;
+    if constexpr (CSG) {
+        if (is_csg(p.type)) {
+            CsgEval e;
+            e.sc = &sc; e.st = csg_state; e.mesh_stack = mesh_stack;
+            Rec rec;
+            csg_first<CSG_MAX_DEPTH>(e, idx, r, rec);
+            if (rec.flags & F_VALID) {
+                cand.prim = idx; cand.t = rec.t; cand.a0 = rec.a0; cand.a1 = rec.a1; cand.u = rec.u; cand.v = rec.v; cand.w = rec.w;
+                cand.leaf = rec.leaf; cand.flags = rec.flags; cand.hx = rec.hx; cand.hy = rec.hy; cand.hz = rec.hz;
+            }
+            return;
+        }
+    }
     const Ray l = to_local(p, r);
     if (p.type == RSX_PRIM_MESH) {
         MeshHit mh;
@@ -477,7 +774,8 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
     if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
 }
 
-__device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, Hit &best) {
+template <bool CSG>
+__device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, NodeSt *csg_state, Hit &best) {
     best.prim = -1;
     double tmin, tmax;
     if (!aabb(sc.wlower, sc.wupper, r, tmin, tmax)) return false;
@@ -500,7 +798,7 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, Hit &best)
             double f, b;
             if (!aabb(p.box_lower, p.box_upper, r, f, b)) continue;          // BoundPrimitive.hit gate
             Hit cand;
-            primitive_first_hit(sc, idx, p, r, mesh_stack, cand);
+            primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
         if (best.prim >= 0) return true;
@@ -512,8 +810,12 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, Hit &best)
     }
 }
 
+template <bool CSG>
 __device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
     const rsx_primitive &p = sc.prims[h.prim];
+    if constexpr (CSG) {
+        if (is_csg(p.type)) { csg_geom(sc, r, h, g); return; }
+    }
     const Ray l = to_local(p, r);
     if (p.type == RSX_PRIM_MESH) mesh_geom(sc.meshes[p.mesh], l, h.t, h.a0, h.u, h.v, h.w, g);
     else analytic_geom(p, l, h.t, h.a0, h.a1, g);
@@ -544,10 +846,12 @@ struct HitOut {
     int32_t *prim; double *t; uint8_t *exiting; int32_t *tri; float *uvw; double *geom;
 };
 
+template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
                                                           const double *maxd, HitOut out, unsigned long long *ticket) {
     const Stack st = lane_stack(sc.wdepth + sc.mdepth);
     const int lane = threadIdx.x % WAVE;
+    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
     for (;;) {
         const long long base = next_batch(ticket);
         if (base >= n) break;
@@ -558,15 +862,18 @@ __global__ __launch_bounds__(WG_THREADS) void k_hit_batch(DScene sc, long long n
         r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
         r.maxd = maxd[i];
         Hit h;
-        const bool hit = world_trace(sc, r, st, h);
+        const bool hit = world_trace<CSG>(sc, r, st, csg_state, h);
         out.prim[i] = hit ? h.prim : -1;
         if (out.t) out.t[i] = hit ? h.t : NAN;
-        const bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
+        bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
+        if constexpr (CSG) {   // a CSG node hands back its operand's MeshIntersection (triangle, u, v, w survive the lift)
+            if (hit && is_csg(sc.prims[h.prim].type)) mesh = sc.prims[h.leaf].type == RSX_PRIM_MESH;
+        }
         if (out.tri) out.tri[i] = mesh ? h.a0 : -1;
         if (out.uvw) { out.uvw[3 * i] = mesh ? h.u : 0.0f; out.uvw[3 * i + 1] = mesh ? h.v : 0.0f; out.uvw[3 * i + 2] = mesh ? h.w : 0.0f; }
         if (out.exiting || out.geom) {
             Geom g;
-            if (hit) finalise(sc, r, h, g);
+            if (hit) finalise<CSG>(sc, r, h, g);
             if (out.exiting) out.exiting[i] = hit ? (g.exiting ? 1 : 0) : 0;
             if (out.geom) {
                 double *o = out.geom + 12 * i;
@@ -581,12 +888,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_hit_batch(DScene sc, long long n
 
 // Primitive.hit + next_intersection() sequence on one primitive (tests / Primitive API parity).
 // Mesh.next_intersection re-traces from hit + d*1e-6 with max - t - 1e-6 (mesh.pyx:1240-1275).
+template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, long long n, const double *origin, const double *direction,
                                                       const double *maxd, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
                                                       unsigned long long *ticket) {
     const Stack st = lane_stack(sc.wdepth + sc.mdepth);
     const int lane = threadIdx.x % WAVE;
     const rsx_primitive &p = sc.prims[pidx];
+    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
     for (;;) {
         const long long base = next_batch(ticket);
         if (base >= n) break;
@@ -598,7 +907,22 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
         r.maxd = maxd[i];
         Ray l = to_local(p, r);
         int32_t c = 0;
-        if (p.type == RSX_PRIM_MESH) {
+        if (CSG && is_csg(p.type)) {
+            if constexpr (CSG) {
+                CsgEval e;
+                e.sc = &sc; e.st = csg_state;
+                e.mesh_stack.t = st.t + sc.wdepth * WAVE;
+                e.mesh_stack.id = st.id + sc.wdepth * WAVE;
+                Rec rec;
+                csg_first<CSG_MAX_DEPTH>(e, pidx, r, rec);
+                while ((rec.flags & F_VALID) && c < max_roots) {
+                    t[i * max_roots + c] = rec.t;
+                    exiting[i * max_roots + c] = (rec.flags & F_EXIT) ? 1 : 0;
+                    ++c;
+                    csg_next<CSG_MAX_DEPTH>(e, pidx, rec);
+                }
+            }
+        } else if (p.type == RSX_PRIM_MESH) {
             const DMesh &m = sc.meshes[p.mesh];
             double accumulated = 0;
             MeshHit mh;
@@ -636,6 +960,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
 
 // World.contains — kdtree3d.pyx:736-792, kdtree.pyx:126-162, primitive contains():
 //   sphere.pyx:202-214, box.pyx:344-361, cylinder.pyx:356-372, mesh.pyx:1277-1297 (+802-830)
+template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n, const double *points, uint8_t *inside,
                                                          unsigned long long *ticket) {
     const Stack st = lane_stack(sc.wdepth + sc.mdepth);
@@ -657,25 +982,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n,
         for (int32_t k = 0; k < nd.count; ++k) {
             const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
             const rsx_primitive &p = sc.prims[idx];
-            if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) continue;
-            double qx, qy, qz;
-            xform_point(p.to_local, px, py, pz, qx, qy, qz);
-            bool in = false;
-            if (p.type == RSX_PRIM_SPHERE) in = (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
-            else if (p.type == RSX_PRIM_BOX) in = aabb_contains(p.params, p.params + 3, qx, qy, qz);
-            else if (p.type == RSX_PRIM_CYLINDER) in = (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
-            else if (p.type == RSX_PRIM_MESH) {
-                const DMesh &m = sc.meshes[p.mesh];
-                if (m.closed) {
-                    Ray zr;
-                    zr.ox = qx; zr.oy = qy; zr.oz = qz; zr.dx = 0; zr.dy = 0; zr.dz = 1; zr.maxd = INFINITY;
-                    MeshHit mh;
-                    Stack ms;
-                    ms.t = st.t + sc.wdepth * WAVE;
-                    ms.id = st.id + sc.wdepth * WAVE;
-                    if (mesh_trace(m, zr, ms, mh)) in = m.tris[3 * (size_t)mh.tri + 2].w > 0.0f;
-                }
-            }
+            Stack ms;
+            ms.t = st.t + sc.wdepth * WAVE;
+            ms.id = st.id + sc.wdepth * WAVE;
+            bool in;
+            if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);   // BoundPrimitive.contains: box gate first
+            else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
             inside[i * sc.n_world + idx] = in ? 1 : 0;
         }
     }
@@ -724,9 +1036,11 @@ __device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, 
 
 // Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
 // 64 rays stay coherent; in task-list mode 64 consecutive tasks.
+template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     const Stack st = lane_stack(sc.wdepth + sc.mdepth);
     const int lane = threadIdx.x % WAVE;
+    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
     const long long total = rp.n_tasks * rp.spp;
     const int w = rp.rect[2] - rp.rect[0], h = rp.rect[3] - rp.rect[1];
     const int tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8;
@@ -768,14 +1082,14 @@ __global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderPa
         Hit hit;
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
-        if (world_trace(sc, r, st, hit)) {                                    // optical/ray.pyx:391-393
+        if (world_trace<CSG>(sc, r, st, csg_state, hit)) {                    // optical/ray.pyx:391-393
             const rsx_primitive &p = sc.prims[hit.prim];
             const rsx_material mat = rp.materials[p.material];
             if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
             else if (mat.type == RSX_MAT_DEBUG_LIGHT) {                      // debug.pyx:67-79
                 if (mat.scale != 0.0) {
                     Geom g;
-                    finalise(sc, r, hit, g);
+                    finalise<CSG>(sc, r, hit, g);
                     double lx, ly, lz;
                     xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
                     const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
@@ -923,6 +1237,7 @@ struct rsx_scene {
     DScene d;
     std::vector<void *> allocs;
     int32_t n_world;
+    bool has_csg;
 };
 
 extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
@@ -1117,8 +1432,10 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     if (desc->n_world < 0 || desc->n_world > desc->n_primitives) return rsx_fail(RSX_EINVAL, "n_world out of range");
     for (int32_t i = 0; i < desc->n_primitives; ++i) {
         const rsx_primitive &p = desc->primitives[i];
-        if (p.type == RSX_PRIM_UNION || p.type == RSX_PRIM_INTERSECT || p.type == RSX_PRIM_SUBTRACT)
-            return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG is not yet on the device path", i);
+        if (p.type == RSX_PRIM_UNION || p.type == RSX_PRIM_INTERSECT || p.type == RSX_PRIM_SUBTRACT) {
+            if (p.child_a <= i || p.child_a >= desc->n_primitives || p.child_b <= i || p.child_b >= desc->n_primitives)
+                return rsx_fail(RSX_EINVAL, "primitive %d: CSG operands must follow their node in the primitive table", i);
+        }
         if (p.type == RSX_PRIM_MESH && (p.mesh < 0 || p.mesh >= desc->n_meshes)) return rsx_fail(RSX_EINVAL, "primitive %d: bad mesh index", i);
         if (p.type < 0 || p.type > RSX_PRIM_NULL) return rsx_fail(RSX_EINVAL, "primitive %d: unknown type %d", i, p.type);
     }
@@ -1129,10 +1446,39 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     if (!sc) return rsx_fail(RSX_ENOMEM, "out of host memory");
     sc->ctx = ctx;
     sc->n_world = desc->n_world;
+    sc->has_csg = false;
     DScene &d = sc->d;
     std::memset(&d, 0, sizeof(d));
+    // CSG bookkeeping: per operand tree assign per-lane state slots, parent links and nesting depth
+    std::vector<CsgInfo> info((size_t)desc->n_primitives, CsgInfo{-1, 0, 0, -1});
+    for (int32_t top = 0; top < desc->n_primitives; ++top) {
+        const int tt = desc->primitives[top].type;
+        const bool csg_node = tt == RSX_PRIM_UNION || tt == RSX_PRIM_INTERSECT || tt == RSX_PRIM_SUBTRACT;
+        if (!csg_node || info[(size_t)top].top >= 0) continue;       // operands were claimed by their top node already
+        sc->has_csg = true;
+        int32_t slots = 0;
+        std::vector<std::pair<int32_t, int>> todo{{top, 0}};
+        info[(size_t)top].top = top;
+        while (!todo.empty()) {
+            const auto [i, depth] = todo.back();
+            todo.pop_back();
+            info[(size_t)i].slot = slots++;
+            const rsx_primitive &q = desc->primitives[i];
+            const bool inner = q.type == RSX_PRIM_UNION || q.type == RSX_PRIM_INTERSECT || q.type == RSX_PRIM_SUBTRACT;
+            if (!inner) continue;
+            if (depth > CSG_MAX_DEPTH) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG nesting deeper than %d levels", top, CSG_MAX_DEPTH + 1); }
+            for (int side = 0; side < 2; ++side) {
+                const int32_t c = side ? q.child_b : q.child_a;
+                if (info[(size_t)c].top >= 0) { delete sc; return rsx_fail(RSX_EINVAL, "primitive %d is an operand of two CSG nodes", c); }
+                info[(size_t)c] = CsgInfo{i, 0, side, top};
+                todo.push_back({c, depth + 1});
+            }
+        }
+        if (slots > CSG_MAX_SLOTS) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG tree with %d nodes (limit %d)", top, slots, CSG_MAX_SLOTS); }
+    }
 #define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
     UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
+    if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
     UP(upload(sc, desc->world_kd.nodes, (size_t)desc->world_kd.n_nodes, &d.wnodes));
     UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
     std::memcpy(d.wlower, desc->world_kd.lower, 24);
@@ -1233,12 +1579,13 @@ extern "C" int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *orig
     Launch l;
     int rc = plan(scene, n, l);
     if (rc) return rc;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hit_batch), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_hit_batch<true>) : reinterpret_cast<const void *>(k_hit_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     rc = reset_ticket(ctx);
     if (rc) return rc;
     HitOut out = {prim, t, exiting, tri, uvw, geom};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL(k_hit_batch, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_hit_batch<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
+    else hipLaunchKernelGGL(k_hit_batch<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     return RSX_OK;
@@ -1297,9 +1644,11 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     HIP_TRY(hipMemsetAsync(d_ex.p, 0, N * R, ctx->stream));
     Launch l;
     if ((rc = plan(scene, n, l))) return rc;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_roots), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_roots<true>) : reinterpret_cast<const void *>(k_roots<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx))) return rc;
-    hipLaunchKernelGGL(k_roots, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
+    if (scene->has_csg) hipLaunchKernelGGL(k_roots<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->ticket);
+    else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
                        d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts, d_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1321,9 +1670,10 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
     HIP_TRY(hipMemcpyAsync(d_p.p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
     Launch l;
     if ((rc = plan(scene, n, l))) return rc;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_contains), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_contains<true>) : reinterpret_cast<const void *>(k_contains<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx))) return rc;
-    hipLaunchKernelGGL(k_contains, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
+    else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(inside, d_in.p, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -1393,14 +1743,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 
     Launch l;
     if ((rc = plan(scene, (long long)S, l))) return rc;
-    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+    HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!ctx->ticket_armed && (rc = reset_ticket(ctx))) return rc;
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
     while (ctx->ring.size() < (size_t)(slot + 1) * 3) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
     hipEvent_t *re = &ctx->ring[(size_t)slot * 3];
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(hipEventRecord(re[0], ctx->stream));
-    hipLaunchKernelGGL(k_render_trace, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
+    else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     HIP_TRY(hipEventRecord(re[1], ctx->stream));

@@ -238,3 +238,72 @@ def test_philox_frame_vs_oracle_full_size(orc, ns):
     assert mean.max() > 0 and (mean[512, 512] > 0).all()
 
 
+
+
+# ------------------------------------------------------------------------------------------------- CSG on the device
+def _check_world(dev, idx, rec):
+    assert eq(dev["prim"], idx)
+    hit = idx >= 0
+    assert eq(dev["t"][hit], rec[hit, 0])
+    assert eq(dev["exiting"][hit], rec[hit, 1])
+    assert eq(dev["geom"][hit], rec[hit, 2:])
+
+
+def test_csg_demo_world(orc, ns, golden):
+    """demos/csg.py tree (Intersect(sphere, Subtract(cube, Union(Union(cyl, cyl), cyl))) x4 + lens): hits with full
+    geometry, next_intersection sequences and contains() against the reference's vectors."""
+    g = golden("f06_csg")
+    world, prims = scenes.build_csg_demo(ns)
+    flat = world.flatten()
+    sc = world.build_accelerator()
+    o, d, m = raysets.scene_rays(12000, 101, 9.0, 4.5)
+    og, dg, mg = raysets.pinhole_grid(64, (0.0, 0.0, -4.0), 75.0)
+    o, d, m = np.concatenate([o, og]), np.concatenate([d, dg]), np.concatenate([m, mg])
+    dev = sc.hit_batch(o, d, m, geometry=True)
+    _check_world(dev, g["world_idx"], g["world_rec"])
+    assert_hits_equal(dev, orc.hit_batch(flat, o, d, m, geometry=True), geometry=True)
+    for name, index in (("obj0", 0), ("lens", 4)):
+        counts, t, ex = sc.roots_batch(index, o[:4000], d[:4000], None, max_roots=64)
+        assert eq(counts, g[name + "_counts"]), name
+        mask = np.arange(64)[None, :] < counts[:, None]
+        assert eq(t[mask], g[name + "_t"]) and eq(ex[mask], g[name + "_ex"]), name
+    assert eq(sc.contains_batch(raysets.points(4000, 102, 4.5)), g["contains"])
+
+
+def test_mixed_world_with_csg_and_instances(orc, ns, golden):
+    g = golden("f07_world")
+    world, prims = scenes.build_mixed(ns)
+    sc = world.build_accelerator()
+    o, d, m = raysets.scene_rays(20000, 111, 6.0, 2.2)
+    dev = sc.hit_batch(o, d, m, geometry=True)
+    _check_world(dev, g["idx"], g["rec"])
+    assert not np.isin(dev["prim"], [2, 3]).any()
+    assert eq(sc.contains_batch(raysets.points(6000, 112, 2.0)), g["contains"])
+
+
+def test_frames_csg_stream_parity(ns, golden):
+    g = golden("f10_frames")
+    world, prims = scenes.build_csg_demo(ns)
+    cam, pipe = scenes.csg_camera(ns, world, (32, 32), spp=6, bins=5)
+    m, v, n = _observe(ns, cam, pipe, 4)
+    assert eq(m, g["csg_mean"]) and eq(v, g["csg_var"]) and eq(n, g["csg_n"])
+
+
+def test_csg_with_mesh_operand_vs_oracle(orc, ns):
+    """A mesh as CSG operand exercises the mesh next_intersection stream inside the merge (no golden: oracle is the checker)."""
+    v, t = scenes.displaced_sphere(24, radius=0.5)
+    world = ns.World()
+    mesh = ns.Mesh(v, t, smoothing=False, transform=ns.translate(0.1, 0, 0))
+    cut = ns.Box(ns.Point3D(-0.3, -1, -1), ns.Point3D(0.25, 1, 1))
+    ns.Subtract(mesh, cut, world, ns.translate(0, 0.1, 0.2) * ns.rotate(10, 20, 30), ns.AbsorbingSurface())
+    mesh2 = ns.Mesh(v, t, smoothing=False)
+    ns.Intersect(ns.Sphere(0.45, transform=ns.translate(0.2, 0, 0)), mesh2, world, ns.translate(1.5, 0, 0), ns.AbsorbingSurface())
+    flat = world.flatten()
+    sc = world.build_accelerator()
+    o, d, m = raysets.scene_rays(20000, 301, 4.0, 1.2)
+    assert_hits_equal(sc.hit_batch(o, d, m, geometry=True), orc.hit_batch(flat, o, d, m, geometry=True))
+    for index in (0, 1):
+        assert all(eq(a, b) for a, b in zip(sc.roots_batch(index, o[:3000], d[:3000], None, max_roots=16),
+                                            orc.roots_batch(flat, index, o[:3000], d[:3000], None, max_roots=16)))
+    pts = raysets.points(3000, 302, 1.5)
+    assert eq(sc.contains_batch(pts), orc.contains_batch(flat, pts))
