@@ -9,7 +9,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "librsx.so")
+LIB_PATH = os.environ.get("RSX_LIB") or os.path.join(_HERE, "lib", "librsx.so")   # RSX_LIB: kernel-variant A/B runs (tools/)
 
 f64p = C.POINTER(C.c_double)
 f32p = C.POINTER(C.c_float)

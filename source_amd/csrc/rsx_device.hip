@@ -29,8 +29,25 @@
 #include "rsx_internal.h"
 
 #define WAVE 64
+#ifndef WG_WAVES
 #define WG_WAVES 4
+#endif
 #define WG_THREADS (WAVE * WG_WAVES)
+#ifndef RSX_WORLD_LDS_LEVELS
+#define RSX_WORLD_LDS_LEVELS 4      // LDS-resident traversal stack entries per lane, world tree
+#endif
+#ifndef RSX_MESH_LDS_LEVELS
+#define RSX_MESH_LDS_LEVELS 10      // ... mesh tree (deeper entries spill to global memory)
+#endif
+#ifndef RSX_MAX_WG_PER_CU
+#define RSX_MAX_WG_PER_CU 8
+#endif
+#ifndef RSX_WAVE_COOP
+#define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
+#endif
+#ifndef RSX_MIN_WAVES_PER_SIMD
+#define RSX_MIN_WAVES_PER_SIMD 1    // __launch_bounds__ second argument for the traversal kernels
+#endif
 
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
@@ -76,7 +93,9 @@ struct DScene {
     const int32_t *witems;
     double wlower[3], wupper[3];
     int32_t n_prims, n_world, n_meshes;
-    int32_t wdepth, mdepth;    // stack levels reserved for the world tree / the deepest mesh tree
+    int32_t wdepth, mdepth;    // stack levels a traversal of the world tree / the deepest mesh tree can need
+    int32_t wlds, mlds;        // how many of those levels are held in LDS (the rest spill)
+    char *spill;               // per-wave global spill regions
     const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
 };
 
@@ -100,10 +119,26 @@ struct Hit {
     double hx, hy, hz;
 };
 
-struct Stack {                 // per-lane view of the wave's LDS stack region
-    double *t;                 // t[level * WAVE]
-    int32_t *id;               // id[level * WAVE]
+// Per-lane traversal stack: the first `lds_levels` entries live in LDS ([level][lane], conflict free), deeper ones spill to a
+// per-wave global buffer with the same layout. 99 % of camera rays on the 69k-triangle mesh never have more than 9 far nodes
+// pending (oracle histogram), so the spill path is cold but keeps the traversal exact for any depth.
+struct Stack {
+    double *t;                 // LDS   t[level * WAVE]
+    int32_t *id;               // LDS   id[level * WAVE]
+    double *gt;                // spill gt[(level - lds_levels) * WAVE]
+    int32_t *gid;
+    int32_t lds_levels;
 };
+
+__device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
+    if (sp < st.lds_levels) { st.t[sp * WAVE] = t; st.id[sp * WAVE] = id; }
+    else { const int32_t g = sp - st.lds_levels; st.gt[g * WAVE] = t; st.gid[g * WAVE] = id; }
+}
+
+__device__ __forceinline__ void stack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
+    if (sp < st.lds_levels) { t = st.t[sp * WAVE]; id = st.id[sp * WAVE]; }
+    else { const int32_t g = sp - st.lds_levels; t = st.gt[g * WAVE]; id = st.gid[g * WAVE]; }
+}
 
 __device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
 __device__ __forceinline__ float sel3f(int i, float x, float y, float z) { return i == 0 ? x : (i == 1 ? y : z); }
@@ -159,6 +194,34 @@ __device__ __forceinline__ bool aabb(const double *lo, const double *hi, const R
     return true;
 }
 
+// Same test with the three reciprocals 1.0/d hoisted by the caller (bit-identical: the reference recomputes the same
+// quotient for every box it tests a ray against).
+__device__ __forceinline__ void slab_rcp(double o, double d, double rcp, double lo, double hi, double &front, double &back) {
+    double tmin, tmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+    }
+    if (tmin > front) front = tmin;
+    if (tmax < back) back = tmax;
+}
+
+__device__ __forceinline__ bool aabb_rcp(const double *lo, const double *hi, const Ray &r, double rx, double ry, double rz, double &front, double &back) {
+    front = -INFINITY;
+    back = INFINITY;
+    slab_rcp(r.ox, r.dx, rx, lo[0], hi[0], front, back);
+    slab_rcp(r.oy, r.dy, ry, lo[1], hi[1], front, back);
+    slab_rcp(r.oz, r.dz, rz, lo[2], hi[2], front, back);
+    if (front > back) return false;
+    if (front < 0.0 && back < 0.0) return false;
+    return true;
+}
+
 __device__ __forceinline__ bool aabb_contains(const double *lo, const double *hi, double x, double y, double z) {
     if (x < lo[0] || x > hi[0]) return false;
     if (y < lo[1] || y > hi[1]) return false;
@@ -188,8 +251,7 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
     const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
     if (plane > tmax || plane <= 0) return near_id;
     if (plane < tmin) return far_id;
-    st.t[sp * WAVE] = tmax;
-    st.id[sp * WAVE] = far_id;
+    stack_push(st, sp, far_id, tmax);
     ++sp;
     tmax = plane;
     return near_id;
@@ -203,11 +265,15 @@ struct MeshHit {
     int32_t tri;
 };
 
-__device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
-    double tmin, tmax;
-    if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
+// ray-space constants of the watertight test — _calc_rayspace_transform, mesh.pyx:566-610
+struct TriRay {
+    double ox, oy, oz, maxd;
+    float sx, sy, sz;
+    int ix, iy, iz;
+};
 
-    // _calc_rayspace_transform, mesh.pyx:566-610
+__device__ __forceinline__ TriRay tri_ray(const Ray &r) {
+    TriRay q;
     int ix, iy, iz;
     const double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
     if (ax > ay && ax > az) { ix = 1; iy = 2; iz = 0; }
@@ -215,9 +281,51 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
     else { ix = 0; iy = 1; iz = 2; }
     const float rdz = (float)sel3(iz, r.dx, r.dy, r.dz);
     if (rdz < 0.0f) { const int tmp = ix; ix = iy; iy = tmp; }
-    const float sz = (float)(1.0 / (double)rdz);
-    const float sx = (float)(sel3(ix, r.dx, r.dy, r.dz) * (double)sz);
-    const float sy = (float)(sel3(iy, r.dx, r.dy, r.dz) * (double)sz);
+    q.sz = (float)(1.0 / (double)rdz);
+    q.sx = (float)(sel3(ix, r.dx, r.dy, r.dz) * (double)q.sz);
+    q.sy = (float)(sel3(iy, r.dx, r.dy, r.dz) * (double)q.sz);
+    q.ix = ix; q.iy = iy; q.iz = iz;
+    q.ox = r.ox; q.oy = r.oy; q.oz = r.oz; q.maxd = r.maxd;
+    return q;
+}
+
+// _hit_triangle, mesh.pyx:616-713 on one 48-byte triangle record. Returns true with normalised (t,u,v,w) on a hit.
+__device__ __forceinline__ bool tri_test(const TriRay &q, const float4 q0, const float4 q1, const float4 q2, float &ht, float &hu, float &hv, float &hw) {
+    // f32 vertex minus f64 origin, rounded to f32
+    const float v1x = (float)((double)q0.x - q.ox), v1y = (float)((double)q0.y - q.oy), v1z = (float)((double)q0.z - q.oz);
+    const float v2x = (float)((double)q0.w - q.ox), v2y = (float)((double)q1.x - q.oy), v2z = (float)((double)q1.y - q.oz);
+    const float v3x = (float)((double)q1.z - q.ox), v3y = (float)((double)q1.w - q.oy), v3z = (float)((double)q2.x - q.oz);
+    const float a1 = sel3f(q.ix, v1x, v1y, v1z), b1 = sel3f(q.iy, v1x, v1y, v1z), c1 = sel3f(q.iz, v1x, v1y, v1z);
+    const float a2 = sel3f(q.ix, v2x, v2y, v2z), b2 = sel3f(q.iy, v2x, v2y, v2z), c2 = sel3f(q.iz, v2x, v2y, v2z);
+    const float a3 = sel3f(q.ix, v3x, v3y, v3z), b3 = sel3f(q.iy, v3x, v3y, v3z), c3 = sel3f(q.iz, v3x, v3y, v3z);
+    const float x1 = a1 - q.sx * c1, x2 = a2 - q.sx * c2, x3 = a3 - q.sx * c3;
+    const float y1 = b1 - q.sy * c1, y2 = b2 - q.sy * c2, y3 = b3 - q.sy * c3;
+    float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
+    if (u == 0.0f || v == 0.0f || w == 0.0f) {
+        u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
+        v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
+        w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+    }
+    if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) return false;
+    const float det = u + v + w;
+    if (det == 0.0f) return false;
+    const float z1 = q.sz * c1, z2 = q.sz * c2, z3 = q.sz * c3;
+    const float t = u * z1 + v * z2 + w * z3;
+    if (det > 0.0f) { if (t < 0.0f || (double)t > q.maxd * (double)det) return false; }
+    else            { if (t > 0.0f || (double)t < q.maxd * (double)det) return false; }
+    const float rdet = (float)(1.0 / (double)det);
+    ht = t * rdet; hu = u * rdet; hv = v * rdet; hw = w * rdet;
+    return true;
+}
+
+#ifndef RSX_LEAF_BATCH
+#define RSX_LEAF_BATCH 4           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
+#endif
+
+__device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
+    double tmin, tmax;
+    if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
+    const TriRay q = tri_ray(r);
 
     int32_t node = 0, sp = 0;
     for (;;) {
@@ -227,47 +335,147 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
             node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
             nd = load_node(m.nodes, node);
         }
-        // _trace_leaf, mesh.pyx:520-563
+        // _trace_leaf, mesh.pyx:520-563 — items are tested in leaf order, strict `<` keeps the first of equal distances
         double distance = r.maxd < tmax ? r.maxd : tmax;
         int32_t closest = -1;
         float bu = 0, bv = 0, bw = 0;
         const int32_t *items = m.items + nd.u.leaf.first_item;
-        for (int32_t k = 0; k < nd.count; ++k) {
-            const int32_t tri = items[k];
-            const float4 q0 = m.tris[3 * (size_t)tri], q1 = m.tris[3 * (size_t)tri + 1], q2 = m.tris[3 * (size_t)tri + 2];
-            // _hit_triangle, mesh.pyx:616-713: f32 vertex minus f64 origin, rounded to f32
-            const float v1x = (float)((double)q0.x - r.ox), v1y = (float)((double)q0.y - r.oy), v1z = (float)((double)q0.z - r.oz);
-            const float v2x = (float)((double)q0.w - r.ox), v2y = (float)((double)q1.x - r.oy), v2z = (float)((double)q1.y - r.oz);
-            const float v3x = (float)((double)q1.z - r.ox), v3y = (float)((double)q1.w - r.oy), v3z = (float)((double)q2.x - r.oz);
-            const float a1 = sel3f(ix, v1x, v1y, v1z), b1 = sel3f(iy, v1x, v1y, v1z), c1 = sel3f(iz, v1x, v1y, v1z);
-            const float a2 = sel3f(ix, v2x, v2y, v2z), b2 = sel3f(iy, v2x, v2y, v2z), c2 = sel3f(iz, v2x, v2y, v2z);
-            const float a3 = sel3f(ix, v3x, v3y, v3z), b3 = sel3f(iy, v3x, v3y, v3z), c3 = sel3f(iz, v3x, v3y, v3z);
-            const float x1 = a1 - sx * c1, x2 = a2 - sx * c2, x3 = a3 - sx * c3;
-            const float y1 = b1 - sy * c1, y2 = b2 - sy * c2, y3 = b3 - sy * c3;
-            float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
-            if (u == 0.0f || v == 0.0f || w == 0.0f) {
-                u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
-                v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
-                w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+        const int32_t count = nd.count;
+        for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+            int32_t tri[RSX_LEAF_BATCH];
+            float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j) tri[j] = items[k + j < count ? k + j : count - 1];
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                const float4 *rec = m.tris + 3 * (size_t)tri[j];
+                t0[j] = rec[0]; t1[j] = rec[1]; t2[j] = rec[2];
             }
-            if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) continue;
-            const float det = u + v + w;
-            if (det == 0.0f) continue;
-            const float z1 = sz * c1, z2 = sz * c2, z3 = sz * c3;
-            const float t = u * z1 + v * z2 + w * z3;
-            if (det > 0.0f) { if (t < 0.0f || (double)t > r.maxd * (double)det) continue; }
-            else            { if (t > 0.0f || (double)t < r.maxd * (double)det) continue; }
-            const float rdet = (float)(1.0 / (double)det);
-            const float ht = t * rdet;
-            if ((double)ht < distance) { distance = (double)ht; closest = tri; bu = u * rdet; bv = v * rdet; bw = w * rdet; }
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                float ht, hu, hv, hw;
+                if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
+                    distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
+                }
+            }
         }
         if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; return true; }
         if (sp == 0) return false;
         --sp;
         tmin = tmax;                    // far range starts where the exhausted near range ended
-        tmax = st.t[sp * WAVE];
-        node = st.id[sp * WAVE];
+        stack_pop(st, sp, node, tmax);
     }
+}
+
+#ifndef RSX_COOP_LEAF
+#define RSX_COOP_LEAF 24           // leaves with at least this many triangles are tested by the whole wave for one ray at a time
+#endif
+
+__device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x, lane, WAVE); }
+
+// Wave-cooperative MeshData.trace: every lane of the wave calls this together (`want` = lane has a ray). Lanes walk their own
+// rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF triangles (high-valence vertices
+// produce leaves of hundreds, mesh.pyx builds them because the depth cap stops the SAH split) is tested by all 64 lanes for one
+// ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic wave-min, which is exactly what the
+// reference's sequential scan with strict `<` returns (the first item among those with the smallest distance). Idle lanes —
+// rays that already finished, or never needed this mesh — serve as helpers.
+__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out) {
+    const int lane = threadIdx.x % WAVE;
+    double tmin = 0, tmax = 0;
+    bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
+    const TriRay q = tri_ray(r);
+    bool hit = false;
+    int32_t node = 0, sp = 0;
+    while (__any(active)) {
+        double distance = 0;
+        int32_t closest = -1, count = 0, first = 0;
+        float bu = 0, bv = 0, bw = 0;
+        if (active) {
+            rsx_kdnode nd = load_node(m.nodes, node);
+            while (nd.type >= 0) {
+                const int axis = nd.type;
+                node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+                nd = load_node(m.nodes, node);
+            }
+            distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
+            count = nd.count;
+            first = nd.u.leaf.first_item;
+            if (count < RSX_COOP_LEAF) {
+                const int32_t *items = m.items + first;
+                for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+                    int32_t tri[RSX_LEAF_BATCH];
+                    float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+#pragma unroll
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) tri[j] = items[k + j < count ? k + j : count - 1];
+#pragma unroll
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                        const float4 *rec = m.tris + 3 * (size_t)tri[j];
+                        t0[j] = rec[0]; t1[j] = rec[1]; t2[j] = rec[2];
+                    }
+#pragma unroll
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                        float ht, hu, hv, hw;
+                        if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
+                            distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- cooperative stage: one big leaf (one ray) at a time, all 64 lanes testing
+        unsigned long long big = __ballot(active && count >= RSX_COOP_LEAF);
+        while (big) {
+            const int leader = __ffsll((long long)big) - 1;
+            big &= big - 1;
+            TriRay lq;
+            lq.ox = shfl_f64(q.ox, leader); lq.oy = shfl_f64(q.oy, leader); lq.oz = shfl_f64(q.oz, leader);
+            lq.maxd = shfl_f64(q.maxd, leader);
+            lq.sx = __shfl(q.sx, leader, WAVE); lq.sy = __shfl(q.sy, leader, WAVE); lq.sz = __shfl(q.sz, leader, WAVE);
+            const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), leader, WAVE);
+            lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
+            const double limit = shfl_f64(distance, leader);
+            const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
+            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris;
+            const int32_t *litems = (const int32_t *)(((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
+                                                      (unsigned)__shfl((int)items_bits, leader, WAVE)) + lfirst;
+            const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
+                                                   (unsigned)__shfl((int)tris_bits, leader, WAVE));
+            // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
+            float mt = INFINITY, mu = 0, mv = 0, mw = 0;
+            int32_t mk = 0x7fffffff, mtri = -1;
+            for (int32_t k = lane; k < lcount; k += WAVE) {
+                const int32_t tri = litems[k];
+                const float4 *rec = ltris + 3 * (size_t)tri;
+                const float4 a = rec[0], b = rec[1], c = rec[2];
+                float ht, hu, hv, hw;
+                if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
+            }
+            // wave-wide lexicographic min of (t, position)
+            float wt = mt;
+            int32_t wk = mk;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const float ot = __shfl_xor(wt, off, WAVE);
+                const int32_t ok = __shfl_xor(wk, off, WAVE);
+                if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
+            }
+            const int winner = wk & (WAVE - 1);              // position k was scanned by lane k % 64
+            const bool found = wk != 0x7fffffff;
+            const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
+            const int32_t rtri = __shfl(mtri, winner, WAVE);
+            if (lane == leader && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
+        }
+        if (active) {
+            if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
+            else if (sp == 0) active = false;
+            else {
+                --sp;
+                tmin = tmax;
+                stack_pop(st, sp, node, tmax);
+            }
+        }
+    }
+    return hit;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -775,13 +983,11 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 }
 
 template <bool CSG>
-__device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, NodeSt *csg_state, Hit &best) {
+__device__ bool world_trace(const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best) {
     best.prim = -1;
     double tmin, tmax;
-    if (!aabb(sc.wlower, sc.wupper, r, tmin, tmax)) return false;
-    Stack mesh_stack;
-    mesh_stack.t = st.t + sc.wdepth * WAVE;
-    mesh_stack.id = st.id + sc.wdepth * WAVE;
+    const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;      // shared by the world box and every primitive box gate
+    if (!aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax)) return false;
     int32_t node = 0, sp = 0;
     for (;;) {
         rsx_kdnode nd = load_node(sc.wnodes, node);
@@ -796,7 +1002,7 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, NodeSt *cs
             const int32_t idx = items[k];
             const rsx_primitive &p = sc.prims[idx];
             double f, b;
-            if (!aabb(p.box_lower, p.box_upper, r, f, b)) continue;          // BoundPrimitive.hit gate
+            if (!aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b)) continue;   // BoundPrimitive.hit gate
             Hit cand;
             primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
@@ -805,9 +1011,64 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, Stack st, NodeSt *cs
         if (sp == 0) return false;
         --sp;
         tmin = tmax;
-        tmax = st.t[sp * WAVE];
-        node = st.id[sp * WAVE];
+        stack_pop(st, sp, node, tmax);
     }
+}
+
+// Wave-cooperative World.hit: same result as world_trace, but every lane of the wave calls it together (`valid` = lane has a
+// ray) and all loops are wave-uniform, so that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves).
+template <bool CSG>
+__device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best) {
+    best.prim = -1;
+    double tmin = 0, tmax = 0;
+    const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
+    bool active = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
+    int32_t node = 0, sp = 0;
+    while (__any(active)) {
+        double distance = 0;
+        int32_t count = 0;
+        const int32_t *items = sc.witems;
+        if (active) {
+            rsx_kdnode nd = load_node(sc.wnodes, node);
+            while (nd.type >= 0) {
+                const int axis = nd.type;
+                node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+                nd = load_node(sc.wnodes, node);
+            }
+            distance = r.maxd < tmax ? r.maxd : tmax;
+            items += nd.u.leaf.first_item;
+            count = nd.count;
+        }
+        for (int32_t k = 0; __any(k < count); ++k) {
+            const bool have = k < count;
+            const int32_t idx = have ? items[k] : 0;
+            const rsx_primitive &p = sc.prims[idx];
+            double f, b;
+            const bool gate = have && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
+            Hit cand;
+            cand.prim = -1;
+            if (__any(is_mesh)) {
+                Ray l = r;
+                if (is_mesh) l = to_local(p, r);
+                MeshHit mh;
+                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh)) {
+                    cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
+                }
+            }
+            if (gate && !is_mesh) primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
+            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
+        }
+        if (active) {
+            if (best.prim >= 0 || sp == 0) active = false;
+            else {
+                --sp;
+                tmin = tmax;
+                stack_pop(st, sp, node, tmax);
+            }
+        }
+    }
+    return best.prim >= 0;
 }
 
 template <bool CSG>
@@ -826,13 +1087,21 @@ __device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) 
 // ---------------------------------------------------------------------------------------------------
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-__device__ __forceinline__ Stack lane_stack(int levels) {
+// carve the wave's LDS region and global spill region into the world stack and the mesh stack
+__device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &ms) {
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
-    char *base = smem + (size_t)wave * levels * WAVE * 12;
-    Stack st;
-    st.t = reinterpret_cast<double *>(base) + lane;
-    st.id = reinterpret_cast<int32_t *>(base + (size_t)levels * WAVE * 8) + lane;
-    return st;
+    const int lds_levels = sc.wlds + sc.mlds;
+    char *base = smem + (size_t)wave * lds_levels * WAVE * 12;
+    double *t = reinterpret_cast<double *>(base) + lane;
+    int32_t *id = reinterpret_cast<int32_t *>(base + (size_t)lds_levels * WAVE * 8) + lane;
+    const int spill_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
+    const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
+    char *gbase = sc.spill + gwave * (size_t)(spill_levels > 0 ? spill_levels : 1) * WAVE * 12;
+    double *gt = reinterpret_cast<double *>(gbase) + lane;
+    int32_t *gid = reinterpret_cast<int32_t *>(gbase + (size_t)spill_levels * WAVE * 8) + lane;
+    ws.t = t; ws.id = id; ws.gt = gt; ws.gid = gid; ws.lds_levels = sc.wlds;
+    ms.t = t + sc.wlds * WAVE; ms.id = id + sc.wlds * WAVE;
+    ms.gt = gt + (sc.wdepth - sc.wlds) * WAVE; ms.gid = gid + (sc.wdepth - sc.wlds) * WAVE; ms.lds_levels = sc.mlds;
 }
 
 // wave-level ticket: lane 0 takes the next batch of 64 work items
@@ -847,22 +1116,31 @@ struct HitOut {
 };
 
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
+__global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
                                                           const double *maxd, HitOut out, unsigned long long *ticket) {
-    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
     for (;;) {
         const long long base = next_batch(ticket);
         if (base >= n) break;
         const long long i = base + lane;
-        if (i >= n) continue;
+        const bool valid = i < n;               // lanes without a ray still walk the loops: they help on big mesh leaves
         Ray r;
-        r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
-        r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
-        r.maxd = maxd[i];
+        r.ox = r.oy = r.oz = 0.0; r.dx = r.dy = 0.0; r.dz = 1.0; r.maxd = 0.0;
+        if (valid) {
+            r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
+            r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
+            r.maxd = maxd[i];
+        }
         Hit h;
-        const bool hit = world_trace<CSG>(sc, r, st, csg_state, h);
+#if RSX_WAVE_COOP
+        const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h);
+#else
+        const bool hit = valid && world_trace<CSG>(sc, r, st, ms, csg_state, h);
+#endif
+        if (!valid) continue;
         out.prim[i] = hit ? h.prim : -1;
         if (out.t) out.t[i] = hit ? h.t : NAN;
         bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
@@ -892,7 +1170,8 @@ template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, long long n, const double *origin, const double *direction,
                                                       const double *maxd, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
                                                       unsigned long long *ticket) {
-    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     const rsx_primitive &p = sc.prims[pidx];
     NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
@@ -911,8 +1190,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
             if constexpr (CSG) {
                 CsgEval e;
                 e.sc = &sc; e.st = csg_state;
-                e.mesh_stack.t = st.t + sc.wdepth * WAVE;
-                e.mesh_stack.id = st.id + sc.wdepth * WAVE;
+                e.mesh_stack = ms;
                 Rec rec;
                 csg_first<CSG_MAX_DEPTH>(e, pidx, r, rec);
                 while ((rec.flags & F_VALID) && c < max_roots) {
@@ -926,9 +1204,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
             const DMesh &m = sc.meshes[p.mesh];
             double accumulated = 0;
             MeshHit mh;
-            Stack ms;
-            ms.t = st.t + sc.wdepth * WAVE;
-            ms.id = st.id + sc.wdepth * WAVE;
             while (c < max_roots && mesh_trace(m, l, ms, mh)) {
                 Geom g;
                 mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
@@ -963,7 +1238,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
 template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n, const double *points, uint8_t *inside,
                                                          unsigned long long *ticket) {
-    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     for (;;) {
         const long long base = next_batch(ticket);
@@ -982,9 +1258,6 @@ __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n,
         for (int32_t k = 0; k < nd.count; ++k) {
             const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
             const rsx_primitive &p = sc.prims[idx];
-            Stack ms;
-            ms.t = st.t + sc.wdepth * WAVE;
-            ms.id = st.id + sc.wdepth * WAVE;
             bool in;
             if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);   // BoundPrimitive.contains: box gate first
             else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
@@ -1037,8 +1310,9 @@ __device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, 
 // Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
 // 64 rays stay coherent; in task-list mode 64 consecutive tasks.
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
-    const Stack st = lane_stack(sc.wdepth + sc.mdepth);
+__global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
     const long long total = rp.n_tasks * rp.spp;
@@ -1050,18 +1324,19 @@ __global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderPa
         if (unit >= n_units) break;
         const int s = (int)(unit % rp.spp);
         const long long chunk = unit / rp.spp;
-        long long k;
-        int ix, iy;
+        long long k = 0;
+        int ix = 0, iy = 0;
+        bool valid;
         if (rp.tasks) {
             k = chunk * 64 + lane;
-            if (k >= rp.n_tasks) continue;
-            task_pixel(rp, k, ix, iy);
+            valid = k < rp.n_tasks;
+            if (valid) task_pixel(rp, k, ix, iy); else k = 0;
         } else {
             const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
             const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
-            if (lx >= w || ly >= h) continue;
-            ix = rp.rect[0] + lx; iy = rp.rect[1] + ly;
-            k = (long long)ly * w + lx;
+            valid = lx < w && ly < h;
+            ix = rp.rect[0] + (valid ? lx : 0); iy = rp.rect[1] + (valid ? ly : 0);
+            k = valid ? (long long)ly * w + lx : 0;
         }
         (void)total;
         // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
@@ -1082,7 +1357,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_render_trace(DScene sc, RenderPa
         Hit hit;
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
-        if (world_trace<CSG>(sc, r, st, csg_state, hit)) {                    // optical/ray.pyx:391-393
+#if RSX_WAVE_COOP
+        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit);
+#else
+        const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
+#endif
+        if (!valid) continue;
+        if (got) {                                                                 // optical/ray.pyx:391-393
             const rsx_primitive &p = sc.prims[hit.prim];
             const rsx_material mat = rp.materials[p.material];
             if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
@@ -1213,6 +1494,8 @@ struct rsx_ctx {
     // ring of per-render-call event triples so a caller can time K back-to-back async renders without syncing
     std::vector<hipEvent_t> ring;      // 3 events per slot
     long long render_calls;
+    void *spill;                       // global spill regions for the traversal stacks
+    size_t spill_bytes;
     bool ticket_armed;                 // ticket is known to be zero on the stream (left so by k_accumulate)
     std::vector<unsigned char> shadow[3];   // host copies of what POOL_MATERIALS / POOL_TABLES / POOL_TASKS hold
     // grow-only device workspace so steady-state render calls never hipMalloc
@@ -1258,6 +1541,8 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     ctx->have_accum = false;
     ctx->render_calls = 0;
     ctx->ticket_armed = false;
+    ctx->spill = nullptr;
+    ctx->spill_bytes = 0;
     for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
@@ -1274,6 +1559,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(ctx->ticket);
+    if (ctx->spill) (void)hipFree(ctx->spill);
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -1526,6 +1812,8 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
+    d.wlds = std::min(d.wdepth, RSX_WORLD_LDS_LEVELS);
+    d.mlds = std::min(d.mdepth, RSX_MESH_LDS_LEVELS);
 #undef UP
     *out = sc;
     return RSX_OK;
@@ -1540,17 +1828,27 @@ struct Launch {
 };
 
 // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stacks allow
-int plan(const rsx_scene *sc, long long work_items, Launch &l) {
-    const int levels = sc->d.wdepth + sc->d.mdepth;
-    l.lds = (size_t)WG_WAVES * levels * WAVE * 12;
-    if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "KD-tree too deep for the LDS traversal stack (%d levels)", levels);
-    int per_cu = (int)std::min<size_t>(8, (160 * 1024) / std::max<size_t>(l.lds, 1));
+int plan(rsx_scene *sc, long long work_items, Launch &l) {
+    const int lds_levels = sc->d.wlds + sc->d.mlds;
+    l.lds = (size_t)WG_WAVES * lds_levels * WAVE * 12;
+    if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "traversal stack does not fit LDS (%d levels)", lds_levels);
+    int per_cu = (int)std::min<size_t>(RSX_MAX_WG_PER_CU, (160 * 1024) / std::max<size_t>(l.lds, 1));
     if (per_cu < 1) per_cu = 1;
     long long wgs = (long long)sc->ctx->n_cus * per_cu;
     const long long needed = (work_items + WG_THREADS - 1) / WG_THREADS;
     if (wgs > needed) wgs = needed;
     if (wgs < 1) wgs = 1;
     l.grid = dim3((unsigned)wgs);
+    // global spill regions: one per wave of the largest grid this ctx launches
+    const int spill_levels = std::max(1, (sc->d.wdepth - sc->d.wlds) + (sc->d.mdepth - sc->d.mlds));
+    const size_t need = (size_t)sc->ctx->n_cus * RSX_MAX_WG_PER_CU * WG_WAVES * spill_levels * WAVE * 12;
+    rsx_ctx *ctx = sc->ctx;
+    if (need > ctx->spill_bytes) {
+        if (ctx->spill) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->spill)); ctx->spill = nullptr; ctx->spill_bytes = 0; }
+        HIP_TRY(hipMalloc(&ctx->spill, need));
+        ctx->spill_bytes = need;
+    }
+    sc->d.spill = static_cast<char *>(ctx->spill);
     return RSX_OK;
 }
 

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Kernel iteration harness (GPU box): renders BASELINE configs[1] K times with the library named by $RSX_LIB and prints the
+per-launch kernel times plus a SHA-256 of the resulting frame (any variant must reproduce the same digest)."""
+import hashlib
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from source_amd import api as ns, scenes  # noqa: E402
+from source_amd.device import get_context  # noqa: E402
+
+steps = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+config = sys.argv[2] if len(sys.argv) > 2 else "c2"
+if config == "c2":
+    world = scenes.build_c2(ns, n=132)[0]
+    cam, pipe = scenes.c2_camera(ns, world, (1024, 1024), spp=1, bins=15)
+elif config == "c3":
+    world = scenes.build_c3(ns, n=132)[0]
+    cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=4, bins=15)
+elif config == "csg":
+    world = scenes.build_csg_demo(ns)[0]
+    cam, pipe = scenes.csg_camera(ns, world, (1024, 1024), spp=1, bins=15)
+cam.frame_sampler = ns.RectFrameSampler2D()
+eng = ns.HipEngine(rng="philox", seed=20250905, timing=False)
+cam.render_engine = eng
+ctx = get_context()
+world.build_accelerator()
+for k in range(3 + steps):
+    eng.sample_offset = k * cam.pixel_samples
+    cam.observe()
+tr, ac = ctx.render_history(steps)
+mean = pipe.frame.mean
+digest = hashlib.sha256(np.ascontiguousarray(mean).tobytes()).hexdigest()[:16]
+print(json.dumps({"lib": os.path.basename(os.environ.get("RSX_LIB", "librsx.so")), "config": config,
+                  "trace_ms": round(float(np.mean(tr)), 4), "trace_min": round(float(np.min(tr)), 4), "trace_max": round(float(np.max(tr)), 4),
+                  "accum_ms": round(float(np.mean(ac)), 4), "digest": digest}))
