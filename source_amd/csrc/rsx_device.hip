@@ -42,6 +42,7 @@
 #ifndef RSX_MAX_WG_PER_CU
 #define RSX_MAX_WG_PER_CU 8
 #endif
+#define STAGE_BYTES (WAVE * 52)     // per-wave leaf staging area: 64 x (48-byte triangle record + 4-byte id)
 #ifndef RSX_WAVE_COOP
 #define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
 #endif
@@ -128,6 +129,7 @@ struct Stack {
     double *gt;                // spill gt[(level - lds_levels) * WAVE]
     int32_t *gid;
     int32_t lds_levels;
+    float4 *stage;             // per-wave LDS staging area: WAVE triangle records (3 x float4) + WAVE triangle ids
 };
 
 __device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
@@ -239,14 +241,62 @@ __device__ __forceinline__ rsx_kdnode load_node(const rsx_kdnode *nodes, int32_t
     return nd;
 }
 
+// Correctly rounded n / d with the d-only part of the division hoisted out of the traversal loop.
+// hipcc expands an IEEE f64 division into v_div_scale, v_rcp_f64, two Newton steps on the reciprocal, q0 = n*y,
+// r = fma(-d, q0, n), v_div_fmas (= fma(r, y, q0) when no scaling is in effect) and v_div_fixup. The reciprocal refinement
+// depends on d alone, and a ray divides by the same three direction components at every KD node, so it is computed once per ray
+// space (refine_rcp) and the per-node work shrinks to mul + 2 fma. The shortcut is taken only when neither operand is anywhere
+// near the exponent ranges where v_div_scale / v_div_fixup intervene; otherwise the plain division runs. tests/test_gpu_parity.py
+// (test_exact_division) checks bit equality against `/` on the device over 2^28 operand pairs including exact and near-tie cases.
+#ifndef RSX_FAST_DIV
+#define RSX_FAST_DIV 1
+#endif
+
+__device__ __forceinline__ double refine_rcp(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double f0 = __builtin_fma(-d, r, 1.0);
+    const double y1 = __builtin_fma(r, f0, r);
+    const double f2 = __builtin_fma(-d, y1, 1.0);
+    return __builtin_fma(y1, f2, y1);
+}
+
+__device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in [2^-300, 2^300]
+    const int e = (int)((__double_as_longlong(x) >> 52) & 0x7ff);
+    return e > 1023 - 300 && e < 1023 + 300;
+}
+
+__device__ __forceinline__ double exact_div(double n, double d, double y, bool d_safe) {
+#if RSX_FAST_DIV
+    if (d_safe && div_operand_safe(n)) {
+        const double q0 = n * y;
+        const double r = __builtin_fma(-d, q0, n);
+        return __builtin_fma(r, y, q0);
+    }
+    if (d_safe && n == 0.0) return n * y;          // signed zero with the quotient's sign (the correction step would lose it)
+#endif
+    return n / d;
+}
+
+struct AxisDiv {               // per ray space: refined reciprocals of the three direction components
+    double yx, yy, yz;
+    int safe;                  // bit k: component k may take the shortcut
+};
+
+__device__ __forceinline__ AxisDiv axis_div(const Ray &r) {
+    AxisDiv a;
+    a.yx = refine_rcp(r.dx); a.yy = refine_rcp(r.dy); a.yz = refine_rcp(r.dz);
+    a.safe = (div_operand_safe(r.dx) ? 1 : 0) | (div_operand_safe(r.dy) ? 2 : 0) | (div_operand_safe(r.dz) ? 4 : 0);
+    return a;
+}
+
 // One KD branch step — KDTree3DCore._trace_branch, core/math/spatial/kdtree3d.pyx:626-700.
 // Returns the next node; pushes (far, tmax) when both children are crossed.
-__device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t node, double o, double d, double tmin, double &tmax,
-                                               Stack st, int32_t &sp) {
+__device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t node, double o, double d, double y, bool d_safe, double tmin,
+                                               double &tmax, const Stack &st, int32_t &sp) {
     const double split = nd.u.split;
     const int32_t lower = node + 1, upper = nd.count;
     if (d == 0) return o < split ? lower : upper;
-    const double plane = (split - o) / d;
+    const double plane = exact_div(split - o, d, y, d_safe);
     const bool below = o < split || (o == split && d < 0);
     const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
     if (plane > tmax || plane <= 0) return near_id;
@@ -255,6 +305,22 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
     ++sp;
     tmax = plane;
     return near_id;
+}
+
+// Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
+// pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
+__device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
+                                              const Stack &st, int32_t &sp) {
+    rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
+    while (nd.type >= 0) {
+        const int axis = nd.type;
+        const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
+                                         (ad.safe >> axis) & 1, tmin, tmax, st, sp);
+        if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
+        nx = load_node(nodes, next + 1);
+        node = next;
+    }
+    return nd;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -326,15 +392,11 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
     double tmin, tmax;
     if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
     const TriRay q = tri_ray(r);
+    const AxisDiv ad = axis_div(r);
 
     int32_t node = 0, sp = 0;
     for (;;) {
-        rsx_kdnode nd = load_node(m.nodes, node);
-        while (nd.type >= 0) {
-            const int axis = nd.type;
-            node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
-            nd = load_node(m.nodes, node);
-        }
+        const rsx_kdnode nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
         // _trace_leaf, mesh.pyx:520-563 — items are tested in leaf order, strict `<` keeps the first of equal distances
         double distance = r.maxd < tmax ? r.maxd : tmax;
         int32_t closest = -1;
@@ -367,6 +429,9 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
     }
 }
 
+#ifndef RSX_STAGE_MIN
+#define RSX_STAGE_MIN 4            // >= this many rays of the wave in the same big leaf: stage the leaf through LDS instead
+#endif
 #ifndef RSX_COOP_LEAF
 #define RSX_COOP_LEAF 24           // leaves with at least this many triangles are tested by the whole wave for one ray at a time
 #endif
@@ -384,6 +449,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
     double tmin = 0, tmax = 0;
     bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
     const TriRay q = tri_ray(r);
+    const AxisDiv ad = axis_div(r);
     bool hit = false;
     int32_t node = 0, sp = 0;
     while (__any(active)) {
@@ -391,12 +457,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
         int32_t closest = -1, count = 0, first = 0;
         float bu = 0, bv = 0, bw = 0;
         if (active) {
-            rsx_kdnode nd = load_node(m.nodes, node);
-            while (nd.type >= 0) {
-                const int axis = nd.type;
-                node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
-                nd = load_node(m.nodes, node);
-            }
+            const rsx_kdnode nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
             distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
             count = nd.count;
             first = nd.u.leaf.first_item;
@@ -422,48 +483,87 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 }
             }
         }
-        // ---- cooperative stage: one big leaf (one ray) at a time, all 64 lanes testing
+        // ---- cooperative stage for big leaves
         unsigned long long big = __ballot(active && count >= RSX_COOP_LEAF);
         while (big) {
             const int leader = __ffsll((long long)big) - 1;
-            big &= big - 1;
-            TriRay lq;
-            lq.ox = shfl_f64(q.ox, leader); lq.oy = shfl_f64(q.oy, leader); lq.oz = shfl_f64(q.oz, leader);
-            lq.maxd = shfl_f64(q.maxd, leader);
-            lq.sx = __shfl(q.sx, leader, WAVE); lq.sy = __shfl(q.sy, leader, WAVE); lq.sz = __shfl(q.sz, leader, WAVE);
-            const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), leader, WAVE);
-            lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
-            const double limit = shfl_f64(distance, leader);
             const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
             const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris;
-            const int32_t *litems = (const int32_t *)(((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
-                                                      (unsigned)__shfl((int)items_bits, leader, WAVE)) + lfirst;
+            const unsigned long long l_items_bits = ((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
+                                                    (unsigned)__shfl((int)items_bits, leader, WAVE);
+            const int32_t *litems = (const int32_t *)l_items_bits + lfirst;
             const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
                                                    (unsigned)__shfl((int)tris_bits, leader, WAVE));
-            // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
-            float mt = INFINITY, mu = 0, mv = 0, mw = 0;
-            int32_t mk = 0x7fffffff, mtri = -1;
-            for (int32_t k = lane; k < lcount; k += WAVE) {
-                const int32_t tri = litems[k];
-                const float4 *rec = ltris + 3 * (size_t)tri;
-                const float4 a = rec[0], b = rec[1], c = rec[2];
-                float ht, hu, hv, hw;
-                if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
+            // lanes whose ray sits in the same leaf as the leader's
+            const bool same = active && count >= RSX_COOP_LEAF && first == lfirst && items_bits == l_items_bits;
+            const unsigned long long group = __ballot(same);
+            big &= ~group;
+            if (__popcll(group) >= RSX_STAGE_MIN) {
+                // (a) coherent rays: stage the leaf through LDS 64 triangles at a time; every lane of the group tests them all,
+                //     in leaf order (the reference's own loop), reading each record as an LDS broadcast
+                float4 *rec = st.stage;
+                int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
+                for (int32_t c = 0; c < lcount; c += WAVE) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int32_t k = c + lane;
+                    if (k < lcount) {
+                        const int32_t tri = litems[k];
+                        const float4 *src = ltris + 3 * (size_t)tri;
+                        rec[3 * lane] = src[0]; rec[3 * lane + 1] = src[1]; rec[3 * lane + 2] = src[2];
+                        ids[lane] = tri;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (same) {
+                        const int32_t nj = lcount - c < WAVE ? lcount - c : WAVE;
+                        for (int32_t j = 0; j < nj; ++j) {
+                            float ht, hu, hv, hw;
+                            if (tri_test(q, rec[3 * j], rec[3 * j + 1], rec[3 * j + 2], ht, hu, hv, hw) && (double)ht < distance) {
+                                distance = (double)ht; closest = ids[j]; bu = hu; bv = hv; bw = hw;
+                            }
+                        }
+                    }
+                }
+                continue;
             }
-            // wave-wide lexicographic min of (t, position)
-            float wt = mt;
-            int32_t wk = mk;
+            // (b) isolated rays: one ray at a time, all 64 lanes testing 64 triangles per step
+            unsigned long long todo = group;
+            while (todo) {
+                const int owner = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                TriRay lq;
+                lq.ox = shfl_f64(q.ox, owner); lq.oy = shfl_f64(q.oy, owner); lq.oz = shfl_f64(q.oz, owner);
+                lq.maxd = shfl_f64(q.maxd, owner);
+                lq.sx = __shfl(q.sx, owner, WAVE); lq.sy = __shfl(q.sy, owner, WAVE); lq.sz = __shfl(q.sz, owner, WAVE);
+                const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), owner, WAVE);
+                lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
+                const double limit = shfl_f64(distance, owner);
+                // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
+                float mt = INFINITY, mu = 0, mv = 0, mw = 0;
+                int32_t mk = 0x7fffffff, mtri = -1;
+                for (int32_t k = lane; k < lcount; k += WAVE) {
+                    const int32_t tri = litems[k];
+                    const float4 *src = ltris + 3 * (size_t)tri;
+                    const float4 a = src[0], b = src[1], c = src[2];
+                    float ht, hu, hv, hw;
+                    if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
+                }
+                // wave-wide lexicographic min of (t, position) == the reference's sequential scan with strict `<`
+                float wt = mt;
+                int32_t wk = mk;
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const float ot = __shfl_xor(wt, off, WAVE);
-                const int32_t ok = __shfl_xor(wk, off, WAVE);
-                if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ot = __shfl_xor(wt, off, WAVE);
+                    const int32_t ok = __shfl_xor(wk, off, WAVE);
+                    if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
+                }
+                const int winner = wk & (WAVE - 1);              // position k was scanned by lane k % 64
+                const bool found = wk != 0x7fffffff;
+                const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
+                const int32_t rtri = __shfl(mtri, winner, WAVE);
+                if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
             }
-            const int winner = wk & (WAVE - 1);              // position k was scanned by lane k % 64
-            const bool found = wk != 0x7fffffff;
-            const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
-            const int32_t rtri = __shfl(mtri, winner, WAVE);
-            if (lane == leader && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
         }
         if (active) {
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
@@ -988,14 +1088,10 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, const Stack &st, con
     double tmin, tmax;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;      // shared by the world box and every primitive box gate
     if (!aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax)) return false;
+    const AxisDiv ad = axis_div(r);
     int32_t node = 0, sp = 0;
     for (;;) {
-        rsx_kdnode nd = load_node(sc.wnodes, node);
-        while (nd.type >= 0) {
-            const int axis = nd.type;
-            node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
-            nd = load_node(sc.wnodes, node);
-        }
+        const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
         double distance = r.maxd < tmax ? r.maxd : tmax;
         const int32_t *items = sc.witems + nd.u.leaf.first_item;
         for (int32_t k = 0; k < nd.count; ++k) {
@@ -1023,18 +1119,14 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
     bool active = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
+    const AxisDiv ad = axis_div(r);
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
         int32_t count = 0;
         const int32_t *items = sc.witems;
         if (active) {
-            rsx_kdnode nd = load_node(sc.wnodes, node);
-            while (nd.type >= 0) {
-                const int axis = nd.type;
-                node = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
-                nd = load_node(sc.wnodes, node);
-            }
+            const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;
             count = nd.count;
@@ -1091,7 +1183,7 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 __device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &ms) {
     const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
     const int lds_levels = sc.wlds + sc.mlds;
-    char *base = smem + (size_t)wave * lds_levels * WAVE * 12;
+    char *base = smem + (size_t)wave * ((size_t)lds_levels * WAVE * 12 + STAGE_BYTES);
     double *t = reinterpret_cast<double *>(base) + lane;
     int32_t *id = reinterpret_cast<int32_t *>(base + (size_t)lds_levels * WAVE * 8) + lane;
     const int spill_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
@@ -1099,6 +1191,8 @@ __device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &
     char *gbase = sc.spill + gwave * (size_t)(spill_levels > 0 ? spill_levels : 1) * WAVE * 12;
     double *gt = reinterpret_cast<double *>(gbase) + lane;
     int32_t *gid = reinterpret_cast<int32_t *>(gbase + (size_t)spill_levels * WAVE * 8) + lane;
+    float4 *stage = reinterpret_cast<float4 *>(base + (size_t)lds_levels * WAVE * 12);
+    ws.stage = stage; ms.stage = stage;
     ws.t = t; ws.id = id; ws.gt = gt; ws.gid = gid; ws.lds_levels = sc.wlds;
     ms.t = t + sc.wlds * WAVE; ms.id = id + sc.wlds * WAVE;
     ms.gt = gt + (sc.wdepth - sc.wlds) * WAVE; ms.gid = gid + (sc.wdepth - sc.wlds) * WAVE; ms.lds_levels = sc.mlds;
@@ -1294,6 +1388,7 @@ struct RenderParams {
     int32_t rect[4];
     int32_t spp, rng_mode;
     uint64_t seed, sample_offset;
+    unsigned long long *unit_times;   // optional [n_units,3]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
 };
 
 // per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
@@ -1324,6 +1419,7 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
         if (unit >= n_units) break;
         const int s = (int)(unit % rp.spp);
         const long long chunk = unit / rp.spp;
+        const unsigned long long t_start = rp.unit_times ? wall_clock64() : 0ULL;
         long long k = 0;
         int ix = 0, iy = 0;
         bool valid;
@@ -1362,6 +1458,11 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
 #else
         const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
 #endif
+        if (rp.unit_times && lane == 0) {
+            rp.unit_times[3 * unit] = t_start;
+            rp.unit_times[3 * unit + 1] = wall_clock64();
+            rp.unit_times[3 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
+        }
         if (!valid) continue;
         if (got) {                                                                 // optical/ray.pyx:391-393
             const rsx_primitive &p = sc.prims[hit.prim];
@@ -1381,6 +1482,35 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
         }
         samples[k * rp.spp + s] = smp;
     }
+}
+
+// Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.
+__global__ void k_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long *mismatches) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long i = gid; i < n; i += stride) {
+        double u1, u2;
+        philox2(seed, i, 0, u1, u2);
+        double a, b;
+        philox2(seed, i, 1, a, b);
+        double num, den;
+        switch (i & 7) {
+        case 0: num = (u1 - 0.5) * 4.0; den = (u2 - 0.5) * 2.0; break;                      // plane distances: (split - o) / d
+        case 1: num = ldexp(u1 - 0.5, (int)(a * 120) - 60); den = ldexp(u2 - 0.5, (int)(b * 120) - 60); break;
+        case 2: den = (u2 - 0.5) * 2.0; num = den * (double)(long long)(u1 * 4096.0 - 2048.0); break;   // exact quotients
+        case 3: den = 1.0 + u2 * 0x1p-30; num = 1.0 + u1 * 0x1p-30; break;                 // quotients hugging 1 (near ties)
+        case 4: den = (double)(1 + (long long)(u2 * 1e6)); num = (double)(long long)(u1 * 2e6 - 1e6); break;   // small integers
+        case 5: num = ldexp(u1 - 0.5, (int)(a * 1200) - 600); den = ldexp(u2 - 0.5, (int)(b * 1200) - 600); break;   // wide exponents (guard path)
+        case 6: num = (i & 8) ? 0.0 : -0.0; den = (u2 - 0.5); break;                        // zero numerators
+        default: den = u2 * 1e-3 + 1e-300 * a; num = u1 - 0.5; break;                       // tiny denominators
+        }
+        if (den == 0.0) continue;
+        const double want = num / den;
+        const double got = exact_div(num, den, refine_rcp(den), div_operand_safe(den));
+        if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
+    }
+    if (bad) atomicAdd(mismatches, bad);
 }
 
 // StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859
@@ -1496,6 +1626,7 @@ struct rsx_ctx {
     long long render_calls;
     void *spill;                       // global spill regions for the traversal stacks
     size_t spill_bytes;
+    unsigned long long *unit_times;    // debug: per-unit timestamps of the next render calls (caller-owned device buffer)
     bool ticket_armed;                 // ticket is known to be zero on the stream (left so by k_accumulate)
     std::vector<unsigned char> shadow[3];   // host copies of what POOL_MATERIALS / POOL_TABLES / POOL_TASKS hold
     // grow-only device workspace so steady-state render calls never hipMalloc
@@ -1541,6 +1672,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     ctx->have_accum = false;
     ctx->render_calls = 0;
     ctx->ticket_armed = false;
+    ctx->unit_times = nullptr;
     ctx->spill = nullptr;
     ctx->spill_bytes = 0;
     for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
@@ -1615,6 +1747,29 @@ extern "C" int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, floa
     return RSX_OK;
 }
 
+extern "C" int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches) {
+    if (!ctx || !mismatches) return rsx_fail(RSX_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long *d = nullptr;
+    HIP_TRY(hipMalloc(&d, 9 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemsetAsync(d, 0, 9 * sizeof(unsigned long long), ctx->stream));
+    hipLaunchKernelGGL(k_selftest_division, dim3(ctx->n_cus * 8), dim3(256), 0, ctx->stream, (unsigned long long)n, (unsigned long long)seed, d);
+    HIP_TRY(hipGetLastError());
+    unsigned long long h[9] = {0};
+    HIP_TRY(hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    HIP_TRY(hipFree(d));
+    *mismatches = h[0];
+    if (h[0]) rsx_fail(RSX_OK, "exact_div mismatches by class: %llu %llu %llu %llu %llu %llu %llu %llu", h[1], h[2], h[3], h[4], h[5], h[6], h[7], h[8]);
+    return RSX_OK;
+}
+
+extern "C" int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    ctx->unit_times = static_cast<unsigned long long *>(dev_buffer);
+    return RSX_OK;
+}
+
 extern "C" int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return rsx_fail(RSX_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -1659,8 +1814,9 @@ namespace {
 template <typename T>
 int upload(rsx_scene *sc, const T *host, size_t count, const T **dev) {
     void *d = nullptr;
-    const size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    const size_t bytes = std::max<size_t>(count * sizeof(T), 16) + 64;   // slack: traversal reads node pairs (id, id+1)
     HIP_TRY(hipMalloc(&d, bytes));
+    HIP_TRY(hipMemset(d, 0, bytes));
     sc->allocs.push_back(d);
     if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
     *dev = static_cast<const T *>(d);
@@ -1830,7 +1986,7 @@ struct Launch {
 // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stacks allow
 int plan(rsx_scene *sc, long long work_items, Launch &l) {
     const int lds_levels = sc->d.wlds + sc->d.mlds;
-    l.lds = (size_t)WG_WAVES * lds_levels * WAVE * 12;
+    l.lds = (size_t)WG_WAVES * ((size_t)lds_levels * WAVE * 12 + STAGE_BYTES);
     if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "traversal stack does not fit LDS (%d levels)", lds_levels);
     int per_cu = (int)std::min<size_t>(RSX_MAX_WG_PER_CU, (160 * 1024) / std::max<size_t>(l.lds, 1));
     if (per_cu < 1) per_cu = 1;
@@ -2038,6 +2194,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.rng_mode = desc->rng_mode;
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
+    rp.unit_times = ctx->unit_times;
 
     Launch l;
     if ((rc = plan(scene, (long long)S, l))) return rc;
