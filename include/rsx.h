@@ -170,7 +170,8 @@ int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumula
  * over n pseudo-random / adversarial operand pairs. */
 int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches);
 /* Tuning aid: when dev_buffer != NULL the next render calls write, per 64-ray work unit, {start, end} wall_clock64 ticks
- * (100 MHz) and the (workgroup << 8 | wave) that processed it into dev_buffer[n_units][3] (u64). NULL switches it off. */
+ * (100 MHz) and the (workgroup << 8 | wave) that processed it into dev_buffer[n_units][12] (u64; slots 3.. are per-phase
+ * cycle counters in RSX_PHASE_PROF builds). NULL switches it off. */
 int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer);
 /* Device allocation helpers so non-torch callers can keep frames resident in HBM. */
 int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr);

@@ -43,6 +43,13 @@
 #define RSX_MAX_WG_PER_CU 8
 #endif
 #define STAGE_BYTES (WAVE * 52)     // per-wave leaf staging area: 64 x (48-byte triangle record + 4-byte id)
+#define RSX_MAX_LANES 4
+#ifndef RSX_RENDER_WG_PER_CU
+#define RSX_RENDER_WG_PER_CU 1
+#endif
+#ifndef RSX_LPT_SCHEDULE
+#define RSX_LPT_SCHEDULE 1          // reorder the 64-ray units of a repeated pass longest-first using the previous pass's timings
+#endif
 #ifndef RSX_WAVE_COOP
 #define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
 #endif
@@ -81,6 +88,8 @@ struct DMesh {
     const rsx_kdnode *nodes;
     const int32_t *items;
     const float4 *tris;        // 3 x float4 per triangle: v1.xyz v2.x | v2.yz v3.xy | v3.z fn.xyz
+    const float4 *leaf;        // 4 x float4 per LEAF ITEM, in items[] order: the 3 above + (triangle id, -, -, -): one 64-byte line per
+                               // test, no id->record indirection, big leaves stream as contiguous memory
     const float *vnormals;     // [nn,3] or null
     const int32_t *nidx;       // [nt,3] vertex-normal indices or null
     double lower[3], upper[3];
@@ -384,6 +393,24 @@ __device__ __forceinline__ bool tri_test(const TriRay &q, const float4 q0, const
     return true;
 }
 
+#ifndef RSX_LEAF_INLINE
+#define RSX_LEAF_INLINE 1          // 1: leaves read 64-byte leaf-ordered triangle records; 0: items[] -> 48-byte records by id
+#endif
+
+// fetch leaf item `pos` (absolute position in items[]): its triangle id and 48-byte record
+__device__ __forceinline__ void leaf_fetch(const int32_t *items, const float4 *tris, const float4 *leaf, int32_t pos, int32_t &tri, float4 &a,
+                                           float4 &b, float4 &c) {
+#if RSX_LEAF_INLINE
+    const float4 *rec = leaf + 4 * (size_t)pos;
+    a = rec[0]; b = rec[1]; c = rec[2];
+    tri = __float_as_int(rec[3].x);
+#else
+    tri = items[pos];
+    const float4 *rec = tris + 3 * (size_t)tri;
+    a = rec[0]; b = rec[1]; c = rec[2];
+#endif
+}
+
 #ifndef RSX_LEAF_BATCH
 #define RSX_LEAF_BATCH 4           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
 #endif
@@ -401,18 +428,14 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
         double distance = r.maxd < tmax ? r.maxd : tmax;
         int32_t closest = -1;
         float bu = 0, bv = 0, bw = 0;
-        const int32_t *items = m.items + nd.u.leaf.first_item;
+        const int32_t first = nd.u.leaf.first_item;
         const int32_t count = nd.count;
         for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
             int32_t tri[RSX_LEAF_BATCH];
             float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
 #pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j) tri[j] = items[k + j < count ? k + j : count - 1];
-#pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
-                const float4 *rec = m.tris + 3 * (size_t)tri[j];
-                t0[j] = rec[0]; t1[j] = rec[1]; t2[j] = rec[2];
-            }
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                leaf_fetch(m.items, m.tris, m.leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
 #pragma unroll
             for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
                 float ht, hu, hv, hw;
@@ -432,6 +455,17 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
 #ifndef RSX_STAGE_MIN
 #define RSX_STAGE_MIN 4            // >= this many rays of the wave in the same big leaf: stage the leaf through LDS instead
 #endif
+#ifndef RSX_PHASE_PROF
+#define RSX_PHASE_PROF 0           // 1: accumulate per-phase s_memtime cycles of the wave-cooperative mesh traversal (tuning builds only)
+#endif
+#if RSX_PHASE_PROF
+__device__ unsigned long long g_phase[8][64];   // unused placeholder to keep the symbol set stable
+#define PHASE_DECL unsigned long long ph_t = clock64();
+#define PHASE_ADD(slot) { const unsigned long long now_ = clock64(); phase_acc[slot] += now_ - ph_t; ph_t = now_; }
+#else
+#define PHASE_DECL
+#define PHASE_ADD(slot)
+#endif
 #ifndef RSX_COOP_LEAF
 #define RSX_COOP_LEAF 24           // leaves with at least this many triangles are tested by the whole wave for one ray at a time
 #endif
@@ -444,8 +478,9 @@ __device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x
 // ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic wave-min, which is exactly what the
 // reference's sequential scan with strict `<` returns (the first item among those with the smallest distance). Idle lanes —
 // rays that already finished, or never needed this mesh — serve as helpers.
-__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out) {
+__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, unsigned long long *phase_acc = nullptr) {
     const int lane = threadIdx.x % WAVE;
+    PHASE_DECL
     double tmin = 0, tmax = 0;
     bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
     const TriRay q = tri_ray(r);
@@ -456,23 +491,22 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
         double distance = 0;
         int32_t closest = -1, count = 0, first = 0;
         float bu = 0, bv = 0, bw = 0;
+        PHASE_ADD(0)
+        rsx_kdnode nd;
+        nd.count = 0; nd.u.leaf.first_item = 0;
+        if (active) nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
+        PHASE_ADD(1)
         if (active) {
-            const rsx_kdnode nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
             distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
             count = nd.count;
             first = nd.u.leaf.first_item;
             if (count < RSX_COOP_LEAF) {
-                const int32_t *items = m.items + first;
                 for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
                     int32_t tri[RSX_LEAF_BATCH];
                     float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
 #pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) tri[j] = items[k + j < count ? k + j : count - 1];
-#pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
-                        const float4 *rec = m.tris + 3 * (size_t)tri[j];
-                        t0[j] = rec[0]; t1[j] = rec[1]; t2[j] = rec[2];
-                    }
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                        leaf_fetch(m.items, m.tris, m.leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
 #pragma unroll
                     for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
                         float ht, hu, hv, hw;
@@ -483,17 +517,23 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 }
             }
         }
+        PHASE_ADD(2)
         // ---- cooperative stage for big leaves
         unsigned long long big = __ballot(active && count >= RSX_COOP_LEAF);
+#if RSX_PHASE_PROF
+        phase_acc[5] += 1; phase_acc[6] += __popcll(big); phase_acc[7] += __popcll(__ballot(active));
+#endif
         while (big) {
             const int leader = __ffsll((long long)big) - 1;
             const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
-            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris;
+            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris, leaf_bits = (unsigned long long)m.leaf;
             const unsigned long long l_items_bits = ((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
                                                     (unsigned)__shfl((int)items_bits, leader, WAVE);
-            const int32_t *litems = (const int32_t *)l_items_bits + lfirst;
+            const int32_t *litems = (const int32_t *)l_items_bits;
             const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
                                                    (unsigned)__shfl((int)tris_bits, leader, WAVE));
+            const float4 *lleaf = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(leaf_bits >> 32), leader, WAVE) << 32) |
+                                                   (unsigned)__shfl((int)leaf_bits, leader, WAVE));
             // lanes whose ray sits in the same leaf as the leader's
             const bool same = active && count >= RSX_COOP_LEAF && first == lfirst && items_bits == l_items_bits;
             const unsigned long long group = __ballot(same);
@@ -507,9 +547,10 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                     __builtin_amdgcn_wave_barrier();
                     const int32_t k = c + lane;
                     if (k < lcount) {
-                        const int32_t tri = litems[k];
-                        const float4 *src = ltris + 3 * (size_t)tri;
-                        rec[3 * lane] = src[0]; rec[3 * lane + 1] = src[1]; rec[3 * lane + 2] = src[2];
+                        int32_t tri;
+                        float4 a, b, cc;
+                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, cc);
+                        rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
                         ids[lane] = tri;
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -543,9 +584,9 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 float mt = INFINITY, mu = 0, mv = 0, mw = 0;
                 int32_t mk = 0x7fffffff, mtri = -1;
                 for (int32_t k = lane; k < lcount; k += WAVE) {
-                    const int32_t tri = litems[k];
-                    const float4 *src = ltris + 3 * (size_t)tri;
-                    const float4 a = src[0], b = src[1], c = src[2];
+                    int32_t tri;
+                    float4 a, b, c;
+                    leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, c);
                     float ht, hu, hv, hw;
                     if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
                 }
@@ -565,6 +606,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
             }
         }
+        PHASE_ADD(3)
         if (active) {
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
             else if (sp == 0) active = false;
@@ -574,7 +616,164 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 stack_pop(st, sp, node, tmax);
             }
         }
+        PHASE_ADD(4)
     }
+    return hit;
+}
+
+#ifndef RSX_STEP_LOOP
+#define RSX_STEP_LOOP 0            // 1: one memory-dependent step per lane per iteration (node visit OR leaf batch); 0: descend-all-then-leaf
+#endif
+
+// Fine-grained variant of mesh_trace_wave. Every iteration each unfinished lane issues exactly one round of loads — the (node,
+// node+1) pair it stands on, or the next RSX_LEAF_BATCH records of the leaf it is in — and then consumes them. Lanes no longer
+// wait for the slowest lane of the wave to reach its leaf before testing theirs, which is what made silhouette tiles (rays grazing
+// the surface through hundreds of cells, a different number for every lane) cost 3x the longest single ray.
+__device__ bool mesh_trace_steps(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, unsigned long long *phase_acc = nullptr) {
+    const int lane = threadIdx.x % WAVE;
+    double tmin = 0, tmax = 0;
+    bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
+    const TriRay q = tri_ray(r);
+    const AxisDiv ad = axis_div(r);
+    bool hit = false;
+    int32_t node = 0, sp = 0;
+    // leaf state (valid while in_leaf)
+    bool in_leaf = false;
+    int32_t first = 0, count = 0, pos = 0, closest = -1;
+    double distance = 0;
+    float bu = 0, bv = 0, bw = 0;
+    while (__any(active)) {
+        bool leaf_done = false;
+        if (active && !in_leaf) {
+            // ---- node step(s): stand on `node`; stepping into the lower child (next record) is free, so take up to two levels
+            rsx_kdnode nd = load_node(m.nodes, node), nx = load_node(m.nodes, node + 1);
+#pragma unroll
+            for (int level = 0; level < 2; ++level) {
+                if (nd.type < 0) break;
+                const int axis = nd.type;
+                const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
+                                                 (ad.safe >> axis) & 1, tmin, tmax, st, sp);
+                const bool adjacent = next == node + 1;
+                node = next;
+                if (!adjacent || level == 1) { nd.type = 3; break; }         // 3 = "branch whose record is not loaded yet"
+                nd = nx;
+            }
+            if (nd.type < 0) {                                                // arrived at a leaf: _trace_leaf, mesh.pyx:520-563
+                in_leaf = true;
+                first = nd.u.leaf.first_item; count = nd.count; pos = 0; closest = -1;
+                distance = r.maxd < tmax ? r.maxd : tmax;
+                if (count == 0) leaf_done = true;
+            }
+        } else if (active && count < RSX_COOP_LEAF) {
+            // ---- leaf step: next batch of records, in leaf order
+            int32_t tri[RSX_LEAF_BATCH];
+            float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                leaf_fetch(m.items, m.tris, m.leaf, first + (pos + j < count ? pos + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                float ht, hu, hv, hw;
+                if (pos + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
+                    distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
+                }
+            }
+            pos += RSX_LEAF_BATCH;
+            if (pos >= count) leaf_done = true;
+        }
+        // ---- big leaves: whole-wave cooperation (a lane enters here in the iteration after it reached the leaf)
+        unsigned long long big = __ballot(active && in_leaf && !leaf_done && count >= RSX_COOP_LEAF);
+        while (big) {
+            const int leader = __ffsll((long long)big) - 1;
+            const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
+            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris, leaf_bits = (unsigned long long)m.leaf;
+            const unsigned long long l_items_bits = ((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
+                                                    (unsigned)__shfl((int)items_bits, leader, WAVE);
+            const int32_t *litems = (const int32_t *)l_items_bits;
+            const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
+                                                   (unsigned)__shfl((int)tris_bits, leader, WAVE));
+            const float4 *lleaf = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(leaf_bits >> 32), leader, WAVE) << 32) |
+                                                   (unsigned)__shfl((int)leaf_bits, leader, WAVE));
+            const bool same = active && in_leaf && !leaf_done && count >= RSX_COOP_LEAF && first == lfirst && items_bits == l_items_bits;
+            const unsigned long long group = __ballot(same);
+            big &= ~group;
+            if (__popcll(group) >= RSX_STAGE_MIN) {
+                float4 *rec = st.stage;
+                int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
+                for (int32_t c = 0; c < lcount; c += WAVE) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int32_t k = c + lane;
+                    if (k < lcount) {
+                        int32_t tri;
+                        float4 a, b, cc;
+                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, cc);
+                        rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
+                        ids[lane] = tri;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (same) {
+                        const int32_t nj = lcount - c < WAVE ? lcount - c : WAVE;
+                        for (int32_t j = 0; j < nj; ++j) {
+                            float ht, hu, hv, hw;
+                            if (tri_test(q, rec[3 * j], rec[3 * j + 1], rec[3 * j + 2], ht, hu, hv, hw) && (double)ht < distance) {
+                                distance = (double)ht; closest = ids[j]; bu = hu; bv = hv; bw = hw;
+                            }
+                        }
+                    }
+                }
+            } else {
+                unsigned long long todo = group;
+                while (todo) {
+                    const int owner = __ffsll((long long)todo) - 1;
+                    todo &= todo - 1;
+                    TriRay lq;
+                    lq.ox = shfl_f64(q.ox, owner); lq.oy = shfl_f64(q.oy, owner); lq.oz = shfl_f64(q.oz, owner);
+                    lq.maxd = shfl_f64(q.maxd, owner);
+                    lq.sx = __shfl(q.sx, owner, WAVE); lq.sy = __shfl(q.sy, owner, WAVE); lq.sz = __shfl(q.sz, owner, WAVE);
+                    const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), owner, WAVE);
+                    lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
+                    const double limit = shfl_f64(distance, owner);
+                    float mt = INFINITY, mu = 0, mv = 0, mw = 0;
+                    int32_t mk = 0x7fffffff, mtri = -1;
+                    for (int32_t k = lane; k < lcount; k += WAVE) {
+                        int32_t tri;
+                        float4 a, b, c;
+                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, c);
+                        float ht, hu, hv, hw;
+                        if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
+                    }
+                    float wt = mt;
+                    int32_t wk = mk;
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) {
+                        const float ot = __shfl_xor(wt, off, WAVE);
+                        const int32_t ok = __shfl_xor(wk, off, WAVE);
+                        if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
+                    }
+                    const int winner = wk & (WAVE - 1);
+                    const bool found = wk != 0x7fffffff;
+                    const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
+                    const int32_t rtri = __shfl(mtri, winner, WAVE);
+                    if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
+                }
+            }
+            if (same) leaf_done = true;
+        }
+        // ---- a finished leaf either ends the ray (hit) or resumes from the stack
+        if (active && leaf_done) {
+            in_leaf = false;
+            if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
+            else if (sp == 0) active = false;
+            else {
+                --sp;
+                tmin = tmax;
+                stack_pop(st, sp, node, tmax);
+            }
+        }
+    }
+    (void)phase_acc;
     return hit;
 }
 
@@ -1114,7 +1313,8 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, const Stack &st, con
 // Wave-cooperative World.hit: same result as world_trace, but every lane of the wave calls it together (`valid` = lane has a
 // ray) and all loops are wave-uniform, so that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves).
 template <bool CSG>
-__device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best) {
+__device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
+                                 unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
@@ -1144,7 +1344,11 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 Ray l = r;
                 if (is_mesh) l = to_local(p, r);
                 MeshHit mh;
-                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh)) {
+#if RSX_STEP_LOOP
+                if (mesh_trace_steps(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, phase_acc)) {
+#else
+                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, phase_acc)) {
+#endif
                     cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                 }
             }
@@ -1388,7 +1592,10 @@ struct RenderParams {
     int32_t rect[4];
     int32_t spp, rng_mode;
     uint64_t seed, sample_offset;
-    unsigned long long *unit_times;   // optional [n_units,3]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
+    uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
+    const uint32_t *unit_order;       // work list or null: ticket k processes work item unit_order[k] = unit | part << 26 | log2(parts) << 29
+    const uint32_t *n_work;           // number of work items in unit_order (device scalar written by k_order_units)
+    unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
 };
 
 // per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
@@ -1414,12 +1621,25 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
     const int w = rp.rect[2] - rp.rect[0], h = rp.rect[3] - rp.rect[1];
     const int tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8;
     const long long n_units = rp.tasks ? ((rp.n_tasks + 63) / 64) * rp.spp : (long long)tiles_x * tiles_y * rp.spp;
+    const long long n_work = rp.unit_order ? (long long)*rp.n_work : n_units;
     for (;;) {
-        const long long unit = next_batch(ticket) / 64;
-        if (unit >= n_units) break;
+        const long long tk = next_batch(ticket) / 64;
+        if (tk >= n_work) break;
+        long long unit = tk;
+        int part = 0, parts_log2 = 0;
+        if (rp.unit_order) {
+            const uint32_t wi = rp.unit_order[tk];
+            unit = (long long)(wi & 0x3ffffffu); part = (int)((wi >> 26) & 7u); parts_log2 = (int)(wi >> 29);
+        }
+        const unsigned long long c_start = wall_clock64();
         const int s = (int)(unit % rp.spp);
         const long long chunk = unit / rp.spp;
         const unsigned long long t_start = rp.unit_times ? wall_clock64() : 0ULL;
+#if RSX_PHASE_PROF
+        unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#else
+        unsigned long long *phase_acc = nullptr;
+#endif
         long long k = 0;
         int ix = 0, iy = 0;
         bool valid;
@@ -1434,6 +1654,8 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
             ix = rp.rect[0] + (valid ? lx : 0); iy = rp.rect[1] + (valid ? ly : 0);
             k = valid ? (long long)ly * w + lx : 0;
         }
+        // a heavy unit is processed as 2/4/8 work items of 32/16/8 consecutive lanes each; the other lanes only help
+        valid = valid && (lane >> (6 - parts_log2)) == part;
         (void)total;
         // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
         double u1, u2;
@@ -1454,14 +1676,22 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
 #if RSX_WAVE_COOP
-        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit);
+        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, phase_acc);
 #else
         const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
 #endif
+        if (lane == 0) {
+            unsigned long long c = (wall_clock64() - c_start) << parts_log2;   // estimate of the unsplit cost (keeps heavy units split)
+            if (c > 0x7fffffffULL) c = 0x7fffffffULL;
+            if (parts_log2) atomicMax(&rp.unit_cost[unit], (uint32_t)c); else rp.unit_cost[unit] = (uint32_t)c;
+        }
         if (rp.unit_times && lane == 0) {
-            rp.unit_times[3 * unit] = t_start;
-            rp.unit_times[3 * unit + 1] = wall_clock64();
-            rp.unit_times[3 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
+            rp.unit_times[12 * unit] = t_start;
+            rp.unit_times[12 * unit + 1] = wall_clock64();
+            rp.unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
+#if RSX_PHASE_PROF
+            for (int ph = 0; ph < 8; ++ph) rp.unit_times[12 * unit + 3 + ph] = phase_acc[ph];
+#endif
         }
         if (!valid) continue;
         if (got) {                                                                 // optical/ray.pyx:391-393
@@ -1511,6 +1741,77 @@ __global__ void k_selftest_division(unsigned long long n, unsigned long long see
         if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
     }
     if (bad) atomicAdd(mismatches, bad);
+}
+
+// Longest-processing-time-first schedule for the next pass over the same units: counting sort of the measured unit costs into
+// 128 logarithmic buckets, most expensive first. A few silhouette tiles cost 50x the median (grazing rays cross hundreds of KD
+// cells); handing them out first lets the cheap bulk fill in behind them instead of leaving one wave to finish alone.
+#define ORDER_BUCKETS 128
+__device__ __forceinline__ int cost_bucket(uint32_t c) {
+    if (c == 0) return 0;
+    const int lg = 31 - __clz((int)c);                      // floor(log2 c)
+    const int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3) : 0;   // two mantissa bits -> quarter-octave resolution
+    const int b = lg * 4 + frac;
+    return b < ORDER_BUCKETS ? b : ORDER_BUCKETS - 1;
+}
+
+#ifndef RSX_SPLIT_HEAVY
+#define RSX_SPLIT_HEAVY 1          // split units far above the mean cost into 2/4/8 work items (fewer lanes per wave, more waves)
+#endif
+
+__device__ __forceinline__ int unit_parts_log2(uint32_t c, unsigned long long mean) {
+#if RSX_SPLIT_HEAVY
+    if ((unsigned long long)c > 24ULL * mean) return 3;
+    if ((unsigned long long)c > 10ULL * mean) return 2;
+    if ((unsigned long long)c > 4ULL * mean) return 1;
+#endif
+    return 0;
+}
+
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *n_work, long long n, long long capacity) {
+    __shared__ unsigned int hist[ORDER_BUCKETS];
+    __shared__ unsigned int offset[ORDER_BUCKETS];
+    __shared__ unsigned long long total;
+    for (int b = threadIdx.x; b < ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long part_sum = 0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) part_sum += cost[i];
+    atomicAdd(&total, part_sum);
+    __syncthreads();
+    const unsigned long long mean = total / (unsigned long long)n + 1;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        atomicAdd(&hist[cost_bucket(c)], 1u << unit_parts_log2(c, mean));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[b] = run; run += hist[b]; }
+        *n_work = run;
+    }
+    __syncthreads();
+    const bool fits = (long long)(offset[0] + hist[0]) <= capacity;        // total work items; if the list would overflow, do not split
+    if (!fits) {
+        __syncthreads();
+        for (int b = threadIdx.x; b < ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
+        __syncthreads();
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            unsigned int run = 0;
+            for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[b] = run; run += hist[b]; }
+            *n_work = run;
+        }
+        __syncthreads();
+    }
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        const int pl = fits ? unit_parts_log2(c, mean) : 0;
+        const unsigned int pos = atomicAdd(&offset[cost_bucket(c)], 1u << pl);
+        for (int part = 0; part < (1 << pl); ++part) order[pos + part] = (uint32_t)i | ((uint32_t)part << 26) | ((uint32_t)pl << 29);
+        if (pl) cost[i] = 0;                                                // parts report with atomicMax
+    }
 }
 
 // StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859
@@ -1612,22 +1913,42 @@ __global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, 
 #define RING_SLOTS 512
 enum { POOL_MATERIALS, POOL_TABLES, POOL_TASKS, POOL_UNIFORMS, POOL_SAMPLES, POOL_MEAN, POOL_VAR, POOL_SLOTS };
 
+// Per-stream state of the traversal kernels. `main` runs on the ctx stream (hit / roots / contains batches, unpipelined renders);
+// two more lanes with private streams let consecutive render passes overlap: the long tail of pass p (a few waves walking grazing
+// rays through hundreds of cells) runs while pass p+1's bulk fills the rest of the chip. Accumulation into the frame stays on the
+// ctx stream, in call order.
+struct TraceLane {
+    hipStream_t stream = nullptr;
+    unsigned long long *ticket = nullptr;
+    bool ticket_armed = false;         // ticket is known to be zero on the stream (left so by k_accumulate)
+    void *spill = nullptr;             // global spill regions for the traversal stacks
+    size_t spill_bytes = 0;
+    uint32_t *unit_cost = nullptr, *unit_order = nullptr, *n_work = nullptr;   // longest-first scheduling state
+    size_t unit_capacity = 0;
+    long long cost_units = 0;          // number of units unit_cost currently describes (0 = none)
+    long long order_units = 0;         // number of units unit_order was sorted for (0 = no valid work list)
+    uint64_t cost_signature = 0;       // (scene, camera, tasks) the costs were measured on
+    void *samples = nullptr, *uniforms = nullptr;
+    size_t samples_bytes = 0, uniforms_bytes = 0;
+    hipEvent_t traced = nullptr, merged = nullptr;
+    bool in_flight = false;
+};
+
 struct rsx_ctx {
     int device;
     hipStream_t stream;        // launch stream (own or external)
     hipStream_t own_stream;
     hipEvent_t ev0, ev1, ev2;  // ev0..ev1 = last traversal kernel, ev1..ev2 = last accumulate kernel
-    unsigned long long *ticket;
+    TraceLane main, lanes[RSX_MAX_LANES];
+    int pipeline_depth;        // 1 = renders run on the ctx stream only; n = rotate over n private lanes
+    long long max_in_flight;   // render passes the host may run ahead of the device
     int n_cus;
     float last_ms;
     bool have_accum;
     // ring of per-render-call event triples so a caller can time K back-to-back async renders without syncing
-    std::vector<hipEvent_t> ring;      // 3 events per slot
+    std::vector<hipEvent_t> ring;      // 4 events per slot: trace begin/end (lane stream), merge begin/end (ctx stream)
     long long render_calls;
-    void *spill;                       // global spill regions for the traversal stacks
-    size_t spill_bytes;
     unsigned long long *unit_times;    // debug: per-unit timestamps of the next render calls (caller-owned device buffer)
-    bool ticket_armed;                 // ticket is known to be zero on the stream (left so by k_accumulate)
     std::vector<unsigned char> shadow[3];   // host copies of what POOL_MATERIALS / POOL_TABLES / POOL_TASKS hold
     // grow-only device workspace so steady-state render calls never hipMalloc
     void *pool[POOL_SLOTS];
@@ -1671,17 +1992,30 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     ctx->last_ms = 0.f;
     ctx->have_accum = false;
     ctx->render_calls = 0;
-    ctx->ticket_armed = false;
     ctx->unit_times = nullptr;
-    ctx->spill = nullptr;
-    ctx->spill_bytes = 0;
+    {
+        const char *env = std::getenv("RSX_PIPELINE");
+        ctx->pipeline_depth = env ? std::atoi(env) : 2;
+        if (ctx->pipeline_depth < 1) ctx->pipeline_depth = 1;
+        if (ctx->pipeline_depth > RSX_MAX_LANES) ctx->pipeline_depth = RSX_MAX_LANES;
+        const char *env2 = std::getenv("RSX_MAX_IN_FLIGHT");
+        ctx->max_in_flight = env2 ? std::atoll(env2) : 4;
+        if (ctx->max_in_flight < 1) ctx->max_in_flight = 1;
+        if (ctx->max_in_flight > RING_SLOTS / 2) ctx->max_in_flight = RING_SLOTS / 2;
+    }
     for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
     HIP_TRY(hipEventCreate(&ctx->ev2));
-    HIP_TRY(hipMalloc(&ctx->ticket, sizeof(unsigned long long)));
+    ctx->main.stream = ctx->stream;
+    for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
+        if (ln != &ctx->main) HIP_TRY(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&ln->ticket, sizeof(unsigned long long)));
+        HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
+    }
     *out = ctx;
     return RSX_OK;
 }
@@ -1690,8 +2024,13 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(ctx->ticket);
-    if (ctx->spill) (void)hipFree(ctx->spill);
+    for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
+        if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms})
+            if (q) (void)hipFree(q);
+        if (ln->traced) (void)hipEventDestroy(ln->traced);
+        if (ln->merged) (void)hipEventDestroy(ln->merged);
+    }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
@@ -1704,12 +2043,14 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
 extern "C" int rsx_set_stream(rsx_ctx *ctx, void *hip_stream) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    ctx->main.stream = ctx->stream;
     return RSX_OK;
 }
 
 extern "C" int rsx_synchronize(rsx_ctx *ctx) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }
@@ -1726,23 +2067,20 @@ extern "C" int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms) {
 extern "C" int rsx_last_render_ms(rsx_ctx *ctx, float *trace_ms, float *accumulate_ms) {
     if (!ctx || !trace_ms || !accumulate_ms) return rsx_fail(RSX_EINVAL, "null argument");
     if (!ctx->have_accum) return rsx_fail(RSX_EINVAL, "no render call has been issued on this context");
-    HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->ev2));
-    HIP_TRY(hipEventElapsedTime(trace_ms, ctx->ev0, ctx->ev1));
-    HIP_TRY(hipEventElapsedTime(accumulate_ms, ctx->ev1, ctx->ev2));
-    return RSX_OK;
+    return rsx_render_history(ctx, 1, trace_ms, accumulate_ms);
 }
 
 extern "C" int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumulate_ms) {
     if (!ctx || n < 1 || !trace_ms || !accumulate_ms) return rsx_fail(RSX_EINVAL, "rsx_render_history: bad arguments");
     if (n > ctx->render_calls || n > RING_SLOTS) return rsx_fail(RSX_EINVAL, "rsx_render_history: only %lld calls recorded (ring of %d)", ctx->render_calls, RING_SLOTS);
     HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (int32_t i = 0; i < n; ++i) {
         const long long call = ctx->render_calls - n + i;
-        hipEvent_t *re = &ctx->ring[(size_t)(call % RING_SLOTS) * 3];
+        hipEvent_t *re = &ctx->ring[(size_t)(call % RING_SLOTS) * 4];
         HIP_TRY(hipEventElapsedTime(&trace_ms[i], re[0], re[1]));
-        HIP_TRY(hipEventElapsedTime(&accumulate_ms[i], re[1], re[2]));
+        HIP_TRY(hipEventElapsedTime(&accumulate_ms[i], re[3], re[2]));
     }
     return RSX_OK;
 }
@@ -1956,6 +2294,17 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             }
         }
         UP(upload(sc, tris.data(), tris.size(), &dm.tris));
+        {
+            std::vector<float4> leaf((size_t)m.kd.n_items * 4);
+            for (int32_t k = 0; k < m.kd.n_items; ++k) {
+                const int32_t t = m.kd.items[k];
+                leaf[4 * (size_t)k] = tris[3 * (size_t)t]; leaf[4 * (size_t)k + 1] = tris[3 * (size_t)t + 1]; leaf[4 * (size_t)k + 2] = tris[3 * (size_t)t + 2];
+                float4 idrec = make_float4(0.f, 0.f, 0.f, 0.f);
+                std::memcpy(&idrec.x, &t, 4);
+                leaf[4 * (size_t)k + 3] = idrec;
+            }
+            UP(upload(sc, leaf.data(), leaf.size(), &dm.leaf));
+        }
         UP(upload(sc, m.kd.nodes, (size_t)m.kd.n_nodes, &dm.nodes));
         UP(upload(sc, m.kd.items, (size_t)m.kd.n_items, &dm.items));
         if (!nidx.empty()) {
@@ -1984,33 +2333,32 @@ struct Launch {
 };
 
 // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stacks allow
-int plan(rsx_scene *sc, long long work_items, Launch &l) {
+int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg_per_cu_cap = RSX_MAX_WG_PER_CU) {
     const int lds_levels = sc->d.wlds + sc->d.mlds;
     l.lds = (size_t)WG_WAVES * ((size_t)lds_levels * WAVE * 12 + STAGE_BYTES);
     if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "traversal stack does not fit LDS (%d levels)", lds_levels);
-    int per_cu = (int)std::min<size_t>(RSX_MAX_WG_PER_CU, (160 * 1024) / std::max<size_t>(l.lds, 1));
+    int per_cu = (int)std::min<size_t>((size_t)wg_per_cu_cap, (160 * 1024) / std::max<size_t>(l.lds, 1));
     if (per_cu < 1) per_cu = 1;
     long long wgs = (long long)sc->ctx->n_cus * per_cu;
     const long long needed = (work_items + WG_THREADS - 1) / WG_THREADS;
     if (wgs > needed) wgs = needed;
     if (wgs < 1) wgs = 1;
     l.grid = dim3((unsigned)wgs);
-    // global spill regions: one per wave of the largest grid this ctx launches
+    // global spill regions: one per wave of the largest grid a lane launches (lanes run concurrently, so each has its own)
     const int spill_levels = std::max(1, (sc->d.wdepth - sc->d.wlds) + (sc->d.mdepth - sc->d.mlds));
     const size_t need = (size_t)sc->ctx->n_cus * RSX_MAX_WG_PER_CU * WG_WAVES * spill_levels * WAVE * 12;
-    rsx_ctx *ctx = sc->ctx;
-    if (need > ctx->spill_bytes) {
-        if (ctx->spill) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->spill)); ctx->spill = nullptr; ctx->spill_bytes = 0; }
-        HIP_TRY(hipMalloc(&ctx->spill, need));
-        ctx->spill_bytes = need;
+    if (need > lane.spill_bytes) {
+        if (lane.spill) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipFree(lane.spill)); lane.spill = nullptr; lane.spill_bytes = 0; }
+        HIP_TRY(hipMalloc(&lane.spill, need));
+        lane.spill_bytes = need;
     }
-    sc->d.spill = static_cast<char *>(ctx->spill);
+    sc->d.spill = static_cast<char *>(lane.spill);
     return RSX_OK;
 }
 
-int reset_ticket(rsx_ctx *ctx) {
-    HIP_TRY(hipMemsetAsync(ctx->ticket, 0, sizeof(unsigned long long), ctx->stream));
-    ctx->ticket_armed = false;          // whoever launches next dirties it again
+int reset_ticket(TraceLane &lane) {
+    HIP_TRY(hipMemsetAsync(lane.ticket, 0, sizeof(unsigned long long), lane.stream));
+    lane.ticket_armed = false;          // whoever launches next dirties it again
     return RSX_OK;
 }
 
@@ -2031,15 +2379,15 @@ extern "C" int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *orig
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     Launch l;
-    int rc = plan(scene, n, l);
+    int rc = plan(scene, n, ctx->main, l);
     if (rc) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_hit_batch<true>) : reinterpret_cast<const void *>(k_hit_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-    rc = reset_ticket(ctx);
+    rc = reset_ticket(ctx->main);
     if (rc) return rc;
     HitOut out = {prim, t, exiting, tri, uvw, geom};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    if (scene->has_csg) hipLaunchKernelGGL(k_hit_batch<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
-    else hipLaunchKernelGGL(k_hit_batch<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_hit_batch<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
+    else hipLaunchKernelGGL(k_hit_batch<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     return RSX_OK;
@@ -2097,13 +2445,13 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     HIP_TRY(hipMemsetAsync(d_t.p, 0, N * R * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_ex.p, 0, N * R, ctx->stream));
     Launch l;
-    if ((rc = plan(scene, n, l))) return rc;
+    if ((rc = plan(scene, n, ctx->main, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_roots<true>) : reinterpret_cast<const void *>(k_roots<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-    if ((rc = reset_ticket(ctx))) return rc;
+    if ((rc = reset_ticket(ctx->main))) return rc;
     if (scene->has_csg) hipLaunchKernelGGL(k_roots<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->ticket);
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->main.ticket);
     else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->ticket);
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->main.ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts, d_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(t, d_t.p, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -2123,11 +2471,11 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
     if ((rc = d_p.alloc(N * 24)) || (rc = d_in.alloc(N * W))) return rc;
     HIP_TRY(hipMemcpyAsync(d_p.p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
     Launch l;
-    if ((rc = plan(scene, n, l))) return rc;
+    if ((rc = plan(scene, n, ctx->main, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_contains<true>) : reinterpret_cast<const void *>(k_contains<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-    if ((rc = reset_ticket(ctx))) return rc;
-    if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
-    else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->ticket);
+    if ((rc = reset_ticket(ctx->main))) return rc;
+    if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->main.ticket);
+    else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->main.ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(inside, d_in.p, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2154,19 +2502,25 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t T = (size_t)desc->n_tasks, S = T * (size_t)desc->spp, B = (size_t)desc->bins;
-    void *d_mat = nullptr, *d_tab = nullptr, *d_tasks = nullptr, *d_uni = nullptr, *d_samples = nullptr, *d_mean = nullptr, *d_var = nullptr;
+    void *d_mat = nullptr, *d_tab = nullptr, *d_tasks = nullptr, *d_mean = nullptr, *d_var = nullptr;
     int rc;
+    // which lane traces this pass: frame renders alternate the two private lanes (passes overlap), everything else stays on the ctx stream
+    const bool pipelined = !h_mean && ctx->pipeline_depth > 1;
+    TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
+    if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+
     if ((rc = pool_get(ctx, POOL_MATERIALS, sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials), &d_mat)) ||
-        (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)std::max(1, desc->n_tables), &d_tab)) ||
-        (rc = pool_get(ctx, POOL_SAMPLES, S * sizeof(Sample), &d_samples))) return rc;
+        (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)std::max(1, desc->n_tables), &d_tab))) return rc;
     // small per-call inputs are uploaded only when they differ from what the device already holds (steady-state
-    // passes of one observe() loop re-send identical materials / tables / task lists)
+    // passes of one observe() loop re-send identical materials / tables / task lists); a change drains the pipeline first
     auto upload_if_changed = [&](int slot, void *dst, const void *src, size_t bytes) -> int {
         std::vector<unsigned char> &sh = ctx->shadow[slot];
         if (sh.size() == bytes && std::memcmp(sh.data(), src, bytes) == 0) return RSX_OK;
+        for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         sh.assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);
         HIP_TRY(hipMemcpyAsync(dst, sh.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));        // sh may be reassigned by the next call
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
         return RSX_OK;
     };
     if (desc->n_materials && (rc = upload_if_changed(0, d_mat, desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials))) return rc;
@@ -2175,19 +2529,33 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if ((rc = pool_get(ctx, POOL_TASKS, T * 8, &d_tasks))) return rc;
         if ((rc = upload_if_changed(2, d_tasks, desc->tasks, T * 8))) return rc;
     }
-    if (desc->rng_mode == RSX_RNG_STREAM) {
-        if ((rc = pool_get(ctx, POOL_UNIFORMS, S * 16, &d_uni))) return rc;
-        HIP_TRY(hipMemcpyAsync(d_uni, desc->uniforms, S * 16, hipMemcpyHostToDevice, ctx->stream));
-    }
     if (h_mean) {
         if ((rc = pool_get(ctx, POOL_MEAN, T * B * 8, &d_mean)) || (rc = pool_get(ctx, POOL_VAR, T * B * 8, &d_var))) return rc;
     }
-    // a camera pixel index must exist in the scene's primitive/material tables
+    // the lane's previous pass must have been merged before its sample buffer (and scheduling state) is reused
+    if (pipelined && lane.in_flight) HIP_TRY(hipStreamWaitEvent(lane.stream, lane.merged, 0));
+    auto lane_buffer = [&](void *&buf, size_t &have, size_t bytes) -> int {
+        if (bytes > have) {
+            if (buf) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(buf)); buf = nullptr; have = 0; }
+            const size_t want = bytes + bytes / 8 + 256;
+            HIP_TRY(hipMalloc(&buf, want));
+            have = want;
+        }
+        return RSX_OK;
+    };
+    if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
+    if (desc->rng_mode == RSX_RNG_STREAM) {
+        if ((rc = lane_buffer(lane.uniforms, lane.uniforms_bytes, S * 16))) return rc;
+        HIP_TRY(hipMemcpyAsync(lane.uniforms, desc->uniforms, S * 16, hipMemcpyHostToDevice, lane.stream));
+    }
+
+    bool want_order = false;
+    long long order_n = 0;
     RenderParams rp;
     rp.cam = desc->camera;
     rp.materials = static_cast<const rsx_material *>(d_mat);
     rp.tasks = desc->tasks ? static_cast<const int32_t *>(d_tasks) : nullptr;
-    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? static_cast<const double *>(d_uni) : nullptr;
+    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? static_cast<const double *>(lane.uniforms) : nullptr;
     rp.n_tasks = desc->n_tasks;
     std::memcpy(rp.rect, desc->rect, sizeof(rp.rect));
     rp.spp = desc->spp;
@@ -2195,24 +2563,73 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.unit_times = ctx->unit_times;
+    // longest-first unit schedule from the costs this lane's previous pass over the same units measured
+    {
+        const long long w = desc->rect[2] - desc->rect[0], h = desc->rect[3] - desc->rect[1];
+        const long long n_units = desc->tasks ? ((desc->n_tasks + 63) / 64) * desc->spp : ((w + 7) / 8) * ((h + 7) / 8) * (long long)desc->spp;
+        uint64_t sig = 1469598103934665603ULL;                       // FNV-1a over what defines the units' content
+        auto mix = [&sig](const void *q, size_t bytes) { const unsigned char *c = static_cast<const unsigned char *>(q); for (size_t i = 0; i < bytes; ++i) { sig ^= c[i]; sig *= 1099511628211ULL; } };
+        const void *scene_id = scene;
+        mix(&scene_id, sizeof(scene_id)); mix(&desc->camera, sizeof(desc->camera)); mix(desc->rect, sizeof(desc->rect));
+        mix(&desc->n_tasks, sizeof(desc->n_tasks)); mix(&desc->spp, sizeof(desc->spp));
+        if (desc->tasks) mix(desc->tasks, (size_t)std::min<long long>(desc->n_tasks, 4096) * 8);
+        if ((size_t)n_units > lane.unit_capacity) {
+            HIP_TRY(hipStreamSynchronize(lane.stream));
+            if (lane.unit_cost) HIP_TRY(hipFree(lane.unit_cost));
+            if (lane.unit_order) HIP_TRY(hipFree(lane.unit_order));
+            lane.unit_capacity = (size_t)n_units + (size_t)n_units / 8 + 64;
+            HIP_TRY(hipMalloc(&lane.unit_cost, lane.unit_capacity * 4));
+            HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4 * 2));      // room for split work items
+            if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 16));
+            lane.cost_units = 0;
+            lane.order_units = 0;
+        }
+        rp.unit_cost = lane.unit_cost;
+        rp.unit_order = nullptr;
+        rp.n_work = nullptr;
+#if RSX_LPT_SCHEDULE
+        // the work list for this pass was sorted right after the lane's previous pass over the same units (see below)
+        if (lane.order_units == n_units && lane.cost_signature == sig) { rp.unit_order = lane.unit_order; rp.n_work = lane.n_work; }
+        lane.order_units = 0;
+        want_order = n_units >= 512 && n_units < (1LL << 26);
+        order_n = n_units;
+#endif
+        lane.cost_units = n_units;
+        lane.cost_signature = sig;
+    }
 
     Launch l;
-    if ((rc = plan(scene, (long long)S, l))) return rc;
+    // pipelined passes share the chip: each takes RSX_RENDER_WG_PER_CU workgroups per CU so that the other lane's pass, the merge
+    // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
+    if ((rc = plan(scene, (long long)S, lane, l, pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-    if (!ctx->ticket_armed && (rc = reset_ticket(ctx))) return rc;
+    if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
-    while (ctx->ring.size() < (size_t)(slot + 1) * 3) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
-    hipEvent_t *re = &ctx->ring[(size_t)slot * 3];
-    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(hipEventRecord(re[0], ctx->stream));
-    if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
-    else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, rp, static_cast<Sample *>(d_samples), ctx->ticket);
+    while (ctx->ring.size() < (size_t)(slot + 1) * 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
+    hipEvent_t *re = &ctx->ring[(size_t)slot * 4];
+    // keep the host at most `max_in_flight` passes ahead of the GPU: a host that queues hundreds of launches ahead fills the HSA
+    // queues and the runtime's back-pressure wait then opens millisecond gaps between kernels (measured: 1.9 vs 0.9 ms per pass)
+    if (ctx->render_calls >= ctx->max_in_flight) {
+        const long long old = ctx->render_calls - ctx->max_in_flight;
+        HIP_TRY(hipEventSynchronize(ctx->ring[(size_t)(old % RING_SLOTS) * 4 + 2]));
+    }
+    HIP_TRY(hipEventRecord(re[0], lane.stream));
+    if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+    else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    HIP_TRY(hipEventRecord(re[1], ctx->stream));
+    HIP_TRY(hipEventRecord(re[1], lane.stream));
+    if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
+    if (want_order) {
+        // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n,
+                           (long long)lane.unit_capacity * 2);
+        HIP_TRY(hipGetLastError());
+        lane.order_units = order_n;
+    }
+    if (pipelined) HIP_TRY(hipStreamWaitEvent(ctx->stream, lane.traced, 0));   // the merge runs on the ctx stream, in call order
 
     AccumParams ap;
-    ap.samples = static_cast<const Sample *>(d_samples);
+    ap.samples = static_cast<const Sample *>(lane.samples);
     ap.tables = static_cast<const double *>(d_tab);
     ap.tasks = rp.tasks;
     ap.n_tasks = desc->n_tasks;
@@ -2223,13 +2640,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.variance = h_mean ? static_cast<double *>(d_var) : nullptr;
     ap.fmean = fmean; ap.fvar = fvar; ap.fn = fn;
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
-    ap.ticket = ctx->ticket;
-    ctx->ticket_armed = true;
+    ap.ticket = lane.ticket;
+    lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
+    HIP_TRY(hipEventRecord(re[3], ctx->stream));
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
     HIP_TRY(hipEventRecord(re[2], ctx->stream));
+    if (pipelined) { HIP_TRY(hipEventRecord(lane.merged, ctx->stream)); lane.in_flight = true; }
     ctx->render_calls++;
     ctx->have_accum = true;
     if (h_mean) {
