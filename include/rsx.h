@@ -173,6 +173,8 @@ int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t seed, uint64_
  * (100 MHz) and the (workgroup << 8 | wave) that processed it into dev_buffer[n_units][12] (u64; slots 3.. are per-phase
  * cycle counters in RSX_PHASE_PROF builds). NULL switches it off. */
 int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer);
+/* Timeline of the last n render calls: t[n][4] = trace begin, trace end, merge begin, merge end in ms since the first of them. */
+int rsx_render_timeline(rsx_ctx *ctx, int32_t n, float *t);
 /* Device allocation helpers so non-torch callers can keep frames resident in HBM. */
 int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr);
 int rsx_dev_free(rsx_ctx *ctx, void *dptr);

@@ -95,6 +95,7 @@ SYMBOLS = [
     ("rsx_render_history", C.c_int, [_vp, C.c_int32, _vp, _vp]),
     ("rsx_selftest_exact_division", C.c_int, [_vp, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)]),
     ("rsx_debug_unit_times", C.c_int, [_vp, _vp]),
+    ("rsx_render_timeline", C.c_int, [_vp, C.c_int32, _vp]),
     ("rsx_dev_alloc", C.c_int, [_vp, C.c_size_t, C.POINTER(_vp)]),
     ("rsx_dev_free", C.c_int, [_vp, _vp]),
     ("rsx_dev_upload", C.c_int, [_vp, _vp, _vp, C.c_size_t]),

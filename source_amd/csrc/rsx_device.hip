@@ -17,6 +17,7 @@
 // Reference lines each device function restates are cited at the function.
 #include <hip/hip_runtime.h>
 
+#include <time.h>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -61,6 +62,14 @@
 // error plumbing
 // ---------------------------------------------------------------------------------------------------
 static thread_local std::string g_error;
+
+// crude host-side profiler of the render call path (RSX_HOST_PROF=1): seconds spent per section, printed by rsx_synchronize
+static double g_hp[8];
+static long g_hp_calls;
+static bool g_hp_on = std::getenv("RSX_HOST_PROF") != nullptr;
+static inline double hp_now() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; }
+#define HP_BEGIN double hp_t0_ = g_hp_on ? hp_now() : 0.0;
+#define HP_MARK(slot) if (g_hp_on) { const double n_ = hp_now(); g_hp[slot] += n_ - hp_t0_; hp_t0_ = n_; }
 
 int rsx_fail(int code, const char *fmt, ...) {
     char buf[512];
@@ -1402,6 +1411,9 @@ __device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &
     ms.gt = gt + (sc.wdepth - sc.wlds) * WAVE; ms.gid = gid + (sc.wdepth - sc.wlds) * WAVE; ms.lds_levels = sc.mlds;
 }
 
+// XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID, bits [3:0]
+__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
+
 // wave-level ticket: lane 0 takes the next batch of 64 work items
 __device__ __forceinline__ long long next_batch(unsigned long long *ticket) {
     long long base = 0;
@@ -1594,7 +1606,7 @@ struct RenderParams {
     uint64_t seed, sample_offset;
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list or null: ticket k processes work item unit_order[k] = unit | part << 26 | log2(parts) << 29
-    const uint32_t *n_work;           // number of work items in unit_order (device scalar written by k_order_units)
+    const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
     unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
 };
 
@@ -1621,16 +1633,26 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
     const int w = rp.rect[2] - rp.rect[0], h = rp.rect[3] - rp.rect[1];
     const int tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8;
     const long long n_units = rp.tasks ? ((rp.n_tasks + 63) / 64) * rp.spp : (long long)tiles_x * tiles_y * rp.spp;
-    const long long n_work = rp.unit_order ? (long long)*rp.n_work : n_units;
+    (void)n_units;
+    // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
+    // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
+    const int my_xcd = xcc_id();
+    int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
     for (;;) {
-        const long long tk = next_batch(ticket) / 64;
-        if (tk >= n_work) break;
-        long long unit = tk;
-        int part = 0, parts_log2 = 0;
-        if (rp.unit_order) {
-            const uint32_t wi = rp.unit_order[tk];
-            unit = (long long)(wi & 0x3ffffffu); part = (int)((wi >> 26) & 7u); parts_log2 = (int)(wi >> 29);
+        long long tk = -1;
+        while (victim < 8) {
+            const int q = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+            const long long begin = rp.seg[q], end = rp.seg[q + 1];
+            long long got = 0;
+            if (lane == 0) got = (long long)atomicAdd(ticket + 16 * q, 1ULL);
+            got = __shfl(got, 0, WAVE) + begin;
+            if (got < end) { tk = got; break; }
+            ++victim;
         }
+        if (tk < 0) break;
+        const uint32_t wi = rp.unit_order[tk];
+        const long long unit = (long long)(wi & 0x3ffffffu);
+        const int part = (int)((wi >> 26) & 7u), parts_log2 = (int)(wi >> 29);
         const unsigned long long c_start = wall_clock64();
         const int s = (int)(unit % rp.spp);
         const long long chunk = unit / rp.spp;
@@ -1759,20 +1781,45 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
 #define RSX_SPLIT_HEAVY 1          // split units far above the mean cost into 2/4/8 work items (fewer lanes per wave, more waves)
 #endif
 
+#ifndef RSX_SPLIT_MAX_LOG2
+#define RSX_SPLIT_MAX_LOG2 0      // 0: no splitting (a silhouette tile is bound by its single slowest ray, parts only multiply the waves)
+#endif
+#ifndef RSX_HEAVY_FACTOR
+#define RSX_HEAVY_FACTOR 3ULL
+#endif
 __device__ __forceinline__ int unit_parts_log2(uint32_t c, unsigned long long mean) {
 #if RSX_SPLIT_HEAVY
-    if ((unsigned long long)c > 24ULL * mean) return 3;
-    if ((unsigned long long)c > 10ULL * mean) return 2;
-    if ((unsigned long long)c > 4ULL * mean) return 1;
-#endif
+    int pl = 0;
+    if ((unsigned long long)c > 24ULL * mean) pl = 3;
+    else if ((unsigned long long)c > 10ULL * mean) pl = 2;
+    else if ((unsigned long long)c > 4ULL * mean) pl = 1;
+    return pl < RSX_SPLIT_MAX_LOG2 ? pl : RSX_SPLIT_MAX_LOG2;
+#else
     return 0;
+#endif
 }
 
-__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *n_work, long long n, long long capacity) {
-    __shared__ unsigned int hist[ORDER_BUCKETS];
-    __shared__ unsigned int offset[ORDER_BUCKETS];
+// which XCD's list a unit belongs to: 4x4-tile blocks (32x32 pixels) are dealt round-robin to the 8 XCDs, so each L2 caches the
+// geometry behind an eighth of the image while every XCD still gets a fair share of cheap and expensive regions
+__device__ __forceinline__ int unit_xcd(long long unit, int tiles_x, int spp) {
+    const long long chunk = unit / spp;
+    if (tiles_x > 0) { const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x); return ((tx >> 2) + 3 * (ty >> 2)) & 7; }
+    return (int)((chunk >> 4) & 7);
+}
+
+// list 0: units well above the mean cost (latency-bound stragglers: every XCD takes them first); lists 1..8: the rest, by XCD
+__device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned long long mean, int tiles_x, int spp) {
+    if ((unsigned long long)c > RSX_HEAVY_FACTOR * mean) return 0;
+    return 1 + unit_xcd(unit, tiles_x, spp);
+}
+
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, long long capacity, int tiles_x, int spp) {
+    __shared__ unsigned int hist[9][ORDER_BUCKETS];
+    __shared__ unsigned int offset[9][ORDER_BUCKETS];
     __shared__ unsigned long long total;
-    for (int b = threadIdx.x; b < ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
+    __shared__ int fits_flag;
+    unsigned int *hflat = &hist[0][0];
+    for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
     if (threadIdx.x == 0) total = 0;
     __syncthreads();
     unsigned long long part_sum = 0;
@@ -1780,37 +1827,36 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     atomicAdd(&total, part_sum);
     __syncthreads();
     const unsigned long long mean = total / (unsigned long long)n + 1;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t c = cost[i];
-        atomicAdd(&hist[cost_bucket(c)], 1u << unit_parts_log2(c, mean));
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[b] = run; run += hist[b]; }
-        *n_work = run;
-    }
-    __syncthreads();
-    const bool fits = (long long)(offset[0] + hist[0]) <= capacity;        // total work items; if the list would overflow, do not split
-    if (!fits) {
-        __syncthreads();
-        for (int b = threadIdx.x; b < ORDER_BUCKETS; b += blockDim.x) hist[b] = 0;
-        __syncthreads();
-        for (long long i = threadIdx.x; i < n; i += blockDim.x) atomicAdd(&hist[cost_bucket(cost[i])], 1u);
+    for (int pass = 0; pass < 2; ++pass) {
+        // pass 0 counts with splitting; if the list would overflow its buffer, pass 1 recounts without
+        const bool split = pass == 0;
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t c = cost[i];
+            atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u << (split ? unit_parts_log2(c, mean) : 0));
+        }
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned int run = 0;
-            for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[b] = run; run += hist[b]; }
-            *n_work = run;
+            for (int x = 0; x < 9; ++x) {
+                seg[x] = run;
+                for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[x][b] = run; run += hist[x][b]; }
+            }
+            seg[9] = run;
+            fits_flag = (long long)run <= capacity;
         }
         __syncthreads();
-    }
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t c = cost[i];
-        const int pl = fits ? unit_parts_log2(c, mean) : 0;
-        const unsigned int pos = atomicAdd(&offset[cost_bucket(c)], 1u << pl);
-        for (int part = 0; part < (1 << pl); ++part) order[pos + part] = (uint32_t)i | ((uint32_t)part << 26) | ((uint32_t)pl << 29);
-        if (pl) cost[i] = 0;                                                // parts report with atomicMax
+        if (fits_flag) {
+            for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+                const uint32_t c = cost[i];
+                const int pl = split ? unit_parts_log2(c, mean) : 0;
+                const unsigned int pos = atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u << pl);
+                for (int part = 0; part < (1 << pl); ++part) order[pos + part] = (uint32_t)i | ((uint32_t)part << 26) | ((uint32_t)pl << 29);
+                if (pl) cost[i] = 0;                                        // parts report with atomicMax
+            }
+            return;
+        }
+        for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
+        __syncthreads();
     }
 }
 
@@ -1861,13 +1907,16 @@ struct AccumParams {
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
     int32_t frame_bins, slice_offset;
     unsigned long long *ticket;         // work ticket of the trace kernel: re-armed here for the next launch
+    unsigned int *blocks_done;          // device counter: the last block to finish publishes `pass_id`
+    volatile unsigned long long *host_done;   // pinned host word the issuing thread spins on (run-ahead throttle without runtime calls)
+    unsigned long long pass_id;
 };
 
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * ap.bins;
-    if (gid == 0 && ap.ticket) *ap.ticket = 0ULL;   // stream order: the trace kernel that used it has finished
-    if (gid >= total) return;
+    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
+    if (gid < total) {
     const long long k = gid / ap.bins;
     const int b = (int)(gid % ap.bins);
     double m = 0, v = 0;
@@ -1891,6 +1940,19 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         int nt;
         combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
         ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
+    }
+    }
+    // publish completion of this pass to the host (last block out)
+    if (ap.host_done) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __threadfence();
+            const unsigned int prev = atomicAdd(ap.blocks_done, 1u);
+            if (prev == gridDim.x - 1) {
+                *ap.blocks_done = 0u;
+                __hip_atomic_store(const_cast<unsigned long long *>(ap.host_done), ap.pass_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
     }
 }
 
@@ -1942,6 +2004,11 @@ struct rsx_ctx {
     TraceLane main, lanes[RSX_MAX_LANES];
     int pipeline_depth;        // 1 = renders run on the ctx stream only; n = rotate over n private lanes
     long long max_in_flight;   // render passes the host may run ahead of the device
+    long poll_ns;
+    unsigned int *blocks_done;         // device
+    unsigned long long *host_done;     // pinned, device-visible: id of the last merged pass (1-based)
+    bool timing;               // record per-call timing events (rsx_render_history); off removes four timed events per pass
+    std::vector<hipEvent_t> gate;   // untimed completion event per recent pass (host run-ahead throttle)
     int n_cus;
     float last_ms;
     bool have_accum;
@@ -1999,9 +2066,13 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         if (ctx->pipeline_depth < 1) ctx->pipeline_depth = 1;
         if (ctx->pipeline_depth > RSX_MAX_LANES) ctx->pipeline_depth = RSX_MAX_LANES;
         const char *env2 = std::getenv("RSX_MAX_IN_FLIGHT");
-        ctx->max_in_flight = env2 ? std::atoll(env2) : 4;
+        ctx->max_in_flight = env2 ? std::atoll(env2) : 16;
         if (ctx->max_in_flight < 1) ctx->max_in_flight = 1;
-        if (ctx->max_in_flight > RING_SLOTS / 2) ctx->max_in_flight = RING_SLOTS / 2;
+        if (ctx->max_in_flight > 48) ctx->max_in_flight = 48;
+        const char *env4 = std::getenv("RSX_TIMING");
+        ctx->timing = env4 ? std::atoi(env4) != 0 : true;
+        const char *env3 = std::getenv("RSX_POLL_NS");
+        ctx->poll_ns = env3 ? std::atol(env3) : 20000;
     }
     for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -2009,10 +2080,17 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
     HIP_TRY(hipEventCreate(&ctx->ev2));
+    HIP_TRY(hipMalloc(&ctx->blocks_done, 64));
+    HIP_TRY(hipMemset(ctx->blocks_done, 0, 64));
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->host_done), 64, hipHostMallocMapped | hipHostMallocCoherent));
+    *ctx->host_done = 0;
     ctx->main.stream = ctx->stream;
+    int lane_no = -1;
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
+        if (ln != &ctx->main && ++lane_no >= ctx->pipeline_depth) continue;      // only the lanes the pipeline depth uses get a stream (= an HSA queue)
+        if (ln != &ctx->main && ctx->pipeline_depth < 2) continue;
         if (ln != &ctx->main) HIP_TRY(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&ln->ticket, sizeof(unsigned long long)));
+        HIP_TRY(hipMalloc(&ln->ticket, 9 * 16 * sizeof(unsigned long long)));   // one ticket per XCD list, a cache line apart
         HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
     }
@@ -2035,7 +2113,10 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev2);
+    (void)hipFree(ctx->blocks_done);
+    (void)hipHostFree(ctx->host_done);
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->gate) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -2049,6 +2130,11 @@ extern "C" int rsx_set_stream(rsx_ctx *ctx, void *hip_stream) {
 
 extern "C" int rsx_synchronize(rsx_ctx *ctx) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    if (g_hp_on && g_hp_calls) {
+        fprintf(stderr, "[rsx host prof] %ld render calls: throttle %.3f ms/call, setup+trace launch %.3f, events/order/wait %.3f, merge launch %.3f\n",
+                g_hp_calls, 1e3 * g_hp[0] / g_hp_calls, 1e3 * g_hp[1] / g_hp_calls, 1e3 * g_hp[2] / g_hp_calls, 1e3 * g_hp[3] / g_hp_calls);
+        g_hp_calls = 0; for (double &v : g_hp) v = 0;
+    }
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
@@ -2072,6 +2158,7 @@ extern "C" int rsx_last_render_ms(rsx_ctx *ctx, float *trace_ms, float *accumula
 
 extern "C" int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumulate_ms) {
     if (!ctx || n < 1 || !trace_ms || !accumulate_ms) return rsx_fail(RSX_EINVAL, "rsx_render_history: bad arguments");
+    if (!ctx->timing) return rsx_fail(RSX_EINVAL, "rsx_render_history: timing events are disabled (RSX_TIMING=0)");
     if (n > ctx->render_calls || n > RING_SLOTS) return rsx_fail(RSX_EINVAL, "rsx_render_history: only %lld calls recorded (ring of %d)", ctx->render_calls, RING_SLOTS);
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
@@ -2105,6 +2192,21 @@ extern "C" int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t se
 extern "C" int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     ctx->unit_times = static_cast<unsigned long long *>(dev_buffer);
+    return RSX_OK;
+}
+
+extern "C" int rsx_render_timeline(rsx_ctx *ctx, int32_t n, float *t) {
+    if (!ctx || n < 1 || !t) return rsx_fail(RSX_EINVAL, "rsx_render_timeline: bad arguments");
+    if (!ctx->timing || n > ctx->render_calls || n > RING_SLOTS) return rsx_fail(RSX_EINVAL, "rsx_render_timeline: not enough timed calls recorded");
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    hipEvent_t origin = ctx->ring[(size_t)((ctx->render_calls - n) % RING_SLOTS) * 4];
+    for (int32_t i = 0; i < n; ++i) {
+        hipEvent_t *re = &ctx->ring[(size_t)((ctx->render_calls - n + i) % RING_SLOTS) * 4];
+        const int order[4] = {0, 1, 3, 2};                 // trace begin, trace end, merge begin, merge end
+        for (int k = 0; k < 4; ++k) HIP_TRY(hipEventElapsedTime(&t[4 * i + k], origin, re[order[k]]));
+    }
     return RSX_OK;
 }
 
@@ -2357,7 +2459,7 @@ int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg
 }
 
 int reset_ticket(TraceLane &lane) {
-    HIP_TRY(hipMemsetAsync(lane.ticket, 0, sizeof(unsigned long long), lane.stream));
+    HIP_TRY(hipMemsetAsync(lane.ticket, 0, 9 * 16 * sizeof(unsigned long long), lane.stream));
     lane.ticket_armed = false;          // whoever launches next dirties it again
     return RSX_OK;
 }
@@ -2551,6 +2653,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 
     bool want_order = false;
     long long order_n = 0;
+    int order_tiles_x = 0;
     RenderParams rp;
     rp.cam = desc->camera;
     rp.materials = static_cast<const rsx_material *>(d_mat);
@@ -2580,20 +2683,28 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             lane.unit_capacity = (size_t)n_units + (size_t)n_units / 8 + 64;
             HIP_TRY(hipMalloc(&lane.unit_cost, lane.unit_capacity * 4));
             HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4 * 2));      // room for split work items
-            if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 16));
+            if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 64));
             lane.cost_units = 0;
             lane.order_units = 0;
         }
         rp.unit_cost = lane.unit_cost;
         rp.unit_order = nullptr;
-        rp.n_work = nullptr;
-#if RSX_LPT_SCHEDULE
-        // the work list for this pass was sorted right after the lane's previous pass over the same units (see below)
-        if (lane.order_units == n_units && lane.cost_signature == sig) { rp.unit_order = lane.unit_order; rp.n_work = lane.n_work; }
+        rp.seg = nullptr;
+        // the work lists for this pass were sorted right after the lane's previous pass over the same units (see below);
+        // a first pass (or a changed camera / task list) sorts zero costs, i.e. natural order split over the XCD lists
+        if (n_units >= (1LL << 26)) return rsx_fail(RSX_EUNSUPPORTED, "render: more than 2^26 work units in one launch; split the call");
+        order_tiles_x = desc->tasks ? 0 : (int)((w + 7) / 8);
+        if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
+            HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
+            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units,
+                               (long long)lane.unit_capacity * 2, order_tiles_x, (int)desc->spp);
+            HIP_TRY(hipGetLastError());
+        }
+        rp.unit_order = lane.unit_order;
+        rp.seg = lane.n_work;
         lane.order_units = 0;
-        want_order = n_units >= 512 && n_units < (1LL << 26);
+        want_order = RSX_LPT_SCHEDULE != 0;
         order_n = n_units;
-#endif
         lane.cost_units = n_units;
         lane.cost_signature = sig;
     }
@@ -2609,20 +2720,26 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     hipEvent_t *re = &ctx->ring[(size_t)slot * 4];
     // keep the host at most `max_in_flight` passes ahead of the GPU: a host that queues hundreds of launches ahead fills the HSA
     // queues and the runtime's back-pressure wait then opens millisecond gaps between kernels (measured: 1.9 vs 0.9 ms per pass)
+    HP_BEGIN
+    // Keep the host at most `max_in_flight` passes ahead of the GPU so that long render loops cannot overflow the HSA queues.
+    while (ctx->gate.size() < (size_t)(2 * RSX_MAX_LANES + 64)) { hipEvent_t e; HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ctx->gate.push_back(e); }
     if (ctx->render_calls >= ctx->max_in_flight) {
         const long long old = ctx->render_calls - ctx->max_in_flight;
-        HIP_TRY(hipEventSynchronize(ctx->ring[(size_t)(old % RING_SLOTS) * 4 + 2]));
+        HIP_TRY(hipEventSynchronize(ctx->gate[(size_t)(old % (long long)ctx->gate.size())]));
     }
-    HIP_TRY(hipEventRecord(re[0], lane.stream));
+    HP_MARK(0)
+    const bool timed = ctx->timing;
+    if (timed) HIP_TRY(hipEventRecord(re[0], lane.stream));
     if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(re[1], lane.stream));
+    HP_MARK(1)
+    if (timed) HIP_TRY(hipEventRecord(re[1], lane.stream));
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
         hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n,
-                           (long long)lane.unit_capacity * 2);
+                           (long long)lane.unit_capacity * 2, order_tiles_x, (int)desc->spp);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
     }
@@ -2642,15 +2759,21 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
     ap.ticket = lane.ticket;
     lane.ticket_armed = true;
+    ap.blocks_done = ctx->blocks_done;
+    ap.host_done = nullptr;            // (pinned-flag completion publishing kept for diagnostics; the throttle uses events)
+    ap.pass_id = (unsigned long long)(ctx->render_calls + 1);
     const long long total = (long long)T * (long long)B;
-    HIP_TRY(hipEventRecord(re[3], ctx->stream));
+    HP_MARK(2)
+    if (timed) HIP_TRY(hipEventRecord(re[3], ctx->stream));
     hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(ctx->ev2, ctx->stream));
-    HIP_TRY(hipEventRecord(re[2], ctx->stream));
+    if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
     if (pipelined) { HIP_TRY(hipEventRecord(lane.merged, ctx->stream)); lane.in_flight = true; }
     ctx->render_calls++;
     ctx->have_accum = true;
+    HP_MARK(3)
+    if (g_hp_on) ++g_hp_calls;
     if (h_mean) {
         HIP_TRY(hipMemcpyAsync(h_mean, d_mean, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_var, d_var, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
