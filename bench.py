@@ -181,9 +181,10 @@ def main():
         b_ray, per_ray = ray_bytes(cnt, len(tasks))
         achieved = b_ray * rays_per_step / (trace_avg * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_pmc_c2.json")
-        if os.path.exists(pmc):
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        import glob
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c2.json")))      # latest committed rocprofv3 --pmc summary
+        if pmcs:
+            traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                     "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "kernel": "k_render_trace",
                     "kernel_ms": round(trace_avg, 4), "accumulate_kernel_ms": round(accum_avg, 4),

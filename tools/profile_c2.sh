@@ -4,12 +4,15 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_${1:-r01}
-mkdir -p "$OUT"
+rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-CMD="python $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline"
+CMD="python $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline"
 timeout 300 rocprofv3 --kernel-trace --stats -d "$OUT/trace" -o c2 --output-format csv -- $CMD > "$OUT/trace.log" 2>&1
+tail -1 "$OUT/trace.log" | cut -c1-300
+# PMC on a short un-pipelined run (counters serialise kernels anyway); fewer passes keep the profiling time bounded
+PCMD="python $R/tools/kbench.py 6 c2"
 for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM SQ_ACTIVE_INST_VALU SQ_THREAD_CYCLES_VALU GRBM_GUI_ACTIVE"; do
     tag=$(echo "$grp" | tr ' ' '_' | cut -c1-40)
-    timeout 300 rocprofv3 --pmc $grp -d "$OUT/pmc_$tag" -o c2 --output-format csv -- $CMD > "$OUT/pmc_$tag.log" 2>&1
+    RSX_PIPELINE=1 timeout 300 rocprofv3 --pmc $grp -d "$OUT/pmc_$tag" -o c2 --output-format csv -- $PCMD > "$OUT/pmc_$tag.log" 2>&1
 done
-ls -R "$OUT" | head -50
+ls "$OUT"
