@@ -6,11 +6,14 @@ and the CPU baseline timed in the same run.
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Workload (N=1): BASELINE.json configs[1] — one ~70k-triangle mesh (synthetic stand-in for the Stanford bunny, see
-source_amd/scenes.py), PinholeCamera 1024x1024, 1 sample/pixel/pass, 15 spectral bins, primary rays only
-(closed-form materials). One "step" = one observe() pass over the whole frame = 1 048 576 primary rays: ray generation
-(Philox jitter) -> two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford merge into the
+Workload (default, --workload c3): BASELINE.json configs[2], the configuration the metric is quoted on — the ~1M-triangle
+instanced scene (15 instances of the 69 432-triangle Stanford-bunny stand-in of source_amd/scenes.py + floor box),
+PinholeCamera 2048x2048, 64 samples/pixel/pass, 15 spectral bins, primary rays only (closed-form materials).
+One "step" = one observe() pass over the whole frame = 268 435 456 primary rays: ray generation (Philox jitter) ->
+two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford over the 64 samples, merged into the
 device-resident spectral frame. Scene, camera tables and the frame are resident in HBM when the timed region starts.
+--workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass); --workload c4 = configs[3] (demos/csg.py
+tree, 1024x1024, 16 spp/pass).
 
 N>1: sample sharding — every rank renders the same frame with its own sample counters (weak scaling: per-GPU work is
 fixed); the only collective is one RCCL all_gather of the (mean, variance, samples) frames after the K passes, followed
@@ -28,9 +31,32 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
-NX = NY = 1024
-SPP = 1
 BINS = 15
+WORKLOADS = {
+    "c3": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
+               name="configs[2]: 1 041 480-triangle instanced scene (15 instances of the 69 432-triangle Stanford-bunny stand-in + floor "
+                    "box), PinholeCamera 2048x2048, 64 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
+    "c2": dict(nx=1024, ny=1024, spp=1, counter_rows=8,
+               name="configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera 1024x1024, 1 spp/pass, "
+                    "15 spectral bins, primary rays only, 1 MI355X per rank"),
+    "c4": dict(nx=1024, ny=1024, spp=16, counter_rows=8,
+               name="configs[3]: demos/csg.py Boolean tree (sphere/box/cylinder Union/Intersect/Subtract, 5 CSG objects), PinholeCamera "
+                    "1024x1024, 16 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
+}
+
+
+def build_workload(key, ns, scenes):
+    w = WORKLOADS[key]
+    if key == "c3":
+        world = scenes.build_c3(ns, n=132)[0]
+        cam, pipe = scenes.c3_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    elif key == "c2":
+        world = scenes.build_c2(ns, n=132)[0]
+        cam, pipe = scenes.c2_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    else:
+        world = scenes.build_csg_demo(ns)[0]
+        cam, pipe = scenes.csg_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    return world, cam, pipe
 
 
 def ray_bytes(counters, n_rays):
@@ -47,8 +73,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-rows", type=int, default=0, help="rows of the frame the CPU baseline renders (0 = auto, ~15 s)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
+    ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     args = ap.parse_args()
+    W = WORKLOADS[args.workload]
+    NX, NY, SPP = W["nx"], W["ny"], W["spp"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -69,8 +98,7 @@ def main():
     from source_amd.device import get_context
     from source_amd.distributed import rank_sample_offset
 
-    world, mesh, box = scenes.build_c2(ns, n=132)
-    cam, pipe = scenes.c2_camera(ns, world, (NX, NY), spp=SPP, bins=BINS)
+    world, cam, pipe = build_workload(args.workload, ns, scenes)
     cam.frame_sampler = ns.RectFrameSampler2D()
     engine = ns.HipEngine(rng="philox", seed=20250905, timing=False)
     cam.render_engine = engine
@@ -114,11 +142,12 @@ def main():
     # here and not inside the W warmup or K timed steps. These passes are ordinary passes into the same accumulating frame.
     prewarm = 0
     t_pre = time.perf_counter()
+    burst = 16 if NX * NY * SPP < (1 << 24) else 1
     while time.perf_counter() - t_pre < 0.4:
-        for _ in range(16):
+        for _ in range(burst):
             step()
         sync()
-        prewarm += 16
+        prewarm += burst
     for _ in range(args.warmup):
         step()
     sync()
@@ -167,8 +196,8 @@ def main():
 
         from oracle import oracle as orc
         flat = scene.flat
-        # mean per-ray traversal counters on every 8th row of the same camera (pixel-centre rays), instrumented oracle
-        rows = np.arange(0, NY, 8)
+        # mean per-ray traversal counters on every k-th row of the same camera (pixel-centre rays), instrumented oracle
+        rows = np.arange(0, NY, W["counter_rows"])
         tasks = np.array([(ix, iy) for iy in rows for ix in range(NX)], dtype=np.int32)
         from source_amd import _lib
         d2 = _lib.RenderDesc()
@@ -182,7 +211,7 @@ def main():
         achieved = b_ray * rays_per_step / (trace_avg * 1e-3) / 1e9
         traffic = None
         import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c2.json")))      # latest committed rocprofv3 --pmc summary
+        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % args.workload)))   # latest committed rocprofv3 --pmc summary
         if pmcs:
             traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -192,37 +221,43 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline:
-            # bounded sample of the same workload on the host cores: every k-th row of the frame, same Philox samples
+            # bounded sample of the same workload on the host cores, same Philox samples: calibrate on a 16-row band, then size
+            # the sample for ~args.cpu_seconds of CPU work — whole passes when one fits, otherwise a centred band of rows
             keep = []
             sl = cam._slice_spectrum()[0]
             engine.sample_offset = 0
-            # calibrate on 16 full passes, then size the sample for ~12 s of CPU work (whole-frame passes, same Philox samples)
-            saved = cam.pixel_samples
-            cam.pixel_samples = 16
-            desc = cam.render_desc(world, None, sl, engine, keep, rect=(0, 0, NX, NY))
+            band = (0, NY // 2 - 8, NX, NY // 2 + 8)
+            desc = cam.render_desc(world, None, sl, engine, keep, rect=band)
             orc.render_pinhole(flat, desc, threads=nthreads)        # thread-pool warm-up
             tcal = time.perf_counter()
             m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
             rate = nr / (time.perf_counter() - tcal)
-            passes = args.cpu_rows or int(min(2048, max(1, round(rate * 12.0 / (NX * NY)))))
-            cam.pixel_samples = passes
-            desc = cam.render_desc(world, None, sl, engine, keep, rect=(0, 0, NX, NY))
+            target = rate * args.cpu_seconds
+            saved = cam.pixel_samples
+            if target >= rays_per_step:
+                passes = int(min(2048, max(1, round(target / rays_per_step))))
+                cam.pixel_samples = SPP * passes
+                rect = (0, 0, NX, NY)
+                what = "%d full %dx%d passes of %d spp" % (passes, NX, NY, SPP)
+            else:
+                nrows = int(max(16, min(NY, target // (NX * SPP))))
+                rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
+                what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, SPP)
+            desc = cam.render_desc(world, None, sl, engine, keep, rect=rect)
             cam.pixel_samples = saved
             tcpu = time.perf_counter()
             m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
             tcpu = time.perf_counter() - tcpu
             assert np.isfinite(m).all()
             cpu = {"value": round(nr / tcpu, 1), "unit": "primary rays/s", "cores": nthreads, "kind": "port",
-                   "sample": "%d full 1024x1024 passes of the same workload (%d rays), oracle/rsx_oracle.c (C restatement of the "
-                             "reference algorithm) with OpenMP on %d host threads, %.1f s" % (passes, nr, nthreads, tcpu)}
+                   "sample": "%s of the same workload (%d rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
+                             "with OpenMP on %d host threads, %.1f s" % (what, nr, nthreads, tcpu)}
 
         out = {
             "metric": "primary rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera "
-                                   "1024x1024, 1 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank",
-                       "rays_per_step_per_gpu": rays_per_step, "rng": "philox4x32-10", "sharding": "sample" if world_size > 1 else "none",
+            "config": {"workload": W["name"], "rays_per_step_per_gpu": rays_per_step, "rng": "philox4x32-10", "sharding": "sample" if world_size > 1 else "none",
                        "collective_ms": round(collective_ms, 3)},
             "roofline": roofline, "cpu_baseline": cpu,
         }

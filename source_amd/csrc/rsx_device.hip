@@ -55,7 +55,9 @@
 #define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
 #endif
 #ifndef RSX_MIN_WAVES_PER_SIMD
-#define RSX_MIN_WAVES_PER_SIMD 1    // __launch_bounds__ second argument for the traversal kernels
+#define RSX_MIN_WAVES_PER_SIMD 2    // __launch_bounds__ second argument for the mesh/analytic traversal kernels: caps them at 256
+                                    // registers (VGPR + AGPR) so two waves fit a SIMD; unconstrained the compiler took 260 and the
+                                    // hardware ran ONE wave per SIMD (measured: 163 -> 86 ms on configs[2]). 3 or 4 force spills and lose.
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -487,7 +489,7 @@ __device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x
 // ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic wave-min, which is exactly what the
 // reference's sequential scan with strict `<` returns (the first item among those with the smallest distance). Idle lanes —
 // rays that already finished, or never needed this mesh — serve as helpers.
-__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, unsigned long long *phase_acc = nullptr) {
+__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
     const int lane = threadIdx.x % WAVE;
     PHASE_DECL
     double tmin = 0, tmax = 0;
@@ -500,6 +502,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
         double distance = 0;
         int32_t closest = -1, count = 0, first = 0;
         float bu = 0, bv = 0, bw = 0;
+        work += 8;                                   // one descend + small-leaf round of the wave (scheduling weight, see k_order_units)
         PHASE_ADD(0)
         rsx_kdnode nd;
         nd.count = 0; nd.u.leaf.first_item = 0;
@@ -552,6 +555,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 //     in leaf order (the reference's own loop), reading each record as an LDS broadcast
                 float4 *rec = st.stage;
                 int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
+                work += 2 + (uint32_t)lcount / 8;
                 for (int32_t c = 0; c < lcount; c += WAVE) {
                     __builtin_amdgcn_wave_barrier();
                     const int32_t k = c + lane;
@@ -582,6 +586,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
             while (todo) {
                 const int owner = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
+                work += 2 + (uint32_t)lcount / 32;
                 TriRay lq;
                 lq.ox = shfl_f64(q.ox, owner); lq.oy = shfl_f64(q.oy, owner); lq.oz = shfl_f64(q.oz, owner);
                 lq.maxd = shfl_f64(q.maxd, owner);
@@ -627,162 +632,6 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
         }
         PHASE_ADD(4)
     }
-    return hit;
-}
-
-#ifndef RSX_STEP_LOOP
-#define RSX_STEP_LOOP 0            // 1: one memory-dependent step per lane per iteration (node visit OR leaf batch); 0: descend-all-then-leaf
-#endif
-
-// Fine-grained variant of mesh_trace_wave. Every iteration each unfinished lane issues exactly one round of loads — the (node,
-// node+1) pair it stands on, or the next RSX_LEAF_BATCH records of the leaf it is in — and then consumes them. Lanes no longer
-// wait for the slowest lane of the wave to reach its leaf before testing theirs, which is what made silhouette tiles (rays grazing
-// the surface through hundreds of cells, a different number for every lane) cost 3x the longest single ray.
-__device__ bool mesh_trace_steps(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, unsigned long long *phase_acc = nullptr) {
-    const int lane = threadIdx.x % WAVE;
-    double tmin = 0, tmax = 0;
-    bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
-    const TriRay q = tri_ray(r);
-    const AxisDiv ad = axis_div(r);
-    bool hit = false;
-    int32_t node = 0, sp = 0;
-    // leaf state (valid while in_leaf)
-    bool in_leaf = false;
-    int32_t first = 0, count = 0, pos = 0, closest = -1;
-    double distance = 0;
-    float bu = 0, bv = 0, bw = 0;
-    while (__any(active)) {
-        bool leaf_done = false;
-        if (active && !in_leaf) {
-            // ---- node step(s): stand on `node`; stepping into the lower child (next record) is free, so take up to two levels
-            rsx_kdnode nd = load_node(m.nodes, node), nx = load_node(m.nodes, node + 1);
-#pragma unroll
-            for (int level = 0; level < 2; ++level) {
-                if (nd.type < 0) break;
-                const int axis = nd.type;
-                const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
-                                                 (ad.safe >> axis) & 1, tmin, tmax, st, sp);
-                const bool adjacent = next == node + 1;
-                node = next;
-                if (!adjacent || level == 1) { nd.type = 3; break; }         // 3 = "branch whose record is not loaded yet"
-                nd = nx;
-            }
-            if (nd.type < 0) {                                                // arrived at a leaf: _trace_leaf, mesh.pyx:520-563
-                in_leaf = true;
-                first = nd.u.leaf.first_item; count = nd.count; pos = 0; closest = -1;
-                distance = r.maxd < tmax ? r.maxd : tmax;
-                if (count == 0) leaf_done = true;
-            }
-        } else if (active && count < RSX_COOP_LEAF) {
-            // ---- leaf step: next batch of records, in leaf order
-            int32_t tri[RSX_LEAF_BATCH];
-            float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
-#pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j)
-                leaf_fetch(m.items, m.tris, m.leaf, first + (pos + j < count ? pos + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
-#pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
-                float ht, hu, hv, hw;
-                if (pos + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
-                    distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
-                }
-            }
-            pos += RSX_LEAF_BATCH;
-            if (pos >= count) leaf_done = true;
-        }
-        // ---- big leaves: whole-wave cooperation (a lane enters here in the iteration after it reached the leaf)
-        unsigned long long big = __ballot(active && in_leaf && !leaf_done && count >= RSX_COOP_LEAF);
-        while (big) {
-            const int leader = __ffsll((long long)big) - 1;
-            const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
-            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris, leaf_bits = (unsigned long long)m.leaf;
-            const unsigned long long l_items_bits = ((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
-                                                    (unsigned)__shfl((int)items_bits, leader, WAVE);
-            const int32_t *litems = (const int32_t *)l_items_bits;
-            const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
-                                                   (unsigned)__shfl((int)tris_bits, leader, WAVE));
-            const float4 *lleaf = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(leaf_bits >> 32), leader, WAVE) << 32) |
-                                                   (unsigned)__shfl((int)leaf_bits, leader, WAVE));
-            const bool same = active && in_leaf && !leaf_done && count >= RSX_COOP_LEAF && first == lfirst && items_bits == l_items_bits;
-            const unsigned long long group = __ballot(same);
-            big &= ~group;
-            if (__popcll(group) >= RSX_STAGE_MIN) {
-                float4 *rec = st.stage;
-                int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
-                for (int32_t c = 0; c < lcount; c += WAVE) {
-                    __builtin_amdgcn_wave_barrier();
-                    const int32_t k = c + lane;
-                    if (k < lcount) {
-                        int32_t tri;
-                        float4 a, b, cc;
-                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, cc);
-                        rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
-                        ids[lane] = tri;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (same) {
-                        const int32_t nj = lcount - c < WAVE ? lcount - c : WAVE;
-                        for (int32_t j = 0; j < nj; ++j) {
-                            float ht, hu, hv, hw;
-                            if (tri_test(q, rec[3 * j], rec[3 * j + 1], rec[3 * j + 2], ht, hu, hv, hw) && (double)ht < distance) {
-                                distance = (double)ht; closest = ids[j]; bu = hu; bv = hv; bw = hw;
-                            }
-                        }
-                    }
-                }
-            } else {
-                unsigned long long todo = group;
-                while (todo) {
-                    const int owner = __ffsll((long long)todo) - 1;
-                    todo &= todo - 1;
-                    TriRay lq;
-                    lq.ox = shfl_f64(q.ox, owner); lq.oy = shfl_f64(q.oy, owner); lq.oz = shfl_f64(q.oz, owner);
-                    lq.maxd = shfl_f64(q.maxd, owner);
-                    lq.sx = __shfl(q.sx, owner, WAVE); lq.sy = __shfl(q.sy, owner, WAVE); lq.sz = __shfl(q.sz, owner, WAVE);
-                    const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), owner, WAVE);
-                    lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
-                    const double limit = shfl_f64(distance, owner);
-                    float mt = INFINITY, mu = 0, mv = 0, mw = 0;
-                    int32_t mk = 0x7fffffff, mtri = -1;
-                    for (int32_t k = lane; k < lcount; k += WAVE) {
-                        int32_t tri;
-                        float4 a, b, c;
-                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, c);
-                        float ht, hu, hv, hw;
-                        if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
-                    }
-                    float wt = mt;
-                    int32_t wk = mk;
-#pragma unroll
-                    for (int off = 32; off >= 1; off >>= 1) {
-                        const float ot = __shfl_xor(wt, off, WAVE);
-                        const int32_t ok = __shfl_xor(wk, off, WAVE);
-                        if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
-                    }
-                    const int winner = wk & (WAVE - 1);
-                    const bool found = wk != 0x7fffffff;
-                    const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
-                    const int32_t rtri = __shfl(mtri, winner, WAVE);
-                    if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
-                }
-            }
-            if (same) leaf_done = true;
-        }
-        // ---- a finished leaf either ends the ray (hit) or resumes from the stack
-        if (active && leaf_done) {
-            in_leaf = false;
-            if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
-            else if (sp == 0) active = false;
-            else {
-                --sp;
-                tmin = tmax;
-                stack_pop(st, sp, node, tmax);
-            }
-        }
-    }
-    (void)phase_acc;
     return hit;
 }
 
@@ -1323,7 +1172,7 @@ __device__ bool world_trace(const DScene &sc, const Ray &r, const Stack &st, con
 // ray) and all loops are wave-uniform, so that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves).
 template <bool CSG>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
-                                 unsigned long long *phase_acc = nullptr) {
+                                 uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
@@ -1349,15 +1198,12 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
             Hit cand;
             cand.prim = -1;
+            work += CSG ? 16 : 4;
             if (__any(is_mesh)) {
                 Ray l = r;
                 if (is_mesh) l = to_local(p, r);
                 MeshHit mh;
-#if RSX_STEP_LOOP
-                if (mesh_trace_steps(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, phase_acc)) {
-#else
-                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, phase_acc)) {
-#endif
+                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, work, phase_acc)) {
                     cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                 }
             }
@@ -1426,7 +1272,7 @@ struct HitOut {
 };
 
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
+__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
                                                           const double *maxd, HitOut out, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
@@ -1446,7 +1292,8 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_hit_batc
         }
         Hit h;
 #if RSX_WAVE_COOP
-        const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h);
+        uint32_t work = 0;
+        const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h, work);
 #else
         const bool hit = valid && world_trace<CSG>(sc, r, st, ms, csg_state, h);
 #endif
@@ -1595,6 +1442,26 @@ __device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t 
     u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
 }
 
+// clock the unit costs are measured with (only ever compared within one lane's cost array)
+// Unit cost that steers the longest-first schedule: 0 = the wave's own count of traversal rounds (free, deterministic);
+// 1 / 2 = s_memrealtime / s_memtime around the unit. Measured on configs[2]: the two clock reads per unit serialise chip-wide
+// (~9 ns each whatever the occupancy) and doubled the kernel time of a 4.2 M-unit pass, so the counter is the default.
+#ifndef RSX_COST_CLOCK
+#define RSX_COST_CLOCK 0
+#endif
+#ifndef RSX_LPT_MAX_UNITS
+#define RSX_LPT_MAX_UNITS (1 << 18)   // passes with more 64-ray units than this are not re-ordered
+#endif
+__device__ __forceinline__ unsigned long long cost_clock() {
+#if RSX_COST_CLOCK == 1
+    return wall_clock64();
+#elif RSX_COST_CLOCK == 2
+    return (unsigned long long)clock64();
+#else
+    return 0ULL;
+#endif
+}
+
 struct RenderParams {
     rsx_camera cam;
     const rsx_material *materials;
@@ -1607,6 +1474,7 @@ struct RenderParams {
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list or null: ticket k processes work item unit_order[k] = unit | part << 26 | log2(parts) << 29
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
+    int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
     unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
 };
 
@@ -1624,7 +1492,7 @@ __device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, 
 // Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
 // 64 rays stay coherent; in task-list mode 64 consecutive tasks.
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -1653,7 +1521,9 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
         const uint32_t wi = rp.unit_order[tk];
         const long long unit = (long long)(wi & 0x3ffffffu);
         const int part = (int)((wi >> 26) & 7u), parts_log2 = (int)(wi >> 29);
-        const unsigned long long c_start = wall_clock64();
+#if RSX_COST_CLOCK
+        const unsigned long long c_start = rp.measure_cost ? cost_clock() : 0ULL;
+#endif
         const int s = (int)(unit % rp.spp);
         const long long chunk = unit / rp.spp;
         const unsigned long long t_start = rp.unit_times ? wall_clock64() : 0ULL;
@@ -1662,19 +1532,21 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
 #else
         unsigned long long *phase_acc = nullptr;
 #endif
-        long long k = 0;
+        long long k = 0, slot = 0;
         int ix = 0, iy = 0;
         bool valid;
         if (rp.tasks) {
             k = chunk * 64 + lane;
             valid = k < rp.n_tasks;
             if (valid) task_pixel(rp, k, ix, iy); else k = 0;
+            slot = k;
         } else {
             const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
             const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
             valid = lx < w && ly < h;
             ix = rp.rect[0] + (valid ? lx : 0); iy = rp.rect[1] + (valid ? ly : 0);
             k = valid ? (long long)ly * w + lx : 0;
+            slot = valid ? (long long)lx * h + ly : 0;     // sample records are stored x-major like the frame (k_accumulate streams both)
         }
         // a heavy unit is processed as 2/4/8 work items of 32/16/8 consecutive lanes each; the other lanes only help
         valid = valid && (lane >> (6 - parts_log2)) == part;
@@ -1698,12 +1570,17 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
 #if RSX_WAVE_COOP
-        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, phase_acc);
+        uint32_t work = 0;
+        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
 #else
         const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
 #endif
-        if (lane == 0) {
-            unsigned long long c = (wall_clock64() - c_start) << parts_log2;   // estimate of the unsplit cost (keeps heavy units split)
+        if (rp.measure_cost && lane == 0) {
+#if RSX_COST_CLOCK
+            unsigned long long c = (cost_clock() - c_start) << parts_log2;   // estimate of the unsplit cost (keeps heavy units split)
+#else
+            unsigned long long c = (unsigned long long)work << parts_log2;
+#endif
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
             if (parts_log2) atomicMax(&rp.unit_cost[unit], (uint32_t)c); else rp.unit_cost[unit] = (uint32_t)c;
         }
@@ -1732,7 +1609,7 @@ __global__ __launch_bounds__(WG_THREADS, RSX_MIN_WAVES_PER_SIMD) void k_render_t
                 }
             }
         }
-        samples[k * rp.spp + s] = smp;
+        samples[slot * rp.spp + s] = smp;
     }
 }
 
@@ -1860,25 +1737,37 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     }
 }
 
-// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859
-__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n) {
+// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859.
+// Every division here is by a small positive integer whose refined reciprocal is shared by the two divisions of consecutive
+// Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
+// rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
+// (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
+struct IntRcp {
+    double d, y;
+    __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
+    __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
+};
+
+// n -> n + 1 samples; `by_n` = IntRcp(n + 1), `by_nm1` = IntRcp(n) (the divisors of the update)
+__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n, const IntRcp &by_n, const IntRcp &by_nm1) {
     if (n == 0) { n = 1; m = x; v = 0; return; }
     const double pm = m, pv = v;
     const int pn = n > 1 ? n : 2;
     n += 1;
-    m = pm + (x - pm) / n;
-    v = (pv * (pn - 1) + (x - pm) * (x - m)) / (n - 1);
+    m = pm + by_n.div(x - pm);
+    v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
 }
 
 __device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
     if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
     if (nx > 1 && ny > 1) {
         nt = nx + ny;
-        mt = (nx * mx + ny * my) / (double)nt;
-        vx = (nx - 1) * vx / (double)nx;
-        vy = (ny - 1) * vy / (double)ny;
-        vt = (nx * (mx * mx + vx) + ny * (my * my + vy)) / (double)nt - mt * mt;
-        vt = nt * vt / (double)(nt - 1);
+        const IntRcp by_nt(nt);
+        mt = by_nt.div(nx * mx + ny * my);
+        vx = IntRcp(nx).div((nx - 1) * vx);
+        vy = IntRcp(ny).div((ny - 1) * vy);
+        vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
+        vt = IntRcp(nt - 1).div(nt * vt);
         return;
     }
     if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
@@ -1887,7 +1776,7 @@ __device__ __forceinline__ void combine_samples(double mx, double vx, int nx, do
         else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
     } else if (nx > 1) {
         nt = nx; mt = mx; vt = vx;
-        if (ny == 1) add_sample(my, mt, vt, nt);
+        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
     } else { nt = 0; mt = 0; vt = 0; }
 }
 
@@ -1906,53 +1795,48 @@ struct AccumParams {
     double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
     int32_t frame_bins, slice_offset;
-    unsigned long long *ticket;         // work ticket of the trace kernel: re-armed here for the next launch
-    unsigned int *blocks_done;          // device counter: the last block to finish publishes `pass_id`
-    volatile unsigned long long *host_done;   // pinned host word the issuing thread spins on (run-ahead throttle without runtime calls)
-    unsigned long long pass_id;
+    unsigned long long *ticket;         // work tickets of the trace kernel: re-armed here for the next launch
 };
 
+// Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
+// kernel wrote, so both streams are read and written as contiguous runs. Task-list mode keeps task order.
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * ap.bins;
     if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
-    if (gid < total) {
-    const long long k = gid / ap.bins;
+    if (gid >= total) return;
+    const long long p = gid / ap.bins;
     const int b = (int)(gid % ap.bins);
+    long long k = p;                                        // task index (row-major in rect mode): addresses the per-task outputs
+    int ix, iy;
+    if (ap.tasks) { ix = ap.tasks[2 * p]; iy = ap.tasks[2 * p + 1]; }
+    else {
+        const int w = ap.rect[2] - ap.rect[0], h = ap.rect[3] - ap.rect[1];
+        const int lx = (int)(p / h), ly = (int)(p % h);
+        ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
+        k = (long long)ly * w + lx;
+    }
     double m = 0, v = 0;
     int n = 0;
-    const Sample *s = ap.samples + k * ap.spp;
+    const Sample *s = ap.samples + p * ap.spp;
+    IntRcp by_nm1(1);
     for (int i = 0; i < ap.spp; ++i) {
+        const IntRcp by_n(i + 1);
         const Sample smp = s[i];
         double x = smp.table < 0 ? 0.0 : smp.a * ap.tables[(size_t)smp.table * ap.bins + b];
         x = x * smp.weight;                                                   // observer.pyx:408
         if (ap.power) x = x * ap.sensitivity;
-        add_sample(x, m, v, n);
+        add_sample(x, m, v, n, by_n, by_nm1);                                 // n: i -> i + 1, divisors i + 1 and i
+        by_nm1 = by_n;
     }
-    if (ap.mean) { ap.mean[gid] = m; ap.variance[gid] = v; }
+    if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
     if (ap.fmean) {
-        int ix, iy;
-        if (ap.tasks) { ix = ap.tasks[2 * k]; iy = ap.tasks[2 * k + 1]; }
-        else { const int w = ap.rect[2] - ap.rect[0]; ix = ap.rect[0] + (int)(k % w); iy = ap.rect[1] + (int)(k / w); }
         const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
         if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
         double mt, vt;
         int nt;
         combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
         ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
-    }
-    }
-    // publish completion of this pass to the host (last block out)
-    if (ap.host_done) {
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            __threadfence();
-            const unsigned int prev = atomicAdd(ap.blocks_done, 1u);
-            if (prev == gridDim.x - 1) {
-                *ap.blocks_done = 0u;
-                __hip_atomic_store(const_cast<unsigned long long *>(ap.host_done), ap.pass_id, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
     }
 }
 
@@ -2002,11 +1886,9 @@ struct rsx_ctx {
     hipStream_t own_stream;
     hipEvent_t ev0, ev1, ev2;  // ev0..ev1 = last traversal kernel, ev1..ev2 = last accumulate kernel
     TraceLane main, lanes[RSX_MAX_LANES];
+    int render_wg_override;    // env RSX_RENDER_WG: workgroups per CU of a pipelined pass (tuning aid; 0 = heuristic)
     int pipeline_depth;        // 1 = renders run on the ctx stream only; n = rotate over n private lanes
     long long max_in_flight;   // render passes the host may run ahead of the device
-    long poll_ns;
-    unsigned int *blocks_done;         // device
-    unsigned long long *host_done;     // pinned, device-visible: id of the last merged pass (1-based)
     bool timing;               // record per-call timing events (rsx_render_history); off removes four timed events per pass
     std::vector<hipEvent_t> gate;   // untimed completion event per recent pass (host run-ahead throttle)
     int n_cus;
@@ -2065,14 +1947,14 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         ctx->pipeline_depth = env ? std::atoi(env) : 2;
         if (ctx->pipeline_depth < 1) ctx->pipeline_depth = 1;
         if (ctx->pipeline_depth > RSX_MAX_LANES) ctx->pipeline_depth = RSX_MAX_LANES;
+        env = std::getenv("RSX_RENDER_WG");
+        ctx->render_wg_override = env ? std::atoi(env) : 0;
         const char *env2 = std::getenv("RSX_MAX_IN_FLIGHT");
         ctx->max_in_flight = env2 ? std::atoll(env2) : 16;
         if (ctx->max_in_flight < 1) ctx->max_in_flight = 1;
         if (ctx->max_in_flight > 48) ctx->max_in_flight = 48;
         const char *env4 = std::getenv("RSX_TIMING");
         ctx->timing = env4 ? std::atoi(env4) != 0 : true;
-        const char *env3 = std::getenv("RSX_POLL_NS");
-        ctx->poll_ns = env3 ? std::atol(env3) : 20000;
     }
     for (int i = 0; i < POOL_SLOTS; ++i) { ctx->pool[i] = nullptr; ctx->pool_bytes[i] = 0; }
     HIP_TRY(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
@@ -2080,10 +1962,6 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     HIP_TRY(hipEventCreate(&ctx->ev0));
     HIP_TRY(hipEventCreate(&ctx->ev1));
     HIP_TRY(hipEventCreate(&ctx->ev2));
-    HIP_TRY(hipMalloc(&ctx->blocks_done, 64));
-    HIP_TRY(hipMemset(ctx->blocks_done, 0, 64));
-    HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ctx->host_done), 64, hipHostMallocMapped | hipHostMallocCoherent));
-    *ctx->host_done = 0;
     ctx->main.stream = ctx->stream;
     int lane_no = -1;
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
@@ -2113,8 +1991,6 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipEventDestroy(ctx->ev0);
     (void)hipEventDestroy(ctx->ev1);
     (void)hipEventDestroy(ctx->ev2);
-    (void)hipFree(ctx->blocks_done);
-    (void)hipHostFree(ctx->host_done);
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->gate) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->own_stream);
@@ -2421,6 +2297,8 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
     d.wlds = std::min(d.wdepth, RSX_WORLD_LDS_LEVELS);
     d.mlds = std::min(d.mdepth, RSX_MESH_LDS_LEVELS);
+    if (const char *env = std::getenv("RSX_WORLD_LDS")) d.wlds = std::max(0, std::min(d.wdepth, std::atoi(env)));   // tuning aids
+    if (const char *env = std::getenv("RSX_MESH_LDS")) d.mlds = std::max(0, std::min(d.mdepth, std::atoi(env)));
 #undef UP
     *out = sc;
     return RSX_OK;
@@ -2607,7 +2485,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     void *d_mat = nullptr, *d_tab = nullptr, *d_tasks = nullptr, *d_mean = nullptr, *d_var = nullptr;
     int rc;
     // which lane traces this pass: frame renders alternate the two private lanes (passes overlap), everything else stays on the ctx stream
-    const bool pipelined = !h_mean && ctx->pipeline_depth > 1;
+    // Small passes are tail-bound and overlap well; a large pass fills the chip by itself (its merge kernel could not even get
+    // registers next to it), so it runs alone on the ctx stream.
+    const long long rect_w = desc->rect[2] - desc->rect[0], rect_h = desc->rect[3] - desc->rect[1];
+    const long long n_units_all = desc->tasks ? ((desc->n_tasks + 63) / 64) * desc->spp : ((rect_w + 7) / 8) * ((rect_h + 7) / 8) * (long long)desc->spp;
+    const bool pipelined = !h_mean && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
 
@@ -2702,8 +2584,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         }
         rp.unit_order = lane.unit_order;
         rp.seg = lane.n_work;
-        lane.order_units = 0;
-        want_order = RSX_LPT_SCHEDULE != 0;
+        // Longest-first ordering pays when a pass is tail-bound (few units per wave); a pass with thousands of units per wave
+        // balances by itself, so it keeps the natural (XCD-blocked) order and the kernel skips the cost bookkeeping.
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS;
+        rp.measure_cost = want_order ? 1 : 0;
+        lane.order_units = want_order ? 0 : n_units;
         order_n = n_units;
         lane.cost_units = n_units;
         lane.cost_signature = sig;
@@ -2712,7 +2597,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     Launch l;
     // pipelined passes share the chip: each takes RSX_RENDER_WG_PER_CU workgroups per CU so that the other lane's pass, the merge
     // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
-    if ((rc = plan(scene, (long long)S, lane, l, pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU))) return rc;
+    // A pipelined (small, tail-bound) pass takes one workgroup per CU and the neighbouring lane's pass fills the idle CUs.
+    int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
+    if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
+    if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
@@ -2759,9 +2647,6 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
     ap.ticket = lane.ticket;
     lane.ticket_armed = true;
-    ap.blocks_done = ctx->blocks_done;
-    ap.host_done = nullptr;            // (pinned-flag completion publishing kept for diagnostics; the throttle uses events)
-    ap.pass_id = (unsigned long long)(ctx->render_calls + 1);
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
     if (timed) HIP_TRY(hipEventRecord(re[3], ctx->stream));

@@ -2,7 +2,7 @@
 Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests). Rays shard with no data-path collective; the only exchange is the final spectral framebuffer:
 
-* sample sharding — every rank renders the full frame with its own Philox sample counters; ``merge_sample_sharded`` all-gathers
+* sample sharding — every rank renders the full frame with its own Philox sample counters; ``merge_sample_sharded`` exchanges
   the (mean, variance, samples) frames and folds them in rank order with the combine_samples law (statsarray.pyx:780-859), so the
   result is deterministic and identical on every rank;
 * tile sharding — ``gather_tiles`` all-gathers column tiles of the x-major frame (contiguous, no arithmetic).
@@ -53,27 +53,59 @@ def combine_arrays(ma, va, na, mb, vb, nb):
     return out_m, out_v, out_n.astype(np.int32)
 
 
-def merge_sample_sharded(mean, variance, samples, dist, combine=None):
+def merge_sample_sharded(mean, variance, samples, dist, combine=None, mode="scatter"):
     """
     mean/variance/samples: this rank's frame as torch tensors (CUDA for nccl, CPU for gloo). Returns the merged frame
     (same on every rank). `combine(m, v, n, mb, vb, nb)` folds b into a in place; default = numpy restatement (CPU tensors).
+
+    Every element of the result is the fold combine(...combine(combine(rank 0, rank 1), rank 2)..., rank W-1): rank order, so the
+    merge is deterministic and independent of how the exchange is routed. Two routings:
+
+    * ``"scatter"`` (default) — the reduce-scatter / all-gather shape of a ring all-reduce with combine_samples as the operator:
+      one all_to_all hands rank j the j-th 1/W segment of every rank's frame, rank j folds its W pieces, one all_gather
+      redistributes the merged segments. Each rank receives 2 (W-1)/W frames instead of W-1 (xGMI links are point to point, so
+      bytes per link is what bounds the exchange);
+    * ``"gather"`` — all_gather of whole frames, every rank folds everything (simple; fine for W = 2).
     """
     import torch
     world = dist.get_world_size()
-    gathered = []
+
+    def fold(parts_m, parts_v, parts_n):
+        m, v, n = parts_m[0].clone(), parts_v[0].clone(), parts_n[0].clone()
+        for r in range(1, world):
+            mb, vb, nb = parts_m[r], parts_v[r], parts_n[r]
+            if combine is not None:
+                combine(m, v, n, mb, vb, nb)
+            else:
+                om, ov, on = combine_arrays(m.numpy(), v.numpy(), n.numpy(), mb.numpy(), np.maximum(vb.numpy(), 0.0), nb.numpy())
+                m, v, n = torch.from_numpy(om), torch.from_numpy(ov), torch.from_numpy(on)
+        return m, v, n
+
+    if mode == "gather" or world == 1:
+        gathered = []
+        for t in (mean, variance, samples):
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.all_gather(parts, t.contiguous())
+            gathered.append(parts)
+        return fold(*gathered)
+
+    shape, length = mean.shape, mean.numel()
+    seg = -(-length // world)                                # segment length, frame padded to world * seg elements
+    pieces = []
     for t in (mean, variance, samples):
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t.contiguous())
-        gathered.append(parts)
-    m, v, n = gathered[0][0].clone(), gathered[1][0].clone(), gathered[2][0].clone()
-    for r in range(1, world):                              # rank order => deterministic, exact reference law
-        mb, vb, nb = gathered[0][r], gathered[1][r], gathered[2][r]
-        if combine is not None:
-            combine(m, v, n, mb, vb, nb)
-        else:
-            om, ov, on = combine_arrays(m.numpy(), v.numpy(), n.numpy(), mb.numpy(), np.maximum(vb.numpy(), 0.0), nb.numpy())
-            m, v, n = torch.from_numpy(om), torch.from_numpy(ov), torch.from_numpy(on)
-    return m, v, n
+        flat = t.contiguous().reshape(-1)
+        if seg * world != length:
+            flat = torch.cat([flat, torch.zeros(seg * world - length, dtype=t.dtype, device=t.device)])   # n = 0: neutral element
+        recv = torch.empty_like(flat)
+        dist.all_to_all_single(recv, flat)                   # recv[r*seg:(r+1)*seg] = rank r's copy of my segment
+        pieces.append([recv[r * seg:(r + 1) * seg] for r in range(world)])
+    m, v, n = fold(*pieces)
+    out = []
+    for t, like in ((m, mean), (v, variance), (n, samples)):
+        full = torch.empty(seg * world, dtype=like.dtype, device=like.device)
+        dist.all_gather_into_tensor(full, t.contiguous())
+        out.append(full[:length].reshape(shape))
+    return tuple(out)
 
 
 def gather_tiles(tile, dist):

@@ -32,6 +32,11 @@ def _worker(rank, world_size, port, out):
     fm, fv = to_frame(m), to_frame(v)
     fn = np.full((nx, ny, bins), spp, dtype=np.int32)
     M, V, N = D.merge_sample_sharded(torch.from_numpy(fm), torch.from_numpy(fv), torch.from_numpy(fn), dist)
+    G = D.merge_sample_sharded(torch.from_numpy(fm), torch.from_numpy(fv), torch.from_numpy(fn), dist, mode="gather")
+    assert all(torch.equal(a, b) for a, b in zip((M, V, N), G))        # both routings give the same fold, bit for bit
+    # odd length (padding path): a 7-element frame
+    odd = [torch.from_numpy(np.ascontiguousarray(a.reshape(-1)[:7])) for a in (fm, fv, fn)]
+    assert all(torch.equal(a, b) for a, b in zip(D.merge_sample_sharded(*odd, dist), D.merge_sample_sharded(*odd, dist, mode="gather")))
     # --- tile sharding -------------------------------------------------------------------------------------
     rect = D.tile_rect(rank, world_size, nx, ny)
     eng2 = ns.HipEngine(rng="philox", seed=5)

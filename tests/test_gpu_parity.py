@@ -240,6 +240,75 @@ def test_philox_frame_vs_oracle_full_size(orc, ns):
 
 
 
+def _full_size_properties(orc, ns, world, cam, pipe, make_camera, strip_rows, spp, seed):
+    """Shared body of the BASELINE full-size checks: one Philox pass on the device, then
+      (1) every frame element holds exactly spp samples, mean finite,
+      (2) a strip of rows equals the oracle's render of the same rows bit for bit (mean AND variance: the per-pixel Welford
+          order s = 0..spp-1 is fixed, statsarray.pyx:743-776),
+      (3) tile sharding: rendering a column band alone reproduces that band of the full frame bit for bit,
+      (4) sample sharding: two spp/2 passes with sample offsets 0 and spp/2 merged by combine_samples agree with the single pass
+          to rel 1e-12 in the mean (different but equivalent summation order, statsarray.pyx:780-859)."""
+    nx, ny = cam.pixels
+    cam.render_engine = ns.HipEngine(rng="philox", seed=seed)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.observe()
+    f = pipe.frame
+    mean, var, n = f.mean.copy(), f.variance.copy(), f.samples.copy()
+    assert (n == spp).all() and np.isfinite(mean).all() and np.isfinite(var).all() and (var >= 0).all() and mean.max() > 0
+    flat = world.flatten()
+    sl = cam._slice_spectrum()[0]
+    y0 = ny // 2 - strip_rows // 2
+    keep = []
+    desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, y0, nx, y0 + strip_rows))
+    m, v, rays = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+    bins = mean.shape[2]
+    assert rays == nx * strip_rows * spp
+    assert eq(mean[:, y0:y0 + strip_rows, :], m.reshape(strip_rows, nx, bins).transpose(1, 0, 2))
+    assert eq(var[:, y0:y0 + strip_rows, :], v.reshape(strip_rows, nx, bins).transpose(1, 0, 2))
+    # (3) a band of columns rendered on its own (what one rank of a tile-sharded job does)
+    x0, x1 = (3 * nx) // 8, (5 * nx) // 8
+    cam2, pipe2 = make_camera()
+    cam2.render_engine = ns.HipEngine(rng="philox", seed=seed)
+    cam2.frame_sampler = ns.RectFrameSampler2D(rect=(x0, 0, x1, ny))
+    cam2.observe()
+    f2 = pipe2.frame
+    assert eq(f2.mean[x0:x1], mean[x0:x1]) and eq(f2.variance[x0:x1], var[x0:x1]) and (f2.samples[x0:x1] == spp).all()
+    assert (f2.samples[:x0] == 0).all() and (f2.samples[x1:] == 0).all()
+    # (4) the same spp samples split over two passes (what two ranks of a sample-sharded job do), merged by combine_samples
+    cam3, pipe3 = make_camera()
+    cam3.pixel_samples = spp // 2
+    cam3.frame_sampler = ns.RectFrameSampler2D(rect=(x0, 0, x1, ny))
+    eng = ns.HipEngine(rng="philox", seed=seed)
+    cam3.render_engine = eng
+    cam3.observe()
+    eng.sample_offset = spp // 2
+    cam3.observe()
+    f3 = pipe3.frame
+    assert (f3.samples[x0:x1] == spp).all()
+    np.testing.assert_allclose(f3.mean[x0:x1], mean[x0:x1], rtol=1e-12, atol=1e-300)
+    # combine_samples forms E[x^2] - mean^2 (statsarray.pyx:815-819), so the merged variance carries an absolute error of a few
+    # ulp of mean^2 whatever the arithmetic: tolerance = 16 eps (mean^2 + var)
+    tol = 16 * np.finfo(np.float64).eps * (mean[x0:x1] ** 2 + var[x0:x1])
+    assert (np.abs(f3.variance[x0:x1] - var[x0:x1]) <= tol).all()
+
+
+def test_c3_full_size_instanced_1m_triangles(orc, ns):
+    """BASELINE configs[2] at full size: 15 instances of the 69 432-triangle mesh (1 041 480 triangles) + floor box,
+    2048x2048, 64 samples/pixel = 268 M primary rays in one pass."""
+    world = scenes.build_c3(ns, n=132)[0]
+    make = lambda: scenes.c3_camera(ns, world, (2048, 2048), spp=64, bins=15)
+    cam, pipe = make()
+    _full_size_properties(orc, ns, world, cam, pipe, make, strip_rows=4, spp=64, seed=11)
+
+
+def test_c4_full_size_csg_demo(orc, ns):
+    """BASELINE configs[3] at full size: the demos/csg.py Boolean tree, 1024x1024, 16 samples/pixel."""
+    world = scenes.build_csg_demo(ns)[0]
+    make = lambda: scenes.csg_camera(ns, world, (1024, 1024), spp=16, bins=15)
+    cam, pipe = make()
+    _full_size_properties(orc, ns, world, cam, pipe, make, strip_rows=8, spp=16, seed=13)
+
+
 # ------------------------------------------------------------------------------------------------- CSG on the device
 def _check_world(dev, idx, rec):
     assert eq(dev["prim"], idx)

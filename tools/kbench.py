@@ -20,6 +20,12 @@ if config == "c2":
 elif config == "c3":
     world = scenes.build_c3(ns, n=132)[0]
     cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=4, bins=15)
+elif config == "c3full":
+    world = scenes.build_c3(ns, n=132)[0]
+    cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=64, bins=15)
+elif config == "c4full":
+    world = scenes.build_csg_demo(ns)[0]
+    cam, pipe = scenes.csg_camera(ns, world, (1024, 1024), spp=16, bins=15)
 elif config == "csg":
     world = scenes.build_csg_demo(ns)[0]
     cam, pipe = scenes.csg_camera(ns, world, (1024, 1024), spp=1, bins=15)
@@ -28,12 +34,22 @@ eng = ns.HipEngine(rng="philox", seed=20250905, timing=False)
 cam.render_engine = eng
 ctx = get_context()
 world.build_accelerator()
-for k in range(3 + steps):
+import time
+warm = int(os.environ.get("KB_WARM", "3"))
+for k in range(warm):
     eng.sample_offset = k * cam.pixel_samples
     cam.observe()
+ctx.synchronize()
+t0 = time.perf_counter()
+for k in range(warm, warm + steps):
+    eng.sample_offset = k * cam.pixel_samples
+    cam.observe()
+ctx.synchronize()
+wall = (time.perf_counter() - t0) / steps
+rays = cam.pixels[0] * cam.pixels[1] * cam.pixel_samples
 tr, ac = ctx.render_history(steps)
 mean = pipe.frame.mean
 digest = hashlib.sha256(np.ascontiguousarray(mean).tobytes()).hexdigest()[:16]
 print(json.dumps({"lib": os.path.basename(os.environ.get("RSX_LIB", "librsx.so")), "config": config,
                   "trace_ms": round(float(np.mean(tr)), 4), "trace_min": round(float(np.min(tr)), 4), "trace_max": round(float(np.max(tr)), 4),
-                  "accum_ms": round(float(np.mean(ac)), 4), "digest": digest}))
+                  "accum_ms": round(float(np.mean(ac)), 4), "wall_ms": round(wall * 1e3, 4), "rays_per_s": round(rays / wall, 1), "digest": digest}))
