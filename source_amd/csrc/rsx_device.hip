@@ -144,22 +144,38 @@ struct Hit {
 // per-wave global buffer with the same layout. 99 % of camera rays on the 69k-triangle mesh never have more than 9 far nodes
 // pending (oracle histogram), so the spill path is cold but keeps the traversal exact for any depth.
 struct Stack {
-    double *t;                 // LDS   t[level * WAVE]
-    int32_t *id;               // LDS   id[level * WAVE]
-    double *gt;                // spill gt[(level - lds_levels) * WAVE]
-    int32_t *gid;
+    // Everything here is wave-uniform (lives in SGPRs); the lane's own slot is addressed as base + (level * WAVE + lane) * size
+    // at each access, so the stack costs the traversal loop no per-lane pointer registers.
+    uint32_t lds_t, lds_id;    // byte offsets in the workgroup's dynamic LDS: t[level][lane] (f64), id[level][lane] (i32)
+    char *gt, *gid;            // spill arrays with the same layout, levels >= lds_levels
     int32_t lds_levels;
     float4 *stage;             // per-wave LDS staging area: WAVE triangle records (3 x float4) + WAVE triangle ids
 };
 
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
 __device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
-    if (sp < st.lds_levels) { st.t[sp * WAVE] = t; st.id[sp * WAVE] = id; }
-    else { const int32_t g = sp - st.lds_levels; st.gt[g * WAVE] = t; st.gid[g * WAVE] = id; }
+    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
+    if (sp < st.lds_levels) {
+        *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
+        *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
+    } else {
+        const int g = slot - st.lds_levels * WAVE;
+        reinterpret_cast<double *>(st.gt)[g] = t;
+        reinterpret_cast<int32_t *>(st.gid)[g] = id;
+    }
 }
 
 __device__ __forceinline__ void stack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
-    if (sp < st.lds_levels) { t = st.t[sp * WAVE]; id = st.id[sp * WAVE]; }
-    else { const int32_t g = sp - st.lds_levels; t = st.gt[g * WAVE]; id = st.gid[g * WAVE]; }
+    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
+    if (sp < st.lds_levels) {
+        t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
+        id = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
+    } else {
+        const int g = slot - st.lds_levels * WAVE;
+        t = reinterpret_cast<const double *>(st.gt)[g];
+        id = reinterpret_cast<const int32_t *>(st.gid)[g];
+    }
 }
 
 __device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
@@ -280,9 +296,9 @@ __device__ __forceinline__ double refine_rcp(double d) {
     return __builtin_fma(y1, f2, y1);
 }
 
-__device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in [2^-300, 2^300]
-    const int e = (int)((__double_as_longlong(x) >> 52) & 0x7ff);
-    return e > 1023 - 300 && e < 1023 + 300;
+__device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in [2^-300, 2^300] (false for NaN): two compares
+    const double a = __builtin_fabs(x);
+    return a >= 0x1p-300 && a <= 0x1p+300;
 }
 
 __device__ __forceinline__ double exact_div(double n, double d, double y, bool d_safe) {
@@ -1177,7 +1193,10 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
     bool active = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
-    const AxisDiv ad = axis_div(r);
+    // the world tree is a handful of nodes per ray: its branch steps use the plain division, which keeps three refined
+    // reciprocals out of the registers that stay live across the mesh traversal
+    AxisDiv ad;
+    ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
@@ -1236,25 +1255,21 @@ __device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) 
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
 // carve the wave's LDS region and global spill region into the world stack and the mesh stack
 __device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &ms) {
-    const int wave = threadIdx.x / WAVE, lane = threadIdx.x % WAVE;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));       // uniform by construction: tell the compiler
     const int lds_levels = sc.wlds + sc.mlds;
-    char *base = smem + (size_t)wave * ((size_t)lds_levels * WAVE * 12 + STAGE_BYTES);
-    double *t = reinterpret_cast<double *>(base) + lane;
-    int32_t *id = reinterpret_cast<int32_t *>(base + (size_t)lds_levels * WAVE * 8) + lane;
+    const uint32_t base = (uint32_t)wave * (uint32_t)(lds_levels * WAVE * 12 + STAGE_BYTES);
+    const uint32_t lds_t = base, lds_id = base + (uint32_t)lds_levels * WAVE * 8;
     const int spill_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
     const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
     char *gbase = sc.spill + gwave * (size_t)(spill_levels > 0 ? spill_levels : 1) * WAVE * 12;
-    double *gt = reinterpret_cast<double *>(gbase) + lane;
-    int32_t *gid = reinterpret_cast<int32_t *>(gbase + (size_t)spill_levels * WAVE * 8) + lane;
-    float4 *stage = reinterpret_cast<float4 *>(base + (size_t)lds_levels * WAVE * 12);
+    char *gt = gbase, *gid = gbase + (size_t)spill_levels * WAVE * 8;
+    float4 *stage = reinterpret_cast<float4 *>(smem + base + (size_t)lds_levels * WAVE * 12);
     ws.stage = stage; ms.stage = stage;
-    ws.t = t; ws.id = id; ws.gt = gt; ws.gid = gid; ws.lds_levels = sc.wlds;
-    ms.t = t + sc.wlds * WAVE; ms.id = id + sc.wlds * WAVE;
-    ms.gt = gt + (sc.wdepth - sc.wlds) * WAVE; ms.gid = gid + (sc.wdepth - sc.wlds) * WAVE; ms.lds_levels = sc.mlds;
+    ws.lds_t = lds_t; ws.lds_id = lds_id; ws.gt = gt; ws.gid = gid; ws.lds_levels = sc.wlds;
+    ms.lds_t = lds_t + (uint32_t)sc.wlds * WAVE * 8; ms.lds_id = lds_id + (uint32_t)sc.wlds * WAVE * 4;
+    ms.gt = gt + (size_t)(sc.wdepth - sc.wlds) * WAVE * 8; ms.gid = gid + (size_t)(sc.wdepth - sc.wlds) * WAVE * 4; ms.lds_levels = sc.mlds;
 }
 
 // XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID, bits [3:0]
