@@ -196,6 +196,28 @@ __device__ __forceinline__ void xform_vector(const double *m, double x, double y
     oz = m[8] * x + m[9] * y + m[10] * z;
 }
 
+// Scene tables (primitives, mesh descriptors) never change while a kernel runs. Read through the constant address space with a
+// wave-uniform index they come in over the scalar data path into SGPRs: no vector registers for a 4x4 matrix or a mesh descriptor.
+#define RSX_CONST_AS __attribute__((address_space(4)))
+typedef const RSX_CONST_AS rsx_primitive *UPrim;
+typedef const RSX_CONST_AS struct DMesh *UMesh;
+__device__ __forceinline__ UPrim uniform_prim(const rsx_primitive *base, int32_t idx) { return (UPrim)(unsigned long long)(base + idx); }
+
+__device__ __forceinline__ Ray to_local_uniform(UPrim p, const Ray &r) {
+    const RSX_CONST_AS double *m = p->to_local;
+    Ray l;
+    double w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15];
+    w = 1.0 / w;
+    l.ox = (m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3]) * w;
+    l.oy = (m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7]) * w;
+    l.oz = (m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11]) * w;
+    l.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz;
+    l.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz;
+    l.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz;
+    l.maxd = r.maxd;
+    return l;
+}
+
 __device__ __forceinline__ Ray to_local(const rsx_primitive &p, const Ray &r) {
     Ray l;
     xform_point(p.to_local, r.ox, r.oy, r.oz, l.ox, l.oy, l.oz);
@@ -499,17 +521,24 @@ __device__ unsigned long long g_phase[8][64];   // unused placeholder to keep th
 
 __device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x, lane, WAVE); }
 
-// Wave-cooperative MeshData.trace: every lane of the wave calls this together (`want` = lane has a ray). Lanes walk their own
-// rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF triangles (high-valence vertices
-// produce leaves of hundreds, mesh.pyx builds them because the depth cap stops the SAH split) is tested by all 64 lanes for one
-// ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic wave-min, which is exactly what the
-// reference's sequential scan with strict `<` returns (the first item among those with the smallest distance). Idle lanes —
-// rays that already finished, or never needed this mesh — serve as helpers.
-__device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
+// Wave-cooperative MeshData.trace: every lane of the wave calls this together on ONE mesh (`m` is wave-uniform; `want` = lane has
+// a ray for it). Lanes walk their own rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF
+// triangles (high-valence vertices produce leaves of hundreds, mesh.pyx builds them because the depth cap stops the SAH split) is
+// tested by all 64 lanes for one ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic
+// wave-min, which is exactly what the reference's sequential scan with strict `<` returns (the first item among those with the
+// smallest distance). Idle lanes — rays that already finished, or never needed this mesh — serve as helpers.
+__device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
     const int lane = threadIdx.x % WAVE;
     PHASE_DECL
+    const rsx_kdnode *nodes = m->nodes;                     // scalar loads: the bases sit in SGPRs, lanes supply 32-bit offsets
+    const float4 *leaf = m->leaf, *tris = m->tris;
+    const int32_t *items = m->items;
     double tmin = 0, tmax = 0;
-    bool active = want && aabb(m.lower, m.upper, r, tmin, tmax);              // kdtree3d.pyx:589-607
+    bool active;
+    {
+        const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
+        active = want && aabb(lo, hi, r, tmin, tmax);                         // kdtree3d.pyx:589-607
+    }
     const TriRay q = tri_ray(r);
     const AxisDiv ad = axis_div(r);
     bool hit = false;
@@ -522,7 +551,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
         PHASE_ADD(0)
         rsx_kdnode nd;
         nd.count = 0; nd.u.leaf.first_item = 0;
-        if (active) nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
+        if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp);
         PHASE_ADD(1)
         if (active) {
             distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
@@ -534,7 +563,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                     float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
 #pragma unroll
                     for (int j = 0; j < RSX_LEAF_BATCH; ++j)
-                        leaf_fetch(m.items, m.tris, m.leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
+                        leaf_fetch(items, tris, leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
 #pragma unroll
                     for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
                         float ht, hu, hv, hw;
@@ -553,17 +582,9 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
 #endif
         while (big) {
             const int leader = __ffsll((long long)big) - 1;
-            const int32_t lcount = __shfl(count, leader, WAVE), lfirst = __shfl(first, leader, WAVE);
-            const unsigned long long items_bits = (unsigned long long)m.items, tris_bits = (unsigned long long)m.tris, leaf_bits = (unsigned long long)m.leaf;
-            const unsigned long long l_items_bits = ((unsigned long long)(unsigned)__shfl((int)(items_bits >> 32), leader, WAVE) << 32) |
-                                                    (unsigned)__shfl((int)items_bits, leader, WAVE);
-            const int32_t *litems = (const int32_t *)l_items_bits;
-            const float4 *ltris = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(tris_bits >> 32), leader, WAVE) << 32) |
-                                                   (unsigned)__shfl((int)tris_bits, leader, WAVE));
-            const float4 *lleaf = (const float4 *)(((unsigned long long)(unsigned)__shfl((int)(leaf_bits >> 32), leader, WAVE) << 32) |
-                                                   (unsigned)__shfl((int)leaf_bits, leader, WAVE));
+            const int32_t lcount = __builtin_amdgcn_readlane(count, leader), lfirst = __builtin_amdgcn_readlane(first, leader);
             // lanes whose ray sits in the same leaf as the leader's
-            const bool same = active && count >= RSX_COOP_LEAF && first == lfirst && items_bits == l_items_bits;
+            const bool same = active && count >= RSX_COOP_LEAF && first == lfirst;
             const unsigned long long group = __ballot(same);
             big &= ~group;
             if (__popcll(group) >= RSX_STAGE_MIN) {
@@ -578,7 +599,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                     if (k < lcount) {
                         int32_t tri;
                         float4 a, b, cc;
-                        leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, cc);
+                        leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, cc);
                         rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
                         ids[lane] = tri;
                     }
@@ -616,7 +637,7 @@ __device__ bool mesh_trace_wave(bool want, const DMesh &m, const Ray &r, const S
                 for (int32_t k = lane; k < lcount; k += WAVE) {
                     int32_t tri;
                     float4 a, b, c;
-                    leaf_fetch(litems, ltris, lleaf, lfirst + k, tri, a, b, c);
+                    leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, c);
                     float ht, hu, hv, hw;
                     if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
                 }
@@ -1218,11 +1239,21 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             Hit cand;
             cand.prim = -1;
             work += CSG ? 16 : 4;
-            if (__any(is_mesh)) {
+            // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
+            // descriptor, array bases: scalar loads, SGPRs). Coherent waves meet one instance per leaf item; a wave that straddles
+            // several instances takes one turn per instance.
+            unsigned long long todo = __ballot(is_mesh);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
+                const bool mine = is_mesh && idx == uidx;
+                todo &= ~__ballot(mine);
+                const UPrim up = uniform_prim(sc.prims, uidx);
                 Ray l = r;
-                if (is_mesh) l = to_local(p, r);
+                if (mine) l = to_local_uniform(up, r);
+                const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
                 MeshHit mh;
-                if (mesh_trace_wave(is_mesh, sc.meshes[is_mesh ? p.mesh : 0], l, mesh_stack, mh, work, phase_acc)) {
+                if (mesh_trace_wave(mine, um, l, mesh_stack, mh, work, phase_acc)) {
                     cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                 }
             }
@@ -1506,111 +1537,139 @@ __device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, 
 
 // Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
 // 64 rays stay coherent; in task-list mode 64 consecutive tasks.
+struct UnitPixel {
+    long long k, slot;         // task index (row-major in rect mode) and sample-record slot (x-major in rect mode, like the frame)
+    int ix, iy, s;
+    bool valid;
+};
+
+__device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams *q, long long unit, int lane) {
+    UnitPixel px;
+    const int spp = q->spp;
+    px.s = (int)(unit % spp);
+    const long long chunk = unit / spp;
+    if (q->tasks) {
+        px.k = chunk * 64 + lane;
+        px.valid = px.k < q->n_tasks;
+        if (!px.valid) px.k = 0;
+        px.ix = q->tasks[2 * px.k]; px.iy = q->tasks[2 * px.k + 1];
+        px.slot = px.k;
+    } else {
+        const int w = q->rect[2] - q->rect[0], h = q->rect[3] - q->rect[1];
+        const int tiles_x = (w + 7) / 8;
+        const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
+        const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        px.valid = lx < w && ly < h;
+        px.ix = q->rect[0] + (px.valid ? lx : 0); px.iy = q->rect[1] + (px.valid ? ly : 0);
+        px.k = px.valid ? (long long)ly * w + lx : 0;
+        px.slot = px.valid ? (long long)lx * h + ly : 0;
+    }
+    return px;
+}
+
 template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
-    const long long total = rp.n_tasks * rp.spp;
-    const int w = rp.rect[2] - rp.rect[0], h = rp.rect[3] - rp.rect[1];
-    const int tiles_x = (w + 7) / 8, tiles_y = (h + 7) / 8;
-    const long long n_units = rp.tasks ? ((rp.n_tasks + 63) / 64) * rp.spp : (long long)tiles_x * tiles_y * rp.spp;
-    (void)n_units;
     // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
     // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
     const int my_xcd = xcc_id();
     int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
     for (;;) {
+        // Render parameters are re-read from the kernel-argument segment at every use site of the unit loop (the pointer is
+        // laundered through an empty asm): hoisted out of the loop, the camera matrix and friends sat in ~30 vector registers
+        // through the whole traversal, where registers decide how many waves fit a SIMD. `rp` itself is only named for its layout.
+        (void)rp;
+        // (`rp` is read where it lies in the kernel-argument segment — second argument, after `sc` — so that no private copy is made)
+        unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
+        asm volatile("" : "+s"(rp_bits));
+        const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
         long long tk = -1;
         while (victim < 8) {
-            const int q = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
-            const long long begin = rp.seg[q], end = rp.seg[q + 1];
-            long long got = 0;
-            if (lane == 0) got = (long long)atomicAdd(ticket + 16 * q, 1ULL);
-            got = __shfl(got, 0, WAVE) + begin;
+            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+            const long long begin = q->seg[list], end = q->seg[list + 1];
+            unsigned long long mine = 0;
+            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
             if (got < end) { tk = got; break; }
             ++victim;
         }
         if (tk < 0) break;
-        const uint32_t wi = rp.unit_order[tk];
-        const long long unit = (long long)(wi & 0x3ffffffu);
-        const int part = (int)((wi >> 26) & 7u), parts_log2 = (int)(wi >> 29);
+        int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
 #if RSX_COST_CLOCK
-        const unsigned long long c_start = rp.measure_cost ? cost_clock() : 0ULL;
+        const unsigned long long c_start = q->measure_cost ? cost_clock() : 0ULL;
 #endif
-        const int s = (int)(unit % rp.spp);
-        const long long chunk = unit / rp.spp;
-        const unsigned long long t_start = rp.unit_times ? wall_clock64() : 0ULL;
+        const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF
         unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #else
         unsigned long long *phase_acc = nullptr;
 #endif
-        long long k = 0, slot = 0;
-        int ix = 0, iy = 0;
-        bool valid;
-        if (rp.tasks) {
-            k = chunk * 64 + lane;
-            valid = k < rp.n_tasks;
-            if (valid) task_pixel(rp, k, ix, iy); else k = 0;
-            slot = k;
-        } else {
-            const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
-            const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
-            valid = lx < w && ly < h;
-            ix = rp.rect[0] + (valid ? lx : 0); iy = rp.rect[1] + (valid ? ly : 0);
-            k = valid ? (long long)ly * w + lx : 0;
-            slot = valid ? (long long)lx * h + ly : 0;     // sample records are stored x-major like the frame (k_accumulate streams both)
-        }
-        // a heavy unit is processed as 2/4/8 work items of 32/16/8 consecutive lanes each; the other lanes only help
-        valid = valid && (lane >> (6 - parts_log2)) == part;
-        (void)total;
+        const UnitPixel px = unit_pixel(q, unit, lane);
+        const bool valid = px.valid;
         // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
         double u1, u2;
-        if (rp.rng_mode == RSX_RNG_STREAM) { u1 = rp.uniforms[2 * (k * rp.spp + s)]; u2 = rp.uniforms[2 * (k * rp.spp + s) + 1]; }
-        else philox2(rp.seed, (uint64_t)ix * (uint64_t)rp.cam.ny + (uint64_t)iy, rp.sample_offset + (uint64_t)s, u1, u2);
-        const double delta = rp.cam.image_delta, half = 0.5 * delta;
-        const double pixel_x = rp.cam.image_start_x - delta * ((double)ix + 0.5);
-        const double pixel_y = rp.cam.image_start_y - delta * ((double)iy + 0.5);
+        if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
+        else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
+        const double delta = q->cam.image_delta, half = 0.5 * delta;
+        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
+        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
         // the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc)
         double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
         normalise3(dx, dy, dz);
         const double weight = dz;
         Ray r;
-        xform_point(rp.cam.to_root, 0.0, 0.0, 0.0, r.ox, r.oy, r.oz);         // observer.pyx:403-404
-        xform_vector(rp.cam.to_root, dx, dy, dz, r.dx, r.dy, r.dz);
+        {
+            const RSX_CONST_AS double *m = q->cam.to_root;                    // observer.pyx:403-404: origin (0,0,0) and direction to world
+            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+            wq = 1.0 / wq;
+            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
+            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
+            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
+        }
         r.maxd = INFINITY;
         Hit hit;
-        Sample smp;
-        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
 #if RSX_WAVE_COOP
         uint32_t work = 0;
         const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
 #else
         const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
 #endif
-        if (rp.measure_cost && lane == 0) {
+        // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
+        // compiler cannot merge this with the computation above)
+        asm volatile("" : "+s"(unit));
+        asm volatile("" : "+s"(rp_bits));
+        const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
+        if (q2->measure_cost && lane == 0) {
 #if RSX_COST_CLOCK
-            unsigned long long c = (cost_clock() - c_start) << parts_log2;   // estimate of the unsplit cost (keeps heavy units split)
+            unsigned long long c = cost_clock() - c_start;
 #else
-            unsigned long long c = (unsigned long long)work << parts_log2;
+            unsigned long long c = (unsigned long long)work;
 #endif
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
-            if (parts_log2) atomicMax(&rp.unit_cost[unit], (uint32_t)c); else rp.unit_cost[unit] = (uint32_t)c;
+            q2->unit_cost[unit] = (uint32_t)c;
         }
-        if (rp.unit_times && lane == 0) {
-            rp.unit_times[12 * unit] = t_start;
-            rp.unit_times[12 * unit + 1] = wall_clock64();
-            rp.unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
+        if (q2->unit_times && lane == 0) {
+            q2->unit_times[12 * unit] = t_start;
+            q2->unit_times[12 * unit + 1] = wall_clock64();
+            q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
 #if RSX_PHASE_PROF
-            for (int ph = 0; ph < 8; ++ph) rp.unit_times[12 * unit + 3 + ph] = phase_acc[ph];
+            for (int ph = 0; ph < 8; ++ph) q2->unit_times[12 * unit + 3 + ph] = phase_acc[ph];
 #endif
         }
-        if (!valid) continue;
+        const UnitPixel px2 = unit_pixel(q2, unit, lane);
+        if (!px2.valid) continue;
+        Sample smp;
+        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
         if (got) {                                                                 // optical/ray.pyx:391-393
             const rsx_primitive &p = sc.prims[hit.prim];
-            const rsx_material mat = rp.materials[p.material];
+            const rsx_material mat = q2->materials[p.material];
             if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
             else if (mat.type == RSX_MAT_DEBUG_LIGHT) {                      // debug.pyx:67-79
                 if (mat.scale != 0.0) {
@@ -1624,7 +1683,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
                 }
             }
         }
-        samples[slot * rp.spp + s] = smp;
+        samples[px2.slot * q2->spp + px2.s] = smp;
     }
 }
 
