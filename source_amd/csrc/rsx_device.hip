@@ -520,6 +520,11 @@ __device__ unsigned long long g_phase[8][64];   // unused placeholder to keep th
 #endif
 
 __device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x, lane, WAVE); }
+__device__ __forceinline__ double readlane_f64(double x, int lane) {          // lane must be wave-uniform; the result is scalar
+    const long long b = __double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
 
 // Wave-cooperative MeshData.trace: every lane of the wave calls this together on ONE mesh (`m` is wave-uniform; `want` = lane has
 // a ray for it). Lanes walk their own rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF
@@ -624,13 +629,16 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
                 const int owner = __ffsll((long long)todo) - 1;
                 todo &= todo - 1;
                 work += 2 + (uint32_t)lcount / 32;
+                // the owner's ray constants are read into scalar registers (owner is wave-uniform): no per-lane copy of the ray
                 TriRay lq;
-                lq.ox = shfl_f64(q.ox, owner); lq.oy = shfl_f64(q.oy, owner); lq.oz = shfl_f64(q.oz, owner);
-                lq.maxd = shfl_f64(q.maxd, owner);
-                lq.sx = __shfl(q.sx, owner, WAVE); lq.sy = __shfl(q.sy, owner, WAVE); lq.sz = __shfl(q.sz, owner, WAVE);
-                const int axes = __shfl(q.ix | (q.iy << 2) | (q.iz << 4), owner, WAVE);
+                lq.ox = readlane_f64(q.ox, owner); lq.oy = readlane_f64(q.oy, owner); lq.oz = readlane_f64(q.oz, owner);
+                lq.maxd = readlane_f64(q.maxd, owner);
+                lq.sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sx), owner));
+                lq.sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sy), owner));
+                lq.sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sz), owner));
+                const int axes = __builtin_amdgcn_readlane(q.ix | (q.iy << 2) | (q.iz << 4), owner);
                 lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
-                const double limit = shfl_f64(distance, owner);
+                const double limit = readlane_f64(distance, owner);
                 // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
                 float mt = INFINITY, mu = 0, mv = 0, mw = 0;
                 int32_t mk = 0x7fffffff, mtri = -1;

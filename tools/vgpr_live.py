@@ -126,3 +126,13 @@ if len(sys.argv) > 4:
         where[(dl, ul)] += 1
     for (dl, ul), c in sorted(where.items(), key=lambda kv: -kv[1]):
         print("  %3d regs  defined %-32s next used %s" % (c, dl, ul))
+    # context of the global peak: distinct source lines of the 400 instructions around it
+    gi = max(range(n), key=lambda i: len(live_in[i]))
+    seen = []
+    for i in range(max(0, gi - 300), min(n, gi + 150)):
+        k = insts[i][3]
+        if not seen or seen[-1][0] != k:
+            seen.append([k, len(live_in[i]), i])
+    print("context of the global peak (instruction %d):" % gi)
+    for k, v, i in seen:
+        print("   @%5d %4d live  %s" % (i, v, k))
