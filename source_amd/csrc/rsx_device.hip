@@ -35,7 +35,8 @@
 #endif
 #define WG_THREADS (WAVE * WG_WAVES)
 #ifndef RSX_WORLD_LDS_LEVELS
-#define RSX_WORLD_LDS_LEVELS 4      // LDS-resident traversal stack entries per lane, world tree
+#define RSX_WORLD_LDS_LEVELS 3      // LDS-resident traversal stack entries per lane, world tree. 3 + 10 levels + the staging area are
+                                    // 13.0 KB per wave = 52 KB per workgroup: three workgroups (three waves per SIMD) fit the 160 KB LDS
 #endif
 #ifndef RSX_MESH_LDS_LEVELS
 #define RSX_MESH_LDS_LEVELS 10      // ... mesh tree (deeper entries spill to global memory)
@@ -55,9 +56,11 @@
 #define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
 #endif
 #ifndef RSX_MIN_WAVES_PER_SIMD
-#define RSX_MIN_WAVES_PER_SIMD 2    // __launch_bounds__ second argument for the mesh/analytic traversal kernels: caps them at 256
-                                    // registers (VGPR + AGPR) so two waves fit a SIMD; unconstrained the compiler took 260 and the
-                                    // hardware ran ONE wave per SIMD (measured: 163 -> 86 ms on configs[2]). 3 or 4 force spills and lose.
+#define RSX_MIN_WAVES_PER_SIMD 3    // __launch_bounds__ second argument for the mesh/analytic traversal kernels: 168 registers per wave.
+                                    // History on configs[2] (268 M rays): unconstrained the compiler took 260 registers and the hardware
+                                    // ran ONE wave per SIMD, 163 ms; capped at 256 (two waves) 87 ms; after the register diet (uniform
+                                    // stack bases, scalar per-primitive loads, kernarg re-reads, scalar owner ray; tools/vgpr_live.py)
+                                    // three waves with ~30 cold spills, 72 ms. Four waves still spill hot values and lose.
 #endif
 
 // ---------------------------------------------------------------------------------------------------
