@@ -228,9 +228,12 @@ int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *origin, const d
 
 /* Primitive.hit + repeated next_intersection() on ONE primitive (sphere.pyx:115-168, box.pyx:157-232,
  * cylinder.pyx:148-285, csg.pyx:132-179, mesh.pyx:1178-1238): up to max_roots ordered roots per ray.
- * counts[n]; t[n,max_roots]; exiting[n,max_roots]. Host buffers. */
+ * counts[n]; t[n,max_roots]; exiting[n,max_roots]. Optional (NULL to skip): geometry[n,max_roots,12] = hit, inside,
+ * outside points and normal of each root in primitive space (intersection.pyx:36-106), triangle[n,max_roots] and
+ * uvw[n,max_roots,3] for roots on a mesh surface (MeshIntersection, mesh.pyx:85-135; -1 / 0 elsewhere). Host buffers. */
 int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double *origin, const double *direction,
-                    const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting);
+                    const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
+                    double *geometry, int32_t *triangle, float *uvw);
 
 /* World.contains for a batch of points (world.pyx:149-168 -> kdtree.pyx:126-162):
  * inside[n, n_world] = 1 where world primitive j contains point i. Host buffers. */

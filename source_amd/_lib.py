@@ -115,7 +115,7 @@ SYMBOLS = [
     ("rsx_scene_free", None, [_vp]),
     ("rsx_hit_batch", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rsx_hit_batch_dev", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
-    ("rsx_roots_batch", C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp]),
+    ("rsx_roots_batch", C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rsx_contains_batch", C.c_int, [_vp, C.c_int64, _vp, _vp]),
     ("rsx_render_pinhole", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rsx_render_pinhole_frame", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),

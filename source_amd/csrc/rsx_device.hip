@@ -1383,7 +1383,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
 template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, long long n, const double *origin, const double *direction,
                                                       const double *maxd, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
-                                                      unsigned long long *ticket) {
+                                                      double *geom, int32_t *tri, float *uvw, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -1400,6 +1400,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
         r.maxd = maxd[i];
         Ray l = to_local(p, r);
         int32_t c = 0;
+        // optional per-root outputs: Intersection geometry in primitive space (hit, inside, outside, normal) and, for mesh
+        // surfaces, the MeshIntersection extras (triangle, u, v, w) — intersection.pyx:36-106, mesh.pyx:85-135
+        auto emit = [&](int32_t k, const Geom &g, int32_t triangle, float bu, float bv, float bw) {
+            const size_t at = (size_t)i * max_roots + k;
+            if (geom) {
+                double *o = geom + 12 * at;
+                for (int q = 0; q < 3; ++q) { o[q] = g.hit[q]; o[3 + q] = g.inside[q]; o[6 + q] = g.outside[q]; o[9 + q] = g.normal[q]; }
+            }
+            if (tri) tri[at] = triangle;
+            if (uvw) { uvw[3 * at] = bu; uvw[3 * at + 1] = bv; uvw[3 * at + 2] = bw; }
+        };
         if (CSG && is_csg(p.type)) {
             if constexpr (CSG) {
                 CsgEval e;
@@ -1410,6 +1421,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
                 while ((rec.flags & F_VALID) && c < max_roots) {
                     t[i * max_roots + c] = rec.t;
                     exiting[i * max_roots + c] = (rec.flags & F_EXIT) ? 1 : 0;
+                    if (geom || tri || uvw) {
+                        Hit h;
+                        h.prim = pidx; h.t = rec.t; h.a0 = rec.a0; h.a1 = rec.a1; h.u = rec.u; h.v = rec.v; h.w = rec.w;
+                        h.leaf = rec.leaf; h.flags = rec.flags; h.hx = rec.hx; h.hy = rec.hy; h.hz = rec.hz;
+                        Geom g;
+                        csg_geom(sc, r, h, g);
+                        const bool on_mesh = sc.prims[rec.leaf].type == RSX_PRIM_MESH;
+                        emit(c, g, on_mesh ? rec.a0 : -1, on_mesh ? rec.u : 0.0f, on_mesh ? rec.v : 0.0f, on_mesh ? rec.w : 0.0f);
+                    }
                     ++c;
                     csg_next<CSG_MAX_DEPTH>(e, pidx, rec);
                 }
@@ -1424,6 +1444,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
                 const double dist = (double)mh.t + accumulated;
                 t[i * max_roots + c] = dist;
                 exiting[i * max_roots + c] = g.exiting ? 1 : 0;
+                emit(c, g, mh.tri, mh.u, mh.v, mh.w);
                 ++c;
                 l.ox = g.hit[0] + l.dx * MESH_EPS; l.oy = g.hit[1] + l.dy * MESH_EPS; l.oz = g.hit[2] + l.dz * MESH_EPS;
                 l.maxd = l.maxd - (double)mh.t - MESH_EPS;
@@ -1440,6 +1461,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
                 analytic_geom(p, l, roots.t[k], roots.a0[k], roots.a1[k], g);
                 t[i * max_roots + c] = roots.t[k];
                 exiting[i * max_roots + c] = g.exiting ? 1 : 0;
+                emit(c, g, -1, 0.0f, 0.0f, 0.0f);
                 ++c;
             }
         }
@@ -2492,7 +2514,8 @@ extern "C" int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, 
 }
 
 extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double *origin, const double *direction,
-                               const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting) {
+                               const double *max_distance, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
+                               double *geometry, int32_t *triangle, float *uvw) {
     if (!scene || n < 0 || !origin || !direction || !max_distance || !counts || !t || !exiting || max_roots < 1)
         return rsx_fail(RSX_EINVAL, "rsx_roots_batch: bad arguments");
     if (primitive < 0 || primitive >= scene->d.n_prims) return rsx_fail(RSX_EINVAL, "rsx_roots_batch: primitive index out of range");
@@ -2500,10 +2523,16 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t N = (size_t)n, R = (size_t)max_roots;
-    Scratch d_o, d_d, d_m, d_c, d_t, d_ex;
+    Scratch d_o, d_d, d_m, d_c, d_t, d_ex, d_g, d_tri, d_uvw;
     int rc;
     if ((rc = d_o.alloc(N * 24)) || (rc = d_d.alloc(N * 24)) || (rc = d_m.alloc(N * 8)) || (rc = d_c.alloc(N * 4)) ||
         (rc = d_t.alloc(N * R * 8)) || (rc = d_ex.alloc(N * R))) return rc;
+    if (geometry && (rc = d_g.alloc(N * R * 96))) return rc;
+    if (triangle && (rc = d_tri.alloc(N * R * 4))) return rc;
+    if (uvw && (rc = d_uvw.alloc(N * R * 12))) return rc;
+    if (geometry) HIP_TRY(hipMemsetAsync(d_g.p, 0, N * R * 96, ctx->stream));
+    if (triangle) HIP_TRY(hipMemsetAsync(d_tri.p, 0xff, N * R * 4, ctx->stream));
+    if (uvw) HIP_TRY(hipMemsetAsync(d_uvw.p, 0, N * R * 12, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_o.p, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_d.p, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(hipMemcpyAsync(d_m.p, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
@@ -2514,13 +2543,18 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_roots<true>) : reinterpret_cast<const void *>(k_roots<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx->main))) return rc;
     if (scene->has_csg) hipLaunchKernelGGL(k_roots<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->main.ticket);
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(),
+                       geometry ? d_g.as<double>() : nullptr, triangle ? d_tri.as<int32_t>() : nullptr, uvw ? d_uvw.as<float>() : nullptr, ctx->main.ticket);
     else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(), ctx->main.ticket);
+                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(),
+                       geometry ? d_g.as<double>() : nullptr, triangle ? d_tri.as<int32_t>() : nullptr, uvw ? d_uvw.as<float>() : nullptr, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(counts, d_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(t, d_t.p, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipMemcpyAsync(exiting, d_ex.p, N * R, hipMemcpyDeviceToHost, ctx->stream));
+    if (geometry) HIP_TRY(hipMemcpyAsync(geometry, d_g.p, N * R * 96, hipMemcpyDeviceToHost, ctx->stream));
+    if (triangle) HIP_TRY(hipMemcpyAsync(triangle, d_tri.p, N * R * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw.p, N * R * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }

@@ -138,28 +138,26 @@ class DeviceScene:
         return self._intersection(ray, obj, r["t"][0], r["exiting"][0], r["tri"][0], r["uvw"][0], r["geom"][0])
 
     # -- Primitive.hit / next_intersection ------------------------------------------------------
-    def roots_batch(self, index, origin, direction, max_distance=None, max_roots=8):
+    def roots_batch(self, index, origin, direction, max_distance=None, max_roots=8, geometry=False):
         o, d = _f64(origin).reshape(-1, 3), _f64(direction).reshape(-1, 3)
         n = o.shape[0]
         m = np.full(n, np.inf) if max_distance is None else _f64(np.broadcast_to(max_distance, (n,)))
         counts = np.zeros(n, dtype=np.int32)
         t = np.zeros((n, max_roots))
         ex = np.zeros((n, max_roots), dtype=np.uint8)
+        g = np.zeros((n, max_roots, 12)) if geometry else None
+        tri = np.full((n, max_roots), -1, dtype=np.int32) if geometry else None
+        uvw = np.zeros((n, max_roots, 3), dtype=np.float32) if geometry else None
         _lib.check(_lib.lib().rsx_roots_batch(self._h, int(index), n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(m), int(max_roots),
-                                              _lib.ptr(counts), _lib.ptr(t), _lib.ptr(ex)))
-        return counts, t, ex
+                                              _lib.ptr(counts), _lib.ptr(t), _lib.ptr(ex), _lib.ptr(g), _lib.ptr(tri), _lib.ptr(uvw)))
+        return (counts, t, ex, g, tri, uvw) if geometry else (counts, t, ex)
 
     def roots_single(self, index, ray, prim_obj, max_roots=64):
-        counts, t, ex = self.roots_batch(index, [[ray.origin.x, ray.origin.y, ray.origin.z]],
-                                         [[ray.direction.x, ray.direction.y, ray.direction.z]], [ray.max_distance], max_roots)
-        out = []
-        for k in range(int(counts[0])):
-            tk = float(t[0, k])
-            local = ray.origin.transform(prim_obj.to_local())
-            ld = ray.direction.transform(prim_obj.to_local())
-            hit = Point3D(local.x + tk * ld.x, local.y + tk * ld.y, local.z + tk * ld.z)
-            out.append(Intersection(ray, tk, prim_obj, hit, hit, hit, Normal3D(0, 0, 1), bool(ex[0, k]), prim_obj.to_local(), prim_obj.to_root()))
-        return out
+        """Primitive.hit(ray) followed by every next_intersection(): the full ordered list of Intersection objects."""
+        counts, t, ex, g, tri, uvw = self.roots_batch(index, [[ray.origin.x, ray.origin.y, ray.origin.z]],
+                                                      [[ray.direction.x, ray.direction.y, ray.direction.z]], [ray.max_distance],
+                                                      max_roots, geometry=True)
+        return [self._intersection(ray, prim_obj, t[0, k], ex[0, k], tri[0, k], uvw[0, k], g[0, k]) for k in range(int(counts[0]))]
 
     # -- World.contains ----------------------------------------------------------------------------
     def contains_batch(self, points):

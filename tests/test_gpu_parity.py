@@ -96,10 +96,16 @@ def test_mesh_next_intersection_and_contains(orc, golden, m70k):
     flat = FlatScene([m70k[0]])
     sc = dev_scene(flat)
     o, d, m = raysets.random_outside(1500, 47)
-    counts, t, ex = sc.roots_batch(0, o, d, m, max_roots=64)
+    counts, t, ex, geom, tri, uvw = sc.roots_batch(0, o, d, m, max_roots=64, geometry=True)
     assert eq(counts, g["seq_counts"])
     mask = np.arange(64)[None, :] < counts[:, None]
     assert eq(t[mask], g["seq_t"]) and eq(ex[mask], g["seq_ex"])
+    # geometry of every root (hit / inside / outside points, normal) == the oracle's next_intersection() sequence
+    oc, ot, oe, og = orc.roots_batch(flat, 0, o, d, m, max_roots=64, geometry=True)
+    assert eq(geom[mask], og[mask]) and (tri[mask] >= 0).all() and (tri[~mask] == -1).all()
+    first = counts > 0
+    ref = orc.hit_batch(flat, o, d, m)                                   # first root == World.hit on the single-mesh scene
+    assert eq(tri[first, 0], ref["tri"][first]) and eq(uvw[first, 0], ref["uvw"][first])
     assert eq(sc.contains_batch(raysets.points(4000, 49, 0.1))[:, 0], g["contains"])
 
 
@@ -137,17 +143,54 @@ def test_analytic_primitives(orc, ns, golden):
         flat = FlatScene([prim])
         sc = dev_scene(flat)
         o, d, m = raysets.primitive_rays(3000, 70 + k)
-        counts, t, ex = sc.roots_batch(0, o, d, m, max_roots=2)
-        ref = g[name]
+        counts, t, ex, geom, tri, uvw = sc.roots_batch(0, o, d, m, max_roots=2, geometry=True)
+        ref = g[name]                                       # [n, 2, 14]: t, exiting, hit, inside, outside, normal (compiled reference)
         valid = ~np.isnan(ref[:, :, 0])
         assert eq(counts, valid.sum(axis=1)), name
         assert eq(t[valid], ref[:, :, 0][valid]) and eq(ex[valid], ref[:, :, 1][valid]), name
+        assert eq(geom[valid], ref[:, :, 2:][valid]) and (tri == -1).all(), name
         # first root with full geometry through the world path
         dev = sc.hit_batch(o, d, m, geometry=True)
         assert_hits_equal(dev, orc.hit_batch(flat, o, d, m, geometry=True))
         first = valid[:, 0] & (dev["prim"] >= 0)
         assert eq(dev["geom"][first], ref[:, 0, 2:][first]), name
         assert eq(sc.contains_batch(raysets.points(2000, 90 + k, 1.2))[:, 0], g[name + "_contains"]), name
+
+
+def test_primitive_object_api(ns, golden):
+    """The reference's per-object API on top of the device: Primitive.hit(ray) -> Intersection, repeated next_intersection(),
+    contains(point), World.hit(ray) — objects carry the same numbers the batch entry points return (golden f05)."""
+    from tests.test_oracle_golden import _prims
+    g = golden("f05_primitives")
+    for k, (name, prim) in enumerate(_prims(ns).items()):
+        o, d, m = raysets.primitive_rays(3000, 70 + k)
+        ref = g[name]
+        picks = [i for i in range(len(o)) if not np.isnan(ref[i, 1, 0])][:3] + [i for i in range(len(o)) if np.isnan(ref[i, 0, 0])][:1]
+        for i in picks:
+            ray = ns.Ray(ns.Point3D(*o[i]), ns.Vector3D(*d[i]), max_distance=float(m[i]))
+            hit = prim.hit(ray)
+            for root in range(2):
+                if np.isnan(ref[i, root, 0]):
+                    assert hit is None
+                    break
+                assert hit is not None and hit.primitive is prim and hit.ray is ray
+                assert hit.ray_distance == ref[i, root, 0] and hit.exiting == bool(ref[i, root, 1])
+                got = [hit.hit_point.x, hit.hit_point.y, hit.hit_point.z, hit.inside_point.x, hit.inside_point.y, hit.inside_point.z,
+                       hit.outside_point.x, hit.outside_point.y, hit.outside_point.z, hit.normal.x, hit.normal.y, hit.normal.z]
+                assert eq(got, ref[i, root, 2:])
+                hit = prim.next_intersection()
+        pts = raysets.points(2000, 90 + k, 1.2)[:40]
+        assert eq([prim.contains(ns.Point3D(*q)) for q in pts], g[name + "_contains"][:40].astype(bool))
+    # World.hit on a small world: same object identity and distance as the batch path
+    world = ns.World()
+    a = ns.Sphere(0.5, world, ns.translate(0, 0, 2))
+    b = ns.Box(ns.Point3D(-1, -1, 4), ns.Point3D(1, 1, 5), world)
+    hit = world.hit(ns.Ray(ns.Point3D(0, 0, 0), ns.Vector3D(0, 0, 1)))
+    assert hit.primitive is a and hit.ray_distance == 1.5 and not hit.exiting
+    hit = world.hit(ns.Ray(ns.Point3D(0.9, 0, 0), ns.Vector3D(0, 0, 1)))
+    assert hit.primitive is b and hit.ray_distance == 4.0
+    assert world.hit(ns.Ray(ns.Point3D(3, 0, 0), ns.Vector3D(0, 0, 1))) is None
+    assert world.contains(ns.Point3D(0, 0, 2)) == [a]
 
 
 def test_instanced_world_vs_oracle(orc, ns):
@@ -372,8 +415,10 @@ def test_csg_with_mesh_operand_vs_oracle(orc, ns):
     o, d, m = raysets.scene_rays(20000, 301, 4.0, 1.2)
     assert_hits_equal(sc.hit_batch(o, d, m, geometry=True), orc.hit_batch(flat, o, d, m, geometry=True))
     for index in (0, 1):
-        assert all(eq(a, b) for a, b in zip(sc.roots_batch(index, o[:3000], d[:3000], None, max_roots=16),
-                                            orc.roots_batch(flat, index, o[:3000], d[:3000], None, max_roots=16)))
+        dc, dt, de, dg, dtri, duvw = sc.roots_batch(index, o[:3000], d[:3000], None, max_roots=16, geometry=True)
+        oc, ot, oe, og = orc.roots_batch(flat, index, o[:3000], d[:3000], None, max_roots=16, geometry=True)
+        mask = np.arange(16)[None, :] < oc[:, None]
+        assert eq(dc, oc) and eq(dt[mask], ot[mask]) and eq(de[mask], oe[mask]) and eq(dg[mask], og[mask])
     pts = raysets.points(3000, 302, 1.5)
     assert eq(sc.contains_batch(pts), orc.contains_batch(flat, pts))
 
