@@ -7,3 +7,4 @@ from .optical.material import AbsorbingSurface, UniformSurfaceEmitter, Light  # 
 from .optical.observer import (PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D,  # noqa: F401
                                HipEngine, RenderEngine, RectFrameSampler2D, RectTasks)
 from .primitive import Sphere, Box, Cylinder, Mesh, Union, Intersect, Subtract  # noqa: F401
+from .primitive.obj import import_obj, export_obj  # noqa: F401

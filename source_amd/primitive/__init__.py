@@ -338,6 +338,52 @@ class MeshData:
         _lib.check(_lib.lib().rsx_mesh_world_bbox(_lib.ptr(self._vertices), self._vertices.shape[0], _lib.ptr(m), _lib.ptr(out)))
         return BoundingBox3D(Point3D(*out[:3]), Point3D(*out[3:]))
 
+    @classmethod
+    def from_file(cls, file):
+        """RSM v1.0 reader (MeshData.load / from_file, mesh.pyx:933-1045): vertices, normals and triangles as stored, the KD-tree
+        taken from the file unchanged, face normals recomputed (mesh.pyx:1012-1013)."""
+        close = False
+        if isinstance(file, str):
+            file = open(file, "rb")
+            close = True
+        try:
+            blob = file.read()
+        finally:
+            if close:
+                file.close()
+        if blob[:3] != b"RSM":
+            raise ValueError("The specified mesh file is not a valid RSM mesh file.")
+        major, minor = struct.unpack_from("<BB", blob, 3)
+        if (major, minor) != (1, 0):
+            raise ValueError("Unsupported Raysect mesh version (v%d.%d)." % (major, minor))
+        smoothing, closed, has_tree = struct.unpack_from("<???", blob, 5)
+        nv, nn, nt = struct.unpack_from("<iii", blob, 8)
+        pos = 20
+        self = cls.__new__(cls)
+        self.smoothing, self.closed = bool(smoothing), bool(closed)
+        self._vertices = np.frombuffer(blob, dtype="<f4", count=3 * nv, offset=pos).reshape(nv, 3).astype(np.float32)
+        pos += 12 * nv
+        self._vertex_normals = None
+        if nn:
+            self._vertex_normals = np.frombuffer(blob, dtype="<f4", count=3 * nn, offset=pos).reshape(nn, 3).astype(np.float32)
+            pos += 12 * nn
+        stride = 6 if nn else 3
+        self._triangles = np.frombuffer(blob, dtype="<i4", count=stride * nt, offset=pos).reshape(nt, stride).astype(np.int32)
+        self._all_triangles = self._triangles
+        pos += 4 * stride * nt
+        L = _lib.lib()
+        self._face_normals = np.zeros((nt, 3), dtype=np.float32)
+        _lib.check(L.rsx_mesh_face_normals(_lib.ptr(self._vertices), _lib.ptr(self._triangles), nt, stride, _lib.ptr(self._face_normals)))
+        if has_tree:
+            self.kd, used = KDTreeHost.from_blob(memoryview(blob)[pos:])
+            self._kd_params = (self.kd.max_depth, self.kd._min_items, self.kd._hit_cost, self.kd._empty_bonus)
+        else:                                                # mesh.pyx:1017-1019: rebuild with the default settings
+            boxes = np.zeros((nt, 6), dtype=np.float64)
+            _lib.check(L.rsx_mesh_triangle_aabbs(_lib.ptr(self._vertices), _lib.ptr(self._triangles), nt, stride, _lib.ptr(boxes)))
+            self._kd_params = (0, 1, 20.0, 0.2)
+            self.kd = KDTreeHost.build(boxes, 0, 1, 20.0, 0.2)
+        return self
+
     def save(self, file):
         """RSM v1.0 writer, byte-compatible with MeshData.save (mesh.pyx:864-931)."""
         close = False
@@ -390,6 +436,37 @@ class KDTreeHost:
         """KDTree3DCore.save() byte layout (kdtree3d.pyx:864-912)."""
         return self._blob
 
+    @classmethod
+    def from_blob(cls, blob):
+        """Rebuilds the flattened tree from a KDTree3DCore.save() blob (kdtree3d.pyx:914-990; layout in SURVEY.md Appendix A):
+        a tree built by the reference is used as stored, node for node. Returns (tree, bytes consumed)."""
+        max_depth, min_items, hit_cost, empty_bonus = struct.unpack_from("<iidd", blob, 0)
+        bounds = struct.unpack_from("<6d", blob, 24)
+        (n_nodes,) = struct.unpack_from("<i", blob, 72)
+        if n_nodes < 0:
+            raise ValueError("Corrupt KD-tree record: negative node count.")
+        nodes = np.zeros(n_nodes, dtype=_lib.KDNODE_DTYPE)
+        raw = nodes.view(np.int32).reshape(n_nodes, 4)
+        items = []
+        pos = 76
+        n_items = 0
+        for i in range(n_nodes):
+            (kind,) = struct.unpack_from("<i", blob, pos)
+            if kind == -1:                                   # leaf: i32 -1, i32 count, i32 items[count]
+                (count,) = struct.unpack_from("<i", blob, pos + 4)
+                items.append(np.frombuffer(blob, dtype="<i4", count=count, offset=pos + 8))
+                raw[i, 0], raw[i, 1], raw[i, 2] = -1, count, n_items
+                n_items += count
+                pos += 8 + 4 * count
+            else:                                            # branch: i32 axis, f64 split, i32 upper child (lower = id + 1)
+                split, upper = struct.unpack_from("<di", blob, pos + 4)
+                nodes["type"][i], nodes["count"][i], nodes["split"][i] = kind, upper, split
+                pos += 16
+        tree = cls(nodes, np.concatenate(items).astype(np.int32) if items else np.zeros(0, dtype=np.int32), bounds[:3], bounds[3:], max_depth)
+        tree._min_items, tree._hit_cost, tree._empty_bonus = min_items, hit_cost, empty_bonus
+        tree._blob = bytes(blob[:pos])
+        return tree, pos
+
     def fill(self, view, keep):
         """Populates a ctypes KDTree struct pointing at this tree's arrays."""
         keep.extend([self.nodes, self.items])
@@ -433,3 +510,16 @@ class Mesh(_DevicePrimitive):
 
     def save(self, file):
         self.data.save(file)
+
+    def load(self, file):                                   # mesh.pyx:1320-1339
+        """Replaces this mesh's data with the contents of an RSM file."""
+        self.data = MeshData.from_file(file)
+        self.notify_geometry_change()
+
+    @classmethod
+    def from_file(cls, file, parent=None, transform=None, material=None, name=None):   # mesh.pyx:1341-1369
+        """Mesh.from_file(file, parent, transform, material, name): instance a mesh from an RSM file."""
+        mesh = Mesh.__new__(Mesh)
+        mesh.data = MeshData.from_file(file)
+        Primitive.__init__(mesh, parent, transform, material, name)
+        return mesh

@@ -106,3 +106,47 @@ def test_observer_defaults_and_slicing(ns):
         cam.fov = 180
     tasks = ns.FullFrameSampler2D().generate_tasks((3, 2))
     assert sorted(tasks) == [(x, y) for x in range(3) for y in range(2)]
+
+
+def test_rsm_reader_and_obj_io(ns, golden, tmp_path):
+    """Mesh I/O: RSM files written by the compiled reference load into the same mesh — KD-tree taken from
+    the file node for node, re-saved bytes identical — and OBJ export/import round-trips geometry."""
+    import io
+    from source_amd import scenes
+    from source_amd.primitive import MeshData
+    g = golden("f03_kd")
+    builders = {"cube": lambda: scenes.cube_mesh(), "fan500": lambda: scenes.fan_mesh()}
+    for name in ("cube", "sphere8", "blob24", "fan500"):
+        blob = g[name].tobytes()
+        data = MeshData.from_file(io.BytesIO(blob))
+        assert np.array_equal(data.face_normals, g[name + "_face_normals"])          # recomputed on load, mesh.pyx:1012-1013
+        out = io.BytesIO()
+        data.save(out)
+        assert out.getvalue() == blob, name
+        if name in builders:                                                          # same tree as building from the arrays
+            v, t = builders[name]()
+            built = ns.Mesh(v, t, smoothing=False)
+            assert np.array_equal(built.data.kd.nodes, data.kd.nodes) and np.array_equal(built.data.kd.items, data.kd.items)
+            assert np.array_equal(built.data.vertices, data.vertices) and np.array_equal(built.data._triangles, data._triangles)
+    mesh = ns.Mesh.from_file(io.BytesIO(g["cube"].tobytes()), transform=ns.translate(0, 0, 1), name="cube")
+    assert mesh.name == "cube" and mesh.data.kd.max_depth >= 0
+    with pytest.raises(ValueError):
+        MeshData.from_file(io.BytesIO(b"XYZ" + g["cube"].tobytes()[3:]))
+    # OBJ: export then import reproduces vertices (to %e precision), triangles and normals
+    v, t = scenes.displaced_sphere(8)
+    normals = scenes.vertex_normals(v, t)
+    src = ns.Mesh(v, np.hstack([t, t]), normals, smoothing=True, name="blob")
+    path = str(tmp_path / "blob.obj")
+    ns.export_obj(src, path)
+    back = ns.import_obj(path, smoothing=True)
+    assert np.array_equal(back.data.triangles, src.data.triangles)
+    assert np.allclose(back.data.vertices, src.data.vertices, rtol=1e-6, atol=0) and back.data.vertex_normals.shape == normals.shape
+    assert np.allclose(back.data.vertex_normals, src.data.vertex_normals, rtol=2e-6, atol=1e-7)
+    plain = ns.Mesh(v, t, smoothing=False)
+    ns.export_obj(plain, path)
+    scaled = ns.import_obj(path, scaling=2.0, smoothing=False)
+    assert scaled.data.vertex_normals is None and np.allclose(scaled.data.vertices, 2.0 * plain.data.vertices, rtol=1e-6)
+    with open(path, "a") as f:
+        f.write("f 1 2 3 4\n")
+    with pytest.raises(ValueError):
+        ns.import_obj(path)
