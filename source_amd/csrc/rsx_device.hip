@@ -1898,6 +1898,7 @@ struct AccumParams {
     long long n_tasks;
     int32_t rect[4];
     int32_t ny, bins, spp, power;
+    int32_t n_tables, pad;
     double sensitivity;
     double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
@@ -1907,35 +1908,72 @@ struct AccumParams {
 
 // Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
 // kernel wrote, so both streams are read and written as contiguous runs. Task-list mode keeps task order.
+#define ACC_RCP_TABLE_MAX 4096      // samples per pixel per pass up to which the reciprocal table is kept in LDS
+#ifndef ACC_BATCH
+#define ACC_BATCH 4                 // sample records whose loads are issued together
+#endif
+
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
+    // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
+    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
+    const bool staged = ap.spp >= 4;                        // few samples per pixel: not worth a barrier, read the tables from global
+    const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
+    const int n_rcp = rcp_table ? ap.spp + 2 : 2;
+    double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
+    if (staged) {
+        for (int d = threadIdx.x + 1; d < n_rcp; d += blockDim.x) acc_rcp[d] = refine_rcp((double)d);
+        for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];
+        __syncthreads();
+    }
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * ap.bins;
     if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
     if (gid >= total) return;
-    const long long p = gid / ap.bins;
-    const int b = (int)(gid % ap.bins);
+    long long p;
+    int b;
+    if (total < (1LL << 31)) { p = (uint32_t)gid / (uint32_t)ap.bins; b = (int)((uint32_t)gid % (uint32_t)ap.bins); }   // 32-bit divide when it fits
+    else { p = gid / ap.bins; b = (int)(gid % ap.bins); }
     long long k = p;                                        // task index (row-major in rect mode): addresses the per-task outputs
     int ix, iy;
     if (ap.tasks) { ix = ap.tasks[2 * p]; iy = ap.tasks[2 * p + 1]; }
     else {
         const int w = ap.rect[2] - ap.rect[0], h = ap.rect[3] - ap.rect[1];
-        const int lx = (int)(p / h), ly = (int)(p % h);
+        const int lx = (int)((uint32_t)p / (uint32_t)h), ly = (int)((uint32_t)p % (uint32_t)h);
         ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
         k = (long long)ly * w + lx;
     }
-    double m = 0, v = 0;
-    int n = 0;
     const Sample *s = ap.samples + p * ap.spp;
-    IntRcp by_nm1(1);
-    for (int i = 0; i < ap.spp; ++i) {
-        const IntRcp by_n(i + 1);
-        const Sample smp = s[i];
-        double x = smp.table < 0 ? 0.0 : smp.a * ap.tables[(size_t)smp.table * ap.bins + b];
-        x = x * smp.weight;                                                   // observer.pyx:408
+    // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
+    auto value = [&](const Sample &smp) {
+        const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
+        const double tab = staged ? acc_tab[e] : ap.tables[e];
+        double x = smp.table < 0 ? 0.0 : smp.a * tab;
+        x = x * smp.weight;
         if (ap.power) x = x * ap.sensitivity;
-        add_sample(x, m, v, n, by_n, by_nm1);                                 // n: i -> i + 1, divisors i + 1 and i
-        by_nm1 = by_n;
+        return x;
+    };
+    // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
+    // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
+    // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
+    double m = value(s[0]), v = 0;
+    double dm = 1.0;                                        // (double)i, advanced by exact additions
+    auto step = [&](double x, int i) {
+        const double dn = dm + 1.0, c = i == 1 ? 1.0 : dm - 1.0;
+        const double yn = rcp_table ? acc_rcp[i + 1] : refine_rcp(dn), ym = rcp_table ? acc_rcp[i] : refine_rcp(dm);
+        const double pm = m, pv = v;
+        m = pm + exact_div(x - pm, dn, yn, true);
+        v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
+        dm = dn;
+    };
+    int i = 1;
+    for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
+        Sample sm[ACC_BATCH];
+#pragma unroll
+        for (int j = 0; j < ACC_BATCH; ++j) sm[j] = s[i + j];
+#pragma unroll
+        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j]), i + j);
     }
+    for (; i < ap.spp; ++i) step(value(s[i]), i);
     if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
     if (ap.fmean) {
         const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
@@ -2769,7 +2807,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
     if (timed) HIP_TRY(hipEventRecord(re[3], ctx->stream));
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
+    ap.n_tables = desc->n_tables; ap.pad = 0;
+    const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
+    if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
+    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), acc_lds, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
