@@ -209,8 +209,11 @@ __device__ __forceinline__ UPrim uniform_prim(const rsx_primitive *base, int32_t
 __device__ __forceinline__ Ray to_local_uniform(UPrim p, const Ray &r) {
     const RSX_CONST_AS double *m = p->to_local;
     Ray l;
-    double w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15];
-    w = 1.0 / w;
+    // Point3D.transform divides by the homogeneous w (point.pyx:253-284). For an affine matrix (last row 0 0 0 1 — every matrix
+    // translate/rotate produce) w is exactly 1 and x * (1.0 / 1.0) == x bit for bit, so the wave-uniform test skips a division.
+    double w = 1.0;
+    const bool affine = m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0;
+    if (!affine) { w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15]; w = 1.0 / w; }
     l.ox = (m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3]) * w;
     l.oy = (m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7]) * w;
     l.oz = (m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11]) * w;
@@ -543,12 +546,16 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
     const int32_t *items = m->items;
     double tmin = 0, tmax = 0;
     bool active;
+    const AxisDiv ad = axis_div(r);
     {
+        // BoundingBox3D.intersect (kdtree3d.pyx:589-607) needs 1.0 / d per axis: formed from the refined reciprocals that the
+        // branch steps use anyway (exact_div(1, d) is the correctly rounded quotient), not by three more full divisions
         const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
-        active = want && aabb(lo, hi, r, tmin, tmax);                         // kdtree3d.pyx:589-607
+        const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
+                     rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
+        active = want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax);
     }
     const TriRay q = tri_ray(r);
-    const AxisDiv ad = axis_div(r);
     bool hit = false;
     int32_t node = 0, sp = 0;
     while (__any(active)) {
@@ -1913,10 +1920,11 @@ struct AccumParams {
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
 
+template <bool STAGED>                  // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
     extern __shared__ __attribute__((aligned(16))) double acc_lds[];
-    const bool staged = ap.spp >= 4;                        // few samples per pixel: not worth a barrier, read the tables from global
+    constexpr bool staged = STAGED;                         // few samples per pixel: not worth a barrier, read the tables from global
     const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
     const int n_rcp = rcp_table ? ap.spp + 2 : 2;
     double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
@@ -2810,7 +2818,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.n_tables = desc->n_tables; ap.pad = 0;
     const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
     if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
-    hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((total + 255) / 256)), dim3(256), acc_lds, ctx->stream, ap);
+    if (desc->spp >= 4) hipLaunchKernelGGL(k_accumulate<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), acc_lds, ctx->stream, ap);
+    else hipLaunchKernelGGL(k_accumulate<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
