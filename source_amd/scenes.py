@@ -238,3 +238,59 @@ def build_mixed(ns):
     prims.append(ns.Union(c, d, world, ns.translate(1.3, 0.9, 0.7) * ns.rotate(-30, 45, 0), absorb()))
     prims.append(ns.Box(ns.Point3D(-4, -4, -4), ns.Point3D(4, 4, 4), world, material=absorb()))
     return world, prims
+
+
+def build_edge_worlds(ns):
+    """Small worlds that pin the edge semantics of SURVEY.md Appendix B (fixture F11): an empty world (B.16), coincident
+    primitives (B.19: last registered wins), t == max_distance on analytic and mesh surfaces (B.18), origins on / inside
+    surfaces, axis-parallel rays along box faces / edges / corners and along a cylinder axis."""
+    worlds = {}
+    worlds["empty"] = (ns.World(), [])
+    w = ns.World()
+    prims = [ns.Sphere(1.0, w, ns.translate(0, 0, 3), ns.AbsorbingSurface()) for _ in range(3)]
+    prims.append(ns.Box(ns.Point3D(-1, -1, 2), ns.Point3D(1, 1, 4), w, material=ns.AbsorbingSurface()))     # touches the spheres at z = 2 and 4
+    worlds["coincident"] = (w, prims)
+    w = ns.World()
+    v, t = cube_mesh(0.5)
+    prims = [ns.Sphere(0.5, w, ns.translate(0, 0, 3), ns.AbsorbingSurface()),
+             ns.Mesh(v, t, smoothing=False, parent=w, transform=ns.translate(2, 0, 4.5), material=ns.AbsorbingSurface()),
+             ns.Box(ns.Point3D(-1, -1, -1), ns.Point3D(1, 1, 1), w, ns.translate(-4, 0, 3), ns.AbsorbingSurface()),
+             ns.Cylinder(0.5, 2.0, w, ns.translate(4, 0, 2), ns.AbsorbingSurface())]
+    worlds["limits"] = (w, prims)
+    return worlds
+
+
+def edge_rays(name):
+    """(origin, direction, max_distance) arrays for build_edge_worlds()[name]: hand-placed rays, all exactly representable."""
+    inf = float("inf")
+    up = lambda x: float(np.nextafter(x, inf))
+    dn = lambda x: float(np.nextafter(x, -inf))
+    z, x, y = (0.0, 0.0, 1.0), (1.0, 0.0, 0.0), (0.0, 1.0, 0.0)
+    if name == "empty":
+        rays = [((0, 0, 0), z, inf), ((1, 2, 3), x, 5.0), ((0, 0, 0), (0.6, 0.0, 0.8), inf)]
+    elif name == "coincident":
+        rays = [((0, 0, 0), z, inf), ((0, 0, 0), z, 2.0), ((0, 0, 0), z, dn(2.0)), ((0, 0, 3), z, inf), ((0, 0, 3), (0.0, 0.0, -1.0), inf),
+                ((0, 0, 2), z, inf), ((0, 0, 4), z, inf), ((0.5, 0.5, 0), z, inf), ((1, 0, 0), z, inf), ((1, 1, 0), z, inf),
+                ((0, 0, 10), (0.0, 0.0, -1.0), inf), ((-5, 0, 3), x, inf), ((0, -5, 3), y, inf), ((0, 0, 3), (0.6, 0.0, 0.8), inf)]
+    else:
+        rays = [((0, 0, 0), z, 2.5), ((0, 0, 0), z, dn(2.5)), ((0, 0, 0), z, up(2.5)), ((0, 0, 0), z, 0.0), ((0, 0, 0), z, 1e-300),
+                ((0, 0, 0), z, 3.5), ((0, 0, 0), z, dn(3.5)),                                   # sphere: exit root at 3.5
+                ((2, 0, 0), z, 4.0), ((2, 0, 0), z, up(4.0)), ((2, 0, 0), z, dn(4.0)), ((2, 0, 0), z, inf),   # mesh face at t = 4
+                ((2, 0, 4.5), z, inf), ((2, 0, 4.0), z, inf), ((2, 0, 5.0), z, inf), ((2.5, 0, 0), z, inf), ((2.5, 0.5, 0), z, inf),
+                ((-4, 0, 0), z, 2.0), ((-4, 0, 0), z, dn(2.0)), ((-3, 0, 0), z, inf), ((-3, 1, 0), z, inf), ((-3, 1, 2), z, inf),
+                ((-4, 0, 3), z, inf), ((-4, 0, 3), x, inf), ((-4, 0, 3), (0.0, -1.0, 0.0), inf), ((-5, -1, 3), y, inf), ((-5, 0, 2), x, inf),
+                ((4, 0, 0), z, inf), ((4, 0, 0), z, 2.0), ((4, 0, 0), z, dn(2.0)), ((4.5, 0, 0), z, inf), ((4.25, 0, 3), z, inf),
+                ((4, 0, 3), z, inf), ((4, 0, 3), x, inf), ((3, 0, 3), x, inf), ((3, 0, 2), x, inf), ((3, 0, 4), x, inf), ((4, -3, 3), y, 2.5),
+                ((4, -3, 3), y, dn(2.5)), ((0, 0, 3), z, inf), ((0, 0, 2.5), z, inf), ((0, 0, 2.5), (0.0, 0.0, -1.0), inf), ((0, 0, 3.5), z, inf)]
+    o = np.array([r[0] for r in rays], dtype=np.float64)
+    d = np.array([r[1] for r in rays], dtype=np.float64)
+    m = np.array([r[2] for r in rays], dtype=np.float64)
+    return o, d, m
+
+
+def edge_camera(ns, world, pixels, spp, bins, mask=None):
+    pipe = ns.SpectralRadiancePipeline2D()
+    sampler = ns.FullFrameSampler2D(mask) if mask is not None else ns.FullFrameSampler2D()
+    cam = ns.PinholeCamera(pixels, fov=50, parent=world, pipelines=[pipe], frame_sampler=sampler, transform=ns.translate(0, 0.16, -0.4) * ns.rotate(0, -12, 0))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
+    return cam, pipe

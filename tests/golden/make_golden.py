@@ -435,6 +435,23 @@ def f10_frames():
     save("f10_frames", **out)
 
 
+def f11_edges():
+    """Edge semantics: empty world, coincident primitives, t == max_distance, origins on surfaces,
+    axis-parallel grazing rays; odd frame shapes (1x1, 3x5 with one bin) and a masked frame sampler (ragged task list)."""
+    out = {}
+    for name, (world, prims) in scenes.build_edge_worlds(NS).items():
+        o, d, m = scenes.edge_rays(name)
+        out[name + "_idx"], out[name + "_rec"] = world_records(world, o, d, m)
+        pts = np.concatenate([o, o + 0.25 * d])
+        out[name + "_contains"] = contains_records(world, pts) if prims else np.zeros((len(pts), 0), dtype=np.uint8)
+    world, mesh, box = scenes.build_c2(NS, n=24)
+    for tag, pixels, spp, bins, mask in (("one", (1, 2), 3, 2, None), ("odd", (3, 5), 2, 1, None),
+                                         ("mask", (9, 7), 2, 3, (np.add.outer(np.arange(9), np.arange(7)) % 3 != 0))):
+        cam, pipe = scenes.edge_camera(NS, world, pixels, spp, bins, mask)
+        out[tag + "_mean"], out[tag + "_var"], out[tag + "_n"] = observe_frame(cam, pipe, 21)
+    save("f11_edges", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -452,3 +469,4 @@ if __name__ == "__main__":
     if run("f08"): f08_camera()
     if run("f09"): f09_stats()
     if run("f10"): f10_frames()
+    if run("f11"): f11_edges()

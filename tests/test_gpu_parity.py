@@ -352,6 +352,33 @@ def test_c4_full_size_csg_demo(orc, ns):
     _full_size_properties(orc, ns, world, cam, pipe, make, strip_rows=8, spp=16, seed=13)
 
 
+def test_edge_semantics_on_device(orc, ns, golden):
+    """Fixture F11 on the device: empty world, coincident primitives, t == max_distance, surface origins, axis-parallel grazing
+    rays, zero-length batches, and 1x2 / 3x5x1 / masked (ragged task list) frames — all bit-exact against the compiled reference."""
+    from tests.test_oracle_golden import EDGE_FRAMES
+    g = golden("f11_edges")
+    for name, (world, prims) in scenes.build_edge_worlds(ns).items():
+        sc = world.build_accelerator()
+        o, d, m = scenes.edge_rays(name)
+        dev = sc.hit_batch(o, d, m, geometry=True)
+        _check_world(dev, g[name + "_idx"], g[name + "_rec"])
+        pts = np.concatenate([o, o + 0.25 * d])
+        assert eq(sc.contains_batch(pts), g[name + "_contains"]), name
+        empty = sc.hit_batch(np.zeros((0, 3)), np.zeros((0, 3)), np.zeros(0))            # n = 0 is a valid call
+        assert len(empty["prim"]) == 0
+        # the object API agrees (World.hit returns None / the right object)
+        for k in range(min(4, len(o))):
+            hit = world.hit(ns.Ray(ns.Point3D(*o[k]), ns.Vector3D(*d[k]), max_distance=float(m[k])))
+            assert (hit is None) == (g[name + "_idx"][k] < 0)
+            if hit is not None:
+                assert hit.primitive is prims[int(g[name + "_idx"][k])] and hit.ray_distance == g[name + "_rec"][k, 0]
+    world, mesh, box = scenes.build_c2(ns, n=24)
+    for tag, pixels, spp, bins, mask in EDGE_FRAMES:
+        cam, pipe = scenes.edge_camera(ns, world, pixels, spp, bins, mask)
+        mean, var, n = _observe(ns, cam, pipe, 21)
+        assert eq(mean, g[tag + "_mean"]) and eq(var, g[tag + "_var"]) and eq(n, g[tag + "_n"]), tag
+
+
 # ------------------------------------------------------------------------------------------------- CSG on the device
 def _check_world(dev, idx, rec):
     assert eq(dev["prim"], idx)

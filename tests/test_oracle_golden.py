@@ -343,3 +343,29 @@ def test_spectral_function_sampling(ns, golden):
     assert eq(sf.sample(480.0, 520.0, 3), g["sf_interp_3"])
     assert eq(sf.sample(200.0, 900.0, 9), g["sf_interp_wide"])
     assert eq(ns.ConstantSF(0.75).sample(375.0, 740.0, 4), g["sf_const"])
+
+
+# ---------------------------------------------------------------------------------------- F11 edge semantics
+EDGE_FRAMES = (("one", (1, 2), 3, 2, None), ("odd", (3, 5), 2, 1, None),
+               ("mask", (9, 7), 2, 3, (np.add.outer(np.arange(9), np.arange(7)) % 3 != 0)))
+
+
+def test_edge_semantics(orc, ns, golden):
+    """Empty world (App. B.16), coincident primitives (B.19), t == max_distance on analytic vs mesh surfaces (B.18), origins on
+    surfaces, axis-parallel rays along faces / edges / a cylinder axis; 1x2, 3x5x1-bin and masked (ragged) frames."""
+    g = golden("f11_edges")
+    for name, (world, prims) in scenes.build_edge_worlds(ns).items():
+        flat = world.flatten()
+        o, d, m = scenes.edge_rays(name)
+        _check_world(orc.hit_batch(flat, o, d, m, geometry=True), g[name + "_idx"], g[name + "_rec"])
+        pts = np.concatenate([o, o + 0.25 * d])
+        assert eq(orc.contains_batch(flat, pts), g[name + "_contains"]), name
+    assert (g["empty_idx"] == -1).all() and (g["coincident_idx"][[0, 3]] == 3).all() and g["coincident_idx"][-1] == 2
+    assert g["limits_idx"][0] == 0 and g["limits_idx"][1] == -1 and g["limits_idx"][7] == -1 and g["limits_idx"][8] == 1   # B.18
+    world, mesh, box = scenes.build_c2(ns, n=24)
+    for tag, pixels, spp, bins, mask in EDGE_FRAMES:
+        cam, pipe = scenes.edge_camera(ns, world, pixels, spp, bins, mask)
+        f = _observe_oracle(orc, ns, cam, pipe, 21)
+        assert eq(f[0], g[tag + "_mean"]) and eq(f[1], g[tag + "_var"]) and eq(f[2], g[tag + "_n"]), tag
+    with pytest.raises(RuntimeError):
+        ns.PinholeCamera((1, 1), parent=world)                 # pinhole.pyx:166-167
