@@ -535,7 +535,10 @@ class PinholeCamera(Observer2D):
             keep.append(u)
             desc.uniforms, desc.rng_mode = _lib.ptr(u), _lib.RNG_STREAM
         else:
-            desc.uniforms, desc.rng_mode, desc.seed = None, _lib.RNG_PHILOX, engine.seed
+            # one independent Philox stream per spectral slice (the reference draws fresh jitter for every slice of a pixel,
+            # observer.pyx:299-305): the slice offset is folded into the key; slice 0 keeps the engine's seed
+            key = (engine.seed + slice_.offset * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+            desc.uniforms, desc.rng_mode, desc.seed = None, _lib.RNG_PHILOX, key
             desc.sample_offset = engine.sample_offset
         return desc
 

@@ -352,6 +352,39 @@ def test_c4_full_size_csg_demo(orc, ns):
     _full_size_properties(orc, ns, world, cam, pipe, make, strip_rows=8, spp=16, seed=13)
 
 
+def test_c5_shape_512_spectral_slices(orc, ns):
+    """BASELINE configs[4]'s frame shape with the closed-form materials this round covers: 1024x1024, 512 spectral bins rendered
+    as 512 one-bin slices (spectral_rays = 512, observer.pyx:311-340), 1 spp — a 10.7 GB device-resident frame and 537 M primary
+    rays. Checks slice offsets over the whole frame, a strip against the oracle and the per-bin spectral table."""
+    world, mesh, box = scenes.build_c2(ns, n=132)
+    sf = ns.InterpolatedSF([300, 490, 510, 590, 610, 800], np.array([0.0, 0.1, 1.0, 0.7, 0.2, 0.4]))
+    mesh.material = ns.Light(ns.Vector3D(-1, -1, 1), 1.0, sf)
+    cam, pipe = scenes.c2_camera(ns, world, (1024, 1024), spp=1, bins=512)
+    cam.spectral_rays = 512
+    cam.render_engine = ns.HipEngine(rng="philox", seed=17)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.observe()
+    f = pipe.frame
+    assert f.shape == (1024, 1024, 512)
+    n = f.samples
+    assert (n == 1).all()
+    mean = f.mean
+    assert np.isfinite(mean).all() and (f.variance == 0).all()
+    # every slice is an independent 1-bin render with its own jitter: compare three slices' strips with the oracle
+    flat = world.flatten()
+    slices = cam._slice_spectrum()
+    assert len(slices) == 512 and all(s.bins == 1 and s.offset == k for k, s in enumerate(slices))
+    for k in (0, 255, 511):
+        keep = []
+        desc = cam.render_desc(world, None, slices[k], cam.render_engine, keep, rect=(0, 508, 1024, 516))
+        m, v, rays = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+        assert eq(mean[:, 508:516, k], m.reshape(8, 1024).T)
+    # slices draw independent jitter (one Philox key per slice): normalised by their table value two slices still differ
+    table = sf.sample(cam.min_wavelength, cam.max_wavelength, 512)
+    assert not np.allclose(mean[:, 508:516, 200] / table[200], mean[:, 508:516, 300] / table[300], rtol=1e-9)
+    f.release()
+
+
 def test_edge_semantics_on_device(orc, ns, golden):
     """Fixture F11 on the device: empty world, coincident primitives, t == max_distance, surface origins, axis-parallel grazing
     rays, zero-length batches, and 1x2 / 3x5x1 / masked (ragged task list) frames — all bit-exact against the compiled reference."""
