@@ -84,7 +84,7 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     dist = None
     torch = None
-    if args.gpus > 1 or world_size > 1:
+    if args.gpus > 1 or world_size > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: take the collective path even for 1 rank
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
