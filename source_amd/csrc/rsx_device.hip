@@ -52,9 +52,6 @@
 #ifndef RSX_LPT_SCHEDULE
 #define RSX_LPT_SCHEDULE 1          // reorder the 64-ray units of a repeated pass longest-first using the previous pass's timings
 #endif
-#ifndef RSX_WAVE_COOP
-#define RSX_WAVE_COOP 1             // 1: wave-cooperative traversal (idle lanes help on big mesh leaves); 0: independent lanes
-#endif
 #ifndef RSX_MIN_WAVES_PER_SIMD
 #define RSX_MIN_WAVES_PER_SIMD 3    // __launch_bounds__ second argument for the mesh/analytic traversal kernels: 168 registers per wave.
                                     // History on configs[2] (268 M rays): unconstrained the compiler took 260 registers and the hardware
@@ -1194,37 +1191,9 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
     if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
 }
 
-template <bool CSG>
-__device__ bool world_trace(const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best) {
-    best.prim = -1;
-    double tmin, tmax;
-    const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;      // shared by the world box and every primitive box gate
-    if (!aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax)) return false;
-    const AxisDiv ad = axis_div(r);
-    int32_t node = 0, sp = 0;
-    for (;;) {
-        const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
-        double distance = r.maxd < tmax ? r.maxd : tmax;
-        const int32_t *items = sc.witems + nd.u.leaf.first_item;
-        for (int32_t k = 0; k < nd.count; ++k) {
-            const int32_t idx = items[k];
-            const rsx_primitive &p = sc.prims[idx];
-            double f, b;
-            if (!aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b)) continue;   // BoundPrimitive.hit gate
-            Hit cand;
-            primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
-            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
-        }
-        if (best.prim >= 0) return true;
-        if (sp == 0) return false;
-        --sp;
-        tmin = tmax;
-        stack_pop(st, sp, node, tmax);
-    }
-}
-
-// Wave-cooperative World.hit: same result as world_trace, but every lane of the wave calls it together (`valid` = lane has a
-// ray) and all loops are wave-uniform, so that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves).
+// World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
+// that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
+// the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
 template <bool CSG>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
@@ -1355,12 +1324,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
             r.maxd = maxd[i];
         }
         Hit h;
-#if RSX_WAVE_COOP
         uint32_t work = 0;
         const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h, work);
-#else
-        const bool hit = valid && world_trace<CSG>(sc, r, st, ms, csg_state, h);
-#endif
         if (!valid) continue;
         out.prim[i] = hit ? h.prim : -1;
         if (out.t) out.t[i] = hit ? h.t : NAN;
@@ -1529,25 +1494,12 @@ __device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t 
 }
 
 // clock the unit costs are measured with (only ever compared within one lane's cost array)
-// Unit cost that steers the longest-first schedule: 0 = the wave's own count of traversal rounds (free, deterministic);
-// 1 / 2 = s_memrealtime / s_memtime around the unit. Measured on configs[2]: the two clock reads per unit serialise chip-wide
-// (~9 ns each whatever the occupancy) and doubled the kernel time of a 4.2 M-unit pass, so the counter is the default.
-#ifndef RSX_COST_CLOCK
-#define RSX_COST_CLOCK 0
-#endif
+// Unit cost that steers the longest-first schedule = the wave's own count of traversal rounds (`work`): free and deterministic.
+// Reading s_memrealtime / s_memtime around every unit was measured on configs[2]: the reads serialise chip-wide (~9 ns each
+// whatever the occupancy) and doubled the kernel time of a 4.2 M-unit pass.
 #ifndef RSX_LPT_MAX_UNITS
 #define RSX_LPT_MAX_UNITS (1 << 18)   // passes with more 64-ray units than this are not re-ordered
 #endif
-__device__ __forceinline__ unsigned long long cost_clock() {
-#if RSX_COST_CLOCK == 1
-    return wall_clock64();
-#elif RSX_COST_CLOCK == 2
-    return (unsigned long long)clock64();
-#else
-    return 0ULL;
-#endif
-}
-
 struct RenderParams {
     rsx_camera cam;
     const rsx_material *materials;
@@ -1558,7 +1510,7 @@ struct RenderParams {
     int32_t spp, rng_mode;
     uint64_t seed, sample_offset;
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
-    const uint32_t *unit_order;       // work list or null: ticket k processes work item unit_order[k] = unit | part << 26 | log2(parts) << 29
+    const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
     int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
     unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
@@ -1639,9 +1591,6 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
         }
         if (tk < 0) break;
         int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
-#if RSX_COST_CLOCK
-        const unsigned long long c_start = q->measure_cost ? cost_clock() : 0ULL;
-#endif
         const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF
         unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -1675,23 +1624,15 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
         }
         r.maxd = INFINITY;
         Hit hit;
-#if RSX_WAVE_COOP
         uint32_t work = 0;
         const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
-#else
-        const bool got = valid && world_trace<CSG>(sc, r, st, ms, csg_state, hit);
-#endif
         // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
         // compiler cannot merge this with the computation above)
         asm volatile("" : "+s"(unit));
         asm volatile("" : "+s"(rp_bits));
         const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
         if (q2->measure_cost && lane == 0) {
-#if RSX_COST_CLOCK
-            unsigned long long c = cost_clock() - c_start;
-#else
             unsigned long long c = (unsigned long long)work;
-#endif
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
             q2->unit_cost[unit] = (uint32_t)c;
         }
@@ -1768,27 +1709,9 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
     return b < ORDER_BUCKETS ? b : ORDER_BUCKETS - 1;
 }
 
-#ifndef RSX_SPLIT_HEAVY
-#define RSX_SPLIT_HEAVY 1          // split units far above the mean cost into 2/4/8 work items (fewer lanes per wave, more waves)
-#endif
-
-#ifndef RSX_SPLIT_MAX_LOG2
-#define RSX_SPLIT_MAX_LOG2 0      // 0: no splitting (a silhouette tile is bound by its single slowest ray, parts only multiply the waves)
-#endif
 #ifndef RSX_HEAVY_FACTOR
 #define RSX_HEAVY_FACTOR 3ULL
 #endif
-__device__ __forceinline__ int unit_parts_log2(uint32_t c, unsigned long long mean) {
-#if RSX_SPLIT_HEAVY
-    int pl = 0;
-    if ((unsigned long long)c > 24ULL * mean) pl = 3;
-    else if ((unsigned long long)c > 10ULL * mean) pl = 2;
-    else if ((unsigned long long)c > 4ULL * mean) pl = 1;
-    return pl < RSX_SPLIT_MAX_LOG2 ? pl : RSX_SPLIT_MAX_LOG2;
-#else
-    return 0;
-#endif
-}
 
 // which XCD's list a unit belongs to: 4x4-tile blocks (32x32 pixels) are dealt round-robin to the 8 XCDs, so each L2 caches the
 // geometry behind an eighth of the image while every XCD still gets a fair share of cheap and expensive regions
@@ -1804,11 +1727,12 @@ __device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned lo
     return 1 + unit_xcd(unit, tiles_x, spp);
 }
 
-__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, long long capacity, int tiles_x, int spp) {
+// One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
+// and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp) {
     __shared__ unsigned int hist[9][ORDER_BUCKETS];
     __shared__ unsigned int offset[9][ORDER_BUCKETS];
     __shared__ unsigned long long total;
-    __shared__ int fits_flag;
     unsigned int *hflat = &hist[0][0];
     for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
     if (threadIdx.x == 0) total = 0;
@@ -1818,36 +1742,23 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     atomicAdd(&total, part_sum);
     __syncthreads();
     const unsigned long long mean = total / (unsigned long long)n + 1;
-    for (int pass = 0; pass < 2; ++pass) {
-        // pass 0 counts with splitting; if the list would overflow its buffer, pass 1 recounts without
-        const bool split = pass == 0;
-        for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t c = cost[i];
-            atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u << (split ? unit_parts_log2(c, mean) : 0));
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int x = 0; x < 9; ++x) {
+            seg[x] = run;
+            for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[x][b] = run; run += hist[x][b]; }
         }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            unsigned int run = 0;
-            for (int x = 0; x < 9; ++x) {
-                seg[x] = run;
-                for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[x][b] = run; run += hist[x][b]; }
-            }
-            seg[9] = run;
-            fits_flag = (long long)run <= capacity;
-        }
-        __syncthreads();
-        if (fits_flag) {
-            for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-                const uint32_t c = cost[i];
-                const int pl = split ? unit_parts_log2(c, mean) : 0;
-                const unsigned int pos = atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u << pl);
-                for (int part = 0; part < (1 << pl); ++part) order[pos + part] = (uint32_t)i | ((uint32_t)part << 26) | ((uint32_t)pl << 29);
-                if (pl) cost[i] = 0;                                        // parts report with atomicMax
-            }
-            return;
-        }
-        for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
-        __syncthreads();
+        seg[9] = run;
+    }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
     }
 }
 
@@ -2729,7 +2640,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             if (lane.unit_order) HIP_TRY(hipFree(lane.unit_order));
             lane.unit_capacity = (size_t)n_units + (size_t)n_units / 8 + 64;
             HIP_TRY(hipMalloc(&lane.unit_cost, lane.unit_capacity * 4));
-            HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4 * 2));      // room for split work items
+            HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4));
             if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 64));
             lane.cost_units = 0;
             lane.order_units = 0;
@@ -2743,8 +2654,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         order_tiles_x = desc->tasks ? 0 : (int)((w + 7) / 8);
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
-            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units,
-                               (long long)lane.unit_capacity * 2, order_tiles_x, (int)desc->spp);
+            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp);
             HIP_TRY(hipGetLastError());
         }
         rp.unit_order = lane.unit_order;
@@ -2791,8 +2701,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
-        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n,
-                           (long long)lane.unit_capacity * 2, order_tiles_x, (int)desc->spp);
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
     }
