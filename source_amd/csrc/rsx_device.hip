@@ -60,6 +60,17 @@
                                     // three waves with ~30 cold spills, 72 ms. Four waves still spill hot values and lose.
 #endif
 
+#ifndef RSX_UTIL_PROF
+#define RSX_UTIL_PROF 0            // 1: lane-utilisation counters per loop level into the rsx_debug_unit_times buffer (tuning builds only)
+#endif
+#if RSX_UTIL_PROF
+// one elected lane adds (active lanes, 64) to a pair of per-unit counters; `acc` points at the unit's slots in global memory
+#define UTIL_COUNT(acc, slot) { const unsigned long long ex_ = __ballot(true); \
+    if (acc && (int)(threadIdx.x % WAVE) == __ffsll((long long)ex_) - 1) { (acc)[slot] += __popcll(ex_); (acc)[(slot) + 1] += WAVE; } }
+#else
+#define UTIL_COUNT(acc, slot)
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------------
@@ -371,9 +382,10 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
 // Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
 // pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
 __device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
-                                              const Stack &st, int32_t &sp) {
+                                              const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
     rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
     while (nd.type >= 0) {
+        UTIL_COUNT(util, 4)
         const int axis = nd.type;
         const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
                                          (ad.safe >> axis) & 1, tmin, tmax, st, sp);
@@ -563,7 +575,8 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
         PHASE_ADD(0)
         rsx_kdnode nd;
         nd.count = 0; nd.u.leaf.first_item = 0;
-        if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp);
+        if (active) { UTIL_COUNT(phase_acc, 2) }
+        if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
         PHASE_ADD(1)
         if (active) {
             distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
@@ -571,6 +584,7 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
             first = nd.u.leaf.first_item;
             if (count < RSX_COOP_LEAF) {
                 for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+                    UTIL_COUNT(phase_acc, 6)
                     int32_t tri[RSX_LEAF_BATCH];
                     float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
 #pragma unroll
@@ -1210,6 +1224,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         double distance = 0;
         int32_t count = 0;
         const int32_t *items = sc.witems;
+        if (active) { UTIL_COUNT(phase_acc, 0) }
         if (active) {
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
             distance = r.maxd < tmax ? r.maxd : tmax;
@@ -1594,6 +1609,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void 
         const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF
         unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#elif RSX_UTIL_PROF
+        unsigned long long *phase_acc = q->unit_times ? q->unit_times + 12 * (long long)unit + 3 : nullptr;   // caller zeroes the buffer
 #else
         unsigned long long *phase_acc = nullptr;
 #endif

@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""Lane-utilisation per loop level (GPU box; needs a librsx built with -DRSX_UTIL_PROF=1, pass it as $RSX_LIB):
+tools/util_prof.py [c2|c3] — renders one pass with the per-unit counter buffer attached and prints active / total lane-slots of the
+world loop, the mesh loop, the node steps and the leaf batches."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from source_amd import api as ns, scenes, _lib  # noqa: E402
+from source_amd.device import get_context  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
+if cfg == "c3":
+    world = scenes.build_c3(ns, n=132)[0]
+    cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=4, bins=15)
+else:
+    world = scenes.build_c2(ns, n=132)[0]
+    cam, pipe = scenes.c2_camera(ns, world, (1024, 1024), spp=1, bins=15)
+cam.frame_sampler = ns.RectFrameSampler2D()
+cam.render_engine = ns.HipEngine(rng="philox", seed=20250905, timing=False)
+ctx = get_context()
+world.build_accelerator()
+n_units = (cam.pixels[0] // 8) * (cam.pixels[1] // 8) * cam.pixel_samples
+buf = ctx.alloc(n_units * 12 * 8)
+ctx.memset(buf, 0, n_units * 12 * 8)
+_lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, buf))
+cam.observe()
+ctx.synchronize()
+_lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, None))
+host = np.zeros((n_units, 12), dtype=np.uint64)
+ctx.download(host, buf)
+c = host[:, 3:11].astype(np.float64).sum(axis=0)
+for name, k in (("world loop", 0), ("mesh loop", 2), ("node steps", 4), ("leaf batches", 6)):
+    print("%-13s active lane-slots %.4g of %.4g  -> utilisation %.3f" % (name, c[k], c[k + 1], c[k] / max(c[k + 1], 1)))
