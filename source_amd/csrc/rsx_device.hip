@@ -71,6 +71,10 @@
 #define UTIL_COUNT(acc, slot)
 #endif
 
+#ifndef RSX_CSG_MIN_WAVES
+#define RSX_CSG_MIN_WAVES 1         // launch-bounds waves per SIMD of the CSG instantiations of the traversal kernels
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // error plumbing
 // ---------------------------------------------------------------------------------------------------
@@ -1320,7 +1324,7 @@ struct HitOut {
 };
 
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
+__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
                                                           const double *maxd, HitOut out, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
@@ -1575,7 +1579,7 @@ __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams 
 }
 
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
