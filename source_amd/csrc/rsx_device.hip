@@ -1942,7 +1942,7 @@ __global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, 
 // host API
 // ---------------------------------------------------------------------------------------------------
 #define RING_SLOTS 512
-enum { POOL_MATERIALS, POOL_TABLES, POOL_TASKS, POOL_UNIFORMS, POOL_SAMPLES, POOL_MEAN, POOL_VAR, POOL_SLOTS };
+enum { POOL_MATERIALS, POOL_TABLES, POOL_TASKS, POOL_QUERY, POOL_MEAN, POOL_VAR, POOL_SLOTS };
 
 // Per-stream state of the traversal kernels. `main` runs on the ctx stream (hit / roots / contains batches, unpipelined renders);
 // two more lanes with private streams let consecutive render passes overlap: the long tail of pass p (a few waves walking grazing
@@ -2427,13 +2427,31 @@ int reset_ticket(TraceLane &lane) {
     return RSX_OK;
 }
 
-// scratch device buffer that frees itself
-struct Scratch {
-    void *p = nullptr;
-    ~Scratch() { if (p) (void)hipFree(p); }
-    int alloc(size_t bytes) { HIP_TRY(hipMalloc(&p, bytes ? bytes : 16)); return RSX_OK; }
-    template <typename T> T *as() { return static_cast<T *>(p); }
+// Device workspace of one synchronous batch query (hit / roots / contains): a single grow-only allocation in the ctx, carved into
+// 256-byte aligned pieces — a per-call hipMalloc / hipFree per array cost more than the kernel for small batches (World.hit(ray)
+// is a batch of one). Safe to reuse: every query call synchronises the stream before it returns.
+struct Carver {
+    char *at = nullptr;
+    size_t left = 0;
+    static size_t padded(size_t bytes) { return (bytes + 255) & ~(size_t)255; }
+    template <typename T> T *take(size_t bytes) {
+        if (bytes == 0) return nullptr;
+        T *out = reinterpret_cast<T *>(at);
+        at += padded(bytes); left -= padded(bytes);
+        return out;
+    }
 };
+
+int query_workspace(rsx_ctx *ctx, std::initializer_list<size_t> sizes, Carver &c) {
+    size_t total = 256;
+    for (size_t b : sizes) total += Carver::padded(b);
+    void *base = nullptr;
+    int rc = pool_get(ctx, POOL_QUERY, total, &base);
+    if (rc) return rc;
+    c.at = static_cast<char *>(base);
+    c.left = total;
+    return RSX_OK;
+}
 
 }  // namespace
 
@@ -2465,28 +2483,27 @@ extern "C" int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, 
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t N = (size_t)n;
-    Scratch d_o, d_d, d_m, d_prim, d_t, d_ex, d_tri, d_uvw, d_geom;
-    int rc;
-#define A(s, bytes) do { rc = (s).alloc(bytes); if (rc) return rc; } while (0)
-    A(d_o, N * 24); A(d_d, N * 24); A(d_m, N * 8); A(d_prim, N * 4);
-    if (t) A(d_t, N * 8);
-    if (exiting) A(d_ex, N);
-    if (tri) A(d_tri, N * 4);
-    if (uvw) A(d_uvw, N * 12);
-    if (geom) A(d_geom, N * 96);
-#undef A
-    HIP_TRY(hipMemcpyAsync(d_o.p, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_d.p, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_m.p, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    rc = rsx_hit_batch_dev(scene, n, d_o.as<double>(), d_d.as<double>(), d_m.as<double>(), d_prim.as<int32_t>(), d_t.as<double>(),
-                           d_ex.as<uint8_t>(), d_tri.as<int32_t>(), d_uvw.as<float>(), d_geom.as<double>());
+    Carver c;
+    int rc = query_workspace(ctx, {N * 24, N * 24, N * 8, N * 4, t ? N * 8 : 0, exiting ? N : 0, tri ? N * 4 : 0, uvw ? N * 12 : 0, geom ? N * 96 : 0}, c);
     if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(prim, d_prim.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (t) HIP_TRY(hipMemcpyAsync(t, d_t.p, N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (exiting) HIP_TRY(hipMemcpyAsync(exiting, d_ex.p, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (tri) HIP_TRY(hipMemcpyAsync(tri, d_tri.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw.p, N * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (geom) HIP_TRY(hipMemcpyAsync(geom, d_geom.p, N * 96, hipMemcpyDeviceToHost, ctx->stream));
+    double *d_o = c.take<double>(N * 24), *d_d = c.take<double>(N * 24), *d_m = c.take<double>(N * 8);
+    int32_t *d_prim = c.take<int32_t>(N * 4);
+    double *d_t = c.take<double>(t ? N * 8 : 0);
+    uint8_t *d_ex = c.take<uint8_t>(exiting ? N : 0);
+    int32_t *d_tri = c.take<int32_t>(tri ? N * 4 : 0);
+    float *d_uvw = c.take<float>(uvw ? N * 12 : 0);
+    double *d_geom = c.take<double>(geom ? N * 96 : 0);
+    HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    rc = rsx_hit_batch_dev(scene, n, d_o, d_d, d_m, d_prim, d_t, d_ex, d_tri, d_uvw, d_geom);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpyAsync(prim, d_prim, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (t) HIP_TRY(hipMemcpyAsync(t, d_t, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (exiting) HIP_TRY(hipMemcpyAsync(exiting, d_ex, N, hipMemcpyDeviceToHost, ctx->stream));
+    if (tri) HIP_TRY(hipMemcpyAsync(tri, d_tri, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw, N * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (geom) HIP_TRY(hipMemcpyAsync(geom, d_geom, N * 96, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }
@@ -2501,38 +2518,39 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t N = (size_t)n, R = (size_t)max_roots;
-    Scratch d_o, d_d, d_m, d_c, d_t, d_ex, d_g, d_tri, d_uvw;
-    int rc;
-    if ((rc = d_o.alloc(N * 24)) || (rc = d_d.alloc(N * 24)) || (rc = d_m.alloc(N * 8)) || (rc = d_c.alloc(N * 4)) ||
-        (rc = d_t.alloc(N * R * 8)) || (rc = d_ex.alloc(N * R))) return rc;
-    if (geometry && (rc = d_g.alloc(N * R * 96))) return rc;
-    if (triangle && (rc = d_tri.alloc(N * R * 4))) return rc;
-    if (uvw && (rc = d_uvw.alloc(N * R * 12))) return rc;
-    if (geometry) HIP_TRY(hipMemsetAsync(d_g.p, 0, N * R * 96, ctx->stream));
-    if (triangle) HIP_TRY(hipMemsetAsync(d_tri.p, 0xff, N * R * 4, ctx->stream));
-    if (uvw) HIP_TRY(hipMemsetAsync(d_uvw.p, 0, N * R * 12, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_o.p, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_d.p, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_m.p, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_t.p, 0, N * R * 8, ctx->stream));
-    HIP_TRY(hipMemsetAsync(d_ex.p, 0, N * R, ctx->stream));
+    Carver c;
+    int rc = query_workspace(ctx, {N * 24, N * 24, N * 8, N * 4, N * R * 8, N * R, geometry ? N * R * 96 : 0, triangle ? N * R * 4 : 0, uvw ? N * R * 12 : 0}, c);
+    if (rc) return rc;
+    double *d_o = c.take<double>(N * 24), *d_d = c.take<double>(N * 24), *d_m = c.take<double>(N * 8);
+    int32_t *d_c = c.take<int32_t>(N * 4);
+    double *d_t = c.take<double>(N * R * 8);
+    uint8_t *d_ex = c.take<uint8_t>(N * R);
+    double *d_g = c.take<double>(geometry ? N * R * 96 : 0);
+    int32_t *d_tri = c.take<int32_t>(triangle ? N * R * 4 : 0);
+    float *d_uvw = c.take<float>(uvw ? N * R * 12 : 0);
+    if (d_g) HIP_TRY(hipMemsetAsync(d_g, 0, N * R * 96, ctx->stream));
+    if (d_tri) HIP_TRY(hipMemsetAsync(d_tri, 0xff, N * R * 4, ctx->stream));
+    if (d_uvw) HIP_TRY(hipMemsetAsync(d_uvw, 0, N * R * 12, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_t, 0, N * R * 8, ctx->stream));
+    HIP_TRY(hipMemsetAsync(d_ex, 0, N * R, ctx->stream));
     Launch l;
     if ((rc = plan(scene, n, ctx->main, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_roots<true>) : reinterpret_cast<const void *>(k_roots<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx->main))) return rc;
-    if (scene->has_csg) hipLaunchKernelGGL(k_roots<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(),
-                       geometry ? d_g.as<double>() : nullptr, triangle ? d_tri.as<int32_t>() : nullptr, uvw ? d_uvw.as<float>() : nullptr, ctx->main.ticket);
-    else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o.as<double>(),
-                       d_d.as<double>(), d_m.as<double>(), max_roots, d_c.as<int32_t>(), d_t.as<double>(), d_ex.as<uint8_t>(),
-                       geometry ? d_g.as<double>() : nullptr, triangle ? d_tri.as<int32_t>() : nullptr, uvw ? d_uvw.as<float>() : nullptr, ctx->main.ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_roots<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o, d_d, d_m,
+                                           max_roots, d_c, d_t, d_ex, d_g, d_tri, d_uvw, ctx->main.ticket);
+    else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o, d_d, d_m,
+                            max_roots, d_c, d_t, d_ex, d_g, d_tri, d_uvw, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(counts, d_c.p, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(t, d_t.p, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(exiting, d_ex.p, N * R, hipMemcpyDeviceToHost, ctx->stream));
-    if (geometry) HIP_TRY(hipMemcpyAsync(geometry, d_g.p, N * R * 96, hipMemcpyDeviceToHost, ctx->stream));
-    if (triangle) HIP_TRY(hipMemcpyAsync(triangle, d_tri.p, N * R * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw.p, N * R * 12, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(counts, d_c, N * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(t, d_t, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(exiting, d_ex, N * R, hipMemcpyDeviceToHost, ctx->stream));
+    if (geometry) HIP_TRY(hipMemcpyAsync(geometry, d_g, N * R * 96, hipMemcpyDeviceToHost, ctx->stream));
+    if (triangle) HIP_TRY(hipMemcpyAsync(triangle, d_tri, N * R * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw, N * R * 12, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }
@@ -2543,18 +2561,20 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
     rsx_ctx *ctx = scene->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t N = (size_t)n, W = (size_t)std::max(1, scene->d.n_world);
-    Scratch d_p, d_in;
-    int rc;
-    if ((rc = d_p.alloc(N * 24)) || (rc = d_in.alloc(N * W))) return rc;
-    HIP_TRY(hipMemcpyAsync(d_p.p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    Carver c;
+    int rc = query_workspace(ctx, {N * 24, N * W}, c);
+    if (rc) return rc;
+    double *d_p = c.take<double>(N * 24);
+    uint8_t *d_in = c.take<uint8_t>(N * W);
+    HIP_TRY(hipMemcpyAsync(d_p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
     Launch l;
     if ((rc = plan(scene, n, ctx->main, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_contains<true>) : reinterpret_cast<const void *>(k_contains<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if ((rc = reset_ticket(ctx->main))) return rc;
-    if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->main.ticket);
-    else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p.as<double>(), d_in.as<uint8_t>(), ctx->main.ticket);
+    if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p, d_in, ctx->main.ticket);
+    else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p, d_in, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(inside, d_in.p, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(inside, d_in, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }
