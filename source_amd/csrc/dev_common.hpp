@@ -1,0 +1,297 @@
+// dev_common.hpp — part of librsx's single device translation unit (included by rsx_device.hip, in order).
+// Scene structs, ray / hit records, traversal stack, box and KD-step primitives shared by every device routine.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// device-resident scene
+// ---------------------------------------------------------------------------------------------------
+struct DMesh {
+    const rsx_kdnode *nodes;
+    const int32_t *items;
+    const float4 *tris;        // 3 x float4 per triangle: v1.xyz v2.x | v2.yz v3.xy | v3.z fn.xyz
+    const float4 *leaf;        // 4 x float4 per LEAF ITEM, in items[] order: the 3 above + (triangle id, -, -, -): one 64-byte line per
+                               // test, no id->record indirection, big leaves stream as contiguous memory
+    const float *vnormals;     // [nn,3] or null
+    const int32_t *nidx;       // [nt,3] vertex-normal indices or null
+    double lower[3], upper[3];
+    int32_t smoothing, closed, n_tris, pad;
+};
+
+struct DScene {
+    const rsx_primitive *prims;
+    const DMesh *meshes;
+    const rsx_kdnode *wnodes;
+    const int32_t *witems;
+    double wlower[3], wupper[3];
+    int32_t n_prims, n_world, n_meshes;
+    int32_t wdepth, mdepth;    // stack levels a traversal of the world tree / the deepest mesh tree can need
+    int32_t wlds, mlds;        // how many of those levels are held in LDS (the rest spill)
+    char *spill;               // per-wave global spill regions
+    const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
+};
+
+struct CsgInfo {
+    int32_t parent, slot, is_b, top;
+};
+
+struct Ray {
+    double ox, oy, oz, dx, dy, dz, maxd;
+};
+
+// candidate kept while searching; full geometry is regenerated once at the end (finalise)
+struct Hit {
+    double t;
+    int32_t prim;              // -1 = none
+    int32_t a0, a1;            // mesh: triangle, - ; box: face, axis ; cylinder: face, type
+    float u, v, w;
+    // CSG hits only: the operand leaf that produced the root, Subtract flip parity / exiting, mesh-leaf hit point
+    int32_t leaf;
+    uint32_t flags;
+    double hx, hy, hz;
+};
+
+// Per-lane traversal stack: the first `lds_levels` entries live in LDS ([level][lane], conflict free), deeper ones spill to a
+// per-wave global buffer with the same layout. 99 % of camera rays on the 69k-triangle mesh never have more than 9 far nodes
+// pending (oracle histogram), so the spill path is cold but keeps the traversal exact for any depth.
+struct Stack {
+    // Everything here is wave-uniform (lives in SGPRs); the lane's own slot is addressed as base + (level * WAVE + lane) * size
+    // at each access, so the stack costs the traversal loop no per-lane pointer registers.
+    uint32_t lds_t, lds_id;    // byte offsets in the workgroup's dynamic LDS: t[level][lane] (f64), id[level][lane] (i32)
+    char *gt, *gid;            // spill arrays with the same layout, levels >= lds_levels
+    int32_t lds_levels;
+    float4 *stage;             // per-wave LDS staging area: WAVE triangle records (3 x float4) + WAVE triangle ids
+};
+
+extern __shared__ __attribute__((aligned(16))) char smem[];
+
+__device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
+    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
+    if (sp < st.lds_levels) {
+        *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
+        *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
+    } else {
+        const int g = slot - st.lds_levels * WAVE;
+        reinterpret_cast<double *>(st.gt)[g] = t;
+        reinterpret_cast<int32_t *>(st.gid)[g] = id;
+    }
+}
+
+__device__ __forceinline__ void stack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
+    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
+    if (sp < st.lds_levels) {
+        t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
+        id = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
+    } else {
+        const int g = slot - st.lds_levels * WAVE;
+        t = reinterpret_cast<const double *>(st.gt)[g];
+        id = reinterpret_cast<const int32_t *>(st.gid)[g];
+    }
+}
+
+__device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
+__device__ __forceinline__ float sel3f(int i, float x, float y, float z) { return i == 0 ? x : (i == 1 ? y : z); }
+
+// Point3D.transform / Vector3D.transform — core/math/point.pyx:253-284, vector.pyx:339-369
+__device__ __forceinline__ void xform_point(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
+    double w = m[12] * x + m[13] * y + m[14] * z + m[15];
+    w = 1.0 / w;
+    ox = (m[0] * x + m[1] * y + m[2] * z + m[3]) * w;
+    oy = (m[4] * x + m[5] * y + m[6] * z + m[7]) * w;
+    oz = (m[8] * x + m[9] * y + m[10] * z + m[11]) * w;
+}
+
+__device__ __forceinline__ void xform_vector(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
+    ox = m[0] * x + m[1] * y + m[2] * z;
+    oy = m[4] * x + m[5] * y + m[6] * z;
+    oz = m[8] * x + m[9] * y + m[10] * z;
+}
+
+// Scene tables (primitives, mesh descriptors) never change while a kernel runs. Read through the constant address space with a
+// wave-uniform index they come in over the scalar data path into SGPRs: no vector registers for a 4x4 matrix or a mesh descriptor.
+#define RSX_CONST_AS __attribute__((address_space(4)))
+typedef const RSX_CONST_AS rsx_primitive *UPrim;
+typedef const RSX_CONST_AS struct DMesh *UMesh;
+__device__ __forceinline__ UPrim uniform_prim(const rsx_primitive *base, int32_t idx) { return (UPrim)(unsigned long long)(base + idx); }
+
+__device__ __forceinline__ Ray to_local_uniform(UPrim p, const Ray &r) {
+    const RSX_CONST_AS double *m = p->to_local;
+    Ray l;
+    // Point3D.transform divides by the homogeneous w (point.pyx:253-284). For an affine matrix (last row 0 0 0 1 — every matrix
+    // translate/rotate produce) w is exactly 1 and x * (1.0 / 1.0) == x bit for bit, so the wave-uniform test skips a division.
+    double w = 1.0;
+    const bool affine = m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0;
+    if (!affine) { w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15]; w = 1.0 / w; }
+    l.ox = (m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3]) * w;
+    l.oy = (m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7]) * w;
+    l.oz = (m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11]) * w;
+    l.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz;
+    l.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz;
+    l.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz;
+    l.maxd = r.maxd;
+    return l;
+}
+
+__device__ __forceinline__ Ray to_local(const rsx_primitive &p, const Ray &r) {
+    Ray l;
+    xform_point(p.to_local, r.ox, r.oy, r.oz, l.ox, l.oy, l.oz);
+    xform_vector(p.to_local, r.dx, r.dy, r.dz, l.dx, l.dy, l.dz);
+    l.maxd = r.maxd;
+    return l;
+}
+
+// BoundingBox3D._slab / intersect — core/boundingbox.pyx:180-245
+__device__ __forceinline__ void slab(double o, double d, double lo, double hi, double &front, double &back) {
+    double tmin, tmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        const double rcp = 1.0 / d;
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+    }
+    if (tmin > front) front = tmin;
+    if (tmax < back) back = tmax;
+}
+
+__device__ __forceinline__ bool aabb(const double *lo, const double *hi, const Ray &r, double &front, double &back) {
+    front = -INFINITY;
+    back = INFINITY;
+    slab(r.ox, r.dx, lo[0], hi[0], front, back);
+    slab(r.oy, r.dy, lo[1], hi[1], front, back);
+    slab(r.oz, r.dz, lo[2], hi[2], front, back);
+    if (front > back) return false;
+    if (front < 0.0 && back < 0.0) return false;
+    return true;
+}
+
+// Same test with the three reciprocals 1.0/d hoisted by the caller (bit-identical: the reference recomputes the same
+// quotient for every box it tests a ray against).
+__device__ __forceinline__ void slab_rcp(double o, double d, double rcp, double lo, double hi, double &front, double &back) {
+    double tmin, tmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+    }
+    if (tmin > front) front = tmin;
+    if (tmax < back) back = tmax;
+}
+
+__device__ __forceinline__ bool aabb_rcp(const double *lo, const double *hi, const Ray &r, double rx, double ry, double rz, double &front, double &back) {
+    front = -INFINITY;
+    back = INFINITY;
+    slab_rcp(r.ox, r.dx, rx, lo[0], hi[0], front, back);
+    slab_rcp(r.oy, r.dy, ry, lo[1], hi[1], front, back);
+    slab_rcp(r.oz, r.dz, rz, lo[2], hi[2], front, back);
+    if (front > back) return false;
+    if (front < 0.0 && back < 0.0) return false;
+    return true;
+}
+
+__device__ __forceinline__ bool aabb_contains(const double *lo, const double *hi, double x, double y, double z) {
+    if (x < lo[0] || x > hi[0]) return false;
+    if (y < lo[1] || y > hi[1]) return false;
+    if (z < lo[2] || z > hi[2]) return false;
+    return true;
+}
+
+__device__ __forceinline__ rsx_kdnode load_node(const rsx_kdnode *nodes, int32_t id) {
+    const int4 raw = *reinterpret_cast<const int4 *>(nodes + id);   // one 16-B load
+    rsx_kdnode nd;
+    nd.type = raw.x;
+    nd.count = raw.y;
+    nd.u.leaf.first_item = raw.z;
+    nd.u.leaf.pad = raw.w;
+    return nd;
+}
+
+// Correctly rounded n / d with the d-only part of the division hoisted out of the traversal loop.
+// hipcc expands an IEEE f64 division into v_div_scale, v_rcp_f64, two Newton steps on the reciprocal, q0 = n*y,
+// r = fma(-d, q0, n), v_div_fmas (= fma(r, y, q0) when no scaling is in effect) and v_div_fixup. The reciprocal refinement
+// depends on d alone, and a ray divides by the same three direction components at every KD node, so it is computed once per ray
+// space (refine_rcp) and the per-node work shrinks to mul + 2 fma. The shortcut is taken only when neither operand is anywhere
+// near the exponent ranges where v_div_scale / v_div_fixup intervene; otherwise the plain division runs. tests/test_gpu_parity.py
+// (test_exact_division) checks bit equality against `/` on the device over 2^28 operand pairs including exact and near-tie cases.
+#ifndef RSX_FAST_DIV
+#define RSX_FAST_DIV 1
+#endif
+
+__device__ __forceinline__ double refine_rcp(double d) {
+    const double r = __builtin_amdgcn_rcp(d);
+    const double f0 = __builtin_fma(-d, r, 1.0);
+    const double y1 = __builtin_fma(r, f0, r);
+    const double f2 = __builtin_fma(-d, y1, 1.0);
+    return __builtin_fma(y1, f2, y1);
+}
+
+__device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in [2^-300, 2^300] (false for NaN): two compares
+    const double a = __builtin_fabs(x);
+    return a >= 0x1p-300 && a <= 0x1p+300;
+}
+
+__device__ __forceinline__ double exact_div(double n, double d, double y, bool d_safe) {
+#if RSX_FAST_DIV
+    if (d_safe && div_operand_safe(n)) {
+        const double q0 = n * y;
+        const double r = __builtin_fma(-d, q0, n);
+        return __builtin_fma(r, y, q0);
+    }
+    if (d_safe && n == 0.0) return n * y;          // signed zero with the quotient's sign (the correction step would lose it)
+#endif
+    return n / d;
+}
+
+struct AxisDiv {               // per ray space: refined reciprocals of the three direction components
+    double yx, yy, yz;
+    int safe;                  // bit k: component k may take the shortcut
+};
+
+__device__ __forceinline__ AxisDiv axis_div(const Ray &r) {
+    AxisDiv a;
+    a.yx = refine_rcp(r.dx); a.yy = refine_rcp(r.dy); a.yz = refine_rcp(r.dz);
+    a.safe = (div_operand_safe(r.dx) ? 1 : 0) | (div_operand_safe(r.dy) ? 2 : 0) | (div_operand_safe(r.dz) ? 4 : 0);
+    return a;
+}
+
+// One KD branch step — KDTree3DCore._trace_branch, core/math/spatial/kdtree3d.pyx:626-700.
+// Returns the next node; pushes (far, tmax) when both children are crossed.
+__device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t node, double o, double d, double y, bool d_safe, double tmin,
+                                               double &tmax, const Stack &st, int32_t &sp) {
+    const double split = nd.u.split;
+    const int32_t lower = node + 1, upper = nd.count;
+    if (d == 0) return o < split ? lower : upper;
+    const double plane = exact_div(split - o, d, y, d_safe);
+    const bool below = o < split || (o == split && d < 0);
+    const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
+    if (plane > tmax || plane <= 0) return near_id;
+    if (plane < tmin) return far_id;
+    stack_push(st, sp, far_id, tmax);
+    ++sp;
+    tmax = plane;
+    return near_id;
+}
+
+// Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
+// pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
+__device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
+                                              const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
+    rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
+    while (nd.type >= 0) {
+        UTIL_COUNT(util, 4)
+        const int axis = nd.type;
+        const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
+                                         (ad.safe >> axis) & 1, tmin, tmax, st, sp);
+        if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
+        nx = load_node(nodes, next + 1);
+        node = next;
+    }
+    return nd;
+}
+

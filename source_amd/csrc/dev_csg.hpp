@@ -1,0 +1,277 @@
+// dev_csg.hpp — part of librsx's single device translation unit (included by rsx_device.hip, in order).
+// CSG: lazy two-stream merge of operand roots (csg.pyx).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// CSG — raysect/primitive/csg.pyx:132-234 (hit / next_intersection / _identify_intersection / _closest_intersection),
+//       :326-348 Union, :421-446 Intersect, :523-568 Subtract (+_modify_intersection)
+//
+// The reference merges two lazily evaluated, ordered root streams per CSG node and keeps the stream heads cached on the
+// node object. Here the same state machine runs per lane with the per-node state in private (scratch) memory, and the
+// recursion over nested CSG nodes is unrolled by a depth template (CSG_MAX_DEPTH nested levels below the top node; deeper
+// trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
+// ---------------------------------------------------------------------------------------------------
+#define CSG_MAX_SLOTS 16
+#define CSG_MAX_DEPTH 4
+#define F_VALID 1u
+#define F_EXIT 2u
+#define F_FLIP 4u
+
+struct Rec {                       // one root of a stream
+    double t, hx, hy, hz;          // distance along the (shared) ray parameter; mesh leaves: hit point in leaf space
+    int32_t leaf, a0, a1;
+    uint32_t flags;
+    float u, v, w, pad;
+};
+
+struct NodeSt {
+    Rec a, b;                      // CSG node: cached stream heads (_cache_intersection_a/_b)
+    double maxd;                   // CSG node: max_distance of the ray hit() was called with
+    int32_t last_is_a, invalid;    // _cache_last_intersection is a / _cache_invalid
+    int32_t tested;                // BoundPrimitive._primitive_tested
+    int32_t further;               // analytic leaf: cached second root
+    double next_t;
+    int32_t next_a0, next_a1;
+    uint32_t next_flags;
+    int32_t seek;                  // mesh leaf: _seek_next_intersection
+    double nox, noy, noz, ndx, ndy, ndz, nmaxd, acc;   // mesh leaf: _next_local_ray, _ray_distance
+};
+
+struct CsgEval {
+    const DScene *sc;
+    NodeSt *st;
+    Stack mesh_stack;
+};
+
+__device__ __forceinline__ bool is_csg(int type) { return type == RSX_PRIM_UNION || type == RSX_PRIM_INTERSECT || type == RSX_PRIM_SUBTRACT; }
+
+// Mesh.hit / next_intersection as a stream (mesh.pyx:1178-1275)
+__device__ __noinline__ void mesh_stream_step(CsgEval &e, int32_t idx, NodeSt &st, const Ray &l, Rec &out) {
+    const DMesh &m = e.sc->meshes[e.sc->prims[idx].mesh];
+    MeshHit mh;
+    out.flags = 0;
+    if (!mesh_trace(m, l, e.mesh_stack, mh)) { st.seek = 0; return; }
+    Geom g;
+    mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
+    out.t = (double)mh.t + st.acc;
+    out.hx = g.hit[0]; out.hy = g.hit[1]; out.hz = g.hit[2];
+    out.leaf = idx; out.a0 = mh.tri; out.a1 = 0; out.u = mh.u; out.v = mh.v; out.w = mh.w;
+    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    st.seek = 1;
+    st.nox = g.hit[0] + l.dx * MESH_EPS; st.noy = g.hit[1] + l.dy * MESH_EPS; st.noz = g.hit[2] + l.dz * MESH_EPS;
+    st.ndx = l.dx; st.ndy = l.dy; st.ndz = l.dz;
+    st.nmaxd = l.maxd - (double)mh.t - MESH_EPS;
+    st.acc = out.t + MESH_EPS;
+}
+
+__device__ __noinline__ void leaf_first(CsgEval &e, int32_t idx, NodeSt &st, const Ray &pr, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    const Ray l = to_local(p, pr);
+    out.flags = 0;
+    st.further = 0;
+    st.seek = 0;
+    if (p.type == RSX_PRIM_MESH) { st.acc = 0; mesh_stream_step(e, idx, st, l, out); return; }
+    Roots roots;
+    roots.n = 0;
+    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
+    if (roots.n == 0) return;
+    Geom g;
+    analytic_geom(p, l, roots.t[0], roots.a0[0], roots.a1[0], g);
+    out.t = roots.t[0]; out.leaf = idx; out.a0 = roots.a0[0]; out.a1 = roots.a1[0]; out.u = out.v = out.w = 0.0f;
+    out.hx = out.hy = out.hz = 0.0;
+    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    if (roots.n == 2) {
+        analytic_geom(p, l, roots.t[1], roots.a0[1], roots.a1[1], g);
+        st.further = 1; st.next_t = roots.t[1]; st.next_a0 = roots.a0[1]; st.next_a1 = roots.a1[1];
+        st.next_flags = F_VALID | (g.exiting ? F_EXIT : 0u);
+    }
+}
+
+__device__ __noinline__ void leaf_next(CsgEval &e, int32_t idx, NodeSt &st, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    out.flags = 0;
+    if (p.type == RSX_PRIM_MESH) {
+        if (!st.seek) return;
+        Ray l;
+        l.ox = st.nox; l.oy = st.noy; l.oz = st.noz; l.dx = st.ndx; l.dy = st.ndy; l.dz = st.ndz; l.maxd = st.nmaxd;
+        mesh_stream_step(e, idx, st, l, out);
+        return;
+    }
+    if (!st.further) return;
+    st.further = 0;
+    out.t = st.next_t; out.leaf = idx; out.a0 = st.next_a0; out.a1 = st.next_a1; out.u = out.v = out.w = 0.0f;
+    out.hx = out.hy = out.hz = 0.0;
+    out.flags = st.next_flags;
+}
+
+// operator truth tables on (inside_a, inside_b, which stream supplied the closest root)
+__device__ __forceinline__ bool csg_valid(int type, const Rec &a, const Rec &b, bool closest_is_a) {
+    const bool ia = (a.flags & F_VALID) && (a.flags & F_EXIT), ib = (b.flags & F_VALID) && (b.flags & F_EXIT);
+    if (type == RSX_PRIM_UNION) return (!ia && !ib) || (ia && !ib && closest_is_a) || (!ia && ib && !closest_is_a);
+    if (type == RSX_PRIM_INTERSECT) return (ia && ib) || (ia && !ib && !closest_is_a) || (!ia && ib && closest_is_a);
+    return (!ia && !ib && closest_is_a) || (ia && !ib) || (ia && ib && !closest_is_a);
+}
+
+// _closest_intersection: 1 = a, 0 = b, -1 = none (a wins only when strictly closer)
+__device__ __forceinline__ int csg_closest(const Rec &a, const Rec &b) {
+    if (!(a.flags & F_VALID)) return (b.flags & F_VALID) ? 0 : -1;
+    if (!(b.flags & F_VALID) || a.t < b.t) return 1;
+    return 0;
+}
+
+template <int D> __device__ void node_next(CsgEval &e, int32_t idx, Rec &out);
+
+template <int D>
+__device__ void csg_identify(CsgEval &e, int32_t idx, NodeSt &st, Rec &a, Rec &b, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    out.flags = 0;
+    int closest = csg_closest(a, b);
+    while (closest >= 0) {
+        const Rec &c = closest ? a : b;
+        if (csg_valid(p.type, a, b, closest != 0)) {
+            if (c.t <= st.maxd) {
+                st.a = a; st.b = b; st.last_is_a = closest; st.invalid = 0;
+                out = c;
+                if (p.type == RSX_PRIM_SUBTRACT && !closest) out.flags ^= (F_EXIT | F_FLIP);   // _modify_intersection
+            }
+            return;
+        }
+        if (closest) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
+        closest = csg_closest(a, b);
+    }
+}
+
+template <int D> __device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out);
+
+template <int D>
+__device__ void csg_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {                     // CSGPrimitive.hit
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    st.invalid = 1;
+    st.maxd = pr.maxd;
+    Ray l = to_local(p, pr);
+    l.maxd = INFINITY;
+    Rec a, b;
+    node_first<D>(e, p.child_a, l, a);
+    if (p.type != RSX_PRIM_UNION && !(a.flags & F_VALID)) return;                                  // terminate_early
+    node_first<D>(e, p.child_b, l, b);
+    csg_identify<D>(e, idx, st, a, b, out);
+}
+
+template <int D>
+__device__ void csg_next(CsgEval &e, int32_t idx, Rec &out) {                                      // CSGPrimitive.next_intersection
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    if (st.invalid) return;
+    Rec a = st.a, b = st.b;
+    if (st.last_is_a) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
+    csg_identify<D>(e, idx, st, a, b, out);
+}
+
+// BoundPrimitive.hit / next_intersection over an operand (boundprimitive.pyx:42-60)
+template <int D>
+__device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    double f, b;
+    out.flags = 0;
+    if (!aabb(p.box_lower, p.box_upper, pr, f, b)) { st.tested = 0; return; }
+    st.tested = 1;
+    if (is_csg(p.type)) {
+        if constexpr (D > 0) csg_first<D - 1>(e, idx, pr, out);
+    } else if (p.type != RSX_PRIM_NULL) {
+        leaf_first(e, idx, st, pr, out);
+    }
+}
+
+template <int D>
+__device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
+    const rsx_primitive &p = e.sc->prims[idx];
+    NodeSt &st = e.st[e.sc->csg[idx].slot];
+    out.flags = 0;
+    if (!st.tested) return;
+    if (is_csg(p.type)) {
+        if constexpr (D > 0) csg_next<D - 1>(e, idx, out);
+    } else if (p.type != RSX_PRIM_NULL) {
+        leaf_next(e, idx, st, out);
+    }
+}
+
+// contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
+__device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
+    double qx, qy, qz;
+    xform_point(p.to_local, px, py, pz, qx, qy, qz);
+    if (p.type == RSX_PRIM_SPHERE) return (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
+    if (p.type == RSX_PRIM_BOX) return aabb_contains(p.params, p.params + 3, qx, qy, qz);
+    if (p.type == RSX_PRIM_CYLINDER) return (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
+    if (p.type == RSX_PRIM_MESH) {
+        const DMesh &m = sc.meshes[p.mesh];
+        if (!m.closed) return false;
+        Ray zr;
+        zr.ox = qx; zr.oy = qy; zr.oz = qz; zr.dx = 0; zr.dy = 0; zr.dz = 1; zr.maxd = INFINITY;
+        MeshHit mh;
+        if (mesh_trace(m, zr, mesh_stack, mh)) return m.tris[3 * (size_t)mh.tri + 2].w > 0.0f;
+    }
+    return false;
+}
+
+template <int D>
+__device__ bool node_contains(const DScene &sc, int32_t idx, double px, double py, double pz, Stack mesh_stack) {
+    const rsx_primitive &p = sc.prims[idx];
+    if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) return false;
+    if (!is_csg(p.type)) return leaf_contains(sc, p, px, py, pz, mesh_stack);
+    if constexpr (D > 0) {
+        double qx, qy, qz;
+        xform_point(p.to_local, px, py, pz, qx, qy, qz);
+        const bool a = node_contains<D - 1>(sc, p.child_a, qx, qy, qz, mesh_stack);
+        if (p.type == RSX_PRIM_UNION) return a || node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+        if (p.type == RSX_PRIM_INTERSECT) return a && node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+        return a && !node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+    }
+    return false;
+}
+
+// Rebuild the Intersection a CSG node returns for a root: leaf geometry in the leaf's space, lifted operand by operand into
+// the top node's space (csg.pyx:198-208), Subtract's swap/negate applied by parity (it commutes with the affine lifts).
+__device__ void csg_geom(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
+    int32_t chain[CSG_MAX_DEPTH + 3];
+    int n = 0;
+    for (int32_t i = h.leaf; i != h.prim && n < CSG_MAX_DEPTH + 2; i = sc.csg[i].parent) chain[n++] = i;
+    Ray l = to_local(sc.prims[h.prim], r);
+    for (int k = n - 1; k >= 0; --k) l = to_local(sc.prims[chain[k]], l);
+    const rsx_primitive &leaf = sc.prims[h.leaf];
+    if (leaf.type == RSX_PRIM_MESH) {
+        const DMesh &m = sc.meshes[leaf.mesh];
+        Ray at = l;                                     // mesh_geom recomputes hit = o + d*t; feed the stored hit point instead
+        at.ox = h.hx; at.oy = h.hy; at.oz = h.hz;
+        mesh_geom(m, at, 0.0, h.a0, h.u, h.v, h.w, g);
+        g.hit[0] = h.hx; g.hit[1] = h.hy; g.hit[2] = h.hz;
+        const float4 q2 = m.tris[3 * (size_t)h.a0 + 2];
+        const double fx = (double)q2.y, fy = (double)q2.z, fz = (double)q2.w;
+        g.inside[0] = h.hx - fx * MESH_EPS; g.inside[1] = h.hy - fy * MESH_EPS; g.inside[2] = h.hz - fz * MESH_EPS;
+        g.outside[0] = h.hx + fx * MESH_EPS; g.outside[1] = h.hy + fy * MESH_EPS; g.outside[2] = h.hz + fz * MESH_EPS;
+    } else {
+        analytic_geom(leaf, l, h.t, h.a0, h.a1, g);
+    }
+    for (int k = 0; k < n; ++k) {
+        const rsx_primitive &c = sc.prims[chain[k]];
+        double x, y, z;
+        xform_point(c.to_root, g.hit[0], g.hit[1], g.hit[2], x, y, z); g.hit[0] = x; g.hit[1] = y; g.hit[2] = z;
+        xform_point(c.to_root, g.inside[0], g.inside[1], g.inside[2], x, y, z); g.inside[0] = x; g.inside[1] = y; g.inside[2] = z;
+        xform_point(c.to_root, g.outside[0], g.outside[1], g.outside[2], x, y, z); g.outside[0] = x; g.outside[1] = y; g.outside[2] = z;
+        const double *mi = c.to_local;                  // Normal3D.transform(to_root) = multiply by inverse transpose
+        x = mi[0] * g.normal[0] + mi[4] * g.normal[1] + mi[8] * g.normal[2];
+        y = mi[1] * g.normal[0] + mi[5] * g.normal[1] + mi[9] * g.normal[2];
+        z = mi[2] * g.normal[0] + mi[6] * g.normal[1] + mi[10] * g.normal[2];
+        g.normal[0] = x; g.normal[1] = y; g.normal[2] = z;
+    }
+    if (h.flags & F_FLIP) {
+        for (int k = 0; k < 3; ++k) { const double tmp = g.inside[k]; g.inside[k] = g.outside[k]; g.outside[k] = tmp; g.normal[k] = -g.normal[k]; }
+    }
+    g.exiting = (h.flags & F_EXIT) != 0;
+}
+

@@ -1,0 +1,309 @@
+// dev_mesh.hpp — part of librsx's single device translation unit (included by rsx_device.hip, in order).
+// Mesh: watertight triangle test, per-lane and wave-cooperative KD traversal (mesh.pyx).
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// Mesh — raysect/primitive/mesh/mesh.pyx:506-713 (MeshData.trace / _trace_leaf / _hit_triangle)
+// ---------------------------------------------------------------------------------------------------
+struct MeshHit {
+    float u, v, w, t;
+    int32_t tri;
+};
+
+// ray-space constants of the watertight test — _calc_rayspace_transform, mesh.pyx:566-610
+struct TriRay {
+    double ox, oy, oz, maxd;
+    float sx, sy, sz;
+    int ix, iy, iz;
+};
+
+__device__ __forceinline__ TriRay tri_ray(const Ray &r) {
+    TriRay q;
+    int ix, iy, iz;
+    const double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
+    if (ax > ay && ax > az) { ix = 1; iy = 2; iz = 0; }
+    else if (ay > ax && ay > az) { ix = 2; iy = 0; iz = 1; }
+    else { ix = 0; iy = 1; iz = 2; }
+    const float rdz = (float)sel3(iz, r.dx, r.dy, r.dz);
+    if (rdz < 0.0f) { const int tmp = ix; ix = iy; iy = tmp; }
+    q.sz = (float)(1.0 / (double)rdz);
+    q.sx = (float)(sel3(ix, r.dx, r.dy, r.dz) * (double)q.sz);
+    q.sy = (float)(sel3(iy, r.dx, r.dy, r.dz) * (double)q.sz);
+    q.ix = ix; q.iy = iy; q.iz = iz;
+    q.ox = r.ox; q.oy = r.oy; q.oz = r.oz; q.maxd = r.maxd;
+    return q;
+}
+
+// _hit_triangle, mesh.pyx:616-713 on one 48-byte triangle record. Returns true with normalised (t,u,v,w) on a hit.
+__device__ __forceinline__ bool tri_test(const TriRay &q, const float4 q0, const float4 q1, const float4 q2, float &ht, float &hu, float &hv, float &hw) {
+    // f32 vertex minus f64 origin, rounded to f32
+    const float v1x = (float)((double)q0.x - q.ox), v1y = (float)((double)q0.y - q.oy), v1z = (float)((double)q0.z - q.oz);
+    const float v2x = (float)((double)q0.w - q.ox), v2y = (float)((double)q1.x - q.oy), v2z = (float)((double)q1.y - q.oz);
+    const float v3x = (float)((double)q1.z - q.ox), v3y = (float)((double)q1.w - q.oy), v3z = (float)((double)q2.x - q.oz);
+    const float a1 = sel3f(q.ix, v1x, v1y, v1z), b1 = sel3f(q.iy, v1x, v1y, v1z), c1 = sel3f(q.iz, v1x, v1y, v1z);
+    const float a2 = sel3f(q.ix, v2x, v2y, v2z), b2 = sel3f(q.iy, v2x, v2y, v2z), c2 = sel3f(q.iz, v2x, v2y, v2z);
+    const float a3 = sel3f(q.ix, v3x, v3y, v3z), b3 = sel3f(q.iy, v3x, v3y, v3z), c3 = sel3f(q.iz, v3x, v3y, v3z);
+    const float x1 = a1 - q.sx * c1, x2 = a2 - q.sx * c2, x3 = a3 - q.sx * c3;
+    const float y1 = b1 - q.sy * c1, y2 = b2 - q.sy * c2, y3 = b3 - q.sy * c3;
+    float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
+    if (u == 0.0f || v == 0.0f || w == 0.0f) {
+        u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
+        v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
+        w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+    }
+    if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) return false;
+    const float det = u + v + w;
+    if (det == 0.0f) return false;
+    const float z1 = q.sz * c1, z2 = q.sz * c2, z3 = q.sz * c3;
+    const float t = u * z1 + v * z2 + w * z3;
+    if (det > 0.0f) { if (t < 0.0f || (double)t > q.maxd * (double)det) return false; }
+    else            { if (t > 0.0f || (double)t < q.maxd * (double)det) return false; }
+    const float rdet = (float)(1.0 / (double)det);
+    ht = t * rdet; hu = u * rdet; hv = v * rdet; hw = w * rdet;
+    return true;
+}
+
+#ifndef RSX_LEAF_INLINE
+#define RSX_LEAF_INLINE 1          // 1: leaves read 64-byte leaf-ordered triangle records; 0: items[] -> 48-byte records by id
+#endif
+
+// fetch leaf item `pos` (absolute position in items[]): its triangle id and 48-byte record
+__device__ __forceinline__ void leaf_fetch(const int32_t *items, const float4 *tris, const float4 *leaf, int32_t pos, int32_t &tri, float4 &a,
+                                           float4 &b, float4 &c) {
+#if RSX_LEAF_INLINE
+    const float4 *rec = leaf + 4 * (size_t)pos;
+    a = rec[0]; b = rec[1]; c = rec[2];
+    tri = __float_as_int(rec[3].x);
+#else
+    tri = items[pos];
+    const float4 *rec = tris + 3 * (size_t)tri;
+    a = rec[0]; b = rec[1]; c = rec[2];
+#endif
+}
+
+#ifndef RSX_LEAF_BATCH
+#define RSX_LEAF_BATCH 4           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
+#endif
+
+__device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
+    double tmin, tmax;
+    if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
+    const TriRay q = tri_ray(r);
+    const AxisDiv ad = axis_div(r);
+
+    int32_t node = 0, sp = 0;
+    for (;;) {
+        const rsx_kdnode nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
+        // _trace_leaf, mesh.pyx:520-563 — items are tested in leaf order, strict `<` keeps the first of equal distances
+        double distance = r.maxd < tmax ? r.maxd : tmax;
+        int32_t closest = -1;
+        float bu = 0, bv = 0, bw = 0;
+        const int32_t first = nd.u.leaf.first_item;
+        const int32_t count = nd.count;
+        for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+            int32_t tri[RSX_LEAF_BATCH];
+            float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                leaf_fetch(m.items, m.tris, m.leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
+#pragma unroll
+            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                float ht, hu, hv, hw;
+                if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
+                    distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
+                }
+            }
+        }
+        if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; return true; }
+        if (sp == 0) return false;
+        --sp;
+        tmin = tmax;                    // far range starts where the exhausted near range ended
+        stack_pop(st, sp, node, tmax);
+    }
+}
+
+#ifndef RSX_STAGE_MIN
+#define RSX_STAGE_MIN 4            // >= this many rays of the wave in the same big leaf: stage the leaf through LDS instead
+#endif
+#ifndef RSX_PHASE_PROF
+#define RSX_PHASE_PROF 0           // 1: accumulate per-phase s_memtime cycles of the wave-cooperative mesh traversal (tuning builds only)
+#endif
+#if RSX_PHASE_PROF
+__device__ unsigned long long g_phase[8][64];   // unused placeholder to keep the symbol set stable
+#define PHASE_DECL unsigned long long ph_t = clock64();
+#define PHASE_ADD(slot) { const unsigned long long now_ = clock64(); phase_acc[slot] += now_ - ph_t; ph_t = now_; }
+#else
+#define PHASE_DECL
+#define PHASE_ADD(slot)
+#endif
+#ifndef RSX_COOP_LEAF
+#define RSX_COOP_LEAF 24           // leaves with at least this many triangles are tested by the whole wave for one ray at a time
+#endif
+
+__device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x, lane, WAVE); }
+__device__ __forceinline__ double readlane_f64(double x, int lane) {          // lane must be wave-uniform; the result is scalar
+    const long long b = __double_as_longlong(x);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+
+// Wave-cooperative MeshData.trace: every lane of the wave calls this together on ONE mesh (`m` is wave-uniform; `want` = lane has
+// a ray for it). Lanes walk their own rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF
+// triangles (high-valence vertices produce leaves of hundreds, mesh.pyx builds them because the depth cap stops the SAH split) is
+// tested by all 64 lanes for one ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic
+// wave-min, which is exactly what the reference's sequential scan with strict `<` returns (the first item among those with the
+// smallest distance). Idle lanes — rays that already finished, or never needed this mesh — serve as helpers.
+__device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
+    const int lane = threadIdx.x % WAVE;
+    PHASE_DECL
+    const rsx_kdnode *nodes = m->nodes;                     // scalar loads: the bases sit in SGPRs, lanes supply 32-bit offsets
+    const float4 *leaf = m->leaf, *tris = m->tris;
+    const int32_t *items = m->items;
+    double tmin = 0, tmax = 0;
+    bool active;
+    const AxisDiv ad = axis_div(r);
+    {
+        // BoundingBox3D.intersect (kdtree3d.pyx:589-607) needs 1.0 / d per axis: formed from the refined reciprocals that the
+        // branch steps use anyway (exact_div(1, d) is the correctly rounded quotient), not by three more full divisions
+        const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
+        const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
+                     rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
+        active = want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax);
+    }
+    const TriRay q = tri_ray(r);
+    bool hit = false;
+    int32_t node = 0, sp = 0;
+    while (__any(active)) {
+        double distance = 0;
+        int32_t closest = -1, count = 0, first = 0;
+        float bu = 0, bv = 0, bw = 0;
+        work += 8;                                   // one descend + small-leaf round of the wave (scheduling weight, see k_order_units)
+        PHASE_ADD(0)
+        rsx_kdnode nd;
+        nd.count = 0; nd.u.leaf.first_item = 0;
+        if (active) { UTIL_COUNT(phase_acc, 2) }
+        if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
+        PHASE_ADD(1)
+        if (active) {
+            distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
+            count = nd.count;
+            first = nd.u.leaf.first_item;
+            if (count < RSX_COOP_LEAF) {
+                for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+                    UTIL_COUNT(phase_acc, 6)
+                    int32_t tri[RSX_LEAF_BATCH];
+                    float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+#pragma unroll
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                        leaf_fetch(items, tris, leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
+#pragma unroll
+                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                        float ht, hu, hv, hw;
+                        if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
+                            distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
+                        }
+                    }
+                }
+            }
+        }
+        PHASE_ADD(2)
+        // ---- cooperative stage for big leaves
+        unsigned long long big = __ballot(active && count >= RSX_COOP_LEAF);
+#if RSX_PHASE_PROF
+        phase_acc[5] += 1; phase_acc[6] += __popcll(big); phase_acc[7] += __popcll(__ballot(active));
+#endif
+        while (big) {
+            const int leader = __ffsll((long long)big) - 1;
+            const int32_t lcount = __builtin_amdgcn_readlane(count, leader), lfirst = __builtin_amdgcn_readlane(first, leader);
+            // lanes whose ray sits in the same leaf as the leader's
+            const bool same = active && count >= RSX_COOP_LEAF && first == lfirst;
+            const unsigned long long group = __ballot(same);
+            big &= ~group;
+            if (__popcll(group) >= RSX_STAGE_MIN) {
+                // (a) coherent rays: stage the leaf through LDS 64 triangles at a time; every lane of the group tests them all,
+                //     in leaf order (the reference's own loop), reading each record as an LDS broadcast
+                float4 *rec = st.stage;
+                int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
+                work += 2 + (uint32_t)lcount / 8;
+                for (int32_t c = 0; c < lcount; c += WAVE) {
+                    __builtin_amdgcn_wave_barrier();
+                    const int32_t k = c + lane;
+                    if (k < lcount) {
+                        int32_t tri;
+                        float4 a, b, cc;
+                        leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, cc);
+                        rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
+                        ids[lane] = tri;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (same) {
+                        const int32_t nj = lcount - c < WAVE ? lcount - c : WAVE;
+                        for (int32_t j = 0; j < nj; ++j) {
+                            float ht, hu, hv, hw;
+                            if (tri_test(q, rec[3 * j], rec[3 * j + 1], rec[3 * j + 2], ht, hu, hv, hw) && (double)ht < distance) {
+                                distance = (double)ht; closest = ids[j]; bu = hu; bv = hv; bw = hw;
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
+            // (b) isolated rays: one ray at a time, all 64 lanes testing 64 triangles per step
+            unsigned long long todo = group;
+            while (todo) {
+                const int owner = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                work += 2 + (uint32_t)lcount / 32;
+                // the owner's ray constants are read into scalar registers (owner is wave-uniform): no per-lane copy of the ray
+                TriRay lq;
+                lq.ox = readlane_f64(q.ox, owner); lq.oy = readlane_f64(q.oy, owner); lq.oz = readlane_f64(q.oz, owner);
+                lq.maxd = readlane_f64(q.maxd, owner);
+                lq.sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sx), owner));
+                lq.sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sy), owner));
+                lq.sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sz), owner));
+                const int axes = __builtin_amdgcn_readlane(q.ix | (q.iy << 2) | (q.iz << 4), owner);
+                lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
+                const double limit = readlane_f64(distance, owner);
+                // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
+                float mt = INFINITY, mu = 0, mv = 0, mw = 0;
+                int32_t mk = 0x7fffffff, mtri = -1;
+                for (int32_t k = lane; k < lcount; k += WAVE) {
+                    int32_t tri;
+                    float4 a, b, c;
+                    leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, c);
+                    float ht, hu, hv, hw;
+                    if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
+                }
+                // wave-wide lexicographic min of (t, position) == the reference's sequential scan with strict `<`
+                float wt = mt;
+                int32_t wk = mk;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    const float ot = __shfl_xor(wt, off, WAVE);
+                    const int32_t ok = __shfl_xor(wk, off, WAVE);
+                    if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
+                }
+                const int winner = wk & (WAVE - 1);              // position k was scanned by lane k % 64
+                const bool found = wk != 0x7fffffff;
+                const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
+                const int32_t rtri = __shfl(mtri, winner, WAVE);
+                if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
+            }
+        }
+        PHASE_ADD(3)
+        if (active) {
+            if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
+            else if (sp == 0) active = false;
+            else {
+                --sp;
+                tmin = tmax;
+                stack_pop(st, sp, node, tmax);
+            }
+        }
+        PHASE_ADD(4)
+    }
+    return hit;
+}
+

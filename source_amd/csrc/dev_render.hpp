@@ -1,0 +1,449 @@
+// dev_render.hpp — part of librsx's single device translation unit (included by rsx_device.hip, in order).
+// observe(): ray generation + trace + shading kernel, unit scheduling, Welford / frame-merge kernels.
+#pragma once
+
+// ---------------------------------------------------------------------------------------------------
+// observe(): sample generation + trace + shading  ->  per-sample records; then per-(pixel,bin) Welford
+// ---------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al. 2011): counter = (pixel, sample), key = seed
+__device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t sample, double &u1, double &u2) {
+    uint32_t c0 = (uint32_t)pixel, c1 = (uint32_t)(pixel >> 32), c2 = (uint32_t)sample, c3 = (uint32_t)(sample >> 32);
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    const uint64_t a = ((uint64_t)c1 << 32) | c0, b = ((uint64_t)c3 << 32) | c2;
+    u1 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
+    u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
+}
+
+// clock the unit costs are measured with (only ever compared within one lane's cost array)
+// Unit cost that steers the longest-first schedule = the wave's own count of traversal rounds (`work`): free and deterministic.
+// Reading s_memrealtime / s_memtime around every unit was measured on configs[2]: the reads serialise chip-wide (~9 ns each
+// whatever the occupancy) and doubled the kernel time of a 4.2 M-unit pass.
+#ifndef RSX_LPT_MAX_UNITS
+#define RSX_LPT_MAX_UNITS (1 << 18)   // passes with more 64-ray units than this are not re-ordered
+#endif
+struct RenderParams {
+    rsx_camera cam;
+    const rsx_material *materials;
+    const int32_t *tasks;      // device [n_tasks,2] or null
+    const double *uniforms;    // device or null
+    long long n_tasks;
+    int32_t rect[4];
+    int32_t spp, rng_mode;
+    uint64_t seed, sample_offset;
+    uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
+    const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
+    const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
+    int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
+    unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
+};
+
+// per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
+struct Sample {
+    double a, weight;
+    int32_t table, pad;
+};
+
+__device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, int &ix, int &iy) {
+    if (rp.tasks) { ix = rp.tasks[2 * k]; iy = rp.tasks[2 * k + 1]; }
+    else { const int w = rp.rect[2] - rp.rect[0]; ix = rp.rect[0] + (int)(k % w); iy = rp.rect[1] + (int)(k / w); }
+}
+
+// Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
+// 64 rays stay coherent; in task-list mode 64 consecutive tasks.
+struct UnitPixel {
+    long long k, slot;         // task index (row-major in rect mode) and sample-record slot (x-major in rect mode, like the frame)
+    int ix, iy, s;
+    bool valid;
+};
+
+__device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams *q, long long unit, int lane) {
+    UnitPixel px;
+    const int spp = q->spp;
+    px.s = (int)(unit % spp);
+    const long long chunk = unit / spp;
+    if (q->tasks) {
+        px.k = chunk * 64 + lane;
+        px.valid = px.k < q->n_tasks;
+        if (!px.valid) px.k = 0;
+        px.ix = q->tasks[2 * px.k]; px.iy = q->tasks[2 * px.k + 1];
+        px.slot = px.k;
+    } else {
+        const int w = q->rect[2] - q->rect[0], h = q->rect[3] - q->rect[1];
+        const int tiles_x = (w + 7) / 8;
+        const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
+        const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
+        px.valid = lx < w && ly < h;
+        px.ix = q->rect[0] + (px.valid ? lx : 0); px.iy = q->rect[1] + (px.valid ? ly : 0);
+        px.k = px.valid ? (long long)ly * w + lx : 0;
+        px.slot = px.valid ? (long long)lx * h + ly : 0;
+    }
+    return px;
+}
+
+template <bool CSG>
+__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
+    const int lane = threadIdx.x % WAVE;
+    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
+    // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
+    // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
+    const int my_xcd = xcc_id();
+    int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
+    for (;;) {
+        // Render parameters are re-read from the kernel-argument segment at every use site of the unit loop (the pointer is
+        // laundered through an empty asm): hoisted out of the loop, the camera matrix and friends sat in ~30 vector registers
+        // through the whole traversal, where registers decide how many waves fit a SIMD. `rp` itself is only named for its layout.
+        (void)rp;
+        // (`rp` is read where it lies in the kernel-argument segment — second argument, after `sc` — so that no private copy is made)
+        unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
+        asm volatile("" : "+s"(rp_bits));
+        const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
+        long long tk = -1;
+        while (victim < 8) {
+            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+            const long long begin = q->seg[list], end = q->seg[list + 1];
+            unsigned long long mine = 0;
+            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
+            if (got < end) { tk = got; break; }
+            ++victim;
+        }
+        if (tk < 0) break;
+        int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
+        const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
+#if RSX_PHASE_PROF
+        unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#elif RSX_UTIL_PROF
+        unsigned long long *phase_acc = q->unit_times ? q->unit_times + 12 * (long long)unit + 3 : nullptr;   // caller zeroes the buffer
+#else
+        unsigned long long *phase_acc = nullptr;
+#endif
+        const UnitPixel px = unit_pixel(q, unit, lane);
+        const bool valid = px.valid;
+        // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
+        double u1, u2;
+        if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
+        else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
+        const double delta = q->cam.image_delta, half = 0.5 * delta;
+        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
+        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
+        // the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc)
+        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+        normalise3(dx, dy, dz);
+        const double weight = dz;
+        Ray r;
+        {
+            const RSX_CONST_AS double *m = q->cam.to_root;                    // observer.pyx:403-404: origin (0,0,0) and direction to world
+            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+            wq = 1.0 / wq;
+            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
+            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
+            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
+        }
+        r.maxd = INFINITY;
+        Hit hit;
+        uint32_t work = 0;
+        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+        // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
+        // compiler cannot merge this with the computation above)
+        asm volatile("" : "+s"(unit));
+        asm volatile("" : "+s"(rp_bits));
+        const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
+        if (q2->measure_cost && lane == 0) {
+            unsigned long long c = (unsigned long long)work;
+            if (c > 0x7fffffffULL) c = 0x7fffffffULL;
+            q2->unit_cost[unit] = (uint32_t)c;
+        }
+        if (q2->unit_times && lane == 0) {
+            q2->unit_times[12 * unit] = t_start;
+            q2->unit_times[12 * unit + 1] = wall_clock64();
+            q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
+#if RSX_PHASE_PROF
+            for (int ph = 0; ph < 8; ++ph) q2->unit_times[12 * unit + 3 + ph] = phase_acc[ph];
+#endif
+        }
+        const UnitPixel px2 = unit_pixel(q2, unit, lane);
+        if (!px2.valid) continue;
+        Sample smp;
+        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
+        if (got) {                                                                 // optical/ray.pyx:391-393
+            const rsx_primitive &p = sc.prims[hit.prim];
+            const rsx_material mat = q2->materials[p.material];
+            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
+            else if (mat.type == RSX_MAT_DEBUG_LIGHT) {                      // debug.pyx:67-79
+                if (mat.scale != 0.0) {
+                    Geom g;
+                    finalise<CSG>(sc, r, hit, g);
+                    double lx, ly, lz;
+                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                    smp.a = mat.scale * (dot > 0 ? dot : 0.0);
+                    smp.table = mat.table;
+                }
+            }
+        }
+        samples[px2.slot * q2->spp + px2.s] = smp;
+    }
+}
+
+// Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.
+__global__ void k_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long *mismatches) {
+    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (unsigned long long i = gid; i < n; i += stride) {
+        double u1, u2;
+        philox2(seed, i, 0, u1, u2);
+        double a, b;
+        philox2(seed, i, 1, a, b);
+        double num, den;
+        switch (i & 7) {
+        case 0: num = (u1 - 0.5) * 4.0; den = (u2 - 0.5) * 2.0; break;                      // plane distances: (split - o) / d
+        case 1: num = ldexp(u1 - 0.5, (int)(a * 120) - 60); den = ldexp(u2 - 0.5, (int)(b * 120) - 60); break;
+        case 2: den = (u2 - 0.5) * 2.0; num = den * (double)(long long)(u1 * 4096.0 - 2048.0); break;   // exact quotients
+        case 3: den = 1.0 + u2 * 0x1p-30; num = 1.0 + u1 * 0x1p-30; break;                 // quotients hugging 1 (near ties)
+        case 4: den = (double)(1 + (long long)(u2 * 1e6)); num = (double)(long long)(u1 * 2e6 - 1e6); break;   // small integers
+        case 5: num = ldexp(u1 - 0.5, (int)(a * 1200) - 600); den = ldexp(u2 - 0.5, (int)(b * 1200) - 600); break;   // wide exponents (guard path)
+        case 6: num = (i & 8) ? 0.0 : -0.0; den = (u2 - 0.5); break;                        // zero numerators
+        default: den = u2 * 1e-3 + 1e-300 * a; num = u1 - 0.5; break;                       // tiny denominators
+        }
+        if (den == 0.0) continue;
+        const double want = num / den;
+        const double got = exact_div(num, den, refine_rcp(den), div_operand_safe(den));
+        if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
+// Longest-processing-time-first schedule for the next pass over the same units: counting sort of the measured unit costs into
+// 128 logarithmic buckets, most expensive first. A few silhouette tiles cost 50x the median (grazing rays cross hundreds of KD
+// cells); handing them out first lets the cheap bulk fill in behind them instead of leaving one wave to finish alone.
+#define ORDER_BUCKETS 128
+__device__ __forceinline__ int cost_bucket(uint32_t c) {
+    if (c == 0) return 0;
+    const int lg = 31 - __clz((int)c);                      // floor(log2 c)
+    const int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3) : 0;   // two mantissa bits -> quarter-octave resolution
+    const int b = lg * 4 + frac;
+    return b < ORDER_BUCKETS ? b : ORDER_BUCKETS - 1;
+}
+
+#ifndef RSX_HEAVY_FACTOR
+#define RSX_HEAVY_FACTOR 3ULL
+#endif
+
+// which XCD's list a unit belongs to: 4x4-tile blocks (32x32 pixels) are dealt round-robin to the 8 XCDs, so each L2 caches the
+// geometry behind an eighth of the image while every XCD still gets a fair share of cheap and expensive regions
+__device__ __forceinline__ int unit_xcd(long long unit, int tiles_x, int spp) {
+    const long long chunk = unit / spp;
+    if (tiles_x > 0) { const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x); return ((tx >> 2) + 3 * (ty >> 2)) & 7; }
+    return (int)((chunk >> 4) & 7);
+}
+
+// list 0: units well above the mean cost (latency-bound stragglers: every XCD takes them first); lists 1..8: the rest, by XCD
+__device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned long long mean, int tiles_x, int spp) {
+    if ((unsigned long long)c > RSX_HEAVY_FACTOR * mean) return 0;
+    return 1 + unit_xcd(unit, tiles_x, spp);
+}
+
+// One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
+// and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp) {
+    __shared__ unsigned int hist[9][ORDER_BUCKETS];
+    __shared__ unsigned int offset[9][ORDER_BUCKETS];
+    __shared__ unsigned long long total;
+    unsigned int *hflat = &hist[0][0];
+    for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
+    if (threadIdx.x == 0) total = 0;
+    __syncthreads();
+    unsigned long long part_sum = 0;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) part_sum += cost[i];
+    atomicAdd(&total, part_sum);
+    __syncthreads();
+    const unsigned long long mean = total / (unsigned long long)n + 1;
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        for (int x = 0; x < 9; ++x) {
+            seg[x] = run;
+            for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[x][b] = run; run += hist[x][b]; }
+        }
+        seg[9] = run;
+    }
+    __syncthreads();
+    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+        const uint32_t c = cost[i];
+        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
+    }
+}
+
+// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859.
+// Every division here is by a small positive integer whose refined reciprocal is shared by the two divisions of consecutive
+// Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
+// rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
+// (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
+struct IntRcp {
+    double d, y;
+    __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
+    __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
+};
+
+// n -> n + 1 samples; `by_n` = IntRcp(n + 1), `by_nm1` = IntRcp(n) (the divisors of the update)
+__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n, const IntRcp &by_n, const IntRcp &by_nm1) {
+    if (n == 0) { n = 1; m = x; v = 0; return; }
+    const double pm = m, pv = v;
+    const int pn = n > 1 ? n : 2;
+    n += 1;
+    m = pm + by_n.div(x - pm);
+    v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
+}
+
+__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
+    if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
+    if (nx > 1 && ny > 1) {
+        nt = nx + ny;
+        const IntRcp by_nt(nt);
+        mt = by_nt.div(nx * mx + ny * my);
+        vx = IntRcp(nx).div((nx - 1) * vx);
+        vy = IntRcp(ny).div((ny - 1) * vy);
+        vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
+        vt = IntRcp(nt - 1).div(nt * vt);
+        return;
+    }
+    if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
+    else if (nx == 1) {
+        if (ny == 0) { nt = 1; mt = mx; vt = 0; }
+        else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
+    } else if (nx > 1) {
+        nt = nx; mt = mx; vt = vx;
+        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
+    } else { nt = 0; mt = 0; vt = 0; }
+}
+
+// One thread per (task, bin): sequential Welford over the task's spp samples in sample order
+// (SpectralRadiance/PowerPixelProcessor.add_sample, pipeline/spectral/power.pyx:468-486, radiance.pyx:245-263).
+// frame == null: write per-task (mean, variance) like _render_pixel packs them; else merge into the
+// device-resident frame with the combine_samples law (Pipeline2D.update, power.pyx:424-437).
+struct AccumParams {
+    const Sample *samples;
+    const double *tables;
+    const int32_t *tasks;
+    long long n_tasks;
+    int32_t rect[4];
+    int32_t ny, bins, spp, power;
+    int32_t n_tables, pad;
+    double sensitivity;
+    double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
+    double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
+    int32_t frame_bins, slice_offset;
+    unsigned long long *ticket;         // work tickets of the trace kernel: re-armed here for the next launch
+};
+
+// Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
+// kernel wrote, so both streams are read and written as contiguous runs. Task-list mode keeps task order.
+#define ACC_RCP_TABLE_MAX 4096      // samples per pixel per pass up to which the reciprocal table is kept in LDS
+#ifndef ACC_BATCH
+#define ACC_BATCH 4                 // sample records whose loads are issued together
+#endif
+
+template <bool STAGED>                  // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form
+__global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
+    // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
+    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
+    constexpr bool staged = STAGED;                         // few samples per pixel: not worth a barrier, read the tables from global
+    const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
+    const int n_rcp = rcp_table ? ap.spp + 2 : 2;
+    double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
+    if (staged) {
+        for (int d = threadIdx.x + 1; d < n_rcp; d += blockDim.x) acc_rcp[d] = refine_rcp((double)d);
+        for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];
+        __syncthreads();
+    }
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = ap.n_tasks * ap.bins;
+    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
+    if (gid >= total) return;
+    long long p;
+    int b;
+    if (total < (1LL << 31)) { p = (uint32_t)gid / (uint32_t)ap.bins; b = (int)((uint32_t)gid % (uint32_t)ap.bins); }   // 32-bit divide when it fits
+    else { p = gid / ap.bins; b = (int)(gid % ap.bins); }
+    long long k = p;                                        // task index (row-major in rect mode): addresses the per-task outputs
+    int ix, iy;
+    if (ap.tasks) { ix = ap.tasks[2 * p]; iy = ap.tasks[2 * p + 1]; }
+    else {
+        const int w = ap.rect[2] - ap.rect[0], h = ap.rect[3] - ap.rect[1];
+        const int lx = (int)((uint32_t)p / (uint32_t)h), ly = (int)((uint32_t)p % (uint32_t)h);
+        ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
+        k = (long long)ly * w + lx;
+    }
+    const Sample *s = ap.samples + p * ap.spp;
+    // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
+    auto value = [&](const Sample &smp) {
+        const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
+        const double tab = staged ? acc_tab[e] : ap.tables[e];
+        double x = smp.table < 0 ? 0.0 : smp.a * tab;
+        x = x * smp.weight;
+        if (ap.power) x = x * ap.sensitivity;
+        return x;
+    };
+    // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
+    // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
+    // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
+    double m = value(s[0]), v = 0;
+    double dm = 1.0;                                        // (double)i, advanced by exact additions
+    auto step = [&](double x, int i) {
+        const double dn = dm + 1.0, c = i == 1 ? 1.0 : dm - 1.0;
+        const double yn = rcp_table ? acc_rcp[i + 1] : refine_rcp(dn), ym = rcp_table ? acc_rcp[i] : refine_rcp(dm);
+        const double pm = m, pv = v;
+        m = pm + exact_div(x - pm, dn, yn, true);
+        v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
+        dm = dn;
+    };
+    int i = 1;
+    for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
+        Sample sm[ACC_BATCH];
+#pragma unroll
+        for (int j = 0; j < ACC_BATCH; ++j) sm[j] = s[i + j];
+#pragma unroll
+        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j]), i + j);
+    }
+    for (; i < ap.spp; ++i) step(value(s[i]), i);
+    if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
+    if (ap.fmean) {
+        const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+        if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
+        double mt, vt;
+        int nt;
+        combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
+        ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, double *va, int32_t *na, const double *mb,
+                                                       const double *vb, const int32_t *nb) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (nb[i] < 1) return;
+    double v = vb[i];
+    if (v < 0) v = 0;
+    double mt, vt;
+    int nt;
+    combine_samples(ma[i], va[i], na[i], mb[i], v, nb[i], mt, vt, nt);
+    ma[i] = mt; va[i] = vt; na[i] = nt;
+}
+

@@ -108,1835 +108,15 @@ extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
     } while (0)
 
 // ---------------------------------------------------------------------------------------------------
-// device-resident scene
+// device code (one translation unit; the pieces are split by subject)
 // ---------------------------------------------------------------------------------------------------
-struct DMesh {
-    const rsx_kdnode *nodes;
-    const int32_t *items;
-    const float4 *tris;        // 3 x float4 per triangle: v1.xyz v2.x | v2.yz v3.xy | v3.z fn.xyz
-    const float4 *leaf;        // 4 x float4 per LEAF ITEM, in items[] order: the 3 above + (triangle id, -, -, -): one 64-byte line per
-                               // test, no id->record indirection, big leaves stream as contiguous memory
-    const float *vnormals;     // [nn,3] or null
-    const int32_t *nidx;       // [nt,3] vertex-normal indices or null
-    double lower[3], upper[3];
-    int32_t smoothing, closed, n_tris, pad;
-};
-
-struct DScene {
-    const rsx_primitive *prims;
-    const DMesh *meshes;
-    const rsx_kdnode *wnodes;
-    const int32_t *witems;
-    double wlower[3], wupper[3];
-    int32_t n_prims, n_world, n_meshes;
-    int32_t wdepth, mdepth;    // stack levels a traversal of the world tree / the deepest mesh tree can need
-    int32_t wlds, mlds;        // how many of those levels are held in LDS (the rest spill)
-    char *spill;               // per-wave global spill regions
-    const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
-};
-
-struct CsgInfo {
-    int32_t parent, slot, is_b, top;
-};
-
-struct Ray {
-    double ox, oy, oz, dx, dy, dz, maxd;
-};
-
-// candidate kept while searching; full geometry is regenerated once at the end (finalise)
-struct Hit {
-    double t;
-    int32_t prim;              // -1 = none
-    int32_t a0, a1;            // mesh: triangle, - ; box: face, axis ; cylinder: face, type
-    float u, v, w;
-    // CSG hits only: the operand leaf that produced the root, Subtract flip parity / exiting, mesh-leaf hit point
-    int32_t leaf;
-    uint32_t flags;
-    double hx, hy, hz;
-};
-
-// Per-lane traversal stack: the first `lds_levels` entries live in LDS ([level][lane], conflict free), deeper ones spill to a
-// per-wave global buffer with the same layout. 99 % of camera rays on the 69k-triangle mesh never have more than 9 far nodes
-// pending (oracle histogram), so the spill path is cold but keeps the traversal exact for any depth.
-struct Stack {
-    // Everything here is wave-uniform (lives in SGPRs); the lane's own slot is addressed as base + (level * WAVE + lane) * size
-    // at each access, so the stack costs the traversal loop no per-lane pointer registers.
-    uint32_t lds_t, lds_id;    // byte offsets in the workgroup's dynamic LDS: t[level][lane] (f64), id[level][lane] (i32)
-    char *gt, *gid;            // spill arrays with the same layout, levels >= lds_levels
-    int32_t lds_levels;
-    float4 *stage;             // per-wave LDS staging area: WAVE triangle records (3 x float4) + WAVE triangle ids
-};
-
-extern __shared__ __attribute__((aligned(16))) char smem[];
-
-__device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
-    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
-    if (sp < st.lds_levels) {
-        *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
-        *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
-    } else {
-        const int g = slot - st.lds_levels * WAVE;
-        reinterpret_cast<double *>(st.gt)[g] = t;
-        reinterpret_cast<int32_t *>(st.gid)[g] = id;
-    }
-}
-
-__device__ __forceinline__ void stack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
-    const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
-    if (sp < st.lds_levels) {
-        t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
-        id = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
-    } else {
-        const int g = slot - st.lds_levels * WAVE;
-        t = reinterpret_cast<const double *>(st.gt)[g];
-        id = reinterpret_cast<const int32_t *>(st.gid)[g];
-    }
-}
-
-__device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
-__device__ __forceinline__ float sel3f(int i, float x, float y, float z) { return i == 0 ? x : (i == 1 ? y : z); }
-
-// Point3D.transform / Vector3D.transform — core/math/point.pyx:253-284, vector.pyx:339-369
-__device__ __forceinline__ void xform_point(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
-    double w = m[12] * x + m[13] * y + m[14] * z + m[15];
-    w = 1.0 / w;
-    ox = (m[0] * x + m[1] * y + m[2] * z + m[3]) * w;
-    oy = (m[4] * x + m[5] * y + m[6] * z + m[7]) * w;
-    oz = (m[8] * x + m[9] * y + m[10] * z + m[11]) * w;
-}
-
-__device__ __forceinline__ void xform_vector(const double *m, double x, double y, double z, double &ox, double &oy, double &oz) {
-    ox = m[0] * x + m[1] * y + m[2] * z;
-    oy = m[4] * x + m[5] * y + m[6] * z;
-    oz = m[8] * x + m[9] * y + m[10] * z;
-}
-
-// Scene tables (primitives, mesh descriptors) never change while a kernel runs. Read through the constant address space with a
-// wave-uniform index they come in over the scalar data path into SGPRs: no vector registers for a 4x4 matrix or a mesh descriptor.
-#define RSX_CONST_AS __attribute__((address_space(4)))
-typedef const RSX_CONST_AS rsx_primitive *UPrim;
-typedef const RSX_CONST_AS struct DMesh *UMesh;
-__device__ __forceinline__ UPrim uniform_prim(const rsx_primitive *base, int32_t idx) { return (UPrim)(unsigned long long)(base + idx); }
-
-__device__ __forceinline__ Ray to_local_uniform(UPrim p, const Ray &r) {
-    const RSX_CONST_AS double *m = p->to_local;
-    Ray l;
-    // Point3D.transform divides by the homogeneous w (point.pyx:253-284). For an affine matrix (last row 0 0 0 1 — every matrix
-    // translate/rotate produce) w is exactly 1 and x * (1.0 / 1.0) == x bit for bit, so the wave-uniform test skips a division.
-    double w = 1.0;
-    const bool affine = m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0;
-    if (!affine) { w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15]; w = 1.0 / w; }
-    l.ox = (m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3]) * w;
-    l.oy = (m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7]) * w;
-    l.oz = (m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11]) * w;
-    l.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz;
-    l.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz;
-    l.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz;
-    l.maxd = r.maxd;
-    return l;
-}
-
-__device__ __forceinline__ Ray to_local(const rsx_primitive &p, const Ray &r) {
-    Ray l;
-    xform_point(p.to_local, r.ox, r.oy, r.oz, l.ox, l.oy, l.oz);
-    xform_vector(p.to_local, r.dx, r.dy, r.dz, l.dx, l.dy, l.dz);
-    l.maxd = r.maxd;
-    return l;
-}
-
-// BoundingBox3D._slab / intersect — core/boundingbox.pyx:180-245
-__device__ __forceinline__ void slab(double o, double d, double lo, double hi, double &front, double &back) {
-    double tmin, tmax;
-    const double inf = INFINITY;
-    if (d != 0.0) {
-        const double rcp = 1.0 / d;
-        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
-        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
-    } else {
-        if (o < lo)      { tmin = -inf; tmax = -inf; }
-        else if (o > hi) { tmin = inf;  tmax = inf; }
-        else             { tmin = -inf; tmax = inf; }
-    }
-    if (tmin > front) front = tmin;
-    if (tmax < back) back = tmax;
-}
-
-__device__ __forceinline__ bool aabb(const double *lo, const double *hi, const Ray &r, double &front, double &back) {
-    front = -INFINITY;
-    back = INFINITY;
-    slab(r.ox, r.dx, lo[0], hi[0], front, back);
-    slab(r.oy, r.dy, lo[1], hi[1], front, back);
-    slab(r.oz, r.dz, lo[2], hi[2], front, back);
-    if (front > back) return false;
-    if (front < 0.0 && back < 0.0) return false;
-    return true;
-}
-
-// Same test with the three reciprocals 1.0/d hoisted by the caller (bit-identical: the reference recomputes the same
-// quotient for every box it tests a ray against).
-__device__ __forceinline__ void slab_rcp(double o, double d, double rcp, double lo, double hi, double &front, double &back) {
-    double tmin, tmax;
-    const double inf = INFINITY;
-    if (d != 0.0) {
-        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; }
-        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; }
-    } else {
-        if (o < lo)      { tmin = -inf; tmax = -inf; }
-        else if (o > hi) { tmin = inf;  tmax = inf; }
-        else             { tmin = -inf; tmax = inf; }
-    }
-    if (tmin > front) front = tmin;
-    if (tmax < back) back = tmax;
-}
-
-__device__ __forceinline__ bool aabb_rcp(const double *lo, const double *hi, const Ray &r, double rx, double ry, double rz, double &front, double &back) {
-    front = -INFINITY;
-    back = INFINITY;
-    slab_rcp(r.ox, r.dx, rx, lo[0], hi[0], front, back);
-    slab_rcp(r.oy, r.dy, ry, lo[1], hi[1], front, back);
-    slab_rcp(r.oz, r.dz, rz, lo[2], hi[2], front, back);
-    if (front > back) return false;
-    if (front < 0.0 && back < 0.0) return false;
-    return true;
-}
-
-__device__ __forceinline__ bool aabb_contains(const double *lo, const double *hi, double x, double y, double z) {
-    if (x < lo[0] || x > hi[0]) return false;
-    if (y < lo[1] || y > hi[1]) return false;
-    if (z < lo[2] || z > hi[2]) return false;
-    return true;
-}
-
-__device__ __forceinline__ rsx_kdnode load_node(const rsx_kdnode *nodes, int32_t id) {
-    const int4 raw = *reinterpret_cast<const int4 *>(nodes + id);   // one 16-B load
-    rsx_kdnode nd;
-    nd.type = raw.x;
-    nd.count = raw.y;
-    nd.u.leaf.first_item = raw.z;
-    nd.u.leaf.pad = raw.w;
-    return nd;
-}
-
-// Correctly rounded n / d with the d-only part of the division hoisted out of the traversal loop.
-// hipcc expands an IEEE f64 division into v_div_scale, v_rcp_f64, two Newton steps on the reciprocal, q0 = n*y,
-// r = fma(-d, q0, n), v_div_fmas (= fma(r, y, q0) when no scaling is in effect) and v_div_fixup. The reciprocal refinement
-// depends on d alone, and a ray divides by the same three direction components at every KD node, so it is computed once per ray
-// space (refine_rcp) and the per-node work shrinks to mul + 2 fma. The shortcut is taken only when neither operand is anywhere
-// near the exponent ranges where v_div_scale / v_div_fixup intervene; otherwise the plain division runs. tests/test_gpu_parity.py
-// (test_exact_division) checks bit equality against `/` on the device over 2^28 operand pairs including exact and near-tie cases.
-#ifndef RSX_FAST_DIV
-#define RSX_FAST_DIV 1
-#endif
-
-__device__ __forceinline__ double refine_rcp(double d) {
-    const double r = __builtin_amdgcn_rcp(d);
-    const double f0 = __builtin_fma(-d, r, 1.0);
-    const double y1 = __builtin_fma(r, f0, r);
-    const double f2 = __builtin_fma(-d, y1, 1.0);
-    return __builtin_fma(y1, f2, y1);
-}
-
-__device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in [2^-300, 2^300] (false for NaN): two compares
-    const double a = __builtin_fabs(x);
-    return a >= 0x1p-300 && a <= 0x1p+300;
-}
-
-__device__ __forceinline__ double exact_div(double n, double d, double y, bool d_safe) {
-#if RSX_FAST_DIV
-    if (d_safe && div_operand_safe(n)) {
-        const double q0 = n * y;
-        const double r = __builtin_fma(-d, q0, n);
-        return __builtin_fma(r, y, q0);
-    }
-    if (d_safe && n == 0.0) return n * y;          // signed zero with the quotient's sign (the correction step would lose it)
-#endif
-    return n / d;
-}
-
-struct AxisDiv {               // per ray space: refined reciprocals of the three direction components
-    double yx, yy, yz;
-    int safe;                  // bit k: component k may take the shortcut
-};
-
-__device__ __forceinline__ AxisDiv axis_div(const Ray &r) {
-    AxisDiv a;
-    a.yx = refine_rcp(r.dx); a.yy = refine_rcp(r.dy); a.yz = refine_rcp(r.dz);
-    a.safe = (div_operand_safe(r.dx) ? 1 : 0) | (div_operand_safe(r.dy) ? 2 : 0) | (div_operand_safe(r.dz) ? 4 : 0);
-    return a;
-}
-
-// One KD branch step — KDTree3DCore._trace_branch, core/math/spatial/kdtree3d.pyx:626-700.
-// Returns the next node; pushes (far, tmax) when both children are crossed.
-__device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t node, double o, double d, double y, bool d_safe, double tmin,
-                                               double &tmax, const Stack &st, int32_t &sp) {
-    const double split = nd.u.split;
-    const int32_t lower = node + 1, upper = nd.count;
-    if (d == 0) return o < split ? lower : upper;
-    const double plane = exact_div(split - o, d, y, d_safe);
-    const bool below = o < split || (o == split && d < 0);
-    const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
-    if (plane > tmax || plane <= 0) return near_id;
-    if (plane < tmin) return far_id;
-    stack_push(st, sp, far_id, tmax);
-    ++sp;
-    tmax = plane;
-    return near_id;
-}
-
-// Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
-// pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
-__device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
-                                              const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
-    rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
-    while (nd.type >= 0) {
-        UTIL_COUNT(util, 4)
-        const int axis = nd.type;
-        const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
-                                         (ad.safe >> axis) & 1, tmin, tmax, st, sp);
-        if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
-        nx = load_node(nodes, next + 1);
-        node = next;
-    }
-    return nd;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Mesh — raysect/primitive/mesh/mesh.pyx:506-713 (MeshData.trace / _trace_leaf / _hit_triangle)
-// ---------------------------------------------------------------------------------------------------
-struct MeshHit {
-    float u, v, w, t;
-    int32_t tri;
-};
-
-// ray-space constants of the watertight test — _calc_rayspace_transform, mesh.pyx:566-610
-struct TriRay {
-    double ox, oy, oz, maxd;
-    float sx, sy, sz;
-    int ix, iy, iz;
-};
-
-__device__ __forceinline__ TriRay tri_ray(const Ray &r) {
-    TriRay q;
-    int ix, iy, iz;
-    const double ax = fabs(r.dx), ay = fabs(r.dy), az = fabs(r.dz);
-    if (ax > ay && ax > az) { ix = 1; iy = 2; iz = 0; }
-    else if (ay > ax && ay > az) { ix = 2; iy = 0; iz = 1; }
-    else { ix = 0; iy = 1; iz = 2; }
-    const float rdz = (float)sel3(iz, r.dx, r.dy, r.dz);
-    if (rdz < 0.0f) { const int tmp = ix; ix = iy; iy = tmp; }
-    q.sz = (float)(1.0 / (double)rdz);
-    q.sx = (float)(sel3(ix, r.dx, r.dy, r.dz) * (double)q.sz);
-    q.sy = (float)(sel3(iy, r.dx, r.dy, r.dz) * (double)q.sz);
-    q.ix = ix; q.iy = iy; q.iz = iz;
-    q.ox = r.ox; q.oy = r.oy; q.oz = r.oz; q.maxd = r.maxd;
-    return q;
-}
-
-// _hit_triangle, mesh.pyx:616-713 on one 48-byte triangle record. Returns true with normalised (t,u,v,w) on a hit.
-__device__ __forceinline__ bool tri_test(const TriRay &q, const float4 q0, const float4 q1, const float4 q2, float &ht, float &hu, float &hv, float &hw) {
-    // f32 vertex minus f64 origin, rounded to f32
-    const float v1x = (float)((double)q0.x - q.ox), v1y = (float)((double)q0.y - q.oy), v1z = (float)((double)q0.z - q.oz);
-    const float v2x = (float)((double)q0.w - q.ox), v2y = (float)((double)q1.x - q.oy), v2z = (float)((double)q1.y - q.oz);
-    const float v3x = (float)((double)q1.z - q.ox), v3y = (float)((double)q1.w - q.oy), v3z = (float)((double)q2.x - q.oz);
-    const float a1 = sel3f(q.ix, v1x, v1y, v1z), b1 = sel3f(q.iy, v1x, v1y, v1z), c1 = sel3f(q.iz, v1x, v1y, v1z);
-    const float a2 = sel3f(q.ix, v2x, v2y, v2z), b2 = sel3f(q.iy, v2x, v2y, v2z), c2 = sel3f(q.iz, v2x, v2y, v2z);
-    const float a3 = sel3f(q.ix, v3x, v3y, v3z), b3 = sel3f(q.iy, v3x, v3y, v3z), c3 = sel3f(q.iz, v3x, v3y, v3z);
-    const float x1 = a1 - q.sx * c1, x2 = a2 - q.sx * c2, x3 = a3 - q.sx * c3;
-    const float y1 = b1 - q.sy * c1, y2 = b2 - q.sy * c2, y3 = b3 - q.sy * c3;
-    float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
-    if (u == 0.0f || v == 0.0f || w == 0.0f) {
-        u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
-        v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
-        w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
-    }
-    if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) return false;
-    const float det = u + v + w;
-    if (det == 0.0f) return false;
-    const float z1 = q.sz * c1, z2 = q.sz * c2, z3 = q.sz * c3;
-    const float t = u * z1 + v * z2 + w * z3;
-    if (det > 0.0f) { if (t < 0.0f || (double)t > q.maxd * (double)det) return false; }
-    else            { if (t > 0.0f || (double)t < q.maxd * (double)det) return false; }
-    const float rdet = (float)(1.0 / (double)det);
-    ht = t * rdet; hu = u * rdet; hv = v * rdet; hw = w * rdet;
-    return true;
-}
-
-#ifndef RSX_LEAF_INLINE
-#define RSX_LEAF_INLINE 1          // 1: leaves read 64-byte leaf-ordered triangle records; 0: items[] -> 48-byte records by id
-#endif
-
-// fetch leaf item `pos` (absolute position in items[]): its triangle id and 48-byte record
-__device__ __forceinline__ void leaf_fetch(const int32_t *items, const float4 *tris, const float4 *leaf, int32_t pos, int32_t &tri, float4 &a,
-                                           float4 &b, float4 &c) {
-#if RSX_LEAF_INLINE
-    const float4 *rec = leaf + 4 * (size_t)pos;
-    a = rec[0]; b = rec[1]; c = rec[2];
-    tri = __float_as_int(rec[3].x);
-#else
-    tri = items[pos];
-    const float4 *rec = tris + 3 * (size_t)tri;
-    a = rec[0]; b = rec[1]; c = rec[2];
-#endif
-}
-
-#ifndef RSX_LEAF_BATCH
-#define RSX_LEAF_BATCH 4           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
-#endif
-
-__device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
-    double tmin, tmax;
-    if (!aabb(m.lower, m.upper, r, tmin, tmax)) return false;                 // kdtree3d.pyx:589-607
-    const TriRay q = tri_ray(r);
-    const AxisDiv ad = axis_div(r);
-
-    int32_t node = 0, sp = 0;
-    for (;;) {
-        const rsx_kdnode nd = descend(m.nodes, node, r, ad, tmin, tmax, st, sp);
-        // _trace_leaf, mesh.pyx:520-563 — items are tested in leaf order, strict `<` keeps the first of equal distances
-        double distance = r.maxd < tmax ? r.maxd : tmax;
-        int32_t closest = -1;
-        float bu = 0, bv = 0, bw = 0;
-        const int32_t first = nd.u.leaf.first_item;
-        const int32_t count = nd.count;
-        for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
-            int32_t tri[RSX_LEAF_BATCH];
-            float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
-#pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j)
-                leaf_fetch(m.items, m.tris, m.leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
-#pragma unroll
-            for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
-                float ht, hu, hv, hw;
-                if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
-                    distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
-                }
-            }
-        }
-        if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; return true; }
-        if (sp == 0) return false;
-        --sp;
-        tmin = tmax;                    // far range starts where the exhausted near range ended
-        stack_pop(st, sp, node, tmax);
-    }
-}
-
-#ifndef RSX_STAGE_MIN
-#define RSX_STAGE_MIN 4            // >= this many rays of the wave in the same big leaf: stage the leaf through LDS instead
-#endif
-#ifndef RSX_PHASE_PROF
-#define RSX_PHASE_PROF 0           // 1: accumulate per-phase s_memtime cycles of the wave-cooperative mesh traversal (tuning builds only)
-#endif
-#if RSX_PHASE_PROF
-__device__ unsigned long long g_phase[8][64];   // unused placeholder to keep the symbol set stable
-#define PHASE_DECL unsigned long long ph_t = clock64();
-#define PHASE_ADD(slot) { const unsigned long long now_ = clock64(); phase_acc[slot] += now_ - ph_t; ph_t = now_; }
-#else
-#define PHASE_DECL
-#define PHASE_ADD(slot)
-#endif
-#ifndef RSX_COOP_LEAF
-#define RSX_COOP_LEAF 24           // leaves with at least this many triangles are tested by the whole wave for one ray at a time
-#endif
-
-__device__ __forceinline__ double shfl_f64(double x, int lane) { return __shfl(x, lane, WAVE); }
-__device__ __forceinline__ double readlane_f64(double x, int lane) {          // lane must be wave-uniform; the result is scalar
-    const long long b = __double_as_longlong(x);
-    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)b, lane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
-}
-
-// Wave-cooperative MeshData.trace: every lane of the wave calls this together on ONE mesh (`m` is wave-uniform; `want` = lane has
-// a ray for it). Lanes walk their own rays through the tree; small leaves are tested per lane, but a leaf with >= RSX_COOP_LEAF
-// triangles (high-valence vertices produce leaves of hundreds, mesh.pyx builds them because the depth cap stops the SAH split) is
-// tested by all 64 lanes for one ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic
-// wave-min, which is exactly what the reference's sequential scan with strict `<` returns (the first item among those with the
-// smallest distance). Idle lanes — rays that already finished, or never needed this mesh — serve as helpers.
-__device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
-    const int lane = threadIdx.x % WAVE;
-    PHASE_DECL
-    const rsx_kdnode *nodes = m->nodes;                     // scalar loads: the bases sit in SGPRs, lanes supply 32-bit offsets
-    const float4 *leaf = m->leaf, *tris = m->tris;
-    const int32_t *items = m->items;
-    double tmin = 0, tmax = 0;
-    bool active;
-    const AxisDiv ad = axis_div(r);
-    {
-        // BoundingBox3D.intersect (kdtree3d.pyx:589-607) needs 1.0 / d per axis: formed from the refined reciprocals that the
-        // branch steps use anyway (exact_div(1, d) is the correctly rounded quotient), not by three more full divisions
-        const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
-        const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
-                     rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
-        active = want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax);
-    }
-    const TriRay q = tri_ray(r);
-    bool hit = false;
-    int32_t node = 0, sp = 0;
-    while (__any(active)) {
-        double distance = 0;
-        int32_t closest = -1, count = 0, first = 0;
-        float bu = 0, bv = 0, bw = 0;
-        work += 8;                                   // one descend + small-leaf round of the wave (scheduling weight, see k_order_units)
-        PHASE_ADD(0)
-        rsx_kdnode nd;
-        nd.count = 0; nd.u.leaf.first_item = 0;
-        if (active) { UTIL_COUNT(phase_acc, 2) }
-        if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
-        PHASE_ADD(1)
-        if (active) {
-            distance = r.maxd < tmax ? r.maxd : tmax;                         // _trace_leaf, mesh.pyx:520-563
-            count = nd.count;
-            first = nd.u.leaf.first_item;
-            if (count < RSX_COOP_LEAF) {
-                for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
-                    UTIL_COUNT(phase_acc, 6)
-                    int32_t tri[RSX_LEAF_BATCH];
-                    float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
-#pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j)
-                        leaf_fetch(items, tris, leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
-#pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
-                        float ht, hu, hv, hw;
-                        if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
-                            distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;
-                        }
-                    }
-                }
-            }
-        }
-        PHASE_ADD(2)
-        // ---- cooperative stage for big leaves
-        unsigned long long big = __ballot(active && count >= RSX_COOP_LEAF);
-#if RSX_PHASE_PROF
-        phase_acc[5] += 1; phase_acc[6] += __popcll(big); phase_acc[7] += __popcll(__ballot(active));
-#endif
-        while (big) {
-            const int leader = __ffsll((long long)big) - 1;
-            const int32_t lcount = __builtin_amdgcn_readlane(count, leader), lfirst = __builtin_amdgcn_readlane(first, leader);
-            // lanes whose ray sits in the same leaf as the leader's
-            const bool same = active && count >= RSX_COOP_LEAF && first == lfirst;
-            const unsigned long long group = __ballot(same);
-            big &= ~group;
-            if (__popcll(group) >= RSX_STAGE_MIN) {
-                // (a) coherent rays: stage the leaf through LDS 64 triangles at a time; every lane of the group tests them all,
-                //     in leaf order (the reference's own loop), reading each record as an LDS broadcast
-                float4 *rec = st.stage;
-                int32_t *ids = reinterpret_cast<int32_t *>(st.stage + 3 * WAVE);
-                work += 2 + (uint32_t)lcount / 8;
-                for (int32_t c = 0; c < lcount; c += WAVE) {
-                    __builtin_amdgcn_wave_barrier();
-                    const int32_t k = c + lane;
-                    if (k < lcount) {
-                        int32_t tri;
-                        float4 a, b, cc;
-                        leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, cc);
-                        rec[3 * lane] = a; rec[3 * lane + 1] = b; rec[3 * lane + 2] = cc;
-                        ids[lane] = tri;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                    __builtin_amdgcn_wave_barrier();
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (same) {
-                        const int32_t nj = lcount - c < WAVE ? lcount - c : WAVE;
-                        for (int32_t j = 0; j < nj; ++j) {
-                            float ht, hu, hv, hw;
-                            if (tri_test(q, rec[3 * j], rec[3 * j + 1], rec[3 * j + 2], ht, hu, hv, hw) && (double)ht < distance) {
-                                distance = (double)ht; closest = ids[j]; bu = hu; bv = hv; bw = hw;
-                            }
-                        }
-                    }
-                }
-                continue;
-            }
-            // (b) isolated rays: one ray at a time, all 64 lanes testing 64 triangles per step
-            unsigned long long todo = group;
-            while (todo) {
-                const int owner = __ffsll((long long)todo) - 1;
-                todo &= todo - 1;
-                work += 2 + (uint32_t)lcount / 32;
-                // the owner's ray constants are read into scalar registers (owner is wave-uniform): no per-lane copy of the ray
-                TriRay lq;
-                lq.ox = readlane_f64(q.ox, owner); lq.oy = readlane_f64(q.oy, owner); lq.oz = readlane_f64(q.oz, owner);
-                lq.maxd = readlane_f64(q.maxd, owner);
-                lq.sx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sx), owner));
-                lq.sy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sy), owner));
-                lq.sz = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q.sz), owner));
-                const int axes = __builtin_amdgcn_readlane(q.ix | (q.iy << 2) | (q.iz << 4), owner);
-                lq.ix = axes & 3; lq.iy = (axes >> 2) & 3; lq.iz = (axes >> 4) & 3;
-                const double limit = readlane_f64(distance, owner);
-                // each lane scans positions lane, lane+64, ... in ascending order (strict `<` keeps its earliest minimum)
-                float mt = INFINITY, mu = 0, mv = 0, mw = 0;
-                int32_t mk = 0x7fffffff, mtri = -1;
-                for (int32_t k = lane; k < lcount; k += WAVE) {
-                    int32_t tri;
-                    float4 a, b, c;
-                    leaf_fetch(items, tris, leaf, lfirst + k, tri, a, b, c);
-                    float ht, hu, hv, hw;
-                    if (tri_test(lq, a, b, c, ht, hu, hv, hw) && (double)ht < limit && ht < mt) { mt = ht; mk = k; mtri = tri; mu = hu; mv = hv; mw = hw; }
-                }
-                // wave-wide lexicographic min of (t, position) == the reference's sequential scan with strict `<`
-                float wt = mt;
-                int32_t wk = mk;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) {
-                    const float ot = __shfl_xor(wt, off, WAVE);
-                    const int32_t ok = __shfl_xor(wk, off, WAVE);
-                    if (ot < wt || (ot == wt && ok < wk)) { wt = ot; wk = ok; }
-                }
-                const int winner = wk & (WAVE - 1);              // position k was scanned by lane k % 64
-                const bool found = wk != 0x7fffffff;
-                const float ru = __shfl(mu, winner, WAVE), rv = __shfl(mv, winner, WAVE), rw = __shfl(mw, winner, WAVE);
-                const int32_t rtri = __shfl(mtri, winner, WAVE);
-                if (lane == owner && found) { distance = (double)wt; closest = rtri; bu = ru; bv = rv; bw = rw; }
-            }
-        }
-        PHASE_ADD(3)
-        if (active) {
-            if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; active = false; }
-            else if (sp == 0) active = false;
-            else {
-                --sp;
-                tmin = tmax;
-                stack_pop(st, sp, node, tmax);
-            }
-        }
-        PHASE_ADD(4)
-    }
-    return hit;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// analytic primitives: ordered roots inside [0, max_distance]
-//   sphere.pyx:115-159, box.pyx:157-294, cylinder.pyx:148-276, utility.pyx:376-419 (solve_quadratic)
-// Each returns 0..2 roots: t[k] plus (a0, a1) = (face, axis|type) needed to rebuild the intersection.
-// ---------------------------------------------------------------------------------------------------
-#define NO_FACE (-1)
-#define LOWER_FACE 0
-#define UPPER_FACE 1
-#define T_CYLINDER 0
-#define T_SLAB 1
-
-struct Roots {
-    int n;
-    double t[2];
-    int32_t a0[2], a1[2];
-};
-
-__device__ __forceinline__ bool solve_quadratic(double a, double b, double c, double &t0, double &t1) {
-    const double d = b * b - 4 * a * c;
-    if (d < 0) return false;
-    double q;
-    if (b < 0) q = -0.5 * (b - sqrt(d)); else q = -0.5 * (b + sqrt(d));
-    t0 = q / a;
-    t1 = c / q;
-    return true;
-}
-
-// shared tail of Sphere/Box/Cylinder.hit: choose closest root and whether a cached further root exists
-__device__ __forceinline__ void pick_roots(double near_t, double far_t, int nf, int na, int ff, int fa, double maxd, Roots &out) {
-    out.n = 0;
-    if (near_t > far_t) return;                                              // (never true for the sphere's sorted roots)
-    if (near_t > maxd || far_t < 0.0) return;
-    if (near_t >= 0.0) {
-        out.t[0] = near_t; out.a0[0] = nf; out.a1[0] = na; out.n = 1;
-        if (far_t <= maxd) { out.t[1] = far_t; out.a0[1] = ff; out.a1[1] = fa; out.n = 2; }
-    } else if (far_t <= maxd) {
-        out.t[0] = far_t; out.a0[0] = ff; out.a1[0] = fa; out.n = 1;
-    }
-}
-
-__device__ void sphere_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
-    out.n = 0;
-    const double radius = p.params[0];
-    const double a = l.dx * l.dx + l.dy * l.dy + l.dz * l.dz;
-    const double b = 2 * (l.dx * l.ox + l.dy * l.oy + l.dz * l.oz);
-    const double c = l.ox * l.ox + l.oy * l.oy + l.oz * l.oz - radius * radius;
-    double t0, t1;
-    if (!solve_quadratic(a, b, c, t0, t1)) return;
-    if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
-    pick_roots(t0, t1, 0, 0, 0, 0, l.maxd, out);
-}
-
-__device__ __forceinline__ void box_slab(int axis, double o, double d, double lo, double hi, double &near_t, double &far_t,
-                                         int &nf, int &ff, int &na, int &fa) {
-    double tmin, tmax;
-    int fmin, fmax;
-    const double inf = INFINITY;
-    if (d != 0.0) {
-        const double rcp = 1.0 / d;
-        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; fmin = LOWER_FACE; fmax = UPPER_FACE; }
-        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; fmin = UPPER_FACE; fmax = LOWER_FACE; }
-    } else {
-        if (o < lo)      { tmin = -inf; tmax = -inf; }
-        else if (o > hi) { tmin = inf;  tmax = inf; }
-        else             { tmin = -inf; tmax = inf; }
-        fmin = NO_FACE; fmax = NO_FACE;
-    }
-    if (tmin > near_t) { near_t = tmin; nf = fmin; na = axis; }
-    if (tmax < far_t)  { far_t = tmax;  ff = fmax; fa = axis; }
-}
-
-__device__ void box_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
-    double near_t = -INFINITY, far_t = INFINITY;
-    int nf = NO_FACE, ff = NO_FACE, na = -1, fa = -1;
-    box_slab(0, l.ox, l.dx, p.params[0], p.params[3], near_t, far_t, nf, ff, na, fa);
-    box_slab(1, l.oy, l.dy, p.params[1], p.params[4], near_t, far_t, nf, ff, na, fa);
-    box_slab(2, l.oz, l.dz, p.params[2], p.params[5], near_t, far_t, nf, ff, na, fa);
-    pick_roots(near_t, far_t, nf, na, ff, fa, l.maxd, out);
-}
-
-__device__ void cylinder_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
-    out.n = 0;
-    const double radius = p.params[0], height = p.params[1];
-    double near_t, far_t, t0, t1;
-    int nf = NO_FACE, ff = NO_FACE, nt, ft, f0, f1;
-    if (l.dx == 0 && l.dy == 0) {
-        if ((l.ox * l.ox + l.oy * l.oy) <= (radius * radius)) { near_t = -INFINITY; far_t = INFINITY; nt = -1; ft = -1; }
-        else return;
-    } else {
-        const double a = l.dx * l.dx + l.dy * l.dy;
-        const double b = 2.0 * (l.dx * l.ox + l.dy * l.oy);
-        const double c = l.ox * l.ox + l.oy * l.oy - radius * radius;
-        if (!solve_quadratic(a, b, c, t0, t1)) return;
-        if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
-        near_t = t0; far_t = t1; nt = T_CYLINDER; ft = T_CYLINDER;
-    }
-    if (l.dz != 0.0) {
-        const double temp = 1.0 / l.dz;
-        if (l.dz > 0) { t0 = -l.oz * temp; t1 = (height - l.oz) * temp; f0 = LOWER_FACE; f1 = UPPER_FACE; }
-        else          { t0 = (height - l.oz) * temp; t1 = -l.oz * temp; f0 = UPPER_FACE; f1 = LOWER_FACE; }
-        if (t0 > near_t) { near_t = t0; nf = f0; nt = T_SLAB; }
-        if (t1 < far_t)  { far_t = t1;  ff = f1; ft = T_SLAB; }
-    }
-    pick_roots(near_t, far_t, nf, nt, ff, ft, l.maxd, out);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// intersection records (Intersection / MeshIntersection) rebuilt from a Hit
-//   sphere.pyx:170-200, box.pyx:296-342, cylinder.pyx:287-354, mesh.pyx:718-800
-// geom = hit_point, inside_point, outside_point, normal (primitive-local space)
-// ---------------------------------------------------------------------------------------------------
-#define PRIM_EPS 1e-9
-#define MESH_EPS 1e-6
-
-__device__ __forceinline__ void normalise3(double &x, double &y, double &z) {
-    double t = x * x + y * y + z * z;
-    t = 1.0 / sqrt(t);
-    x *= t; y *= t; z *= t;
-}
-
-__device__ __forceinline__ double box_interior_offset(double hit, double lo, double hi) {
-    if (fabs(hit - lo) < PRIM_EPS) return PRIM_EPS;
-    if (fabs(hit - hi) < PRIM_EPS) return -PRIM_EPS;
-    return 0.0;
-}
-
-struct Geom {
-    double hit[3], inside[3], outside[3], normal[3];
-    bool exiting;
-};
-
-__device__ void analytic_geom(const rsx_primitive &p, const Ray &l, double t, int a0, int a1, Geom &g) {
-    g.hit[0] = l.ox + t * l.dx; g.hit[1] = l.oy + t * l.dy; g.hit[2] = l.oz + t * l.dz;
-    if (p.type == RSX_PRIM_SPHERE) {
-        g.normal[0] = g.hit[0]; g.normal[1] = g.hit[1]; g.normal[2] = g.hit[2];
-        normalise3(g.normal[0], g.normal[1], g.normal[2]);
-        for (int k = 0; k < 3; ++k) {
-            const double delta = PRIM_EPS * g.normal[k];
-            g.inside[k] = g.hit[k] - delta; g.outside[k] = g.hit[k] + delta;
-        }
-    } else if (p.type == RSX_PRIM_BOX) {
-        g.normal[0] = 0; g.normal[1] = 0; g.normal[2] = 0;
-        const double s = a0 == LOWER_FACE ? -1.0 : 1.0;
-        if (a1 == 0) g.normal[0] = s; else if (a1 == 1) g.normal[1] = s; else if (a1 == 2) g.normal[2] = s;
-        for (int k = 0; k < 3; ++k) {
-            g.inside[k] = g.hit[k] + box_interior_offset(g.hit[k], p.params[k], p.params[3 + k]);
-            g.outside[k] = g.hit[k] + PRIM_EPS * g.normal[k];
-        }
-    } else {  // cylinder
-        const double radius = p.params[0], height = p.params[1];
-        double off[3];
-        if (a1 == T_CYLINDER) {
-            g.normal[0] = g.hit[0]; g.normal[1] = g.hit[1]; g.normal[2] = 0;
-            normalise3(g.normal[0], g.normal[1], g.normal[2]);
-            off[0] = -PRIM_EPS * g.normal[0]; off[1] = -PRIM_EPS * g.normal[1];
-        } else {
-            g.normal[0] = 0; g.normal[1] = 0; g.normal[2] = a0 == LOWER_FACE ? -1.0 : 1.0;
-            off[0] = 0; off[1] = 0;
-            if (g.hit[0] != 0.0 && g.hit[1] != 0.0) {
-                double length = sqrt(g.hit[0] * g.hit[0] + g.hit[1] * g.hit[1]);
-                if ((length - radius) < PRIM_EPS) {
-                    length = 1.0 / length;
-                    off[0] = -PRIM_EPS * length * g.hit[0]; off[1] = -PRIM_EPS * length * g.hit[1];
-                }
-            }
-        }
-        if (fabs(g.hit[2]) < PRIM_EPS) off[2] = PRIM_EPS;
-        else if (fabs(g.hit[2] - height) < PRIM_EPS) off[2] = -PRIM_EPS;
-        else off[2] = 0;
-        for (int k = 0; k < 3; ++k) { g.inside[k] = g.hit[k] + off[k]; g.outside[k] = g.hit[k] + PRIM_EPS * g.normal[k]; }
-    }
-    g.exiting = (l.dx * g.normal[0] + l.dy * g.normal[1] + l.dz * g.normal[2]) >= 0.0;
-}
-
-// MeshData.calc_intersection / _intersection_normal. `t` is the LOCAL distance from l's origin.
-__device__ void mesh_geom(const DMesh &m, const Ray &l, double t, int32_t tri, float u, float v, float w, Geom &g) {
-    const float4 q2 = m.tris[3 * (size_t)tri + 2];
-    const double fx = (double)q2.y, fy = (double)q2.z, fz = (double)q2.w;
-    g.hit[0] = l.ox + l.dx * t; g.hit[1] = l.oy + l.dy * t; g.hit[2] = l.oz + l.dz * t;
-    g.inside[0] = g.hit[0] - fx * MESH_EPS; g.inside[1] = g.hit[1] - fy * MESH_EPS; g.inside[2] = g.hit[2] - fz * MESH_EPS;
-    g.outside[0] = g.hit[0] + fx * MESH_EPS; g.outside[1] = g.hit[1] + fy * MESH_EPS; g.outside[2] = g.hit[2] + fz * MESH_EPS;
-    if (m.smoothing && m.vnormals) {
-        const int32_t n1 = m.nidx[3 * (size_t)tri], n2 = m.nidx[3 * (size_t)tri + 1], n3 = m.nidx[3 * (size_t)tri + 2];
-        for (int k = 0; k < 3; ++k) {   // f32 arithmetic, then widened (mesh.pyx:783-787)
-            const float nk = u * m.vnormals[3 * (size_t)n1 + k] + v * m.vnormals[3 * (size_t)n2 + k] + w * m.vnormals[3 * (size_t)n3 + k];
-            g.normal[k] = (double)nk;
-        }
-    } else {
-        g.normal[0] = fx; g.normal[1] = fy; g.normal[2] = fz;
-    }
-    normalise3(g.normal[0], g.normal[1], g.normal[2]);
-    g.exiting = (l.dx * fx + l.dy * fy + l.dz * fz) > 0.0;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// CSG — raysect/primitive/csg.pyx:132-234 (hit / next_intersection / _identify_intersection / _closest_intersection),
-//       :326-348 Union, :421-446 Intersect, :523-568 Subtract (+_modify_intersection)
-//
-// The reference merges two lazily evaluated, ordered root streams per CSG node and keeps the stream heads cached on the
-// node object. Here the same state machine runs per lane with the per-node state in private (scratch) memory, and the
-// recursion over nested CSG nodes is unrolled by a depth template (CSG_MAX_DEPTH nested levels below the top node; deeper
-// trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
-// ---------------------------------------------------------------------------------------------------
-#define CSG_MAX_SLOTS 16
-#define CSG_MAX_DEPTH 4
-#define F_VALID 1u
-#define F_EXIT 2u
-#define F_FLIP 4u
-
-struct Rec {                       // one root of a stream
-    double t, hx, hy, hz;          // distance along the (shared) ray parameter; mesh leaves: hit point in leaf space
-    int32_t leaf, a0, a1;
-    uint32_t flags;
-    float u, v, w, pad;
-};
-
-struct NodeSt {
-    Rec a, b;                      // CSG node: cached stream heads (_cache_intersection_a/_b)
-    double maxd;                   // CSG node: max_distance of the ray hit() was called with
-    int32_t last_is_a, invalid;    // _cache_last_intersection is a / _cache_invalid
-    int32_t tested;                // BoundPrimitive._primitive_tested
-    int32_t further;               // analytic leaf: cached second root
-    double next_t;
-    int32_t next_a0, next_a1;
-    uint32_t next_flags;
-    int32_t seek;                  // mesh leaf: _seek_next_intersection
-    double nox, noy, noz, ndx, ndy, ndz, nmaxd, acc;   // mesh leaf: _next_local_ray, _ray_distance
-};
-
-struct CsgEval {
-    const DScene *sc;
-    NodeSt *st;
-    Stack mesh_stack;
-};
-
-__device__ __forceinline__ bool is_csg(int type) { return type == RSX_PRIM_UNION || type == RSX_PRIM_INTERSECT || type == RSX_PRIM_SUBTRACT; }
-
-// Mesh.hit / next_intersection as a stream (mesh.pyx:1178-1275)
-__device__ __noinline__ void mesh_stream_step(CsgEval &e, int32_t idx, NodeSt &st, const Ray &l, Rec &out) {
-    const DMesh &m = e.sc->meshes[e.sc->prims[idx].mesh];
-    MeshHit mh;
-    out.flags = 0;
-    if (!mesh_trace(m, l, e.mesh_stack, mh)) { st.seek = 0; return; }
-    Geom g;
-    mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
-    out.t = (double)mh.t + st.acc;
-    out.hx = g.hit[0]; out.hy = g.hit[1]; out.hz = g.hit[2];
-    out.leaf = idx; out.a0 = mh.tri; out.a1 = 0; out.u = mh.u; out.v = mh.v; out.w = mh.w;
-    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
-    st.seek = 1;
-    st.nox = g.hit[0] + l.dx * MESH_EPS; st.noy = g.hit[1] + l.dy * MESH_EPS; st.noz = g.hit[2] + l.dz * MESH_EPS;
-    st.ndx = l.dx; st.ndy = l.dy; st.ndz = l.dz;
-    st.nmaxd = l.maxd - (double)mh.t - MESH_EPS;
-    st.acc = out.t + MESH_EPS;
-}
-
-__device__ __noinline__ void leaf_first(CsgEval &e, int32_t idx, NodeSt &st, const Ray &pr, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    const Ray l = to_local(p, pr);
-    out.flags = 0;
-    st.further = 0;
-    st.seek = 0;
-    if (p.type == RSX_PRIM_MESH) { st.acc = 0; mesh_stream_step(e, idx, st, l, out); return; }
-    Roots roots;
-    roots.n = 0;
-    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
-    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
-    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
-    if (roots.n == 0) return;
-    Geom g;
-    analytic_geom(p, l, roots.t[0], roots.a0[0], roots.a1[0], g);
-    out.t = roots.t[0]; out.leaf = idx; out.a0 = roots.a0[0]; out.a1 = roots.a1[0]; out.u = out.v = out.w = 0.0f;
-    out.hx = out.hy = out.hz = 0.0;
-    out.flags = F_VALID | (g.exiting ? F_EXIT : 0u);
-    if (roots.n == 2) {
-        analytic_geom(p, l, roots.t[1], roots.a0[1], roots.a1[1], g);
-        st.further = 1; st.next_t = roots.t[1]; st.next_a0 = roots.a0[1]; st.next_a1 = roots.a1[1];
-        st.next_flags = F_VALID | (g.exiting ? F_EXIT : 0u);
-    }
-}
-
-__device__ __noinline__ void leaf_next(CsgEval &e, int32_t idx, NodeSt &st, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    out.flags = 0;
-    if (p.type == RSX_PRIM_MESH) {
-        if (!st.seek) return;
-        Ray l;
-        l.ox = st.nox; l.oy = st.noy; l.oz = st.noz; l.dx = st.ndx; l.dy = st.ndy; l.dz = st.ndz; l.maxd = st.nmaxd;
-        mesh_stream_step(e, idx, st, l, out);
-        return;
-    }
-    if (!st.further) return;
-    st.further = 0;
-    out.t = st.next_t; out.leaf = idx; out.a0 = st.next_a0; out.a1 = st.next_a1; out.u = out.v = out.w = 0.0f;
-    out.hx = out.hy = out.hz = 0.0;
-    out.flags = st.next_flags;
-}
-
-// operator truth tables on (inside_a, inside_b, which stream supplied the closest root)
-__device__ __forceinline__ bool csg_valid(int type, const Rec &a, const Rec &b, bool closest_is_a) {
-    const bool ia = (a.flags & F_VALID) && (a.flags & F_EXIT), ib = (b.flags & F_VALID) && (b.flags & F_EXIT);
-    if (type == RSX_PRIM_UNION) return (!ia && !ib) || (ia && !ib && closest_is_a) || (!ia && ib && !closest_is_a);
-    if (type == RSX_PRIM_INTERSECT) return (ia && ib) || (ia && !ib && !closest_is_a) || (!ia && ib && closest_is_a);
-    return (!ia && !ib && closest_is_a) || (ia && !ib) || (ia && ib && !closest_is_a);
-}
-
-// _closest_intersection: 1 = a, 0 = b, -1 = none (a wins only when strictly closer)
-__device__ __forceinline__ int csg_closest(const Rec &a, const Rec &b) {
-    if (!(a.flags & F_VALID)) return (b.flags & F_VALID) ? 0 : -1;
-    if (!(b.flags & F_VALID) || a.t < b.t) return 1;
-    return 0;
-}
-
-template <int D> __device__ void node_next(CsgEval &e, int32_t idx, Rec &out);
-
-template <int D>
-__device__ void csg_identify(CsgEval &e, int32_t idx, NodeSt &st, Rec &a, Rec &b, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    out.flags = 0;
-    int closest = csg_closest(a, b);
-    while (closest >= 0) {
-        const Rec &c = closest ? a : b;
-        if (csg_valid(p.type, a, b, closest != 0)) {
-            if (c.t <= st.maxd) {
-                st.a = a; st.b = b; st.last_is_a = closest; st.invalid = 0;
-                out = c;
-                if (p.type == RSX_PRIM_SUBTRACT && !closest) out.flags ^= (F_EXIT | F_FLIP);   // _modify_intersection
-            }
-            return;
-        }
-        if (closest) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
-        closest = csg_closest(a, b);
-    }
-}
-
-template <int D> __device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out);
-
-template <int D>
-__device__ void csg_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {                     // CSGPrimitive.hit
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    st.invalid = 1;
-    st.maxd = pr.maxd;
-    Ray l = to_local(p, pr);
-    l.maxd = INFINITY;
-    Rec a, b;
-    node_first<D>(e, p.child_a, l, a);
-    if (p.type != RSX_PRIM_UNION && !(a.flags & F_VALID)) return;                                  // terminate_early
-    node_first<D>(e, p.child_b, l, b);
-    csg_identify<D>(e, idx, st, a, b, out);
-}
-
-template <int D>
-__device__ void csg_next(CsgEval &e, int32_t idx, Rec &out) {                                      // CSGPrimitive.next_intersection
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    if (st.invalid) return;
-    Rec a = st.a, b = st.b;
-    if (st.last_is_a) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
-    csg_identify<D>(e, idx, st, a, b, out);
-}
-
-// BoundPrimitive.hit / next_intersection over an operand (boundprimitive.pyx:42-60)
-template <int D>
-__device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    double f, b;
-    out.flags = 0;
-    if (!aabb(p.box_lower, p.box_upper, pr, f, b)) { st.tested = 0; return; }
-    st.tested = 1;
-    if (is_csg(p.type)) {
-        if constexpr (D > 0) csg_first<D - 1>(e, idx, pr, out);
-    } else if (p.type != RSX_PRIM_NULL) {
-        leaf_first(e, idx, st, pr, out);
-    }
-}
-
-template <int D>
-__device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    if (!st.tested) return;
-    if (is_csg(p.type)) {
-        if constexpr (D > 0) csg_next<D - 1>(e, idx, out);
-    } else if (p.type != RSX_PRIM_NULL) {
-        leaf_next(e, idx, st, out);
-    }
-}
-
-// contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
-__device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
-    double qx, qy, qz;
-    xform_point(p.to_local, px, py, pz, qx, qy, qz);
-    if (p.type == RSX_PRIM_SPHERE) return (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
-    if (p.type == RSX_PRIM_BOX) return aabb_contains(p.params, p.params + 3, qx, qy, qz);
-    if (p.type == RSX_PRIM_CYLINDER) return (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
-    if (p.type == RSX_PRIM_MESH) {
-        const DMesh &m = sc.meshes[p.mesh];
-        if (!m.closed) return false;
-        Ray zr;
-        zr.ox = qx; zr.oy = qy; zr.oz = qz; zr.dx = 0; zr.dy = 0; zr.dz = 1; zr.maxd = INFINITY;
-        MeshHit mh;
-        if (mesh_trace(m, zr, mesh_stack, mh)) return m.tris[3 * (size_t)mh.tri + 2].w > 0.0f;
-    }
-    return false;
-}
-
-template <int D>
-__device__ bool node_contains(const DScene &sc, int32_t idx, double px, double py, double pz, Stack mesh_stack) {
-    const rsx_primitive &p = sc.prims[idx];
-    if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) return false;
-    if (!is_csg(p.type)) return leaf_contains(sc, p, px, py, pz, mesh_stack);
-    if constexpr (D > 0) {
-        double qx, qy, qz;
-        xform_point(p.to_local, px, py, pz, qx, qy, qz);
-        const bool a = node_contains<D - 1>(sc, p.child_a, qx, qy, qz, mesh_stack);
-        if (p.type == RSX_PRIM_UNION) return a || node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
-        if (p.type == RSX_PRIM_INTERSECT) return a && node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
-        return a && !node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
-    }
-    return false;
-}
-
-// Rebuild the Intersection a CSG node returns for a root: leaf geometry in the leaf's space, lifted operand by operand into
-// the top node's space (csg.pyx:198-208), Subtract's swap/negate applied by parity (it commutes with the affine lifts).
-__device__ void csg_geom(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
-    int32_t chain[CSG_MAX_DEPTH + 3];
-    int n = 0;
-    for (int32_t i = h.leaf; i != h.prim && n < CSG_MAX_DEPTH + 2; i = sc.csg[i].parent) chain[n++] = i;
-    Ray l = to_local(sc.prims[h.prim], r);
-    for (int k = n - 1; k >= 0; --k) l = to_local(sc.prims[chain[k]], l);
-    const rsx_primitive &leaf = sc.prims[h.leaf];
-    if (leaf.type == RSX_PRIM_MESH) {
-        const DMesh &m = sc.meshes[leaf.mesh];
-        Ray at = l;                                     // mesh_geom recomputes hit = o + d*t; feed the stored hit point instead
-        at.ox = h.hx; at.oy = h.hy; at.oz = h.hz;
-        mesh_geom(m, at, 0.0, h.a0, h.u, h.v, h.w, g);
-        g.hit[0] = h.hx; g.hit[1] = h.hy; g.hit[2] = h.hz;
-        const float4 q2 = m.tris[3 * (size_t)h.a0 + 2];
-        const double fx = (double)q2.y, fy = (double)q2.z, fz = (double)q2.w;
-        g.inside[0] = h.hx - fx * MESH_EPS; g.inside[1] = h.hy - fy * MESH_EPS; g.inside[2] = h.hz - fz * MESH_EPS;
-        g.outside[0] = h.hx + fx * MESH_EPS; g.outside[1] = h.hy + fy * MESH_EPS; g.outside[2] = h.hz + fz * MESH_EPS;
-    } else {
-        analytic_geom(leaf, l, h.t, h.a0, h.a1, g);
-    }
-    for (int k = 0; k < n; ++k) {
-        const rsx_primitive &c = sc.prims[chain[k]];
-        double x, y, z;
-        xform_point(c.to_root, g.hit[0], g.hit[1], g.hit[2], x, y, z); g.hit[0] = x; g.hit[1] = y; g.hit[2] = z;
-        xform_point(c.to_root, g.inside[0], g.inside[1], g.inside[2], x, y, z); g.inside[0] = x; g.inside[1] = y; g.inside[2] = z;
-        xform_point(c.to_root, g.outside[0], g.outside[1], g.outside[2], x, y, z); g.outside[0] = x; g.outside[1] = y; g.outside[2] = z;
-        const double *mi = c.to_local;                  // Normal3D.transform(to_root) = multiply by inverse transpose
-        x = mi[0] * g.normal[0] + mi[4] * g.normal[1] + mi[8] * g.normal[2];
-        y = mi[1] * g.normal[0] + mi[5] * g.normal[1] + mi[9] * g.normal[2];
-        z = mi[2] * g.normal[0] + mi[6] * g.normal[1] + mi[10] * g.normal[2];
-        g.normal[0] = x; g.normal[1] = y; g.normal[2] = z;
-    }
-    if (h.flags & F_FLIP) {
-        for (int k = 0; k < 3; ++k) { const double tmp = g.inside[k]; g.inside[k] = g.outside[k]; g.outside[k] = tmp; g.normal[k] = -g.normal[k]; }
-    }
-    g.exiting = (h.flags & F_EXIT) != 0;
-}
-
-// ---------------------------------------------------------------------------------------------------
-// World.hit — core/scenegraph/world.pyx:125-146, core/acceleration/kdtree.pyx:73-122,170-175,
-//             boundprimitive.pyx:42-51
-// ---------------------------------------------------------------------------------------------------
-template <bool CSG>
-__device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t idx, const rsx_primitive &p, const Ray &r, Stack mesh_stack,
-                                                    NodeSt *csg_state, Hit &cand) {
-    cand.prim = -1;
-    if constexpr (CSG) {
-        if (is_csg(p.type)) {
-            CsgEval e;
-            e.sc = &sc; e.st = csg_state; e.mesh_stack = mesh_stack;
-            Rec rec;
-            csg_first<CSG_MAX_DEPTH>(e, idx, r, rec);
-            if (rec.flags & F_VALID) {
-                cand.prim = idx; cand.t = rec.t; cand.a0 = rec.a0; cand.a1 = rec.a1; cand.u = rec.u; cand.v = rec.v; cand.w = rec.w;
-                cand.leaf = rec.leaf; cand.flags = rec.flags; cand.hx = rec.hx; cand.hy = rec.hy; cand.hz = rec.hz;
-            }
-            return;
-        }
-    }
-    const Ray l = to_local(p, r);
-    if (p.type == RSX_PRIM_MESH) {
-        MeshHit mh;
-        if (mesh_trace(sc.meshes[p.mesh], l, mesh_stack, mh)) {
-            cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
-        }
-        return;
-    }
-    Roots roots;
-    roots.n = 0;
-    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
-    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
-    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
-    if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
-}
-
-// World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
-// that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
-// the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
-template <bool CSG>
-__device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
-                                 uint32_t &work, unsigned long long *phase_acc = nullptr) {
-    best.prim = -1;
-    double tmin = 0, tmax = 0;
-    const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
-    bool active = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
-    // the world tree is a handful of nodes per ray: its branch steps use the plain division, which keeps three refined
-    // reciprocals out of the registers that stay live across the mesh traversal
-    AxisDiv ad;
-    ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
-    int32_t node = 0, sp = 0;
-    while (__any(active)) {
-        double distance = 0;
-        int32_t count = 0;
-        const int32_t *items = sc.witems;
-        if (active) { UTIL_COUNT(phase_acc, 0) }
-        if (active) {
-            const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
-            distance = r.maxd < tmax ? r.maxd : tmax;
-            items += nd.u.leaf.first_item;
-            count = nd.count;
-        }
-        for (int32_t k = 0; __any(k < count); ++k) {
-            const bool have = k < count;
-            const int32_t idx = have ? items[k] : 0;
-            const rsx_primitive &p = sc.prims[idx];
-            double f, b;
-            const bool gate = have && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
-            const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
-            Hit cand;
-            cand.prim = -1;
-            work += CSG ? 16 : 4;
-            // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
-            // descriptor, array bases: scalar loads, SGPRs). Coherent waves meet one instance per leaf item; a wave that straddles
-            // several instances takes one turn per instance.
-            unsigned long long todo = __ballot(is_mesh);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
-                const bool mine = is_mesh && idx == uidx;
-                todo &= ~__ballot(mine);
-                const UPrim up = uniform_prim(sc.prims, uidx);
-                Ray l = r;
-                if (mine) l = to_local_uniform(up, r);
-                const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
-                MeshHit mh;
-                if (mesh_trace_wave(mine, um, l, mesh_stack, mh, work, phase_acc)) {
-                    cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
-                }
-            }
-            if (gate && !is_mesh) primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
-            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
-        }
-        if (active) {
-            if (best.prim >= 0 || sp == 0) active = false;
-            else {
-                --sp;
-                tmin = tmax;
-                stack_pop(st, sp, node, tmax);
-            }
-        }
-    }
-    return best.prim >= 0;
-}
-
-template <bool CSG>
-__device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
-    const rsx_primitive &p = sc.prims[h.prim];
-    if constexpr (CSG) {
-        if (is_csg(p.type)) { csg_geom(sc, r, h, g); return; }
-    }
-    const Ray l = to_local(p, r);
-    if (p.type == RSX_PRIM_MESH) mesh_geom(sc.meshes[p.mesh], l, h.t, h.a0, h.u, h.v, h.w, g);
-    else analytic_geom(p, l, h.t, h.a0, h.a1, g);
-}
-
-// ---------------------------------------------------------------------------------------------------
-// kernels
-// ---------------------------------------------------------------------------------------------------
-// carve the wave's LDS region and global spill region into the world stack and the mesh stack
-__device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &ms) {
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));       // uniform by construction: tell the compiler
-    const int lds_levels = sc.wlds + sc.mlds;
-    const uint32_t base = (uint32_t)wave * (uint32_t)(lds_levels * WAVE * 12 + STAGE_BYTES);
-    const uint32_t lds_t = base, lds_id = base + (uint32_t)lds_levels * WAVE * 8;
-    const int spill_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
-    const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
-    char *gbase = sc.spill + gwave * (size_t)(spill_levels > 0 ? spill_levels : 1) * WAVE * 12;
-    char *gt = gbase, *gid = gbase + (size_t)spill_levels * WAVE * 8;
-    float4 *stage = reinterpret_cast<float4 *>(smem + base + (size_t)lds_levels * WAVE * 12);
-    ws.stage = stage; ms.stage = stage;
-    ws.lds_t = lds_t; ws.lds_id = lds_id; ws.gt = gt; ws.gid = gid; ws.lds_levels = sc.wlds;
-    ms.lds_t = lds_t + (uint32_t)sc.wlds * WAVE * 8; ms.lds_id = lds_id + (uint32_t)sc.wlds * WAVE * 4;
-    ms.gt = gt + (size_t)(sc.wdepth - sc.wlds) * WAVE * 8; ms.gid = gid + (size_t)(sc.wdepth - sc.wlds) * WAVE * 4; ms.lds_levels = sc.mlds;
-}
-
-// XCD (accelerator complex die) this wave runs on: HW_REG_XCC_ID, bits [3:0]
-__device__ __forceinline__ int xcc_id() { return (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u); }
-
-// wave-level ticket: lane 0 takes the next batch of 64 work items
-__device__ __forceinline__ long long next_batch(unsigned long long *ticket) {
-    long long base = 0;
-    if (threadIdx.x % WAVE == 0) base = (long long)atomicAdd(ticket, 64ULL);
-    return __shfl(base, 0, WAVE);
-}
-
-struct HitOut {
-    int32_t *prim; double *t; uint8_t *exiting; int32_t *tri; float *uvw; double *geom;
-};
-
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
-                                                          const double *maxd, HitOut out, unsigned long long *ticket) {
-    Stack st, ms;
-    wave_stacks(sc, st, ms);
-    const int lane = threadIdx.x % WAVE;
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
-    for (;;) {
-        const long long base = next_batch(ticket);
-        if (base >= n) break;
-        const long long i = base + lane;
-        const bool valid = i < n;               // lanes without a ray still walk the loops: they help on big mesh leaves
-        Ray r;
-        r.ox = r.oy = r.oz = 0.0; r.dx = r.dy = 0.0; r.dz = 1.0; r.maxd = 0.0;
-        if (valid) {
-            r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
-            r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
-            r.maxd = maxd[i];
-        }
-        Hit h;
-        uint32_t work = 0;
-        const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h, work);
-        if (!valid) continue;
-        out.prim[i] = hit ? h.prim : -1;
-        if (out.t) out.t[i] = hit ? h.t : NAN;
-        bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
-        if constexpr (CSG) {   // a CSG node hands back its operand's MeshIntersection (triangle, u, v, w survive the lift)
-            if (hit && is_csg(sc.prims[h.prim].type)) mesh = sc.prims[h.leaf].type == RSX_PRIM_MESH;
-        }
-        if (out.tri) out.tri[i] = mesh ? h.a0 : -1;
-        if (out.uvw) { out.uvw[3 * i] = mesh ? h.u : 0.0f; out.uvw[3 * i + 1] = mesh ? h.v : 0.0f; out.uvw[3 * i + 2] = mesh ? h.w : 0.0f; }
-        if (out.exiting || out.geom) {
-            Geom g;
-            if (hit) finalise<CSG>(sc, r, h, g);
-            if (out.exiting) out.exiting[i] = hit ? (g.exiting ? 1 : 0) : 0;
-            if (out.geom) {
-                double *o = out.geom + 12 * i;
-                for (int k = 0; k < 3; ++k) {
-                    o[k] = hit ? g.hit[k] : NAN; o[3 + k] = hit ? g.inside[k] : NAN;
-                    o[6 + k] = hit ? g.outside[k] : NAN; o[9 + k] = hit ? g.normal[k] : NAN;
-                }
-            }
-        }
-    }
-}
-
-// Primitive.hit + next_intersection() sequence on one primitive (tests / Primitive API parity).
-// Mesh.next_intersection re-traces from hit + d*1e-6 with max - t - 1e-6 (mesh.pyx:1240-1275).
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, long long n, const double *origin, const double *direction,
-                                                      const double *maxd, int32_t max_roots, int32_t *counts, double *t, uint8_t *exiting,
-                                                      double *geom, int32_t *tri, float *uvw, unsigned long long *ticket) {
-    Stack st, ms;
-    wave_stacks(sc, st, ms);
-    const int lane = threadIdx.x % WAVE;
-    const rsx_primitive &p = sc.prims[pidx];
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
-    for (;;) {
-        const long long base = next_batch(ticket);
-        if (base >= n) break;
-        const long long i = base + lane;
-        if (i >= n) continue;
-        Ray r;
-        r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
-        r.dx = direction[3 * i]; r.dy = direction[3 * i + 1]; r.dz = direction[3 * i + 2];
-        r.maxd = maxd[i];
-        Ray l = to_local(p, r);
-        int32_t c = 0;
-        // optional per-root outputs: Intersection geometry in primitive space (hit, inside, outside, normal) and, for mesh
-        // surfaces, the MeshIntersection extras (triangle, u, v, w) — intersection.pyx:36-106, mesh.pyx:85-135
-        auto emit = [&](int32_t k, const Geom &g, int32_t triangle, float bu, float bv, float bw) {
-            const size_t at = (size_t)i * max_roots + k;
-            if (geom) {
-                double *o = geom + 12 * at;
-                for (int q = 0; q < 3; ++q) { o[q] = g.hit[q]; o[3 + q] = g.inside[q]; o[6 + q] = g.outside[q]; o[9 + q] = g.normal[q]; }
-            }
-            if (tri) tri[at] = triangle;
-            if (uvw) { uvw[3 * at] = bu; uvw[3 * at + 1] = bv; uvw[3 * at + 2] = bw; }
-        };
-        if (CSG && is_csg(p.type)) {
-            if constexpr (CSG) {
-                CsgEval e;
-                e.sc = &sc; e.st = csg_state;
-                e.mesh_stack = ms;
-                Rec rec;
-                csg_first<CSG_MAX_DEPTH>(e, pidx, r, rec);
-                while ((rec.flags & F_VALID) && c < max_roots) {
-                    t[i * max_roots + c] = rec.t;
-                    exiting[i * max_roots + c] = (rec.flags & F_EXIT) ? 1 : 0;
-                    if (geom || tri || uvw) {
-                        Hit h;
-                        h.prim = pidx; h.t = rec.t; h.a0 = rec.a0; h.a1 = rec.a1; h.u = rec.u; h.v = rec.v; h.w = rec.w;
-                        h.leaf = rec.leaf; h.flags = rec.flags; h.hx = rec.hx; h.hy = rec.hy; h.hz = rec.hz;
-                        Geom g;
-                        csg_geom(sc, r, h, g);
-                        const bool on_mesh = sc.prims[rec.leaf].type == RSX_PRIM_MESH;
-                        emit(c, g, on_mesh ? rec.a0 : -1, on_mesh ? rec.u : 0.0f, on_mesh ? rec.v : 0.0f, on_mesh ? rec.w : 0.0f);
-                    }
-                    ++c;
-                    csg_next<CSG_MAX_DEPTH>(e, pidx, rec);
-                }
-            }
-        } else if (p.type == RSX_PRIM_MESH) {
-            const DMesh &m = sc.meshes[p.mesh];
-            double accumulated = 0;
-            MeshHit mh;
-            while (c < max_roots && mesh_trace(m, l, ms, mh)) {
-                Geom g;
-                mesh_geom(m, l, (double)mh.t, mh.tri, mh.u, mh.v, mh.w, g);
-                const double dist = (double)mh.t + accumulated;
-                t[i * max_roots + c] = dist;
-                exiting[i * max_roots + c] = g.exiting ? 1 : 0;
-                emit(c, g, mh.tri, mh.u, mh.v, mh.w);
-                ++c;
-                l.ox = g.hit[0] + l.dx * MESH_EPS; l.oy = g.hit[1] + l.dy * MESH_EPS; l.oz = g.hit[2] + l.dz * MESH_EPS;
-                l.maxd = l.maxd - (double)mh.t - MESH_EPS;
-                accumulated = dist + MESH_EPS;
-            }
-        } else if (p.type <= RSX_PRIM_CYLINDER) {
-            Roots roots;
-            roots.n = 0;
-            if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
-            else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
-            else cylinder_roots(p, l, roots);
-            for (int k = 0; k < roots.n && c < max_roots; ++k) {
-                Geom g;
-                analytic_geom(p, l, roots.t[k], roots.a0[k], roots.a1[k], g);
-                t[i * max_roots + c] = roots.t[k];
-                exiting[i * max_roots + c] = g.exiting ? 1 : 0;
-                emit(c, g, -1, 0.0f, 0.0f, 0.0f);
-                ++c;
-            }
-        }
-        counts[i] = c;
-    }
-}
-
-// World.contains — kdtree3d.pyx:736-792, kdtree.pyx:126-162, primitive contains():
-//   sphere.pyx:202-214, box.pyx:344-361, cylinder.pyx:356-372, mesh.pyx:1277-1297 (+802-830)
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n, const double *points, uint8_t *inside,
-                                                         unsigned long long *ticket) {
-    Stack st, ms;
-    wave_stacks(sc, st, ms);
-    const int lane = threadIdx.x % WAVE;
-    for (;;) {
-        const long long base = next_batch(ticket);
-        if (base >= n) break;
-        const long long i = base + lane;
-        if (i >= n) continue;
-        const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
-        for (int j = 0; j < sc.n_world; ++j) inside[i * sc.n_world + j] = 0;
-        if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) continue;
-        int32_t node = 0;
-        rsx_kdnode nd = load_node(sc.wnodes, node);
-        while (nd.type >= 0) {
-            node = sel3(nd.type, px, py, pz) < nd.u.split ? node + 1 : nd.count;
-            nd = load_node(sc.wnodes, node);
-        }
-        for (int32_t k = 0; k < nd.count; ++k) {
-            const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
-            const rsx_primitive &p = sc.prims[idx];
-            bool in;
-            if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);   // BoundPrimitive.contains: box gate first
-            else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
-            inside[i * sc.n_world + idx] = in ? 1 : 0;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// observe(): sample generation + trace + shading  ->  per-sample records; then per-(pixel,bin) Welford
-// ---------------------------------------------------------------------------------------------------
-// Philox4x32-10 (Salmon et al. 2011): counter = (pixel, sample), key = seed
-__device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t sample, double &u1, double &u2) {
-    uint32_t c0 = (uint32_t)pixel, c1 = (uint32_t)(pixel >> 32), c2 = (uint32_t)sample, c3 = (uint32_t)(sample >> 32);
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
-        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1, n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
-        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    const uint64_t a = ((uint64_t)c1 << 32) | c0, b = ((uint64_t)c3 << 32) | c2;
-    u1 = (double)(a >> 11) * (1.0 / 9007199254740992.0);
-    u2 = (double)(b >> 11) * (1.0 / 9007199254740992.0);
-}
-
-// clock the unit costs are measured with (only ever compared within one lane's cost array)
-// Unit cost that steers the longest-first schedule = the wave's own count of traversal rounds (`work`): free and deterministic.
-// Reading s_memrealtime / s_memtime around every unit was measured on configs[2]: the reads serialise chip-wide (~9 ns each
-// whatever the occupancy) and doubled the kernel time of a 4.2 M-unit pass.
-#ifndef RSX_LPT_MAX_UNITS
-#define RSX_LPT_MAX_UNITS (1 << 18)   // passes with more 64-ray units than this are not re-ordered
-#endif
-struct RenderParams {
-    rsx_camera cam;
-    const rsx_material *materials;
-    const int32_t *tasks;      // device [n_tasks,2] or null
-    const double *uniforms;    // device or null
-    long long n_tasks;
-    int32_t rect[4];
-    int32_t spp, rng_mode;
-    uint64_t seed, sample_offset;
-    uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
-    const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
-    const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
-    int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
-    unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
-};
-
-// per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
-struct Sample {
-    double a, weight;
-    int32_t table, pad;
-};
-
-__device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, int &ix, int &iy) {
-    if (rp.tasks) { ix = rp.tasks[2 * k]; iy = rp.tasks[2 * k + 1]; }
-    else { const int w = rp.rect[2] - rp.rect[0]; ix = rp.rect[0] + (int)(k % w); iy = rp.rect[1] + (int)(k / w); }
-}
-
-// Work item g = (task k, sample s). In rect mode a wave covers an 8x8 pixel tile of one sample index so its
-// 64 rays stay coherent; in task-list mode 64 consecutive tasks.
-struct UnitPixel {
-    long long k, slot;         // task index (row-major in rect mode) and sample-record slot (x-major in rect mode, like the frame)
-    int ix, iy, s;
-    bool valid;
-};
-
-__device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams *q, long long unit, int lane) {
-    UnitPixel px;
-    const int spp = q->spp;
-    px.s = (int)(unit % spp);
-    const long long chunk = unit / spp;
-    if (q->tasks) {
-        px.k = chunk * 64 + lane;
-        px.valid = px.k < q->n_tasks;
-        if (!px.valid) px.k = 0;
-        px.ix = q->tasks[2 * px.k]; px.iy = q->tasks[2 * px.k + 1];
-        px.slot = px.k;
-    } else {
-        const int w = q->rect[2] - q->rect[0], h = q->rect[3] - q->rect[1];
-        const int tiles_x = (w + 7) / 8;
-        const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
-        const int lx = tx * 8 + (lane & 7), ly = ty * 8 + (lane >> 3);
-        px.valid = lx < w && ly < h;
-        px.ix = q->rect[0] + (px.valid ? lx : 0); px.iy = q->rect[1] + (px.valid ? ly : 0);
-        px.k = px.valid ? (long long)ly * w + lx : 0;
-        px.slot = px.valid ? (long long)lx * h + ly : 0;
-    }
-    return px;
-}
-
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
-    Stack st, ms;
-    wave_stacks(sc, st, ms);
-    const int lane = threadIdx.x % WAVE;
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
-    // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
-    // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
-    const int my_xcd = xcc_id();
-    int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
-    for (;;) {
-        // Render parameters are re-read from the kernel-argument segment at every use site of the unit loop (the pointer is
-        // laundered through an empty asm): hoisted out of the loop, the camera matrix and friends sat in ~30 vector registers
-        // through the whole traversal, where registers decide how many waves fit a SIMD. `rp` itself is only named for its layout.
-        (void)rp;
-        // (`rp` is read where it lies in the kernel-argument segment — second argument, after `sc` — so that no private copy is made)
-        unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
-        asm volatile("" : "+s"(rp_bits));
-        const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
-        long long tk = -1;
-        while (victim < 8) {
-            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
-            const long long begin = q->seg[list], end = q->seg[list + 1];
-            unsigned long long mine = 0;
-            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
-            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
-                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
-            if (got < end) { tk = got; break; }
-            ++victim;
-        }
-        if (tk < 0) break;
-        int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
-        const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
-#if RSX_PHASE_PROF
-        unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#elif RSX_UTIL_PROF
-        unsigned long long *phase_acc = q->unit_times ? q->unit_times + 12 * (long long)unit + 3 : nullptr;   // caller zeroes the buffer
-#else
-        unsigned long long *phase_acc = nullptr;
-#endif
-        const UnitPixel px = unit_pixel(q, unit, lane);
-        const bool valid = px.valid;
-        // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
-        double u1, u2;
-        if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
-        else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
-        const double delta = q->cam.image_delta, half = 0.5 * delta;
-        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
-        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
-        // the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc)
-        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
-        normalise3(dx, dy, dz);
-        const double weight = dz;
-        Ray r;
-        {
-            const RSX_CONST_AS double *m = q->cam.to_root;                    // observer.pyx:403-404: origin (0,0,0) and direction to world
-            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
-            wq = 1.0 / wq;
-            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
-            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
-            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
-            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
-            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
-            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
-        }
-        r.maxd = INFINITY;
-        Hit hit;
-        uint32_t work = 0;
-        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
-        // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
-        // compiler cannot merge this with the computation above)
-        asm volatile("" : "+s"(unit));
-        asm volatile("" : "+s"(rp_bits));
-        const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
-        if (q2->measure_cost && lane == 0) {
-            unsigned long long c = (unsigned long long)work;
-            if (c > 0x7fffffffULL) c = 0x7fffffffULL;
-            q2->unit_cost[unit] = (uint32_t)c;
-        }
-        if (q2->unit_times && lane == 0) {
-            q2->unit_times[12 * unit] = t_start;
-            q2->unit_times[12 * unit + 1] = wall_clock64();
-            q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
-#if RSX_PHASE_PROF
-            for (int ph = 0; ph < 8; ++ph) q2->unit_times[12 * unit + 3 + ph] = phase_acc[ph];
-#endif
-        }
-        const UnitPixel px2 = unit_pixel(q2, unit, lane);
-        if (!px2.valid) continue;
-        Sample smp;
-        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
-        if (got) {                                                                 // optical/ray.pyx:391-393
-            const rsx_primitive &p = sc.prims[hit.prim];
-            const rsx_material mat = q2->materials[p.material];
-            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }   // emitter/uniform.pyx:67-81
-            else if (mat.type == RSX_MAT_DEBUG_LIGHT) {                      // debug.pyx:67-79
-                if (mat.scale != 0.0) {
-                    Geom g;
-                    finalise<CSG>(sc, r, hit, g);
-                    double lx, ly, lz;
-                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
-                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
-                    smp.a = mat.scale * (dot > 0 ? dot : 0.0);
-                    smp.table = mat.table;
-                }
-            }
-        }
-        samples[px2.slot * q2->spp + px2.s] = smp;
-    }
-}
-
-// Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.
-__global__ void k_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long *mismatches) {
-    const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-    unsigned long long bad = 0;
-    for (unsigned long long i = gid; i < n; i += stride) {
-        double u1, u2;
-        philox2(seed, i, 0, u1, u2);
-        double a, b;
-        philox2(seed, i, 1, a, b);
-        double num, den;
-        switch (i & 7) {
-        case 0: num = (u1 - 0.5) * 4.0; den = (u2 - 0.5) * 2.0; break;                      // plane distances: (split - o) / d
-        case 1: num = ldexp(u1 - 0.5, (int)(a * 120) - 60); den = ldexp(u2 - 0.5, (int)(b * 120) - 60); break;
-        case 2: den = (u2 - 0.5) * 2.0; num = den * (double)(long long)(u1 * 4096.0 - 2048.0); break;   // exact quotients
-        case 3: den = 1.0 + u2 * 0x1p-30; num = 1.0 + u1 * 0x1p-30; break;                 // quotients hugging 1 (near ties)
-        case 4: den = (double)(1 + (long long)(u2 * 1e6)); num = (double)(long long)(u1 * 2e6 - 1e6); break;   // small integers
-        case 5: num = ldexp(u1 - 0.5, (int)(a * 1200) - 600); den = ldexp(u2 - 0.5, (int)(b * 1200) - 600); break;   // wide exponents (guard path)
-        case 6: num = (i & 8) ? 0.0 : -0.0; den = (u2 - 0.5); break;                        // zero numerators
-        default: den = u2 * 1e-3 + 1e-300 * a; num = u1 - 0.5; break;                       // tiny denominators
-        }
-        if (den == 0.0) continue;
-        const double want = num / den;
-        const double got = exact_div(num, den, refine_rcp(den), div_operand_safe(den));
-        if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
-    }
-    if (bad) atomicAdd(mismatches, bad);
-}
-
-// Longest-processing-time-first schedule for the next pass over the same units: counting sort of the measured unit costs into
-// 128 logarithmic buckets, most expensive first. A few silhouette tiles cost 50x the median (grazing rays cross hundreds of KD
-// cells); handing them out first lets the cheap bulk fill in behind them instead of leaving one wave to finish alone.
-#define ORDER_BUCKETS 128
-__device__ __forceinline__ int cost_bucket(uint32_t c) {
-    if (c == 0) return 0;
-    const int lg = 31 - __clz((int)c);                      // floor(log2 c)
-    const int frac = lg >= 2 ? (int)((c >> (lg - 2)) & 3) : 0;   // two mantissa bits -> quarter-octave resolution
-    const int b = lg * 4 + frac;
-    return b < ORDER_BUCKETS ? b : ORDER_BUCKETS - 1;
-}
-
-#ifndef RSX_HEAVY_FACTOR
-#define RSX_HEAVY_FACTOR 3ULL
-#endif
-
-// which XCD's list a unit belongs to: 4x4-tile blocks (32x32 pixels) are dealt round-robin to the 8 XCDs, so each L2 caches the
-// geometry behind an eighth of the image while every XCD still gets a fair share of cheap and expensive regions
-__device__ __forceinline__ int unit_xcd(long long unit, int tiles_x, int spp) {
-    const long long chunk = unit / spp;
-    if (tiles_x > 0) { const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x); return ((tx >> 2) + 3 * (ty >> 2)) & 7; }
-    return (int)((chunk >> 4) & 7);
-}
-
-// list 0: units well above the mean cost (latency-bound stragglers: every XCD takes them first); lists 1..8: the rest, by XCD
-__device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned long long mean, int tiles_x, int spp) {
-    if ((unsigned long long)c > RSX_HEAVY_FACTOR * mean) return 0;
-    return 1 + unit_xcd(unit, tiles_x, spp);
-}
-
-// One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
-// and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
-__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp) {
-    __shared__ unsigned int hist[9][ORDER_BUCKETS];
-    __shared__ unsigned int offset[9][ORDER_BUCKETS];
-    __shared__ unsigned long long total;
-    unsigned int *hflat = &hist[0][0];
-    for (int b = threadIdx.x; b < 9 * ORDER_BUCKETS; b += blockDim.x) hflat[b] = 0;
-    if (threadIdx.x == 0) total = 0;
-    __syncthreads();
-    unsigned long long part_sum = 0;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) part_sum += cost[i];
-    atomicAdd(&total, part_sum);
-    __syncthreads();
-    const unsigned long long mean = total / (unsigned long long)n + 1;
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t c = cost[i];
-        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u);
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned int run = 0;
-        for (int x = 0; x < 9; ++x) {
-            seg[x] = run;
-            for (int b = ORDER_BUCKETS - 1; b >= 0; --b) { offset[x][b] = run; run += hist[x][b]; }
-        }
-        seg[9] = run;
-    }
-    __syncthreads();
-    for (long long i = threadIdx.x; i < n; i += blockDim.x) {
-        const uint32_t c = cost[i];
-        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
-    }
-}
-
-// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859.
-// Every division here is by a small positive integer whose refined reciprocal is shared by the two divisions of consecutive
-// Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
-// rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
-// (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
-struct IntRcp {
-    double d, y;
-    __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
-    __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
-};
-
-// n -> n + 1 samples; `by_n` = IntRcp(n + 1), `by_nm1` = IntRcp(n) (the divisors of the update)
-__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n, const IntRcp &by_n, const IntRcp &by_nm1) {
-    if (n == 0) { n = 1; m = x; v = 0; return; }
-    const double pm = m, pv = v;
-    const int pn = n > 1 ? n : 2;
-    n += 1;
-    m = pm + by_n.div(x - pm);
-    v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
-}
-
-__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
-    if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
-    if (nx > 1 && ny > 1) {
-        nt = nx + ny;
-        const IntRcp by_nt(nt);
-        mt = by_nt.div(nx * mx + ny * my);
-        vx = IntRcp(nx).div((nx - 1) * vx);
-        vy = IntRcp(ny).div((ny - 1) * vy);
-        vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
-        vt = IntRcp(nt - 1).div(nt * vt);
-        return;
-    }
-    if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
-    else if (nx == 1) {
-        if (ny == 0) { nt = 1; mt = mx; vt = 0; }
-        else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
-    } else if (nx > 1) {
-        nt = nx; mt = mx; vt = vx;
-        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
-    } else { nt = 0; mt = 0; vt = 0; }
-}
-
-// One thread per (task, bin): sequential Welford over the task's spp samples in sample order
-// (SpectralRadiance/PowerPixelProcessor.add_sample, pipeline/spectral/power.pyx:468-486, radiance.pyx:245-263).
-// frame == null: write per-task (mean, variance) like _render_pixel packs them; else merge into the
-// device-resident frame with the combine_samples law (Pipeline2D.update, power.pyx:424-437).
-struct AccumParams {
-    const Sample *samples;
-    const double *tables;
-    const int32_t *tasks;
-    long long n_tasks;
-    int32_t rect[4];
-    int32_t ny, bins, spp, power;
-    int32_t n_tables, pad;
-    double sensitivity;
-    double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
-    double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
-    int32_t frame_bins, slice_offset;
-    unsigned long long *ticket;         // work tickets of the trace kernel: re-armed here for the next launch
-};
-
-// Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
-// kernel wrote, so both streams are read and written as contiguous runs. Task-list mode keeps task order.
-#define ACC_RCP_TABLE_MAX 4096      // samples per pixel per pass up to which the reciprocal table is kept in LDS
-#ifndef ACC_BATCH
-#define ACC_BATCH 4                 // sample records whose loads are issued together
-#endif
-
-template <bool STAGED>                  // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form
-__global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
-    // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
-    extern __shared__ __attribute__((aligned(16))) double acc_lds[];
-    constexpr bool staged = STAGED;                         // few samples per pixel: not worth a barrier, read the tables from global
-    const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
-    const int n_rcp = rcp_table ? ap.spp + 2 : 2;
-    double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
-    if (staged) {
-        for (int d = threadIdx.x + 1; d < n_rcp; d += blockDim.x) acc_rcp[d] = refine_rcp((double)d);
-        for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];
-        __syncthreads();
-    }
-    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = ap.n_tasks * ap.bins;
-    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
-    if (gid >= total) return;
-    long long p;
-    int b;
-    if (total < (1LL << 31)) { p = (uint32_t)gid / (uint32_t)ap.bins; b = (int)((uint32_t)gid % (uint32_t)ap.bins); }   // 32-bit divide when it fits
-    else { p = gid / ap.bins; b = (int)(gid % ap.bins); }
-    long long k = p;                                        // task index (row-major in rect mode): addresses the per-task outputs
-    int ix, iy;
-    if (ap.tasks) { ix = ap.tasks[2 * p]; iy = ap.tasks[2 * p + 1]; }
-    else {
-        const int w = ap.rect[2] - ap.rect[0], h = ap.rect[3] - ap.rect[1];
-        const int lx = (int)((uint32_t)p / (uint32_t)h), ly = (int)((uint32_t)p % (uint32_t)h);
-        ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
-        k = (long long)ly * w + lx;
-    }
-    const Sample *s = ap.samples + p * ap.spp;
-    // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
-    auto value = [&](const Sample &smp) {
-        const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
-        const double tab = staged ? acc_tab[e] : ap.tables[e];
-        double x = smp.table < 0 ? 0.0 : smp.a * tab;
-        x = x * smp.weight;
-        if (ap.power) x = x * ap.sensitivity;
-        return x;
-    };
-    // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
-    // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
-    // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
-    double m = value(s[0]), v = 0;
-    double dm = 1.0;                                        // (double)i, advanced by exact additions
-    auto step = [&](double x, int i) {
-        const double dn = dm + 1.0, c = i == 1 ? 1.0 : dm - 1.0;
-        const double yn = rcp_table ? acc_rcp[i + 1] : refine_rcp(dn), ym = rcp_table ? acc_rcp[i] : refine_rcp(dm);
-        const double pm = m, pv = v;
-        m = pm + exact_div(x - pm, dn, yn, true);
-        v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
-        dm = dn;
-    };
-    int i = 1;
-    for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
-        Sample sm[ACC_BATCH];
-#pragma unroll
-        for (int j = 0; j < ACC_BATCH; ++j) sm[j] = s[i + j];
-#pragma unroll
-        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j]), i + j);
-    }
-    for (; i < ap.spp; ++i) step(value(s[i]), i);
-    if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
-    if (ap.fmean) {
-        const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
-        if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
-        double mt, vt;
-        int nt;
-        combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
-        ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, double *va, int32_t *na, const double *mb,
-                                                       const double *vb, const int32_t *nb) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    if (nb[i] < 1) return;
-    double v = vb[i];
-    if (v < 0) v = 0;
-    double mt, vt;
-    int nt;
-    combine_samples(ma[i], va[i], na[i], mb[i], v, nb[i], mt, vt, nt);
-    ma[i] = mt; va[i] = vt; na[i] = nt;
-}
+#include "dev_common.hpp"
+#include "dev_mesh.hpp"
+#include "dev_analytic.hpp"
+#include "dev_csg.hpp"
+#include "dev_world.hpp"
+#include "dev_query_kernels.hpp"
+#include "dev_render.hpp"
 
 // ---------------------------------------------------------------------------------------------------
 // host API

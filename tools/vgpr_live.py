@@ -2,7 +2,7 @@
 """Register-pressure map of one kernel from hipcc's device assembly (tuning aid).
 
     hipcc --offload-arch=gfx950 -O3 ... -gline-tables-only --offload-device-only -S rsx_device.hip -o dev.s
-    tools/vgpr_live.py dev.s _Z14k_render_traceILb0E [top]
+    tools/vgpr_live.py dev.s _Z14k_render_traceILb0E [top] [file:first-last,file:first-last,...]
 
 Backward liveness over the kernel's basic blocks on the VGPR operands (first operand of a VALU / load instruction = definition,
 everything else = use; compares, stores, readlane define no VGPR), then the live count at every instruction, reported per source
@@ -101,8 +101,12 @@ for k, v in sorted(per_line.items(), key=lambda kv: -kv[1])[:top]:
 
 # optional: passengers at the peak — live registers that no instruction of the given source-line ranges touches
 if len(sys.argv) > 4:
-    ranges = [tuple(int(x) for x in r.split("-")) for r in sys.argv[4].split(",")]
-    inside = lambda k: k and k[0].startswith("rsx_device") and any(a <= k[1] <= b for a, b in ranges)
+    ranges = []
+    for r in sys.argv[4].split(","):
+        name, span = r.split(":")
+        first, last = span.split("-")
+        ranges.append((name, int(first), int(last)))
+    inside = lambda k: k and any(k[0] == f and a <= k[1] <= b for f, a, b in ranges)
     touched = set()
     for op, d, u, loc, tgt in insts:
         if inside(loc):
