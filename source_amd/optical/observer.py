@@ -73,6 +73,25 @@ class HipEngine(RenderEngine):
         observer._render_slice_device(tasks, slice_id, template, self, update, update_args, update_kwargs)
 
 
+class SerialEngine(HipEngine):
+    """Drop-in for raysect.core.SerialEngine (workflow.py:100-146): same constructor, and — for the closed-form materials this
+    round covers — the same frames bit for bit, because the jitter is drawn from the reference's MT19937-64 stream in task order."""
+
+    def __init__(self):
+        super().__init__(rng="stream")
+
+
+class MulticoreEngine(HipEngine):
+    """Drop-in for raysect.core.MulticoreEngine (workflow.py:149-326). The reference farms tasks to `processes` workers, each
+    re-seeded from os.urandom (workflow.py:302-305), so it defines no reproducible stream; here the work goes to the GPU with the
+    counter-based generator. `processes`, `tasks_per_job` and `start_method` are accepted and ignored."""
+
+    def __init__(self, processes=None, tasks_per_job=None, start_method="fork", seed=None):
+        import os as _os
+        super().__init__(rng="philox", seed=int.from_bytes(_os.urandom(8), "little") if seed is None else seed)
+        self.processes, self.tasks_per_job, self.start_method = processes, tasks_per_job, start_method
+
+
 # ---------------------------------------------------------------------------------------------------
 # frame sampler / pipelines
 # ---------------------------------------------------------------------------------------------------

@@ -221,6 +221,15 @@ def test_frames_c2_stream_parity(ns, golden):
     cam, pipe = scenes.c2_camera(ns, world, (40, 40), spp=4, bins=15)
     m, v, n = _observe(ns, cam, pipe, 1)
     assert eq(m, g["c2_mean"]) and eq(v, g["c2_var"]) and eq(n, g["c2_n"])
+    # the same script a Raysect user writes: seed both generators, camera.render_engine = SerialEngine(), observe()
+    import random as pyrandom
+    from source_amd.core import random as rsrandom
+    cam2, pipe2 = scenes.c2_camera(ns, world, (40, 40), spp=4, bins=15)
+    pyrandom.seed(1)
+    rsrandom.seed(1)
+    cam2.render_engine = ns.SerialEngine()
+    cam2.observe()
+    assert eq(pipe2.frame.mean, g["c2_mean"]) and eq(pipe2.frame.variance, g["c2_var"])
     m, v, n = _observe(ns, cam, pipe, 2)                     # accumulate=True second pass
     assert eq(m, g["c2_mean2"]) and eq(v, g["c2_var2"]) and eq(n, g["c2_n2"])
 

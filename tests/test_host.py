@@ -106,6 +106,11 @@ def test_observer_defaults_and_slicing(ns):
         cam.fov = 180
     tasks = ns.FullFrameSampler2D().generate_tasks((3, 2))
     assert sorted(tasks) == [(x, y) for x in range(3) for y in range(2)]
+    # the reference's engine names are accepted where a render engine is expected
+    serial, multi = ns.SerialEngine(), ns.MulticoreEngine(processes=8)
+    assert isinstance(serial, ns.RenderEngine) and serial.rng == "stream" and serial.worker_count() == 1
+    assert multi.rng == "philox" and multi.processes == 8 and ns.MulticoreEngine(seed=5).seed == 5
+    cam.render_engine = serial
 
 
 def test_rsm_reader_and_obj_io(ns, golden, tmp_path):

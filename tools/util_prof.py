@@ -32,5 +32,13 @@ _lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, None))
 host = np.zeros((n_units, 12), dtype=np.uint64)
 ctx.download(host, buf)
 c = host[:, 3:11].astype(np.float64).sum(axis=0)
+if os.environ.get("PHASES"):       # library built with -DRSX_PHASE_PROF=1: s_memtime cycles per phase of mesh_trace_wave
+    total = (host[:, 1] - host[:, 0]).astype(np.float64).sum()       # 100 MHz ticks per unit, summed
+    names = ["loop head", "descend", "small leaves", "big leaves (coop)", "pop"]
+    tot = c[:5].sum()
+    for nme, v in zip(names, c[:5]):
+        print("%-18s %.3f of the mesh loop" % (nme, v / tot))
+    print("mesh-loop iterations %.4g, lanes active per iteration %.1f, big-leaf lanes per iteration %.3f" % (c[5], c[7] / c[5], c[6] / c[5]))
+    sys.exit(0)
 for name, k in (("world loop", 0), ("mesh loop", 2), ("node steps", 4), ("leaf batches", 6)):
     print("%-13s active lane-slots %.4g of %.4g  -> utilisation %.3f" % (name, c[k], c[k + 1], c[k] / max(c[k + 1], 1)))
