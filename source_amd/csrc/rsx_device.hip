@@ -785,7 +785,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // Small passes are tail-bound and overlap well; a large pass fills the chip by itself (its merge kernel could not even get
     // registers next to it), so it runs alone on the ctx stream.
     const long long rect_w = desc->rect[2] - desc->rect[0], rect_h = desc->rect[3] - desc->rect[1];
-    const long long n_units_all = desc->tasks ? ((desc->n_tasks + 63) / 64) * desc->spp : ((rect_w + 7) / 8) * ((rect_h + 7) / 8) * (long long)desc->spp;
+    // unit shape (see UnitShape in dev_render.hpp): spu samples of 64 / spu pixels per 64-ray unit
+    int spu_log2 = 0;
+    while (spu_log2 < 6 && desc->spp % (2 << spu_log2) == 0) ++spu_log2;
+    const int pix_log2 = 6 - spu_log2, pw_log2 = (pix_log2 + 1) / 2, ph_log2 = pix_log2 / 2;      // 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
+    const long long groups = desc->spp >> spu_log2;
+    const long long tiles_x_all = (rect_w + (1 << pw_log2) - 1) >> pw_log2, tiles_y_all = (rect_h + (1 << ph_log2) - 1) >> ph_log2;
+    const long long n_units_all = (desc->tasks ? (desc->n_tasks + (WAVE >> spu_log2) - 1) / (WAVE >> spu_log2) : tiles_x_all * tiles_y_all) * groups;
     const bool pipelined = !h_mean && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
@@ -845,10 +851,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.unit_times = ctx->unit_times;
+    rp.spu_log2 = spu_log2; rp.pw_log2 = pw_log2; rp.ph_log2 = ph_log2; rp.groups = (int32_t)groups;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured
     {
         const long long w = desc->rect[2] - desc->rect[0], h = desc->rect[3] - desc->rect[1];
-        const long long n_units = desc->tasks ? ((desc->n_tasks + 63) / 64) * desc->spp : ((w + 7) / 8) * ((h + 7) / 8) * (long long)desc->spp;
+        const long long n_units = n_units_all;
+        (void)w; (void)h;
         uint64_t sig = 1469598103934665603ULL;                       // FNV-1a over what defines the units' content
         auto mix = [&sig](const void *q, size_t bytes) { const unsigned char *c = static_cast<const unsigned char *>(q); for (size_t i = 0; i < bytes; ++i) { sig ^= c[i]; sig *= 1099511628211ULL; } };
         const void *scene_id = scene;
@@ -872,10 +880,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // the work lists for this pass were sorted right after the lane's previous pass over the same units (see below);
         // a first pass (or a changed camera / task list) sorts zero costs, i.e. natural order split over the XCD lists
         if (n_units >= (1LL << 26)) return rsx_fail(RSX_EUNSUPPORTED, "render: more than 2^26 work units in one launch; split the call");
-        order_tiles_x = desc->tasks ? 0 : (int)((w + 7) / 8);
+        order_tiles_x = desc->tasks ? 0 : (int)tiles_x_all;
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
-            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp);
+            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)groups, pw_log2, ph_log2);
             HIP_TRY(hipGetLastError());
         }
         rp.unit_order = lane.unit_order;
@@ -922,7 +930,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
-        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp);
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)groups, pw_log2, ph_log2);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
     }
