@@ -82,7 +82,7 @@ __device__ __forceinline__ void leaf_fetch(const int32_t *items, const float4 *t
 }
 
 #ifndef RSX_LEAF_BATCH
-#define RSX_LEAF_BATCH 4           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
+#define RSX_LEAF_BATCH 3           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
 #endif
 
 __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
