@@ -14,7 +14,7 @@ from source_amd.device import get_context  # noqa: E402
 cfg = sys.argv[1] if len(sys.argv) > 1 else "c3"
 if cfg == "c3":
     world = scenes.build_c3(ns, n=132)[0]
-    cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=4, bins=15)
+    cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=int(os.environ.get("SPP", "4")), bins=15)
 else:
     world = scenes.build_c2(ns, n=132)[0]
     cam, pipe = scenes.c2_camera(ns, world, (1024, 1024), spp=1, bins=15)
@@ -22,7 +22,7 @@ cam.frame_sampler = ns.RectFrameSampler2D()
 cam.render_engine = ns.HipEngine(rng="philox", seed=20250905, timing=False)
 ctx = get_context()
 world.build_accelerator()
-n_units = (cam.pixels[0] // 8) * (cam.pixels[1] // 8) * cam.pixel_samples
+n_units = cam.pixels[0] * cam.pixels[1] * cam.pixel_samples // 64
 buf = ctx.alloc(n_units * 12 * 8)
 ctx.memset(buf, 0, n_units * 12 * 8)
 _lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, buf))
