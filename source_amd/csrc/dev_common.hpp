@@ -266,8 +266,25 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
                                                double &tmax, const Stack &st, int32_t &sp) {
     const double split = nd.u.split;
     const int32_t lower = node + 1, upper = nd.count;
-    if (d == 0) return o < split ? lower : upper;
-    const double plane = exact_div(split - o, d, y, d_safe);
+    // the two rare cases — a ray parallel to the plane, operands outside the range of the hoisted-reciprocal quotient — sit behind
+    // wave-level tests: a scalar jump over them in the common case instead of an exec-mask save / restore around each
+    if (__builtin_expect(__any(d == 0), 0)) {
+        if (d == 0) return o < split ? lower : upper;
+    }
+    const double num = split - o;
+#if RSX_FAST_DIV
+    const double q0 = num * y;
+    const double rem = __builtin_fma(-d, q0, num);
+    double plane = __builtin_fma(rem, y, q0);
+    const bool zero = num == 0.0;
+    plane = zero ? q0 : plane;                          // 0 * y: signed zero with the quotient's sign
+    const bool exact = d_safe & (div_operand_safe(num) | zero);
+    if (__builtin_expect(__any(!exact), 0)) {
+        if (!exact) plane = num / d;
+    }
+#else
+    const double plane = num / d;
+#endif
     const bool below = o < split || (o == split && d < 0);
     const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
     if (plane > tmax || plane <= 0) return near_id;
