@@ -66,26 +66,31 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 
 __device__ __forceinline__ void stack_push(const Stack &st, int32_t sp, int32_t id, double t) {
     const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
-    if (sp < st.lds_levels) {
-        *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
-        *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
-    } else {
-        const int g = slot - st.lds_levels * WAVE;
-        reinterpret_cast<double *>(st.gt)[g] = t;
-        reinterpret_cast<int32_t *>(st.gid)[g] = id;
+    // the global spill levels are cold: one wave-level test keeps them out of the common path
+    if (__builtin_expect(__any(sp >= st.lds_levels), 0)) {
+        if (sp >= st.lds_levels) {
+            const int g = slot - st.lds_levels * WAVE;
+            reinterpret_cast<double *>(st.gt)[g] = t;
+            reinterpret_cast<int32_t *>(st.gid)[g] = id;
+            return;
+        }
     }
+    *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
+    *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
 }
 
 __device__ __forceinline__ void stack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
     const int slot = sp * WAVE + (int)(threadIdx.x % WAVE);
-    if (sp < st.lds_levels) {
-        t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
-        id = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
-    } else {
-        const int g = slot - st.lds_levels * WAVE;
-        t = reinterpret_cast<const double *>(st.gt)[g];
-        id = reinterpret_cast<const int32_t *>(st.gid)[g];
+    if (__builtin_expect(__any(sp >= st.lds_levels), 0)) {
+        if (sp >= st.lds_levels) {
+            const int g = slot - st.lds_levels * WAVE;
+            t = reinterpret_cast<const double *>(st.gt)[g];
+            id = reinterpret_cast<const int32_t *>(st.gid)[g];
+            return;
+        }
     }
+    t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
+    id = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
 }
 
 __device__ __forceinline__ double sel3(int i, double x, double y, double z) { return i == 0 ? x : (i == 1 ? y : z); }
