@@ -46,10 +46,13 @@ __device__ __forceinline__ bool tri_test(const TriRay &q, const float4 q0, const
     const float x1 = a1 - q.sx * c1, x2 = a2 - q.sx * c2, x3 = a3 - q.sx * c3;
     const float y1 = b1 - q.sy * c1, y2 = b2 - q.sy * c2, y3 = b3 - q.sy * c3;
     float u = x3 * y2 - y3 * x2, v = x1 * y3 - y1 * x3, w = x2 * y1 - y2 * x1;
-    if (u == 0.0f || v == 0.0f || w == 0.0f) {
-        u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
-        v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
-        w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+    const bool on_edge = (u == 0.0f) | (v == 0.0f) | (w == 0.0f);           // rare: recompute in f64 (mesh.pyx:668-680), behind a wave-level test
+    if (__builtin_expect(__any(on_edge), 0)) {
+        if (on_edge) {
+            u = (float)((double)x3 * (double)y2 - (double)y3 * (double)x2);
+            v = (float)((double)x1 * (double)y3 - (double)y1 * (double)x3);
+            w = (float)((double)x2 * (double)y1 - (double)y2 * (double)x1);
+        }
     }
     if ((u < 0.0f || v < 0.0f || w < 0.0f) && (u > 0.0f || v > 0.0f || w > 0.0f)) return false;
     const float det = u + v + w;
