@@ -132,7 +132,6 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
 #define RSX_PHASE_PROF 0           // 1: accumulate per-phase s_memtime cycles of the wave-cooperative mesh traversal (tuning builds only)
 #endif
 #if RSX_PHASE_PROF
-__device__ unsigned long long g_phase[8][64];   // unused placeholder to keep the symbol set stable
 #define PHASE_DECL unsigned long long ph_t = clock64();
 #define PHASE_ADD(slot) { const unsigned long long now_ = clock64(); phase_acc[slot] += now_ - ph_t; ph_t = now_; }
 #else
