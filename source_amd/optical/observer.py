@@ -465,6 +465,8 @@ class Observer2D(_ObserverBase):
 class PinholeCamera(Observer2D):
     """optical/observer/imaging/pinhole.pyx:42-207"""
 
+    MAX_RAYS_PER_CALL = 1 << 29       # rays per librsx render call (12.9 GB of sample records); larger slices are cut, see _render_slice_device
+
     def __init__(self, pixels, fov=None, sensitivity=None, frame_sampler=None, pipelines=None, parent=None, transform=None, name=None):
         pipelines = pipelines or [SpectralRadiancePipeline2D()]     # reference default is the (out-of-scope) RGB pipeline
         frame_sampler = frame_sampler or FullFrameSampler2D()
@@ -566,25 +568,37 @@ class PinholeCamera(Observer2D):
         scene = world.build_accelerator()
         sl = self._slices[slice_id]
         keep = []
-        if isinstance(tasks, RectTasks):
-            desc = self.render_desc(world, None, sl, engine, keep, rect=tasks.rect)
-        else:
-            desc = self.render_desc(world, tasks, sl, engine, keep)
         L = _lib.lib()
         rays = C.c_uint64(0)
         if engine.fused:
-            for pipe in self._pipelines:
-                desc.power = 1 if pipe.power else 0
-                fm, fv, fn = pipe.frame._device(scene.context)
-                _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
-                pipe.frame._mark_device_written()
-                if engine.timing:
-                    tr, ac = scene.context.last_render_ms()
-                    engine.last_kernel_ms = tr
-                    self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + tr
-                    self.stats["accumulate_ms"] = self.stats.get("accumulate_ms", 0.0) + ac
-            self.stats["rays"] = self.stats.get("rays", 0) + rays.value
+            # One library call renders at most MAX_RAYS_PER_CALL rays (its sample-record buffer is 24 B per ray): larger slices go
+            # band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
+            # and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut.
+            per_call = max(1, self.MAX_RAYS_PER_CALL // self._pixel_samples)
+            if isinstance(tasks, RectTasks):
+                x0, y0, x1, y1 = tasks.rect
+                band = max(1, per_call // max(1, y1 - y0))
+                pieces = [dict(rect=(xa, y0, min(xa + band, x1), y1)) for xa in range(x0, x1, band)]
+            else:
+                pieces = [dict(tasks=tasks[a:a + per_call]) for a in range(0, len(tasks), per_call)]
+            for piece in pieces:
+                desc = self.render_desc(world, piece.get("tasks"), sl, engine, keep, rect=piece.get("rect"))
+                for pipe in self._pipelines:
+                    desc.power = 1 if pipe.power else 0
+                    fm, fv, fn = pipe.frame._device(scene.context)
+                    _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
+                    pipe.frame._mark_device_written()
+                    if engine.timing:
+                        tr, ac = scene.context.last_render_ms()
+                        engine.last_kernel_ms = tr
+                        self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + tr
+                        self.stats["accumulate_ms"] = self.stats.get("accumulate_ms", 0.0) + ac
+                self.stats["rays"] = self.stats.get("rays", 0) + rays.value
         else:
+            if isinstance(tasks, RectTasks):
+                desc = self.render_desc(world, None, sl, engine, keep, rect=tasks.rect)
+            else:
+                desc = self.render_desc(world, tasks, sl, engine, keep)
             n = desc.n_tasks
             results = []
             for pipe in self._pipelines:

@@ -230,6 +230,21 @@ def test_frames_c2_stream_parity(ns, golden):
     cam2.render_engine = ns.SerialEngine()
     cam2.observe()
     assert eq(pipe2.frame.mean, g["c2_mean"]) and eq(pipe2.frame.variance, g["c2_var"])
+    # an oversized slice is cut into several library calls (here: 777 rays per call); the MT stream is consumed in the same order
+    cam3, pipe3 = scenes.c2_camera(ns, world, (40, 40), spp=4, bins=15)
+    cam3.MAX_RAYS_PER_CALL = 777
+    m, v, n = _observe(ns, cam3, pipe3, 1)
+    assert eq(m, g["c2_mean"]) and eq(v, g["c2_var"]) and eq(n, g["c2_n"])
+    # ... and in rect / Philox mode the bands reproduce the single-call frame
+    frames = []
+    for limit in (1 << 29, 5000):
+        cam4, pipe4 = scenes.c2_camera(ns, world, (40, 40), spp=4, bins=15)
+        cam4.MAX_RAYS_PER_CALL = limit
+        cam4.frame_sampler = ns.RectFrameSampler2D()
+        cam4.render_engine = ns.HipEngine(rng="philox", seed=3)
+        cam4.observe()
+        frames.append((pipe4.frame.mean.copy(), pipe4.frame.variance.copy(), pipe4.frame.samples.copy()))
+    assert all(eq(a, b) for a, b in zip(*frames)) and (frames[0][2] == 4).all()
     m, v, n = _observe(ns, cam, pipe, 2)                     # accumulate=True second pass
     assert eq(m, g["c2_mean2"]) and eq(v, g["c2_var2"]) and eq(n, g["c2_n2"])
 
