@@ -209,7 +209,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     ctx->unit_times = nullptr;
     {
         const char *env = std::getenv("RSX_PIPELINE");
-        ctx->pipeline_depth = env ? std::atoi(env) : 2;
+        ctx->pipeline_depth = env ? std::atoi(env) : 3;    // three lanes x one workgroup per CU = the three waves per SIMD the kernel fits
         if (ctx->pipeline_depth < 1) ctx->pipeline_depth = 1;
         if (ctx->pipeline_depth > RSX_MAX_LANES) ctx->pipeline_depth = RSX_MAX_LANES;
         env = std::getenv("RSX_RENDER_WG");
