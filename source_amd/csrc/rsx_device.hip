@@ -125,7 +125,7 @@ extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
 enum { POOL_MATERIALS, POOL_TABLES, POOL_TASKS, POOL_QUERY, POOL_MEAN, POOL_VAR, POOL_SLOTS };
 
 // Per-stream state of the traversal kernels. `main` runs on the ctx stream (hit / roots / contains batches, unpipelined renders);
-// two more lanes with private streams let consecutive render passes overlap: the long tail of pass p (a few waves walking grazing
+// up to RSX_MAX_LANES more lanes with private streams let consecutive small render passes overlap: the long tail of pass p (a few waves walking grazing
 // rays through hundreds of cells) runs while pass p+1's bulk fills the rest of the chip. Accumulation into the frame stays on the
 // ctx stream, in call order.
 struct TraceLane {
@@ -201,6 +201,9 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         return rsx_fail(RSX_ENODEV, "device %d is %s; librsx is built for gfx950 only", device_ordinal, prop.gcnArchName);
     rsx_ctx *ctx = new (std::nothrow) rsx_ctx();
     if (!ctx) return rsx_fail(RSX_ENOMEM, "out of host memory");
+    struct Guard { rsx_ctx *c; ~Guard() { if (c) rsx_free(c); } } guard{ctx};      // a failing HIP call below must not leak the half-built ctx
+    ctx->stream = ctx->own_stream = nullptr;
+    ctx->ev0 = ctx->ev1 = ctx->ev2 = nullptr;
     ctx->device = device_ordinal;
     ctx->n_cus = prop.multiProcessorCount;
     ctx->last_ms = 0.f;
@@ -237,6 +240,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
     }
+    guard.c = nullptr;
     *out = ctx;
     return RSX_OK;
 }
@@ -253,9 +257,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
         if (ln->merged) (void)hipEventDestroy(ln->merged);
     }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
-    (void)hipEventDestroy(ctx->ev0);
-    (void)hipEventDestroy(ctx->ev1);
-    (void)hipEventDestroy(ctx->ev2);
+    for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev2}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->gate) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(ctx->own_stream);
