@@ -516,3 +516,21 @@ def test_exact_division():
     for seed in (1, 2):
         _lib.check(_lib.lib().rsx_selftest_exact_division(get_context().handle, 1 << 28, seed, C.byref(bad)))
         assert bad.value == 0
+
+
+def test_pipelining_does_not_change_frames():
+    """Render-pass pipelining (private lanes, longest-first unit order, XCD work lists) only changes which wave renders which unit:
+    120 accumulating passes give the same frame digest with 1, 3 and 4 lanes (separate processes: the depth is read at rsx_init)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for depth in ("1", "3", "4"):
+        env = dict(os.environ, RSX_PIPELINE=depth, KB_WARM="20")
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "kbench.py"), "100", "c2"], env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        digests.append(json.loads(out.stdout.strip().splitlines()[-1])["digest"])
+    assert len(set(digests)) == 1, digests
+
