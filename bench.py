@@ -220,7 +220,7 @@ def main():
                     "bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()}}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world_size == 1:       # the CPU baseline is timed at N = 1 only (the other ranks would idle at the barrier)
             # bounded sample of the same workload on the host cores, same Philox samples: calibrate on a 16-row band, then size
             # the sample for ~args.cpu_seconds of CPU work — whole passes when one fits, otherwise a centred band of rows
             keep = []
