@@ -43,7 +43,13 @@ enum {
 enum {
     RSX_MAT_ABSORBER = 0,        /* optical/material/absorber.pyx:37-55  -> zero spectrum                     */
     RSX_MAT_UNIFORM_EMITTER = 1, /* optical/material/emitter/uniform.pyx:36-88 -> table[bin] * scale         */
-    RSX_MAT_DEBUG_LIGHT = 2      /* optical/material/debug.pyx:41-79 -> scale*max(0,-L_local.n) * table[bin] */
+    RSX_MAT_DEBUG_LIGHT = 2,     /* optical/material/debug.pyx:41-79 -> scale*max(0,-L_local.n) * table[bin] */
+    /* Transparent boundaries: the ray carries on from the far side of the surface with its depth unchanged and Russian roulette
+     * disabled (NullSurface / NullMaterial.evaluate_surface, optical/material/material.pyx:118-178), and every segment of the path
+     * collects the volume emission of the primitives that contain the segment's origin (Ray._sample_volumes, optical/ray.pyx:422-455;
+     * HomogeneousVolumeEmitter.evaluate_volume, emitter/homogeneous.pyx:55-102): spectrum[bin] += (table[bin] * scale) * length. */
+    RSX_MAT_NULL = 3,                    /* NullMaterial: null surface, no volume                                   */
+    RSX_MAT_UNIFORM_VOLUME_EMITTER = 4   /* UniformVolumeEmitter (emitter/uniform.pyx:91-131): null surface + table[bin] * scale per unit length */
 };
 
 /* ---- flattened KD-tree (raysect/core/math/spatial/kdtree3d.pxd:38-43 `kdnode`, 32 B -> 16 B) -- */

@@ -78,7 +78,7 @@ class MT(C.Structure):
 
 
 PRIM_SPHERE, PRIM_BOX, PRIM_CYLINDER, PRIM_MESH, PRIM_UNION, PRIM_INTERSECT, PRIM_SUBTRACT, PRIM_NULL = range(8)
-MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT = range(3)
+MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT, MAT_NULL, MAT_UNIFORM_VOLUME_EMITTER = range(5)
 RNG_STREAM, RNG_PHILOX = 0, 1
 
 # every symbol include/rsx.h declares: (name, restype, argtypes)

@@ -1,9 +1,10 @@
 """
 Materials. The material plugin API (evaluate_surface / evaluate_volume, raysect/optical/material/material.pxd:36-47)
-is kept as the host-side interface. Three closed-form materials are lowered to the device render kernel
-(SURVEY.md §8 a23): AbsorbingSurface, UniformSurfaceEmitter and the debug Light — none of them spawns daughter
-rays, so Ray.trace() is one world.hit() plus a bins-wide multiply. Any other material raises when an
-observer tries to render it on the device (there is no CPU fallback).
+is kept as the host-side interface. The closed-form materials are lowered to the device render kernel: AbsorbingSurface,
+UniformSurfaceEmitter and the debug Light (one world.hit() plus a bins-wide multiply) and — first slice of the
+§8(f) "next" rows — the deterministic transparent ones, NullMaterial and UniformVolumeEmitter (null surfaces continue the ray,
+every segment integrates the emission of the volumes it starts in). Any other material raises when an observer tries to render it
+on the device (there is no CPU fallback).
 
 Mirrors raysect/optical/material/{material,absorber,debug}.pyx and emitter/uniform.pyx.
 """
@@ -104,6 +105,52 @@ class Light(NullVolume):
         tables.append(self.spectrum.sample(min_wavelength, max_wavelength, bins))
         d = self.light_direction
         return _record(_lib.MAT_DEBUG_LIGHT, len(tables) - 1, float(self.intensity), (d.x, d.y, d.z))
+
+
+class NullSurface(Material):
+    """material.pyx:104-147 — a surface the ray passes straight through: the daughter ray starts on the far side of the boundary
+    with the same direction, its depth is not increased and Russian roulette is disabled, so the continuation is deterministic."""
+
+    def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal,
+                         world_to_primitive, primitive_to_world, intersection):
+        origin = (outside_point if exiting else inside_point).transform(primitive_to_world)
+        daughter = ray.spawn_daughter(origin, ray.direction)
+        daughter.depth -= 1
+        return daughter.trace(world, keep_alive=True)
+
+
+class NullMaterial(NullSurface):
+    """material.pyx:166-200 — perfectly transparent: null surface and no volume contribution."""
+
+    def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, world_to_primitive, primitive_to_world):
+        return spectrum
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        return _record(_lib.MAT_NULL, 0, 0.0)
+
+
+class UniformVolumeEmitter(NullSurface):
+    """emitter/uniform.pyx:91-131 over HomogeneousVolumeEmitter (emitter/homogeneous.pyx:40-102): a transparent boundary whose
+    interior emits emission_spectrum * scale (W/m^3/str/nm) — a path segment that starts inside adds emission * segment length."""
+
+    def __init__(self, emission_spectrum, scale=1.0):
+        super().__init__()
+        self.emission_spectrum = emission_spectrum
+        self.scale = float(scale)
+        self.importance = 1.0
+
+    def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, world_to_primitive, primitive_to_world):
+        start, end = start_point.transform(world_to_primitive), end_point.transform(world_to_primitive)
+        length = end.vector_to(start).length
+        if length == 0:
+            return spectrum
+        emission = self.emission_spectrum.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins) * self.scale
+        spectrum.samples[:] = spectrum.samples + emission * length
+        return spectrum
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        tables.append(self.emission_spectrum.sample(min_wavelength, max_wavelength, bins))
+        return _record(_lib.MAT_UNIFORM_VOLUME_EMITTER, len(tables) - 1, self.scale)
 
 
 # convenience used by scene builders

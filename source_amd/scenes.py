@@ -294,3 +294,30 @@ def edge_camera(ns, world, pixels, spp, bins, mask=None):
     cam = ns.PinholeCamera(pixels, fov=50, parent=world, pipelines=[pipe], frame_sampler=sampler, transform=ns.translate(0, 0.16, -0.4) * ns.rotate(0, -12, 0))
     cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
     return cam, pipe
+
+
+def build_volumes(ns):
+    """Volume-emission scene (fixture F12): overlapping emitting sphere / box / cylinder / CSG lens with transparent boundaries,
+    a NullMaterial shell, an opaque emitter behind them and an emitting box that contains the camera itself."""
+    world = ns.World()
+    sf = ns.InterpolatedSF([300, 490, 510, 590, 610, 800], np.array([0.0, 0.1, 1.0, 0.7, 0.2, 0.4]))
+    prims = [
+        ns.Sphere(0.5, world, ns.translate(0.0, 0.0, 2.0), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.7)),
+        ns.Box(ns.Point3D(-0.3, -0.3, -0.3), ns.Point3D(0.3, 0.3, 0.3), world, ns.translate(0.45, 0.1, 2.1) * ns.rotate(20, 30, 0),
+               ns.UniformVolumeEmitter(sf, 1.3)),
+        ns.Cylinder(0.2, 1.4, world, ns.translate(-0.6, -0.5, 1.6) * ns.rotate(0, 70, 0), ns.UniformVolumeEmitter(ns.ConstantSF(0.5), 2.0)),
+        ns.Sphere(0.9, world, ns.translate(0.0, 0.0, 2.0), ns.NullMaterial()),
+        ns.Intersect(ns.Sphere(0.5, transform=ns.translate(0, 0, 0.3)), ns.Sphere(0.5, transform=ns.translate(0, 0, -0.3)), world,
+                     ns.translate(-0.2, 0.55, 1.5), ns.UniformVolumeEmitter(sf, 0.9)),
+        ns.Box(ns.Point3D(-1.0, -1.0, 3.2), ns.Point3D(1.0, 0.2, 3.4), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.25)),
+        ns.Box(ns.Point3D(-4, -4, -4), ns.Point3D(4, 4, 4), world, material=ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.01)),
+        ns.Box(ns.Point3D(-6, -6, -6), ns.Point3D(6, 6, 6), world, material=ns.AbsorbingSurface()),
+    ]
+    return world, prims
+
+
+def volumes_camera(ns, world, pixels=(48, 40), spp=3, bins=6):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=55, parent=world, pipelines=[pipe], frame_sampler=ns.FullFrameSampler2D(), transform=ns.translate(0.05, 0.1, 0.0))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
+    return cam, pipe

@@ -34,7 +34,7 @@ from raysect.core.math import random as rsrandom  # noqa: E402
 from raysect.core.acceleration.kdtree import _PrimitiveKDTree  # noqa: E402
 from raysect.primitive import Mesh, Sphere, Box, Cylinder, Union, Intersect, Subtract  # noqa: E402
 from raysect.optical import World, ConstantSF, InterpolatedSF, Ray as OpticalRay  # noqa: E402
-from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter  # noqa: E402
+from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial  # noqa: E402
 from raysect.optical.material.debug import Light  # noqa: E402
 from raysect.optical.observer import PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D  # noqa: E402
 
@@ -45,7 +45,8 @@ NS = types.SimpleNamespace(
     World=World, Mesh=Mesh, Sphere=Sphere, Box=Box, Cylinder=Cylinder, Union=Union, Intersect=Intersect,
     Subtract=Subtract, Point3D=Point3D, Vector3D=Vector3D, translate=translate, rotate=rotate,
     ConstantSF=ConstantSF, InterpolatedSF=InterpolatedSF, AbsorbingSurface=AbsorbingSurface,
-    UniformSurfaceEmitter=UniformSurfaceEmitter, Light=Light, PinholeCamera=PinholeCamera,
+    UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light,
+    PinholeCamera=PinholeCamera,
     FullFrameSampler2D=FullFrameSampler2D, SpectralRadiancePipeline2D=SpectralRadiancePipeline2D,
     SpectralPowerPipeline2D=SpectralPowerPipeline2D)
 
@@ -452,6 +453,18 @@ def f11_edges():
     save("f11_edges", **out)
 
 
+def f12_volumes():
+    """Transparent boundaries and volume emission (NullMaterial, UniformVolumeEmitter): deterministic continuation rays
+    (material.pyx:118-178) and the per-segment volume pass (ray.pyx:422-455, homogeneous.pyx:55-102)."""
+    out = {}
+    world, prims = scenes.build_volumes(NS)
+    cam, pipe = scenes.volumes_camera(NS, world)
+    out["mean"], out["var"], out["n"] = observe_frame(cam, pipe, 31)
+    pyrandom.seed(32); rsrandom.seed(32); cam.observe()                       # accumulate pass
+    out["mean2"], out["var2"], out["n2"] = np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples)
+    save("f12_volumes", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -470,3 +483,4 @@ if __name__ == "__main__":
     if run("f09"): f09_stats()
     if run("f10"): f10_frames()
     if run("f11"): f11_edges()
+    if run("f12"): f12_volumes()

@@ -369,3 +369,16 @@ def test_edge_semantics(orc, ns, golden):
         assert eq(f[0], g[tag + "_mean"]) and eq(f[1], g[tag + "_var"]) and eq(f[2], g[tag + "_n"]), tag
     with pytest.raises(RuntimeError):
         ns.PinholeCamera((1, 1), parent=world)                 # pinhole.pyx:166-167
+
+
+# ---------------------------------------------------------------------------------------- F12 transparent boundaries / volume emission
+def test_frames_volume_emitters(orc, ns, golden):
+    """NullMaterial + UniformVolumeEmitter (first slice of SURVEY.md §8f row 1): null surfaces continue the ray deterministically,
+    each path segment integrates the emission of the volumes containing its origin in world.contains() order."""
+    g = golden("f12_volumes")
+    world, prims = scenes.build_volumes(ns)
+    cam, pipe = scenes.volumes_camera(ns, world)
+    f = _observe_oracle(orc, ns, cam, pipe, 31)
+    assert eq(f[0], g["mean"]) and eq(f[1], g["var"]) and eq(f[2], g["n"])
+    f = _observe_oracle(orc, ns, cam, pipe, 32, f)
+    assert eq(f[0], g["mean2"]) and eq(f[1], g["var2"]) and eq(f[2], g["n2"])
