@@ -205,6 +205,149 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Transparent boundaries and volume emission (first slice of SURVEY.md §8f row 1)
+// ---------------------------------------------------------------------------------------------------
+// NullMaterial / UniformVolumeEmitter surfaces let the ray through (NullSurface.evaluate_surface, material.pyx:118-147: daughter
+// ray from the far side of the boundary, same direction, depth unchanged, keep_alive) and every segment of the path adds the
+// emission of the volume emitters that contain the segment's origin times the segment length in the emitter's space
+// (Ray._sample_volumes, ray.pyx:422-455; HomogeneousVolumeEmitter.evaluate_volume, homogeneous.pyx:55-102). The path is
+// deterministic, so frames stay bit-identical to the reference. A ray leaves up to max_terms VolTerm records (scale, length,
+// table, segment) next to its Sample; k_accumulate adds them in the reference's order — deepest segment first, world.contains()
+// order within a segment. Scenes without such materials never run this kernel (k_render_trace is untouched).
+struct VolTerm {
+    double scale, length;
+    int32_t table, seg;
+};
+#define VOL_MAX_SEGMENTS 64
+
+// world.contains(point) in leaf order (kdtree3d.pyx:736-792, kdtree.pyx:126-162): calls f(primitive index) for every world
+// primitive whose bounding box and surface contain the point
+template <bool CSG, typename F>
+__device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, F f) {
+    if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) return;
+    int32_t node = 0;
+    rsx_kdnode nd = load_node(sc.wnodes, node);
+    while (nd.type >= 0) {
+        node = sel3(nd.type, px, py, pz) < nd.u.split ? node + 1 : nd.count;
+        nd = load_node(sc.wnodes, node);
+    }
+    for (int32_t k = 0; k < nd.count; ++k) {
+        const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
+        const rsx_primitive &p = sc.prims[idx];
+        bool in;
+        if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
+        else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+        if (in) f(idx);
+    }
+}
+
+template <bool CSG>
+__global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket,
+                                                                    VolTerm *terms, int max_terms, unsigned int *overflow) {
+    Stack st, ms;
+    wave_stacks(sc, st, ms);
+    const int lane = threadIdx.x % WAVE;
+    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
+    const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
+    const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
+    (void)rp;
+    const int my_xcd = xcc_id();
+    int victim = -1;
+    for (;;) {
+        long long tk = -1;
+        while (victim < 8) {
+            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+            const long long begin = q->seg[list], end = q->seg[list + 1];
+            unsigned long long mine = 0;
+            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
+            if (got < end) { tk = got; break; }
+            ++victim;
+        }
+        if (tk < 0) break;
+        const int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
+        const UnitPixel px = unit_pixel(q, unit, lane);
+        double u1, u2;
+        if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
+        else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
+        const double delta = q->cam.image_delta, half = 0.5 * delta;
+        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
+        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
+        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+        normalise3(dx, dy, dz);
+        Ray r;
+        {
+            const RSX_CONST_AS double *m = q->cam.to_root;
+            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+            wq = 1.0 / wq;
+            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
+            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
+            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
+        }
+        r.maxd = INFINITY;
+        Sample smp;
+        smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
+        const long long record = px.slot * q->spp + px.s;
+        VolTerm *mine_terms = terms + record * max_terms;
+        int n_terms = 0;
+        bool active = px.valid;
+        uint32_t work = 0;
+        for (int seg = 0; __any(active); ++seg) {
+            Hit hit;
+            const bool got = world_trace_wave<CSG>(active, sc, r, st, ms, csg_state, hit, work);
+            if (!active) continue;
+            if (!got) { active = false; continue; }                         // new_spectrum(): no volume pass for a segment that hits nothing
+            const rsx_primitive &p = sc.prims[hit.prim];
+            const rsx_material mat = q->materials[p.material];
+            Geom g;
+            finalise<CSG>(sc, r, hit, g);
+            double hx, hy, hz;                                                // hit_point.transform(primitive_to_world)
+            xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
+            // volume emitters containing this segment's origin, in world.contains() order
+            world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
+                const rsx_primitive &vp = sc.prims[idx];
+                const rsx_material vm = q->materials[vp.material];
+                if (vm.type != RSX_MAT_UNIFORM_VOLUME_EMITTER) return;        // NullVolume.evaluate_volume: unchanged
+                double sx, sy, sz, ex, ey, ez;
+                xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
+                xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
+                const double vx = sx - ex, vy = sy - ey, vz = sz - ez;        // end.vector_to(start)
+                const double length = sqrt(vx * vx + vy * vy + vz * vz);
+                if (length == 0) return;
+                if (n_terms < max_terms) {
+                    VolTerm t;
+                    t.scale = vm.scale; t.length = length; t.table = vm.table; t.seg = seg;
+                    mine_terms[n_terms] = t;
+                } else atomicOr(overflow, 1u);
+                ++n_terms;
+            });
+            if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
+                const double *from = g.exiting ? g.outside : g.inside;
+                xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                if (seg + 1 >= VOL_MAX_SEGMENTS) { atomicOr(overflow, 2u); active = false; }
+                continue;
+            }
+            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
+            else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
+                double lx, ly, lz;
+                xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                smp.a = mat.scale * (dot > 0 ? dot : 0.0);
+                smp.table = mat.table;
+            }
+            active = false;
+        }
+        if (!px.valid) continue;
+        smp.pad = n_terms < max_terms ? n_terms : max_terms;
+        samples[record] = smp;
+    }
+}
+
 // Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.
 __global__ void k_selftest_division(unsigned long long n, unsigned long long seed, unsigned long long *mismatches) {
     const unsigned long long gid = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -362,6 +505,8 @@ struct AccumParams {
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
     int32_t frame_bins, slice_offset;
     unsigned long long *ticket;         // work tickets of the trace kernel: re-armed here for the next launch
+    const struct VolTerm *terms;        // volume-emission terms of each sample (or null), max_terms per sample; Sample.pad = count
+    int32_t max_terms, pad2;
 };
 
 // Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
@@ -403,10 +548,26 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     }
     const Sample *s = ap.samples + p * ap.spp;
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
-    auto value = [&](const Sample &smp) {
+    auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
         const double tab = staged ? acc_tab[e] : ap.tables[e];
         double x = smp.table < 0 ? 0.0 : smp.a * tab;
+        if (ap.terms && smp.pad > 0) {
+            // _sample_volumes while the reference's recursion unwinds: deepest segment first, contains() order inside a segment
+            const VolTerm *t = ap.terms + record * ap.max_terms;
+            const int n = smp.pad;
+            int hi = n;
+            while (hi > 0) {
+                int lo = hi - 1;
+                while (lo > 0 && t[lo - 1].seg == t[hi - 1].seg) --lo;
+                for (int j = lo; j < hi; ++j) {
+                    const double tv = staged ? acc_tab[t[j].table * ap.bins + b] : ap.tables[t[j].table * ap.bins + b];
+                    const double emission = 0.0 + tv * t[j].scale;          // uniform.pyx:129-131 on a zero spectrum
+                    x = x + emission * t[j].length;                           // homogeneous.pyx:99-100
+                }
+                hi = lo;
+            }
+        }
         x = x * smp.weight;
         if (ap.power) x = x * ap.sensitivity;
         return x;
@@ -414,7 +575,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
     // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
     // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
-    double m = value(s[0]), v = 0;
+    const long long rec0 = p * ap.spp;
+    double m = value(s[0], rec0), v = 0;
     double dm = 1.0;                                        // (double)i, advanced by exact additions
     auto step = [&](double x, int i) {
         const double dn = dm + 1.0, c = i == 1 ? 1.0 : dm - 1.0;
@@ -430,9 +592,9 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
 #pragma unroll
         for (int j = 0; j < ACC_BATCH; ++j) sm[j] = s[i + j];
 #pragma unroll
-        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j]), i + j);
+        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j], rec0 + i + j), i + j);
     }
-    for (; i < ap.spp; ++i) step(value(s[i]), i);
+    for (; i < ap.spp; ++i) step(value(s[i], rec0 + i), i);
     if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
     if (ap.fmean) {
         const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;

@@ -139,8 +139,9 @@ struct TraceLane {
     long long cost_units = 0;          // number of units unit_cost currently describes (0 = none)
     long long order_units = 0;         // number of units unit_order was sorted for (0 = no valid work list)
     uint64_t cost_signature = 0;       // (scene, camera, tasks) the costs were measured on
-    void *samples = nullptr, *uniforms = nullptr;
-    size_t samples_bytes = 0, uniforms_bytes = 0;
+    void *samples = nullptr, *uniforms = nullptr, *terms = nullptr;   // terms: VolTerm records of the volume-emission path
+    size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0;
+    unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
 };
@@ -251,7 +252,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, (void *)ln->overflow})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -774,7 +775,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (w <= 0 || h <= 0 || w * h != desc->n_tasks) return rsx_fail(RSX_EINVAL, "render: rect does not match n_tasks");
     }
     for (int32_t i = 0; i < desc->n_materials; ++i)
-        if (desc->materials[i].type != RSX_MAT_ABSORBER && (desc->materials[i].table < 0 || desc->materials[i].table >= desc->n_tables))
+        if (desc->materials[i].type != RSX_MAT_ABSORBER && desc->materials[i].type != RSX_MAT_NULL &&
+            (desc->materials[i].table < 0 || desc->materials[i].table >= desc->n_tables))
             return rsx_fail(RSX_EINVAL, "render: material %d references table %d of %d", i, desc->materials[i].table, desc->n_tables);
     if (ray_count) *ray_count = (uint64_t)desc->n_tasks * (uint64_t)desc->spp;
     if (desc->n_tasks == 0) return RSX_OK;
@@ -794,7 +796,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const long long groups = desc->spp >> spu_log2;
     const long long tiles_x_all = (rect_w + (1 << pw_log2) - 1) >> pw_log2, tiles_y_all = (rect_h + (1 << ph_log2) - 1) >> ph_log2;
     const long long n_units_all = (desc->tasks ? (desc->n_tasks + (WAVE >> spu_log2) - 1) / (WAVE >> spu_log2) : tiles_x_all * tiles_y_all) * groups;
-    const bool pipelined = !h_mean && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // transparent-boundary / volume-emitter materials take the multi-segment kernel (k_render_trace_vol), un-pipelined
+    bool has_vol = false;
+    for (int32_t i = 0; i < desc->n_materials; ++i) has_vol = has_vol || desc->materials[i].type == RSX_MAT_NULL || desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;
+    const int max_terms = 32;                             // volume terms kept per ray (768 B); a ray that needs more fails the call loudly
+    const bool pipelined = !h_mean && !has_vol && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
 
@@ -833,6 +839,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
+    if (has_vol) {
+        if (S * (size_t)max_terms * sizeof(VolTerm) > ((size_t)16 << 30))
+            return rsx_fail(RSX_EUNSUPPORTED, "render: %zu rays with volume terms in one call; split the call (at most %zu rays)", S, ((size_t)16 << 30) / (max_terms * sizeof(VolTerm)));
+        if ((rc = lane_buffer(lane.terms, lane.terms_bytes, S * (size_t)max_terms * sizeof(VolTerm)))) return rc;
+        if (!lane.overflow) HIP_TRY(hipMalloc(&lane.overflow, 64));
+        HIP_TRY(hipMemsetAsync(lane.overflow, 0, 64, lane.stream));
+    }
     if (desc->rng_mode == RSX_RNG_STREAM) {
         if ((rc = lane_buffer(lane.uniforms, lane.uniforms_bytes, S * 16))) return rc;
         HIP_TRY(hipMemcpyAsync(lane.uniforms, desc->uniforms, S * 16, hipMemcpyHostToDevice, lane.stream));
@@ -924,7 +937,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     HP_MARK(0)
     const bool timed = ctx->timing;
     if (timed) HIP_TRY(hipEventRecord(re[0], lane.stream));
-    if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+    if (has_vol) {
+        HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_vol<true>) : reinterpret_cast<const void *>(k_render_trace_vol<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_vol<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket,
+                                               static_cast<VolTerm *>(lane.terms), max_terms, lane.overflow);
+        else hipLaunchKernelGGL(k_render_trace_vol<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket,
+                                static_cast<VolTerm *>(lane.terms), max_terms, lane.overflow);
+    } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
     HP_MARK(1)
@@ -951,6 +970,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.fmean = fmean; ap.fvar = fvar; ap.fn = fn;
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
     ap.ticket = lane.ticket;
+    ap.terms = has_vol ? static_cast<const VolTerm *>(lane.terms) : nullptr;
+    ap.max_terms = max_terms; ap.pad2 = 0;
     lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
@@ -972,6 +993,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         HIP_TRY(hipMemcpyAsync(h_mean, d_mean, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipMemcpyAsync(h_var, d_var, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+    if (has_vol) {                                          // a ray that ran out of term slots or segments must not go unnoticed
+        unsigned int flags = 0;
+        HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: a ray crossed more than %d emitting volume segments (limit of this build)", max_terms);
+        if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a ray crossed more than %d transparent boundaries (limit of this build)", VOL_MAX_SEGMENTS);
     }
     // frame form: asynchronous — the pooled workspace stays alive in the ctx, stream order protects reuse
     return RSX_OK;

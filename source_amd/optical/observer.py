@@ -574,7 +574,11 @@ class PinholeCamera(Observer2D):
             # One library call renders at most MAX_RAYS_PER_CALL rays (its sample-record buffer is 24 B per ray): larger slices go
             # band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
             # and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut.
-            per_call = max(1, self.MAX_RAYS_PER_CALL // self._pixel_samples)
+            limit = self.MAX_RAYS_PER_CALL
+            from .material import NullSurface
+            if any(isinstance(p.material, NullSurface) for p in world._primitives):
+                limit = min(limit, 1 << 24)                 # the volume path also keeps 768 B of emission terms per ray
+            per_call = max(1, limit // self._pixel_samples)
             if isinstance(tasks, RectTasks):
                 x0, y0, x1, y1 = tasks.rect
                 band = max(1, per_call // max(1, y1 - y0))

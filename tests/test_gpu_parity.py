@@ -518,6 +518,36 @@ def test_exact_division():
         assert bad.value == 0
 
 
+def test_frames_volume_emitters_stream_parity(orc, ns, golden):
+    """NullMaterial + UniformVolumeEmitter on the device (k_render_trace_vol): frames bit-identical to the reference's SerialEngine,
+    incl. the accumulate pass; Philox mode equals the oracle; a ray through more emitting segments than the build keeps fails loudly."""
+    g = golden("f12_volumes")
+    world, prims = scenes.build_volumes(ns)
+    cam, pipe = scenes.volumes_camera(ns, world)
+    m, v, n = _observe(ns, cam, pipe, 31)
+    assert eq(m, g["mean"]) and eq(v, g["var"]) and eq(n, g["n"])
+    m, v, n = _observe(ns, cam, pipe, 32)
+    assert eq(m, g["mean2"]) and eq(v, g["var2"]) and eq(n, g["n2"])
+    # throughput mode at a larger size against the oracle
+    cam2, pipe2 = scenes.volumes_camera(ns, world, (256, 192), spp=8, bins=6)
+    cam2.frame_sampler = ns.RectFrameSampler2D()
+    cam2.render_engine = ns.HipEngine(rng="philox", seed=9)
+    cam2.observe()
+    keep = []
+    desc = cam2.render_desc(world, None, cam2._slice_spectrum()[0], cam2.render_engine, keep, rect=(0, 0, 256, 192))
+    om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    assert eq(pipe2.frame.mean, om.reshape(192, 256, 6).transpose(1, 0, 2)) and eq(pipe2.frame.variance, ov.reshape(192, 256, 6).transpose(1, 0, 2))
+    # forty nested emitting shells: more volume terms per ray than the build stores -> RSX_EUNSUPPORTED, not a silently wrong frame
+    from source_amd._lib import RsxError
+    deep = ns.World()
+    for k in range(40):
+        ns.Sphere(0.2 + 0.02 * k, deep, ns.translate(0, 0, 3), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.1))
+    cam3, pipe3 = scenes.volumes_camera(ns, deep, (16, 16), spp=1, bins=2)
+    cam3.render_engine = ns.HipEngine(rng="philox", seed=1)
+    with pytest.raises(RsxError):
+        cam3.observe()
+
+
 def test_pipelining_does_not_change_frames():
     """Render-pass pipelining (private lanes, longest-first unit order, XCD work lists) only changes which wave renders which unit:
     120 accumulating passes give the same frame digest with 1, 3 and 4 lanes (separate processes: the depth is read at rsx_init)."""
