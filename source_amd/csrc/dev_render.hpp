@@ -516,7 +516,8 @@ struct AccumParams {
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
 
-template <bool STAGED>                  // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form
+template <bool STAGED, bool VOL>        // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
+                                        // VOL = samples carry volume-emission terms (k_render_trace_vol)
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
     extern __shared__ __attribute__((aligned(16))) double acc_lds[];
@@ -552,7 +553,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
         const double tab = staged ? acc_tab[e] : ap.tables[e];
         double x = smp.table < 0 ? 0.0 : smp.a * tab;
-        if (ap.terms && smp.pad > 0) {
+        if (VOL && smp.pad > 0) {
             // _sample_volumes while the reference's recursion unwinds: deepest segment first, contains() order inside a segment
             const VolTerm *t = ap.terms + record * ap.max_terms;
             const int n = smp.pad;

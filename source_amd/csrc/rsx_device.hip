@@ -979,8 +979,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.n_tables = desc->n_tables; ap.pad = 0;
     const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
     if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
-    if (desc->spp >= 4) hipLaunchKernelGGL(k_accumulate<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), acc_lds, ctx->stream, ap);
-    else hipLaunchKernelGGL(k_accumulate<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ap);
+    const dim3 acc_grid((unsigned)((total + 255) / 256));
+    if (has_vol) {
+        if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, true>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
+        else hipLaunchKernelGGL((k_accumulate<false, true>), acc_grid, dim3(256), 0, ctx->stream, ap);
+    } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, false>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
+    else hipLaunchKernelGGL((k_accumulate<false, false>), acc_grid, dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
