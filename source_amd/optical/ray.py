@@ -33,8 +33,20 @@ class Ray(CoreRay):
                 self.important_path_weight)
         return r
 
-    def trace(self, world, keep_alive=False):               # ray.pyx:338-401 (depth-0 primary ray: no roulette)
-        self.ray_count = 1
+    def spawn_daughter(self, origin, direction):            # ray.pyx:506-545
+        """A daughter ray: same spectral configuration, depth + 1."""
+        r = Ray(origin, direction, self.min_wavelength, self.max_wavelength, self.bins, self.max_distance, self.extinction_prob,
+                self.extinction_min_depth, self.max_depth, self.importance_sampling, self.important_path_weight)
+        r.depth = self.depth + 1
+        return r
+
+    def trace(self, world, keep_alive=False):               # ray.pyx:338-401
+        if self.depth == 0:
+            self.ray_count = 1
+        if not (keep_alive or self.depth < self.extinction_min_depth):
+            # Russian roulette (ray.pyx:380-386) draws from the MT stream: only stochastic materials reach this depth, and they have
+            # no lowering in this build
+            raise NotImplementedError("Ray.trace(): Russian roulette at depth %d is part of the stochastic-material scope row" % self.depth)
         intersection = world.hit(self)
         if intersection is None:
             return self.new_spectrum()

@@ -537,6 +537,13 @@ def test_frames_volume_emitters_stream_parity(orc, ns, golden):
     desc = cam2.render_desc(world, None, cam2._slice_spectrum()[0], cam2.render_engine, keep, rect=(0, 0, 256, 192))
     om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
     assert eq(pipe2.frame.mean, om.reshape(192, 256, 6).transpose(1, 0, 2)) and eq(pipe2.frame.variance, ov.reshape(192, 256, 6).transpose(1, 0, 2))
+    # the single-ray API walks the same path on the host side of the plugin interface: a unit-scale emitting sphere of radius 0.5
+    # seen along a diameter radiates its diameter (minus the two 1e-9 surface nudges), through a transparent shell and back out
+    single = ns.World()
+    ns.Sphere(0.5, single, ns.translate(0, 0, 2), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 1.0))
+    ns.Sphere(0.8, single, ns.translate(0, 0, 2), ns.NullMaterial())
+    spectrum = ns.Ray(ns.Point3D(0, 0, 0), ns.Vector3D(0, 0, 1), bins=4).trace(single)
+    assert np.allclose(spectrum.samples, 1.0, rtol=0, atol=1e-8) and (spectrum.samples < 1.0).all()
     # forty nested emitting shells: more volume terms per ray than the build stores -> RSX_EUNSUPPORTED, not a silently wrong frame
     from source_amd._lib import RsxError
     deep = ns.World()
