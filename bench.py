@@ -67,6 +67,13 @@ def ray_bytes(counters, n_rays):
     return b, per
 
 
+def _lib_combine(ctx, m, v, n, mb, vb, nb):
+    """combine_samples law applied in place on the device (rsx_frame_combine_dev) to torch tensors."""
+    from source_amd import _lib
+    _lib.check(_lib.lib().rsx_frame_combine_dev(ctx.handle, m.numel(), m.data_ptr(), v.data_ptr(), n.data_ptr(),
+                                                mb.data_ptr(), vb.data_ptr(), nb.data_ptr()))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,6 +157,14 @@ def main():
         prewarm += burst
     for _ in range(args.warmup):
         step()
+    if dist is not None:
+        # untimed: the first all_to_all / all_gather of a process group sets up its RCCL channels and peer connections (tens of
+        # ms); run the frame merge once on small dummy tensors so that this one-time cost is not charged to the timed steps
+        from source_amd import distributed as D0
+        tiny = [torch.zeros(4096, dtype=torch.float64, device="cuda"), torch.zeros(4096, dtype=torch.float64, device="cuda"),
+                torch.ones(4096, dtype=torch.int32, device="cuda")]
+        D0.merge_sample_sharded(tiny[0], tiny[1], tiny[2], dist,
+                                lambda m, v, n, mb, vb, nb: _lib_combine(ctx, m, v, n, mb, vb, nb))
     sync()
     barrier()
     sync()
@@ -160,12 +175,9 @@ def main():
     if dist is not None:
         sync()
         tc = time.perf_counter()
-        from source_amd import _lib, distributed as D
-
-        def combine(m, v, n, mb, vb, nb):                   # exact combine_samples law on the device, in place
-            _lib.check(_lib.lib().rsx_frame_combine_dev(ctx.handle, m.numel(), m.data_ptr(), v.data_ptr(), n.data_ptr(),
-                                                        mb.data_ptr(), vb.data_ptr(), nb.data_ptr()))
-        merged = D.merge_sample_sharded(frames[0], frames[1], frames[2], dist, combine)
+        from source_amd import distributed as D
+        merged = D.merge_sample_sharded(frames[0], frames[1], frames[2], dist,
+                                        lambda m, v, n, mb, vb, nb: _lib_combine(ctx, m, v, n, mb, vb, nb))
         sync()
         collective_ms = (time.perf_counter() - tc) * 1e3
     sync()
