@@ -168,6 +168,8 @@ struct rsx_ctx {
     // grow-only device workspace so steady-state render calls never hipMalloc
     void *pool[POOL_SLOTS];
     size_t pool_bytes[POOL_SLOTS];
+    void *staging;             // pinned host mirror of small query workspaces: one copy in, one copy out per call
+    size_t staging_bytes;
 };
 
 static int pool_get(rsx_ctx *ctx, int slot, size_t bytes, void **out) {
@@ -258,6 +260,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
         if (ln->merged) (void)hipEventDestroy(ln->merged);
     }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
+    if (ctx->staging) (void)hipHostFree(ctx->staging);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev2}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->gate) (void)hipEventDestroy(e);
@@ -676,11 +679,38 @@ extern "C" int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, 
     int32_t *d_tri = c.take<int32_t>(tri ? N * 4 : 0);
     float *d_uvw = c.take<float>(uvw ? N * 12 : 0);
     double *d_geom = c.take<double>(geom ? N * 96 : 0);
-    HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    // Small batches (World.hit(ray) is a batch of one) are latency-bound on the number of copies: the workspace is mirrored in a pinned
+    // host buffer, so the inputs go up in one transfer and every requested output comes back in one.
+    char *ws_begin = reinterpret_cast<char *>(d_o), *in_end = reinterpret_cast<char *>(d_prim), *ws_end = c.at;
+    const size_t ws_bytes = (size_t)(ws_end - ws_begin), in_bytes = (size_t)(in_end - ws_begin);
+    const bool staged = ws_bytes <= ((size_t)1 << 20);
+    if (staged) {
+        if (ws_bytes > ctx->staging_bytes) {
+            if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
+            ctx->staging = nullptr; ctx->staging_bytes = 0;
+            HIP_TRY(hipHostMalloc(&ctx->staging, (size_t)1 << 20, hipHostMallocDefault));
+            ctx->staging_bytes = (size_t)1 << 20;
+        }
+        char *h = static_cast<char *>(ctx->staging);
+        std::memcpy(h + (reinterpret_cast<char *>(d_o) - ws_begin), origin, N * 24);
+        std::memcpy(h + (reinterpret_cast<char *>(d_d) - ws_begin), direction, N * 24);
+        std::memcpy(h + (reinterpret_cast<char *>(d_m) - ws_begin), max_distance, N * 8);
+        HIP_TRY(hipMemcpyAsync(ws_begin, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    }
     rc = rsx_hit_batch_dev(scene, n, d_o, d_d, d_m, d_prim, d_t, d_ex, d_tri, d_uvw, d_geom);
     if (rc) return rc;
+    if (staged) {
+        char *h = static_cast<char *>(ctx->staging);
+        HIP_TRY(hipMemcpyAsync(h + in_bytes, in_end, ws_bytes - in_bytes, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        auto back = [&](void *dst, const void *dev, size_t bytes) { if (dst) std::memcpy(dst, h + (static_cast<const char *>(dev) - ws_begin), bytes); };
+        back(prim, d_prim, N * 4); back(t, d_t, N * 8); back(exiting, d_ex, N); back(tri, d_tri, N * 4); back(uvw, d_uvw, N * 12); back(geom, d_geom, N * 96);
+        return RSX_OK;
+    }
     HIP_TRY(hipMemcpyAsync(prim, d_prim, N * 4, hipMemcpyDeviceToHost, ctx->stream));
     if (t) HIP_TRY(hipMemcpyAsync(t, d_t, N * 8, hipMemcpyDeviceToHost, ctx->stream));
     if (exiting) HIP_TRY(hipMemcpyAsync(exiting, d_ex, N, hipMemcpyDeviceToHost, ctx->stream));
