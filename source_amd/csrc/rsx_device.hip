@@ -24,6 +24,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "../../include/rsx.h"
@@ -639,6 +640,63 @@ int query_workspace(rsx_ctx *ctx, std::initializer_list<size_t> sizes, Carver &c
     return RSX_OK;
 }
 
+// One synchronous query = inputs up, kernel, outputs back. For small workspaces (<= 1 MiB) both directions go through the ctx's
+// pinned mirror of the workspace: one transfer each way instead of one per array (World.hit(ray) is a batch of one).
+struct QueryIO {
+    rsx_ctx *ctx;
+    char *ws_begin, *ws_end;
+    bool staged;
+    std::vector<std::tuple<void *, const void *, size_t>> in;       // (device, host, bytes)
+    std::vector<std::tuple<void *, const void *, size_t>> out;      // (host, device, bytes)
+    char *lowest_out = nullptr;
+
+    int begin(rsx_ctx *c, void *first, char *end) {
+        ctx = c; ws_begin = static_cast<char *>(first); ws_end = end;
+        staged = (size_t)(ws_end - ws_begin) <= ((size_t)1 << 20);
+        if (staged && ctx->staging_bytes < ((size_t)1 << 20)) {
+            if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
+            ctx->staging = nullptr; ctx->staging_bytes = 0;
+            HIP_TRY(hipHostMalloc(&ctx->staging, (size_t)1 << 20, hipHostMallocDefault));
+            ctx->staging_bytes = (size_t)1 << 20;
+        }
+        return RSX_OK;
+    }
+    void input(void *dev, const void *host, size_t bytes) { if (dev && bytes) in.emplace_back(dev, host, bytes); }
+    void output(void *host, const void *dev, size_t bytes) {
+        if (!host || !dev || !bytes) return;
+        out.emplace_back(host, dev, bytes);
+        char *d = const_cast<char *>(static_cast<const char *>(dev));
+        if (!lowest_out || d < lowest_out) lowest_out = d;
+    }
+    int upload() {
+        if (!staged) {
+            for (auto &e : in) HIP_TRY(hipMemcpyAsync(std::get<0>(e), std::get<1>(e), std::get<2>(e), hipMemcpyHostToDevice, ctx->stream));
+            return RSX_OK;
+        }
+        char *h = static_cast<char *>(ctx->staging);
+        size_t hi = 0;
+        for (auto &e : in) {
+            const size_t off = (size_t)(static_cast<char *>(std::get<0>(e)) - ws_begin);
+            std::memcpy(h + off, std::get<1>(e), std::get<2>(e));
+            hi = std::max(hi, off + std::get<2>(e));
+        }
+        if (hi) HIP_TRY(hipMemcpyAsync(ws_begin, h, hi, hipMemcpyHostToDevice, ctx->stream));
+        return RSX_OK;
+    }
+    int download() {                                                  // synchronises the stream
+        if (!staged) {
+            for (auto &e : out) HIP_TRY(hipMemcpyAsync(std::get<0>(e), std::get<1>(e), std::get<2>(e), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            return RSX_OK;
+        }
+        char *h = static_cast<char *>(ctx->staging);
+        if (lowest_out) HIP_TRY(hipMemcpyAsync(h + (lowest_out - ws_begin), lowest_out, (size_t)(ws_end - lowest_out), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (auto &e : out) std::memcpy(std::get<0>(e), h + (static_cast<const char *>(std::get<1>(e)) - ws_begin), std::get<2>(e));
+        return RSX_OK;
+    }
+};
+
 }  // namespace
 
 extern "C" int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *origin, const double *direction, const double *max_distance,
@@ -679,46 +737,15 @@ extern "C" int rsx_hit_batch(rsx_scene *scene, int64_t n, const double *origin, 
     int32_t *d_tri = c.take<int32_t>(tri ? N * 4 : 0);
     float *d_uvw = c.take<float>(uvw ? N * 12 : 0);
     double *d_geom = c.take<double>(geom ? N * 96 : 0);
-    // Small batches (World.hit(ray) is a batch of one) are latency-bound on the number of copies: the workspace is mirrored in a pinned
-    // host buffer, so the inputs go up in one transfer and every requested output comes back in one.
-    char *ws_begin = reinterpret_cast<char *>(d_o), *in_end = reinterpret_cast<char *>(d_prim), *ws_end = c.at;
-    const size_t ws_bytes = (size_t)(ws_end - ws_begin), in_bytes = (size_t)(in_end - ws_begin);
-    const bool staged = ws_bytes <= ((size_t)1 << 20);
-    if (staged) {
-        if (ws_bytes > ctx->staging_bytes) {
-            if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
-            ctx->staging = nullptr; ctx->staging_bytes = 0;
-            HIP_TRY(hipHostMalloc(&ctx->staging, (size_t)1 << 20, hipHostMallocDefault));
-            ctx->staging_bytes = (size_t)1 << 20;
-        }
-        char *h = static_cast<char *>(ctx->staging);
-        std::memcpy(h + (reinterpret_cast<char *>(d_o) - ws_begin), origin, N * 24);
-        std::memcpy(h + (reinterpret_cast<char *>(d_d) - ws_begin), direction, N * 24);
-        std::memcpy(h + (reinterpret_cast<char *>(d_m) - ws_begin), max_distance, N * 8);
-        HIP_TRY(hipMemcpyAsync(ws_begin, h, in_bytes, hipMemcpyHostToDevice, ctx->stream));
-    } else {
-        HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
-    }
+    QueryIO io;
+    if ((rc = io.begin(ctx, d_o, c.at))) return rc;
+    io.input(d_o, origin, N * 24); io.input(d_d, direction, N * 24); io.input(d_m, max_distance, N * 8);
+    if ((rc = io.upload())) return rc;
     rc = rsx_hit_batch_dev(scene, n, d_o, d_d, d_m, d_prim, d_t, d_ex, d_tri, d_uvw, d_geom);
     if (rc) return rc;
-    if (staged) {
-        char *h = static_cast<char *>(ctx->staging);
-        HIP_TRY(hipMemcpyAsync(h + in_bytes, in_end, ws_bytes - in_bytes, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        auto back = [&](void *dst, const void *dev, size_t bytes) { if (dst) std::memcpy(dst, h + (static_cast<const char *>(dev) - ws_begin), bytes); };
-        back(prim, d_prim, N * 4); back(t, d_t, N * 8); back(exiting, d_ex, N); back(tri, d_tri, N * 4); back(uvw, d_uvw, N * 12); back(geom, d_geom, N * 96);
-        return RSX_OK;
-    }
-    HIP_TRY(hipMemcpyAsync(prim, d_prim, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (t) HIP_TRY(hipMemcpyAsync(t, d_t, N * 8, hipMemcpyDeviceToHost, ctx->stream));
-    if (exiting) HIP_TRY(hipMemcpyAsync(exiting, d_ex, N, hipMemcpyDeviceToHost, ctx->stream));
-    if (tri) HIP_TRY(hipMemcpyAsync(tri, d_tri, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw, N * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (geom) HIP_TRY(hipMemcpyAsync(geom, d_geom, N * 96, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RSX_OK;
+    io.output(prim, d_prim, N * 4); io.output(t, d_t, N * 8); io.output(exiting, d_ex, N); io.output(tri, d_tri, N * 4);
+    io.output(uvw, d_uvw, N * 12); io.output(geom, d_geom, N * 96);
+    return io.download();
 }
 
 extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double *origin, const double *direction,
@@ -744,9 +771,10 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     if (d_g) HIP_TRY(hipMemsetAsync(d_g, 0, N * R * 96, ctx->stream));
     if (d_tri) HIP_TRY(hipMemsetAsync(d_tri, 0xff, N * R * 4, ctx->stream));
     if (d_uvw) HIP_TRY(hipMemsetAsync(d_uvw, 0, N * R * 12, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_o, origin, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_d, direction, N * 24, hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(d_m, max_distance, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    QueryIO io;
+    if ((rc = io.begin(ctx, d_o, c.at))) return rc;
+    io.input(d_o, origin, N * 24); io.input(d_d, direction, N * 24); io.input(d_m, max_distance, N * 8);
+    if ((rc = io.upload())) return rc;
     HIP_TRY(hipMemsetAsync(d_t, 0, N * R * 8, ctx->stream));
     HIP_TRY(hipMemsetAsync(d_ex, 0, N * R, ctx->stream));
     Launch l;
@@ -758,14 +786,9 @@ extern "C" int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, c
     else hipLaunchKernelGGL(k_roots<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, primitive, (long long)n, d_o, d_d, d_m,
                             max_roots, d_c, d_t, d_ex, d_g, d_tri, d_uvw, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(counts, d_c, N * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(t, d_t, N * R * 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipMemcpyAsync(exiting, d_ex, N * R, hipMemcpyDeviceToHost, ctx->stream));
-    if (geometry) HIP_TRY(hipMemcpyAsync(geometry, d_g, N * R * 96, hipMemcpyDeviceToHost, ctx->stream));
-    if (triangle) HIP_TRY(hipMemcpyAsync(triangle, d_tri, N * R * 4, hipMemcpyDeviceToHost, ctx->stream));
-    if (uvw) HIP_TRY(hipMemcpyAsync(uvw, d_uvw, N * R * 12, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RSX_OK;
+    io.output(counts, d_c, N * 4); io.output(t, d_t, N * R * 8); io.output(exiting, d_ex, N * R);
+    io.output(geometry, d_g, N * R * 96); io.output(triangle, d_tri, N * R * 4); io.output(uvw, d_uvw, N * R * 12);
+    return io.download();
 }
 
 extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *points, uint8_t *inside) {
@@ -779,7 +802,10 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
     if (rc) return rc;
     double *d_p = c.take<double>(N * 24);
     uint8_t *d_in = c.take<uint8_t>(N * W);
-    HIP_TRY(hipMemcpyAsync(d_p, points, N * 24, hipMemcpyHostToDevice, ctx->stream));
+    QueryIO io;
+    if ((rc = io.begin(ctx, d_p, c.at))) return rc;
+    io.input(d_p, points, N * 24);
+    if ((rc = io.upload())) return rc;
     Launch l;
     if ((rc = plan(scene, n, ctx->main, l))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_contains<true>) : reinterpret_cast<const void *>(k_contains<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
@@ -787,9 +813,8 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
     if (scene->has_csg) hipLaunchKernelGGL(k_contains<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p, d_in, ctx->main.ticket);
     else hipLaunchKernelGGL(k_contains<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, d_p, d_in, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(inside, d_in, N * (size_t)scene->d.n_world, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
-    return RSX_OK;
+    io.output(inside, d_in, N * (size_t)scene->d.n_world);
+    return io.download();
 }
 
 namespace {
