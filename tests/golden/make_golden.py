@@ -462,6 +462,9 @@ def f12_volumes():
     out["mean"], out["var"], out["n"] = observe_frame(cam, pipe, 31)
     pyrandom.seed(32); rsrandom.seed(32); cam.observe()                       # accumulate pass
     out["mean2"], out["var2"], out["n2"] = np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples)
+    world, prims = scenes.build_volumes(NS, enclosed=False)                   # paths that leave the scene (ray.pyx:389-391)
+    cam, pipe = scenes.volumes_camera(NS, world)
+    out["open_mean"], out["open_var"], out["open_n"] = observe_frame(cam, pipe, 33)
     save("f12_volumes", **out)
 
 

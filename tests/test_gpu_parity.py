@@ -528,6 +528,10 @@ def test_frames_volume_emitters_stream_parity(orc, ns, golden):
     assert eq(m, g["mean"]) and eq(v, g["var"]) and eq(n, g["n"])
     m, v, n = _observe(ns, cam, pipe, 32)
     assert eq(m, g["mean2"]) and eq(v, g["var2"]) and eq(n, g["n2"])
+    open_world, _ = scenes.build_volumes(ns, enclosed=False)
+    cam_o, pipe_o = scenes.volumes_camera(ns, open_world)
+    m, v, n = _observe(ns, cam_o, pipe_o, 33)
+    assert eq(m, g["open_mean"]) and eq(v, g["open_var"]) and eq(n, g["open_n"])
     # throughput mode at a larger size against the oracle
     cam2, pipe2 = scenes.volumes_camera(ns, world, (256, 192), spp=8, bins=6)
     cam2.frame_sampler = ns.RectFrameSampler2D()

@@ -382,3 +382,7 @@ def test_frames_volume_emitters(orc, ns, golden):
     assert eq(f[0], g["mean"]) and eq(f[1], g["var"]) and eq(f[2], g["n"])
     f = _observe_oracle(orc, ns, cam, pipe, 32, f)
     assert eq(f[0], g["mean2"]) and eq(f[1], g["var2"]) and eq(f[2], g["n2"])
+    world, prims = scenes.build_volumes(ns, enclosed=False)      # most paths end in a miss: that segment contributes nothing
+    cam, pipe = scenes.volumes_camera(ns, world)
+    f = _observe_oracle(orc, ns, cam, pipe, 33)
+    assert eq(f[0], g["open_mean"]) and eq(f[1], g["open_var"]) and eq(f[2], g["open_n"])
