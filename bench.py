@@ -13,7 +13,7 @@ One "step" = one observe() pass over the whole frame = 268 435 456 primary rays:
 two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford over the 64 samples, merged into the
 device-resident spectral frame. Scene, camera tables and the frame are resident in HBM when the timed region starts.
 --workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass); --workload c4 = configs[3] (demos/csg.py
-tree, 1024x1024, 16 spp/pass).
+tree, 1024x1024, 16 spp/pass); --workload flat = one 1M-triangle mesh without instancing (geometry far larger than L2).
 
 N>1: sample sharding — every rank renders the same frame with its own sample counters (weak scaling: per-GPU work is
 fixed); the only collective is one RCCL all_gather of the (mean, variance, samples) frames after the K passes, followed
@@ -39,6 +39,9 @@ WORKLOADS = {
     "c2": dict(nx=1024, ny=1024, spp=1, counter_rows=8,
                name="configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera 1024x1024, 1 spp/pass, "
                     "15 spectral bins, primary rays only, 1 MI355X per rank"),
+    "flat": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
+                 name="HBM stress (SURVEY.md 8d M1M-flat): ONE 1 047 552-triangle displaced-sphere mesh (no instancing), PinholeCamera "
+                      "2048x2048, 64 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
     "c4": dict(nx=1024, ny=1024, spp=16, counter_rows=8,
                name="configs[3]: demos/csg.py Boolean tree (sphere/box/cylinder Union/Intersect/Subtract, 5 CSG objects), PinholeCamera "
                     "1024x1024, 16 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
@@ -52,6 +55,9 @@ def build_workload(key, ns, scenes):
         cam, pipe = scenes.c3_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
     elif key == "c2":
         world = scenes.build_c2(ns, n=132)[0]
+        cam, pipe = scenes.c2_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    elif key == "flat":
+        world = scenes.build_flat(ns, n=512)[0]
         cam, pipe = scenes.c2_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
     else:
         world = scenes.build_csg_demo(ns)[0]

@@ -125,6 +125,12 @@ def build_c2(ns, n=132, smoothing=False, with_normals=False):
     return world, mesh, box
 
 
+def build_flat(ns, n=512):
+    """HBM-stress variant of configs[1] (SURVEY.md §8d "M1M-flat"): ONE mesh of 1 048 576 triangles (n = 512; 0.45 GB of nodes and
+    leaf records on the device — far more than the 32 MB of L2), same materials and camera geometry as build_c2."""
+    return build_c2(ns, n=n)
+
+
 def c2_camera(ns, world, pixels=(1024, 1024), spp=1, bins=15):
     pipe = ns.SpectralRadiancePipeline2D()
     cam = ns.PinholeCamera(pixels, fov=45, parent=world, pipelines=[pipe],

@@ -5,7 +5,7 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 WL=${2:-c3}
-KB=$WL; [ "$WL" = c3 ] && KB=c3full; [ "$WL" = c4 ] && KB=c4full
+KB=$WL; [ "$WL" = c3 ] && KB=c3full; [ "$WL" = c4 ] && KB=c4full    # flat, c2: same name
 OUT=$R/gpurun_out/prof_${1:-r01}_$WL
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
