@@ -2,17 +2,21 @@
 // intersection, pinhole ray generation, closed-form shading and spectral accumulation.
 //
 // Design:
-//  * one ray per lane, 64-wide wavefronts, persistent workgroups pulling 64-ray batches from a global
-//    ticket counter (dynamic load balance across the 256 CUs; per-XCD L2 keeps the flattened trees hot);
-//  * explicit per-lane traversal stacks in LDS, laid out [level][lane] so that every ds_read/ds_write of a
-//    wave is bank-conflict free whatever level each lane is at; an entry is (far node id, far tmax): the
-//    far range's tmin is the tmax of the leaf that was just exhausted, so it is never stored;
-//  * KD nodes are 16 B (one dwordx4 load), triangles are pre-gathered into 48 B records
-//    (9 vertex floats + face normal = three dwordx4 loads, no index indirection);
-//  * arithmetic follows the reference operation for operation (f64 traversal and analytic primitives,
-//    f32 watertight triangle test with its f64 casts): compiled with -ffp-contract=off, IEEE div/sqrt,
-//    so hit ids and distances are bit-identical to the reference's;
-//  * no MFMA: the path is branchy traversal, bound by memory latency/bandwidth, not by a contraction.
+//  * one ray per lane, 64-wide wavefronts, persistent workgroups pulling 64-ray units from per-XCD work lists; a unit is as many
+//    samples of as few pixels as the pass allows (one pixel x 64 samples at 64 spp), so the lanes of a wave walk nearly the same path;
+//  * explicit per-lane traversal stacks in LDS, laid out [level][lane] so that every ds_read/ds_write of a wave is bank-conflict
+//    free whatever level each lane is at; an entry is (far node id, far tmax): the far range's tmin is the tmax of the leaf that
+//    was just exhausted, so it is never stored; deeper levels spill to a per-wave global array;
+//  * KD nodes are 16 B (one dwordx4 load, fetched as (node, node+1) pairs); mesh leaves read leaf-ordered 64 B triangle records
+//    (9 vertex floats + face normal + triangle id: no index indirection); big leaves are tested by the whole wave;
+//  * arithmetic follows the reference operation for operation (f64 traversal and analytic primitives, f32 watertight triangle
+//    test with its f64 casts): compiled with -ffp-contract=off, IEEE div/sqrt — the per-step division is the one exception in
+//    form, not in value: a hoisted, refined reciprocal reproduces the correctly rounded quotient (exact_div);
+//  * 168 registers per wave = three waves per SIMD; the register diet that got there is described in DESIGN.md section 5;
+//  * no MFMA: the path is branchy traversal, bound by instruction issue and divergence, not by a contraction.
+//
+// The device code is one translation unit split by subject: dev_common.hpp (records, stacks, KD step), dev_mesh.hpp, dev_analytic.hpp,
+// dev_csg.hpp, dev_world.hpp, dev_query_kernels.hpp (hit / roots / contains), dev_render.hpp (observe: trace, scheduling, Welford).
 //
 // Reference lines each device function restates are cited at the function.
 #include <hip/hip_runtime.h>
