@@ -39,6 +39,7 @@ if os.environ.get("PHASES"):       # library built with -DRSX_PHASE_PROF=1: s_me
     for nme, v in zip(names, c[:5]):
         print("%-18s %.3f of the mesh loop" % (nme, v / tot))
     print("mesh-loop iterations %.4g, lanes active per iteration %.1f, big-leaf lanes per iteration %.3f" % (c[5], c[7] / c[5], c[6] / c[5]))
+    print("mesh loop = %.3f of the units' wall time (both in s_memtime / s_memrealtime ticks)" % (tot / total))
     sys.exit(0)
 for name, k in (("world loop", 0), ("mesh loop", 2), ("node steps", 4), ("leaf batches", 6)):
     print("%-13s active lane-slots %.4g of %.4g  -> utilisation %.3f" % (name, c[k], c[k + 1], c[k] / max(c[k + 1], 1)))
