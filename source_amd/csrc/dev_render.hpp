@@ -41,7 +41,6 @@ struct RenderParams {
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
     int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
-    int32_t spu_log2, pw_log2, ph_log2, groups;   // unit shape, see UnitShape
     unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
 };
 
@@ -56,11 +55,11 @@ __device__ __forceinline__ void task_pixel(const RenderParams &rp, long long k, 
     else { const int w = rp.rect[2] - rp.rect[0]; ix = rp.rect[0] + (int)(k % w); iy = rp.rect[1] + (int)(k / w); }
 }
 
-// A 64-ray unit = (a few pixels) x (as many samples of each as fit): with spp samples per pixel per pass, spu = the largest power
-// of two that divides spp (at most 64) samples of pw x ph = 64 / spu pixels. Rays through one pixel differ only by sub-pixel jitter,
-// so the lanes of a wave walk the same nodes and leaves: at 64 spp a wave is ONE pixel. (An 8x8-pixel tile of one sample index —
-// the spp = 1 case of the same rule — had 27 % of its lanes busy in the KD steps on configs[2].) Unit id = chunk * groups + g with
-// chunk the pixel tile (or the run of 64 / spu tasks of a task list) and g the sample group, groups = spp / spu.
+// The rays of a pass are numbered g = pixel * spp + sample, with the pixels taken tile by tile (8x8 tiles, row-major inside a
+// tile; the entries of the list in task mode), and unit u renders rays 64u .. 64u + 63. So a unit is always the most coherent bundle
+// the pass offers: one 8x8 tile of one sample index at 1 spp, ONE pixel at 64 spp, at most two neighbouring pixels at the
+// reference's default 100 spp. Rays through one pixel differ only by sub-pixel jitter, so the lanes of a wave walk nearly the same
+// nodes and leaves (an 8x8 tile per sample index, whatever the spp, had 27 % of its lanes busy in the KD steps on configs[2]).
 struct UnitPixel {
     long long k;               // task index (row-major in rect mode)
     long long slot;            // sample-record slot of the pixel (x-major in rect mode, like the frame)
@@ -70,22 +69,24 @@ struct UnitPixel {
 
 __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams *q, long long unit, int lane) {
     UnitPixel px;
-    const int spu_log2 = q->spu_log2, groups = q->groups;
-    px.s = (int)(unit % groups) * (1 << spu_log2) + (lane & ((1 << spu_log2) - 1));
-    const long long chunk = unit / groups;
-    const int pl = lane >> spu_log2;                        // which pixel of the unit this lane renders
+    const uint32_t spp = (uint32_t)q->spp;
+    const unsigned long long g = (unsigned long long)unit * WAVE + (unsigned)lane;
+    unsigned long long pixel;
+    if (g < (1ULL << 32)) { pixel = (uint32_t)g / spp; px.s = (int)((uint32_t)g % spp); }      // 32-bit divide when it fits
+    else { pixel = g / spp; px.s = (int)(g % spp); }
     if (q->tasks) {
-        px.k = chunk * (WAVE >> spu_log2) + pl;
+        px.k = (long long)pixel;
         px.valid = px.k < q->n_tasks;
         if (!px.valid) px.k = 0;
         px.ix = q->tasks[2 * px.k]; px.iy = q->tasks[2 * px.k + 1];
         px.slot = px.k;
     } else {
         const int w = q->rect[2] - q->rect[0], h = q->rect[3] - q->rect[1];
-        const int pw_log2 = q->pw_log2, ph_log2 = q->ph_log2;
-        const int tiles_x = (w + (1 << pw_log2) - 1) >> pw_log2;
-        const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
-        const int lx = (tx << pw_log2) + (pl & ((1 << pw_log2) - 1)), ly = (ty << ph_log2) + (pl >> pw_log2);
+        const int tiles_x = (w + 7) >> 3;
+        const long long tile = (long long)(pixel >> 6);
+        const int within = (int)(pixel & 63);
+        const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x);
+        const int lx = (tx << 3) + (within & 7), ly = (ty << 3) + (within >> 3);
         px.valid = lx < w && ly < h;
         px.ix = q->rect[0] + (px.valid ? lx : 0); px.iy = q->rect[1] + (px.valid ? ly : 0);
         px.k = px.valid ? (long long)ly * w + lx : 0;
@@ -395,24 +396,21 @@ __device__ __forceinline__ int cost_bucket(uint32_t c) {
 
 // which XCD's list a unit belongs to: 4x4-tile blocks (32x32 pixels) are dealt round-robin to the 8 XCDs, so each L2 caches the
 // geometry behind an eighth of the image while every XCD still gets a fair share of cheap and expensive regions
-__device__ __forceinline__ int unit_xcd(long long unit, int tiles_x, int groups, int pw_log2, int ph_log2) {
-    const long long chunk = unit / groups;
-    if (tiles_x > 0) {
-        const int tx = (int)(chunk % tiles_x), ty = (int)(chunk / tiles_x);
-        return ((((tx << pw_log2) >> 5)) + 3 * ((ty << ph_log2) >> 5)) & 7;      // 32x32-pixel blocks, whatever the unit shape
-    }
-    return (int)((chunk >> 4) & 7);
+__device__ __forceinline__ int unit_xcd(long long unit, int tiles_x, int spp) {
+    const long long tile = unit / spp;                       // first pixel of the unit = 64 * unit / spp; 64 pixels per tile
+    if (tiles_x > 0) { const int tx = (int)(tile % tiles_x), ty = (int)(tile / tiles_x); return ((tx >> 2) + 3 * (ty >> 2)) & 7; }
+    return (int)((tile >> 4) & 7);
 }
 
 // list 0: units well above the mean cost (latency-bound stragglers: every XCD takes them first); lists 1..8: the rest, by XCD
-__device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned long long mean, int tiles_x, int groups, int pw_log2, int ph_log2) {
+__device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned long long mean, int tiles_x, int spp) {
     if ((unsigned long long)c > RSX_HEAVY_FACTOR * mean) return 0;
-    return 1 + unit_xcd(unit, tiles_x, groups, pw_log2, ph_log2);
+    return 1 + unit_xcd(unit, tiles_x, spp);
 }
 
 // One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
 // and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
-__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int groups, int pw_log2, int ph_log2) {
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp) {
     __shared__ unsigned int hist[9][ORDER_BUCKETS];
     __shared__ unsigned int offset[9][ORDER_BUCKETS];
     __shared__ unsigned long long total;
@@ -427,7 +425,7 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     const unsigned long long mean = total / (unsigned long long)n + 1;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t c = cost[i];
-        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, groups, pw_log2, ph_log2)][cost_bucket(c)], 1u);
+        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -441,7 +439,7 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     __syncthreads();
     for (long long i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t c = cost[i];
-        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, groups, pw_log2, ph_log2)][cost_bucket(c)], 1u)] = (uint32_t)i;
+        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
     }
 }
 

@@ -2,8 +2,9 @@
 // intersection, pinhole ray generation, closed-form shading and spectral accumulation.
 //
 // Design:
-//  * one ray per lane, 64-wide wavefronts, persistent workgroups pulling 64-ray units from per-XCD work lists; a unit is as many
-//    samples of as few pixels as the pass allows (one pixel x 64 samples at 64 spp), so the lanes of a wave walk nearly the same path;
+//  * one ray per lane, 64-wide wavefronts, persistent workgroups pulling 64-ray units from per-XCD work lists; a unit is 64
+//    consecutive rays of the numbering pixel * spp + sample (one pixel x 64 samples at 64 spp), so the lanes of a wave walk nearly
+//    the same path;
 //  * explicit per-lane traversal stacks in LDS, laid out [level][lane] so that every ds_read/ds_write of a wave is bank-conflict
 //    free whatever level each lane is at; an entry is (far node id, far tmax): the far range's tmin is the tmax of the leaf that
 //    was just exhausted, so it is never stored; deeper levels spill to a per-wave global array;
@@ -848,13 +849,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // Small passes are tail-bound and overlap well; a large pass fills the chip by itself (its merge kernel could not even get
     // registers next to it), so it runs alone on the ctx stream.
     const long long rect_w = desc->rect[2] - desc->rect[0], rect_h = desc->rect[3] - desc->rect[1];
-    // unit shape (see UnitShape in dev_render.hpp): spu samples of 64 / spu pixels per 64-ray unit
-    int spu_log2 = 0;
-    while (spu_log2 < 6 && desc->spp % (2 << spu_log2) == 0) ++spu_log2;
-    const int pix_log2 = 6 - spu_log2, pw_log2 = (pix_log2 + 1) / 2, ph_log2 = pix_log2 / 2;      // 8x8, 8x4, 4x4, 4x2, 2x2, 2x1, 1x1
-    const long long groups = desc->spp >> spu_log2;
-    const long long tiles_x_all = (rect_w + (1 << pw_log2) - 1) >> pw_log2, tiles_y_all = (rect_h + (1 << ph_log2) - 1) >> ph_log2;
-    const long long n_units_all = (desc->tasks ? (desc->n_tasks + (WAVE >> spu_log2) - 1) / (WAVE >> spu_log2) : tiles_x_all * tiles_y_all) * groups;
+    // 64-ray units over the rays g = pixel * spp + sample, pixels tile by tile (see unit_pixel in dev_render.hpp)
+    const long long tiles_x_all = (rect_w + 7) >> 3, tiles_y_all = (rect_h + 7) >> 3;
+    const long long n_units_all = desc->tasks ? (desc->n_tasks * (long long)desc->spp + WAVE - 1) / WAVE : tiles_x_all * tiles_y_all * (long long)desc->spp;
     // transparent-boundary / volume-emitter materials take the multi-segment kernel (k_render_trace_vol), un-pipelined
     bool has_vol = false;
     for (int32_t i = 0; i < desc->n_materials; ++i) has_vol = has_vol || desc->materials[i].type == RSX_MAT_NULL || desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;
@@ -925,7 +922,6 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.unit_times = ctx->unit_times;
-    rp.spu_log2 = spu_log2; rp.pw_log2 = pw_log2; rp.ph_log2 = ph_log2; rp.groups = (int32_t)groups;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured
     {
         const long long w = desc->rect[2] - desc->rect[0], h = desc->rect[3] - desc->rect[1];
@@ -957,7 +953,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         order_tiles_x = desc->tasks ? 0 : (int)tiles_x_all;
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
-            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)groups, pw_log2, ph_log2);
+            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp);
             HIP_TRY(hipGetLastError());
         }
         rp.unit_order = lane.unit_order;
@@ -1010,7 +1006,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
-        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)groups, pw_log2, ph_log2);
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
     }

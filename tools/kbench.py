@@ -23,6 +23,12 @@ elif config == "c3":
 elif config == "c3full":
     world = scenes.build_c3(ns, n=132)[0]
     cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=64, bins=15)
+elif config == "c3s100":                  # the reference's default pixel_samples
+    world = scenes.build_c3(ns, n=132)[0]
+    cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=100, bins=15)
+elif config == "c3s24":
+    world = scenes.build_c3(ns, n=132)[0]
+    cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=24, bins=15)
 elif config == "flat":
     world = scenes.build_flat(ns, n=512)[0]
     cam, pipe = scenes.c2_camera(ns, world, (2048, 2048), spp=64, bins=15)
