@@ -49,7 +49,12 @@ enum {
      * collects the volume emission of the primitives that contain the segment's origin (Ray._sample_volumes, optical/ray.pyx:422-455;
      * HomogeneousVolumeEmitter.evaluate_volume, emitter/homogeneous.pyx:55-102): spectrum[bin] += (table[bin] * scale) * length. */
     RSX_MAT_NULL = 3,                    /* NullMaterial: null surface, no volume                                   */
-    RSX_MAT_UNIFORM_VOLUME_EMITTER = 4   /* UniformVolumeEmitter (emitter/uniform.pyx:91-131): null surface + table[bin] * scale per unit length */
+    RSX_MAT_UNIFORM_VOLUME_EMITTER = 4,  /* UniformVolumeEmitter (emitter/uniform.pyx:91-131): null surface + table[bin] * scale per unit length */
+    /* Lambert (optical/material/lambert.pyx:40-112 under ContinuousBSDF.evaluate_surface, material.pyx:286-361, without important
+     * primitives): one cosine-weighted daughter ray (HemisphereCosineSampler, core/math/sampler/solidangle.pyx:208-238) from the
+     * incident side, depth + 1, Russian roulette per Ray.trace (optical/ray.pyx:382-388);
+     * spectrum = trace(daughter) * table[bin] * pdf / pdf. Stochastic: RSX_RNG_PHILOX only. */
+    RSX_MAT_LAMBERT = 5
 };
 
 /* ---- flattened KD-tree (raysect/core/math/spatial/kdtree3d.pxd:38-43 `kdnode`, 32 B -> 16 B) -- */
@@ -133,6 +138,9 @@ typedef struct rsx_material {
 
 #define RSX_RNG_STREAM 0  /* uniforms[] supplied by caller: 2 per sample in task order (reference MT19937-64 parity) */
 #define RSX_RNG_PHILOX 1  /* on-device Philox4x32-10 keyed by (seed; pixel, sample): order/shard independent      */
+/* Philox counter = (pixel, sample | draw << 48): draw 0 = the camera's sub-pixel jitter; for a ray of depth d >= 1 draw 2d is its
+ * Russian-roulette uniform and draw 2d + 1 the pair of uniforms of the scattering event that spawns the depth d + 1 ray (draw 1
+ * for the primary ray's). Paths therefore reproduce whatever wave, GPU or rank renders them. */
 
 typedef struct rsx_render_desc {
     rsx_camera camera;
@@ -150,6 +158,10 @@ typedef struct rsx_render_desc {
     int32_t rng_mode;
     uint64_t seed;
     uint64_t sample_offset;         /* RSX_RNG_PHILOX: first sample counter (sample-sharded ranks use rank*spp) */
+    /* secondary rays (optical/ray.pyx:72-106; observer defaults observer.pyx:114-127). Only read when a material spawns them. */
+    int32_t ray_max_depth;            /* Ray.max_depth */
+    int32_t ray_extinction_min_depth; /* Ray.extinction_min_depth */
+    double ray_extinction_prob;       /* Ray.extinction_prob */
 } rsx_render_desc;
 
 typedef struct rsx_ctx rsx_ctx;

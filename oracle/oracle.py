@@ -52,6 +52,8 @@ def lib():
         L.orc_add_samples.argtypes = [C.c_int64, vp, vp]
         L.orc_frame_combine.argtypes = [C.c_int64, vp, vp, vp, vp, vp, vp]
         L.orc_render_pinhole.argtypes = [C.POINTER(S.SceneDesc), C.POINTER(S.RenderDesc), vp, vp, C.POINTER(C.c_uint64), C.c_int]
+        L.orc_render_pinhole_mt.argtypes = [C.POINTER(S.SceneDesc), C.POINTER(S.RenderDesc), vp, vp, vp, C.POINTER(C.c_uint64)]
+        L.orc_set_libm_trig.argtypes = [C.c_int]
         L.orc_pinhole_rays.argtypes = [C.POINTER(S.RenderDesc), vp]
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -83,6 +85,28 @@ def mt_uniform(seed, n):
     out = np.empty(n)
     lib().orc_mt_uniform(p(st), n, p(out))
     return out
+
+
+def mt_state(seed):
+    """A seeded MT19937-64 state (random.pyx:215-243) for render_pinhole_mt."""
+    st = np.zeros(313, dtype=np.uint64)
+    words = np.frombuffer(int(seed).to_bytes(8 * 312, "big"), dtype=">u8").astype(np.uint64)
+    lib().orc_mt_seed_words(p(st), p(words), 312)
+    return st
+
+
+def render_pinhole_mt(flat, desc, state):
+    """The reference's SerialEngine: jitter, scattering and roulette draws all come from ``state`` in execution order."""
+    mean = np.zeros((desc.n_tasks, desc.bins))
+    var = np.zeros((desc.n_tasks, desc.bins))
+    rays = C.c_uint64(0)
+    lib().orc_render_pinhole_mt(C.byref(flat.desc), C.byref(desc), p(state), p(mean), p(var), C.byref(rays))
+    return mean, var, int(rays.value)
+
+
+def set_libm_trig(on):
+    """Philox-mode scattering uses libm's sin/cos (like the reference) instead of the portable pair the device restates."""
+    lib().orc_set_libm_trig(int(bool(on)))
 
 
 def philox(seed, pixel, sample):

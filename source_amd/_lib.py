@@ -70,7 +70,8 @@ class RenderDesc(C.Structure):
     _fields_ = [("camera", Camera), ("materials", C.POINTER(Material)), ("tables", C.c_void_p), ("tasks", C.c_void_p),
                 ("uniforms", C.c_void_p), ("n_tasks", C.c_int64), ("rect", C.c_int32 * 4), ("n_materials", C.c_int32),
                 ("n_tables", C.c_int32), ("bins", C.c_int32), ("spp", C.c_int32), ("power", C.c_int32),
-                ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("sample_offset", C.c_uint64)]
+                ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
+                ("ray_max_depth", C.c_int32), ("ray_extinction_min_depth", C.c_int32), ("ray_extinction_prob", C.c_double)]
 
 
 class MT(C.Structure):
@@ -78,7 +79,7 @@ class MT(C.Structure):
 
 
 PRIM_SPHERE, PRIM_BOX, PRIM_CYLINDER, PRIM_MESH, PRIM_UNION, PRIM_INTERSECT, PRIM_SUBTRACT, PRIM_NULL = range(8)
-MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT, MAT_NULL, MAT_UNIFORM_VOLUME_EMITTER = range(5)
+MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT, MAT_NULL, MAT_UNIFORM_VOLUME_EMITTER, MAT_LAMBERT = range(6)
 RNG_STREAM, RNG_PHILOX = 0, 1
 
 # every symbol include/rsx.h declares: (name, restype, argtypes)

@@ -3,7 +3,8 @@ Materials. The material plugin API (evaluate_surface / evaluate_volume, raysect/
 is kept as the host-side interface. The closed-form materials are lowered to the device render kernel: AbsorbingSurface,
 UniformSurfaceEmitter and the debug Light (one world.hit() plus a bins-wide multiply) and — first slice of the
 §8(f) "next" rows — the deterministic transparent ones, NullMaterial and UniformVolumeEmitter (null surfaces continue the ray,
-every segment integrates the emission of the volumes it starts in). Any other material raises when an observer tries to render it
+every segment integrates the emission of the volumes it starts in) and Lambert (stochastic secondary rays, Philox-keyed). Any
+other material raises when an observer tries to render it
 on the device (there is no CPU fallback).
 
 Mirrors raysect/optical/material/{material,absorber,debug}.pyx and emitter/uniform.pyx.
@@ -151,6 +152,20 @@ class UniformVolumeEmitter(NullSurface):
     def device_material(self, tables, min_wavelength, max_wavelength, bins):
         tables.append(self.emission_spectrum.sample(min_wavelength, max_wavelength, bins))
         return _record(_lib.MAT_UNIFORM_VOLUME_EMITTER, len(tables) - 1, self.scale)
+
+
+class Lambert(NullVolume):
+    """lambert.pyx:40-112 under ContinuousBSDF.evaluate_surface (material.pyx:286-361) — ideal diffuse reflector: one cosine-weighted
+    daughter ray per hit, spectrum = trace(daughter) * reflectivity * pdf / pdf. Rendered on the device with Philox-keyed scattering
+    (RSX_MAT_LAMBERT); worlds with important primitives (multiple importance sampling) are not lowered yet."""
+
+    def __init__(self, reflectivity=None):
+        super().__init__()
+        self.reflectivity = ConstantSF(0.5) if reflectivity is None else reflectivity
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        tables.append(self.reflectivity.sample(min_wavelength, max_wavelength, bins))
+        return _record(_lib.MAT_LAMBERT, len(tables) - 1, 1.0)
 
 
 # convenience used by scene builders

@@ -540,6 +540,8 @@ class PinholeCamera(Observer2D):
         desc.materials, desc.n_materials = mat_arr, len(mats)
         desc.tables, desc.n_tables = _lib.ptr(tab) if len(tables) else None, len(tables)
         desc.bins, desc.spp = slice_.bins, self._pixel_samples
+        desc.ray_max_depth, desc.ray_extinction_min_depth = int(self.ray_max_depth), int(self.ray_extinction_min_depth)
+        desc.ray_extinction_prob = float(self.ray_extinction_prob)
         if rect is not None:
             desc.tasks = None
             for i in range(4):
@@ -575,8 +577,8 @@ class PinholeCamera(Observer2D):
             # band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
             # and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut.
             limit = self.MAX_RAYS_PER_CALL
-            from .material import NullSurface
-            if any(isinstance(p.material, NullSurface) for p in world._primitives):
+            from .material import NullSurface, Lambert
+            if any(isinstance(p.material, (NullSurface, Lambert)) for p in world._primitives):
                 limit = min(limit, 1 << 24)                 # the volume path also keeps 768 B of emission terms per ray
             per_call = max(1, limit // self._pixel_samples)
             if isinstance(tasks, RectTasks):

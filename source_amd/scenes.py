@@ -328,3 +328,41 @@ def volumes_camera(ns, world, pixels=(48, 40), spp=3, bins=6):
     cam = ns.PinholeCamera(pixels, fov=55, parent=world, pipelines=[pipe], frame_sampler=ns.FullFrameSampler2D(), transform=ns.translate(0.05, 0.1, 0.0))
     cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
     return cam, pipe
+
+
+def build_lambert(ns, with_volume=True):
+    """Diffuse inter-reflection scene (fixture F13): an open-fronted room of Lambert walls with spectrally different reflectivities,
+    an emitting ceiling panel, a Lambert sphere, a smooth-shaded Lambert mesh, a Lambert CSG solid, and — so that scattering,
+    transparent boundaries and volume emission meet on one path — a glowing volume and a NullMaterial shell."""
+    world = ns.World()
+    red = ns.InterpolatedSF([300, 560, 600, 800], np.array([0.08, 0.1, 0.75, 0.8]))
+    green = ns.InterpolatedSF([300, 480, 520, 580, 620, 800], np.array([0.1, 0.12, 0.7, 0.65, 0.1, 0.08]))
+    white = ns.ConstantSF(0.7)
+    P = ns.Point3D
+    prims = [
+        ns.Box(P(-1.0, -1.05, 0.0), P(1.0, -1.0, 2.0), world, material=ns.Lambert(white)),        # floor
+        ns.Box(P(-1.0, 1.0, 0.0), P(1.0, 1.05, 2.0), world, material=ns.Lambert(white)),          # ceiling
+        ns.Box(P(-1.0, -1.0, 2.0), P(1.0, 1.0, 2.05), world, material=ns.Lambert(white)),         # back
+        ns.Box(P(-1.05, -1.0, 0.0), P(-1.0, 1.0, 2.0), world, material=ns.Lambert(red)),          # left
+        ns.Box(P(1.0, -1.0, 0.0), P(1.05, 1.0, 2.0), world, material=ns.Lambert(green)),          # right
+        ns.Box(P(-0.4, 0.98, 0.6), P(0.4, 0.999, 1.4), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 8.0)),   # light
+        ns.Sphere(0.3, world, ns.translate(-0.45, -0.7, 1.3), ns.Lambert(ns.ConstantSF(0.9))),
+        ns.Subtract(ns.Box(P(-0.25, -0.25, -0.25), P(0.25, 0.25, 0.25)), ns.Sphere(0.3, transform=ns.translate(0.2, 0.2, -0.2)), world,
+                    ns.translate(0.45, -0.75, 0.9) * ns.rotate(25, 0, 0), ns.Lambert(green)),
+    ]
+    v, t = displaced_sphere(10, radius=0.25)
+    nv = vertex_normals(v, t)
+    prims.append(ns.Mesh(v, np.concatenate([t, t], axis=1), normals=nv, smoothing=True, parent=world, transform=ns.translate(0.1, -0.2, 1.5), material=ns.Lambert(red)))
+    if with_volume:
+        prims.append(ns.Sphere(0.2, world, ns.translate(0.3, 0.3, 1.0), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.6)))
+        prims.append(ns.Sphere(0.35, world, ns.translate(-0.3, 0.2, 0.8), ns.NullMaterial()))
+    return world, prims
+
+
+def lambert_camera(ns, world, pixels=(24, 20), spp=4, bins=5, extinction=(0.1, 2, 12)):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=50, parent=world, pipelines=[pipe], frame_sampler=ns.FullFrameSampler2D(), transform=ns.translate(0.0, 0.0, -1.9))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
+    cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = extinction
+    cam.ray_importance_sampling = False                     # multiple importance sampling is the next scope row (SURVEY.md §8f row 2)
+    return cam, pipe

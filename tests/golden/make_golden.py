@@ -34,7 +34,7 @@ from raysect.core.math import random as rsrandom  # noqa: E402
 from raysect.core.acceleration.kdtree import _PrimitiveKDTree  # noqa: E402
 from raysect.primitive import Mesh, Sphere, Box, Cylinder, Union, Intersect, Subtract  # noqa: E402
 from raysect.optical import World, ConstantSF, InterpolatedSF, Ray as OpticalRay  # noqa: E402
-from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial  # noqa: E402
+from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial, Lambert  # noqa: E402
 from raysect.optical.material.debug import Light  # noqa: E402
 from raysect.optical.observer import PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D  # noqa: E402
 
@@ -45,7 +45,7 @@ NS = types.SimpleNamespace(
     World=World, Mesh=Mesh, Sphere=Sphere, Box=Box, Cylinder=Cylinder, Union=Union, Intersect=Intersect,
     Subtract=Subtract, Point3D=Point3D, Vector3D=Vector3D, translate=translate, rotate=rotate,
     ConstantSF=ConstantSF, InterpolatedSF=InterpolatedSF, AbsorbingSurface=AbsorbingSurface,
-    UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light,
+    UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light, Lambert=Lambert,
     PinholeCamera=PinholeCamera,
     FullFrameSampler2D=FullFrameSampler2D, SpectralRadiancePipeline2D=SpectralRadiancePipeline2D,
     SpectralPowerPipeline2D=SpectralPowerPipeline2D)
@@ -468,6 +468,25 @@ def f12_volumes():
     save("f12_volumes", **out)
 
 
+def f13_lambert():
+    """Stochastic secondary rays: Lambert (lambert.pyx:76-104 under ContinuousBSDF.evaluate_surface, material.pyx:286-361, importance
+    sampling off), Russian roulette and the depth limit (ray.pyx:382-388), mixed with null surfaces and volume emission. SerialEngine
+    consumes ONE MT19937-64 stream in execution order, which the oracle's orc_render_pinhole_mt replays."""
+    out = {}
+    world, prims = scenes.build_lambert(NS)
+    cam, pipe = scenes.lambert_camera(NS, world)
+    out["mean"], out["var"], out["n"] = observe_frame(cam, pipe, 41)
+    pyrandom.seed(42); rsrandom.seed(42); cam.observe()                       # accumulate pass
+    out["mean2"], out["var2"], out["n2"] = np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples)
+    world, prims = scenes.build_lambert(NS, with_volume=False)                # observer defaults: roulette 0.01 from depth 3, max depth 500
+    cam, pipe = scenes.lambert_camera(NS, world, pixels=(12, 10), spp=3, bins=3, extinction=(0.01, 3, 500))
+    out["deep_mean"], out["deep_var"], out["deep_n"] = observe_frame(cam, pipe, 43)
+    cam, pipe = scenes.lambert_camera(NS, world, pixels=(12, 10), spp=3, bins=4, extinction=(0.3, 1, 3))   # roulette from the first daughter on, shallow depth limit
+    cam.spectral_rays = 2
+    out["rr0_mean"], out["rr0_var"], out["rr0_n"] = observe_frame(cam, pipe, 44)
+    save("f13_lambert", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -487,3 +506,4 @@ if __name__ == "__main__":
     if run("f10"): f10_frames()
     if run("f11"): f11_edges()
     if run("f12"): f12_volumes()
+    if run("f13"): f13_lambert()

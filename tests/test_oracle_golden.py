@@ -386,3 +386,51 @@ def test_frames_volume_emitters(orc, ns, golden):
     cam, pipe = scenes.volumes_camera(ns, world)
     f = _observe_oracle(orc, ns, cam, pipe, 33)
     assert eq(f[0], g["open_mean"]) and eq(f[1], g["open_var"]) and eq(f[2], g["open_n"])
+
+
+# ---------------------------------------------------------------------------------------- F13 Lambert: stochastic secondary rays
+def _observe_oracle_mt(orc, ns, cam, pipe, seed, frame=None):
+    """The reference's SerialEngine on a scene with scattering materials: jitter, hemisphere samples and roulette draws interleave
+    in ONE MT19937-64 stream, so the oracle replays the stream itself (orc_render_pinhole_mt) instead of taking a jitter table."""
+    import random as pyrandom
+    from source_amd.optical.observer import HipEngine
+    pyrandom.seed(seed)
+    state = orc.mt_state(seed)
+    world = cam.root
+    flat = world.flatten()
+    tasks = cam._generate_tasks()
+    nx, ny = cam.pixels
+    bins = cam.spectral_bins
+    if frame is None:
+        frame = [np.zeros((nx, ny, bins)), np.zeros((nx, ny, bins)), np.zeros((nx, ny, bins), dtype=np.int32)]
+    t = np.array(tasks)
+    eng = HipEngine(rng="philox")
+    for sl in cam._slice_spectrum():
+        keep = []
+        desc = cam.render_desc(world, tasks, sl, eng, keep)
+        mean, var, rays = orc.render_pinhole_mt(flat, desc, state)
+        z = slice(sl.offset, sl.offset + sl.bins)
+        sub = [f[t[:, 0], t[:, 1], z] for f in frame]
+        m, v, n = orc.frame_combine(sub[0], sub[1], sub[2], mean, np.maximum(var, 0), np.full(mean.shape, cam.pixel_samples, dtype=np.int32))
+        frame[0][t[:, 0], t[:, 1], z], frame[1][t[:, 0], t[:, 1], z], frame[2][t[:, 0], t[:, 1], z] = m, v, n
+    return frame
+
+
+def test_frames_lambert(orc, ns, golden):
+    """Lambert + Russian roulette + depth limit, mixed with null surfaces and volume emission, bit for bit against the reference's
+    SerialEngine frames (importance sampling off)."""
+    g = golden("f13_lambert")
+    world, prims = scenes.build_lambert(ns)
+    cam, pipe = scenes.lambert_camera(ns, world)
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 41)
+    assert eq(f[0], g["mean"]) and eq(f[1], g["var"]) and eq(f[2], g["n"])
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 42, f)
+    assert eq(f[0], g["mean2"]) and eq(f[1], g["var2"]) and eq(f[2], g["n2"])
+    world, prims = scenes.build_lambert(ns, with_volume=False)
+    cam, pipe = scenes.lambert_camera(ns, world, pixels=(12, 10), spp=3, bins=3, extinction=(0.01, 3, 500))
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 43)
+    assert eq(f[0], g["deep_mean"]) and eq(f[1], g["deep_var"]) and eq(f[2], g["deep_n"])
+    cam, pipe = scenes.lambert_camera(ns, world, pixels=(12, 10), spp=3, bins=4, extinction=(0.3, 1, 3))
+    cam.spectral_rays = 2
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 44)
+    assert eq(f[0], g["rr0_mean"]) and eq(f[1], g["rr0_var"]) and eq(f[2], g["rr0_n"])
