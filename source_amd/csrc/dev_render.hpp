@@ -37,6 +37,8 @@ struct RenderParams {
     int32_t rect[4];
     int32_t spp, rng_mode;
     uint64_t seed, sample_offset;
+    int32_t ray_max_depth, ray_min_depth;      // Ray.max_depth / extinction_min_depth / extinction_prob: path kernel only
+    double ray_extinction_prob;
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
@@ -207,20 +209,50 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Transparent boundaries and volume emission (first slice of SURVEY.md §8f row 1)
+// Paths: transparent boundaries, volume emission and Lambert scattering
 // ---------------------------------------------------------------------------------------------------
 // NullMaterial / UniformVolumeEmitter surfaces let the ray through (NullSurface.evaluate_surface, material.pyx:118-147: daughter
-// ray from the far side of the boundary, same direction, depth unchanged, keep_alive) and every segment of the path adds the
-// emission of the volume emitters that contain the segment's origin times the segment length in the emitter's space
-// (Ray._sample_volumes, ray.pyx:422-455; HomogeneousVolumeEmitter.evaluate_volume, homogeneous.pyx:55-102). The path is
-// deterministic, so frames stay bit-identical to the reference. A ray leaves up to max_terms VolTerm records (scale, length,
-// table, segment) next to its Sample; k_accumulate adds them in the reference's order — deepest segment first, world.contains()
-// order within a segment. Scenes without such materials never run this kernel (k_render_trace is untouched).
-struct VolTerm {
-    double scale, length;
-    int32_t table, seg;
+// ray from the far side of the boundary, same direction, depth unchanged, keep_alive); every segment of the path adds the emission
+// of the volume emitters that contain the segment's origin times the segment length in the emitter's space (Ray._sample_volumes,
+// ray.pyx:422-455; HomogeneousVolumeEmitter.evaluate_volume, homogeneous.pyx:55-102); a Lambert surface scatters one cosine-weighted
+// daughter ray (lambert.pyx:76-104 under ContinuousBSDF.evaluate_surface, material.pyx:286-361; Russian roulette per ray.pyx:382-388).
+//
+// The reference evaluates a path innermost ray first while its recursion unwinds, per spectral bin. Here the trace kernel walks the
+// path forward and leaves a list of PathTerm records next to the ray's Sample; k_accumulate replays the list backwards per bin with
+// the reference's own operations in the reference's own order, so a frame equals the oracle's bit for bit. The list lives in
+// 16-slot blocks: the first block of every ray is preallocated (block id = record index); a ray that needs more takes blocks
+// from a shared arena (one atomic per 15 terms), each linked back to its predecessor through slot 0. Scenes without such
+// materials never run this kernel (k_render_trace is untouched).
+struct PathTerm {
+    double a, b;               // VOL: segment length, emitter scale.  LAMBERT: pdf, 1 / pdf
+    int32_t table;             // spectral table row (emission / reflectivity).  LINK: id of the previous block
+    int32_t kind;
 };
-#define VOL_MAX_SEGMENTS 64
+enum { TERM_VOL = 0, TERM_LAMBERT = 1, TERM_LAMBERT_NORM = 2, TERM_LINK = 3 };   // _NORM: the daughter survived roulette, its result is scaled first
+#define PATH_BLOCK 16
+#define PATH_MAX_SEGMENTS (1 << 20)        // guard against a path that never ends (each Lambert bounce and each null surface is a segment)
+#define PATH_VOL_OVERLAP 4                 // volume emitters that may contain one point
+
+// sin and cos of phi in [0, 2 pi]: the oracle's portable_sincos (oracle/rsx_oracle.c) operation for operation — quadrant by Cody-Waite
+// reduction against a two-term pi/2, minimax polynomials on [-pi/4, pi/4], IEEE + and * only (no FMA: -ffp-contract=off).
+__device__ __forceinline__ void portable_sincos(double phi, double &sn, double &cs) {
+    const double PIO2_HI = 1.57079632673412561417e+00, PIO2_LO = 6.07710050650619224932e-11, TWO_OVER_PI = 6.36619772367581382433e-01;
+    const double S1 = -1.66666666666666324348e-01, S2 = 8.33333333332248946124e-03, S3 = -1.98412698298579493134e-04,
+                 S4 = 2.75573137070700676789e-06, S5 = -2.50507602534068634195e-08, S6 = 1.58969099521155010221e-10;
+    const double C1 = 4.16666666666666019037e-02, C2 = -1.38888888888741095749e-03, C3 = 2.48015872894767294178e-05,
+                 C4 = -2.75573143513906633035e-07, C5 = 2.08757232129817482790e-09, C6 = -1.13596475577881948265e-11;
+    const double kf = floor(phi * TWO_OVER_PI + 0.5);
+    const double r = (phi - kf * PIO2_HI) - kf * PIO2_LO;
+    const double z = r * r;
+    const double ps = r + (r * z) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))));
+    const double pc = (1.0 - 0.5 * z) + (z * z) * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))));
+    switch ((int)kf & 3) {
+    case 0: sn = ps; cs = pc; break;
+    case 1: sn = pc; cs = -ps; break;
+    case 2: sn = -ps; cs = -pc; break;
+    default: sn = -pc; cs = ps; break;
+    }
+}
 
 // world.contains(point) in leaf order (kdtree3d.pyx:736-792, kdtree.pyx:126-162): calls f(primitive index) for every world
 // primitive whose bounding box and surface contain the point
@@ -243,9 +275,17 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
     }
 }
 
+struct PathStore {
+    PathTerm *pool;            // [(n_records + arena_blocks) * PATH_BLOCK]
+    int32_t *tail;             // [n_records] last block of each ray's list (Sample.pad = slots used in it)
+    long long n_records;
+    unsigned int arena_blocks;
+    unsigned int *arena_next;  // bump allocator over the arena
+    unsigned int *flags;       // bit 0: arena exhausted, bit 1: segment guard, bit 2: more than PATH_VOL_OVERLAP emitters at a point
+};
+
 template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket,
-                                                                    VolTerm *terms, int max_terms, unsigned int *overflow) {
+__global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -270,9 +310,10 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, R
         if (tk < 0) break;
         const int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
         const UnitPixel px = unit_pixel(q, unit, lane);
+        const uint64_t rng_pixel = (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, rng_sample = q->sample_offset + (uint64_t)px.s;
         double u1, u2;
         if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
-        else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
+        else philox2(q->seed, rng_pixel, rng_sample, u1, u2);
         const double delta = q->cam.image_delta, half = 0.5 * delta;
         const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
         const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
@@ -294,8 +335,25 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, R
         Sample smp;
         smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
         const long long record = px.slot * q->spp + px.s;
-        VolTerm *mine_terms = terms + record * max_terms;
-        int n_terms = 0;
+        // the ray's term list: current block and the next free slot in it
+        long long blk = record;
+        int pos = 0;
+        auto push = [&](double a, double b, int32_t table, int32_t kind) {
+            if (pos == PATH_BLOCK) {
+                const unsigned int nb = atomicAdd(ps.arena_next, 1u);
+                if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
+                PathTerm link;
+                link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
+                blk = ps.n_records + nb;
+                ps.pool[blk * PATH_BLOCK] = link;
+                pos = 1;
+            }
+            PathTerm t;
+            t.a = a; t.b = b; t.table = table; t.kind = kind;
+            ps.pool[blk * PATH_BLOCK + pos] = t;
+            ++pos;
+        };
+        int depth = 0;
         bool active = px.valid;
         uint32_t work = 0;
         for (int seg = 0; __any(active); ++seg) {
@@ -309,7 +367,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, R
             finalise<CSG>(sc, r, hit, g);
             double hx, hy, hz;                                                // hit_point.transform(primitive_to_world)
             xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
-            // volume emitters containing this segment's origin, in world.contains() order
+            // volume emitters containing this segment's origin: found in world.contains() order, pushed newest first because the
+            // list is replayed backwards
+            double v_len[PATH_VOL_OVERLAP], v_scale[PATH_VOL_OVERLAP];
+            int32_t v_table[PATH_VOL_OVERLAP];
+            int n_vol = 0;
             world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
                 const rsx_primitive &vp = sc.prims[idx];
                 const rsx_material vm = q->materials[vp.material];
@@ -320,17 +382,70 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, R
                 const double vx = sx - ex, vy = sy - ey, vz = sz - ez;        // end.vector_to(start)
                 const double length = sqrt(vx * vx + vy * vy + vz * vz);
                 if (length == 0) return;
-                if (n_terms < max_terms) {
-                    VolTerm t;
-                    t.scale = vm.scale; t.length = length; t.table = vm.table; t.seg = seg;
-                    mine_terms[n_terms] = t;
-                } else atomicOr(overflow, 1u);
-                ++n_terms;
+                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u);
+#pragma unroll
+                for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; }
+                v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table;
+                ++n_vol;
             });
+#pragma unroll
+            for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], TERM_VOL);
+            if (seg + 1 >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; continue; }
             if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
                 const double *from = g.exiting ? g.outside : g.inside;
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
-                if (seg + 1 >= VOL_MAX_SEGMENTS) { atomicOr(overflow, 2u); active = false; }
+                continue;
+            }
+            if (mat.type == RSX_MAT_LAMBERT) {
+                // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
+                // normal.pyx:346-370); the normal faces the incident side
+                const double *from = g.exiting ? g.inside : g.outside;
+                double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
+                if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
+                double ux = nx, uy = ny, uz = nz;
+                normalise3(ux, uy, uz);
+                double vx = 1, vy = 0, vz = 0;
+                if (fabs(ux * vx + uy * vy + uz * vz) > 0.5) { vx = 0; vy = 1; }
+                const double m = ux * vx + uy * vy + uz * vz;
+                double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
+                normalise3(tx, ty, tz);
+                const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
+                // HemisphereCosineSampler.sample / pdf (solidangle.pyx:223-233)
+                double h1, h2, sn, cs;
+                philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                const double rad = sqrt(h1);
+                portable_sincos(2.0 * M_PI * h2, sn, cs);
+                const double sx = rad * cs, sy = rad * sn;
+                const double sz2 = 1.0 - sx * sx - sy * sy;
+                const double sz = sqrt(sz2 > 0 ? sz2 : 0);
+                const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;
+                const double rcp = 1.0 / pdf;                                 // div_scalar (spectrum.pyx:459-467)
+                if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; continue; }   // zero spectrum, then * (1 / 0)
+                // direction = s_outgoing.transform(primitive_to_world.mul(surface_to_primitive)), affinematrix.pyx:255-273
+                const double *a = p.to_root;
+                double stw[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
+                    stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
+                    stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
+                }
+                xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                ++depth;
+                // Russian roulette of the daughter (ray.pyx:382-388)
+                int32_t kind = TERM_LAMBERT;
+                if (depth >= q->ray_min_depth) {
+                    if (depth >= q->ray_max_depth) active = false;
+                    else {
+                        double k1, k2;
+                        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
+                        if (k1 < q->ray_extinction_prob) active = false; else kind = TERM_LAMBERT_NORM;
+                    }
+                }
+                push(pdf, rcp, mat.table, kind);
                 continue;
             }
             if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
@@ -344,8 +459,9 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_vol(DScene sc, R
             active = false;
         }
         if (!px.valid) continue;
-        smp.pad = n_terms < max_terms ? n_terms : max_terms;
+        smp.pad = pos;
         samples[record] = smp;
+        ps.tail[record] = (int32_t)blk;
     }
 }
 
@@ -503,8 +619,10 @@ struct AccumParams {
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
     int32_t frame_bins, slice_offset;
     unsigned long long *ticket;         // work tickets of the trace kernel: re-armed here for the next launch
-    const struct VolTerm *terms;        // volume-emission terms of each sample (or null), max_terms per sample; Sample.pad = count
-    int32_t max_terms, pad2;
+    const struct PathTerm *pool;        // path terms (k_render_trace_path) or null: block b = pool[b * PATH_BLOCK ..]
+    const int32_t *tail;                // last block of each sample's list; Sample.pad = slots used in it
+    long long n_records;                // block ids below this are the samples' own first blocks, above it arena blocks (slot 0 = link)
+    double roulette_norm;               // 1 / (1 - extinction_prob)
 };
 
 // Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
@@ -515,7 +633,7 @@ struct AccumParams {
 #endif
 
 template <bool STAGED, bool VOL>        // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
-                                        // VOL = samples carry volume-emission terms (k_render_trace_vol)
+                                        // VOL = samples carry path terms (k_render_trace_path)
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
     extern __shared__ __attribute__((aligned(16))) double acc_lds[];
@@ -551,20 +669,31 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
         const double tab = staged ? acc_tab[e] : ap.tables[e];
         double x = smp.table < 0 ? 0.0 : smp.a * tab;
-        if (VOL && smp.pad > 0) {
-            // _sample_volumes while the reference's recursion unwinds: deepest segment first, contains() order inside a segment
-            const VolTerm *t = ap.terms + record * ap.max_terms;
-            const int n = smp.pad;
-            int hi = n;
-            while (hi > 0) {
-                int lo = hi - 1;
-                while (lo > 0 && t[lo - 1].seg == t[hi - 1].seg) --lo;
-                for (int j = lo; j < hi; ++j) {
-                    const double tv = staged ? acc_tab[t[j].table * ap.bins + b] : ap.tables[t[j].table * ap.bins + b];
-                    const double emission = 0.0 + tv * t[j].scale;          // uniform.pyx:129-131 on a zero spectrum
-                    x = x + emission * t[j].length;                           // homogeneous.pyx:99-100
+        if (VOL) {
+            // the reference's recursion unwinding: newest term first. VOL: += (0 + table * scale) * length (uniform.pyx:129-131,
+            // homogeneous.pyx:99-100). LAMBERT: [daughter's roulette normalisation, ray.pyx:399] * reflectivity * pdf * (1 / pdf)
+            // (lambert.pyx:101-103, material.pyx:356-358).
+            long long blk = ap.tail[record];
+            int n = smp.pad;
+            for (;;) {
+                const PathTerm *t = ap.pool + blk * PATH_BLOCK;
+                const int first = blk < ap.n_records ? 0 : 1;
+                for (int j = n - 1; j >= first; --j) {
+                    const PathTerm tm = t[j];
+                    const double tv = staged ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
+                    if (tm.kind == TERM_VOL) {
+                        const double emission = 0.0 + tv * tm.b;
+                        x = x + emission * tm.a;
+                    } else {
+                        if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;
+                        x = x * tv;
+                        x = x * tm.a;
+                        x = x * tm.b;
+                    }
                 }
-                hi = lo;
+                if (first == 0) break;
+                blk = t[0].table;
+                n = PATH_BLOCK;
             }
         }
         x = x * smp.weight;

@@ -145,8 +145,8 @@ struct TraceLane {
     long long cost_units = 0;          // number of units unit_cost currently describes (0 = none)
     long long order_units = 0;         // number of units unit_order was sorted for (0 = no valid work list)
     uint64_t cost_signature = 0;       // (scene, camera, tasks) the costs were measured on
-    void *samples = nullptr, *uniforms = nullptr, *terms = nullptr;   // terms: VolTerm records of the volume-emission path
-    size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0;
+    void *samples = nullptr, *uniforms = nullptr, *terms = nullptr, *tail = nullptr;   // terms / tail: PathTerm blocks of the path kernel
+    size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0, tail_bytes = 0;
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
@@ -260,7 +260,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, (void *)ln->overflow})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, (void *)ln->overflow})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -852,10 +852,21 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // 64-ray units over the rays g = pixel * spp + sample, pixels tile by tile (see unit_pixel in dev_render.hpp)
     const long long tiles_x_all = (rect_w + 7) >> 3, tiles_y_all = (rect_h + 7) >> 3;
     const long long n_units_all = desc->tasks ? (desc->n_tasks * (long long)desc->spp + WAVE - 1) / WAVE : tiles_x_all * tiles_y_all * (long long)desc->spp;
-    // transparent-boundary / volume-emitter materials take the multi-segment kernel (k_render_trace_vol), un-pipelined
-    bool has_vol = false;
-    for (int32_t i = 0; i < desc->n_materials; ++i) has_vol = has_vol || desc->materials[i].type == RSX_MAT_NULL || desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;
-    const int max_terms = 32;                             // volume terms kept per ray (768 B); a ray that needs more fails the call loudly
+    // transparent boundaries, volume emitters and scattering surfaces take the path kernel (k_render_trace_path), un-pipelined
+    bool has_vol = false, has_scatter = false;
+    for (int32_t i = 0; i < desc->n_materials; ++i) {
+        const int32_t mt = desc->materials[i].type;
+        has_vol = has_vol || mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT;
+        has_scatter = has_scatter || mt == RSX_MAT_LAMBERT;
+    }
+    if (has_scatter) {
+        if (desc->rng_mode != RSX_RNG_PHILOX)
+            return rsx_fail(RSX_EUNSUPPORTED, "render: scattering materials draw per-path random numbers; use RSX_RNG_PHILOX (a serial MT19937-64 stream cannot be consumed in parallel)");
+        if (desc->ray_extinction_min_depth < 1) return rsx_fail(RSX_EINVAL, "render: the minimum extinction depth cannot be less than 1");   // ray.pyx:276
+        if (desc->ray_max_depth < desc->ray_extinction_min_depth) return rsx_fail(RSX_EINVAL, "render: the maximum depth cannot be less than the minimum extinction depth");
+        if (!(desc->ray_extinction_prob >= 0.0 && desc->ray_extinction_prob <= 1.0)) return rsx_fail(RSX_EINVAL, "render: the extinction probability must lie in [0, 1]");
+        if (desc->ray_max_depth >= (1 << 15)) return rsx_fail(RSX_EUNSUPPORTED, "render: ray_max_depth %d exceeds the Philox draw counter's range (32767)", desc->ray_max_depth);
+    }
     const bool pipelined = !h_mean && !has_vol && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
@@ -895,10 +906,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
+    // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
+    size_t arena_blocks = 0;
     if (has_vol) {
-        if (S * (size_t)max_terms * sizeof(VolTerm) > ((size_t)16 << 30))
-            return rsx_fail(RSX_EUNSUPPORTED, "render: %zu rays with volume terms in one call; split the call (at most %zu rays)", S, ((size_t)16 << 30) / (max_terms * sizeof(VolTerm)));
-        if ((rc = lane_buffer(lane.terms, lane.terms_bytes, S * (size_t)max_terms * sizeof(VolTerm)))) return rc;
+        arena_blocks = std::max<size_t>((size_t)1 << 16, (has_scatter ? 2 : 1) * S);
+        if (const char *e = std::getenv("RSX_PATH_ARENA")) arena_blocks = (size_t)std::max(0ll, std::atoll(e));
+        const size_t pool_bytes = (S + arena_blocks) * PATH_BLOCK * sizeof(PathTerm);
+        if (S + arena_blocks >= ((size_t)1 << 31) || pool_bytes > ((size_t)48 << 30))
+            return rsx_fail(RSX_EUNSUPPORTED, "render: %zu rays with path terms in one call; split the call (at most %zu rays)", S, ((size_t)48 << 30) / (3 * PATH_BLOCK * sizeof(PathTerm)));
+        if ((rc = lane_buffer(lane.terms, lane.terms_bytes, pool_bytes)) || (rc = lane_buffer(lane.tail, lane.tail_bytes, S * sizeof(int32_t)))) return rc;
         if (!lane.overflow) HIP_TRY(hipMalloc(&lane.overflow, 64));
         HIP_TRY(hipMemsetAsync(lane.overflow, 0, 64, lane.stream));
     }
@@ -921,6 +937,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.rng_mode = desc->rng_mode;
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
+    rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured
     {
@@ -993,11 +1010,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const bool timed = ctx->timing;
     if (timed) HIP_TRY(hipEventRecord(re[0], lane.stream));
     if (has_vol) {
-        HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_vol<true>) : reinterpret_cast<const void *>(k_render_trace_vol<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_vol<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket,
-                                               static_cast<VolTerm *>(lane.terms), max_terms, lane.overflow);
-        else hipLaunchKernelGGL(k_render_trace_vol<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket,
-                                static_cast<VolTerm *>(lane.terms), max_terms, lane.overflow);
+        PathStore ps;
+        ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
+        ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
+        HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_path<true>) : reinterpret_cast<const void *>(k_render_trace_path<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+        else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
@@ -1025,8 +1043,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.fmean = fmean; ap.fvar = fvar; ap.fn = fn;
     ap.frame_bins = frame_bins; ap.slice_offset = slice_offset;
     ap.ticket = lane.ticket;
-    ap.terms = has_vol ? static_cast<const VolTerm *>(lane.terms) : nullptr;
-    ap.max_terms = max_terms; ap.pad2 = 0;
+    ap.pool = has_vol ? static_cast<const PathTerm *>(lane.terms) : nullptr;
+    ap.tail = has_vol ? static_cast<const int32_t *>(lane.tail) : nullptr;
+    ap.n_records = (long long)S;
+    ap.roulette_norm = 1 / (1 - desc->ray_extinction_prob);      // ray.pyx:388
     lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
@@ -1057,8 +1077,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         unsigned int flags = 0;
         HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: a ray crossed more than %d emitting volume segments (limit of this build)", max_terms);
-        if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a ray crossed more than %d transparent boundaries (limit of this build)", VOL_MAX_SEGMENTS);
+        if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: the path-term arena (%zu blocks of %d terms) ran out; render fewer rays per call or raise RSX_PATH_ARENA", arena_blocks, PATH_BLOCK - 1);
+        if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a path crossed more than %d surfaces (limit of this build)", PATH_MAX_SEGMENTS);
+        if (flags & 4u) return rsx_fail(RSX_EUNSUPPORTED, "render: more than %d volume emitters overlap at one point (limit of this build)", PATH_VOL_OVERLAP);
     }
     // frame form: asynchronous — the pooled workspace stays alive in the ctx, stream order protects reuse
     return RSX_OK;

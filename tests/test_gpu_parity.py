@@ -519,8 +519,8 @@ def test_exact_division():
 
 
 def test_frames_volume_emitters_stream_parity(orc, ns, golden):
-    """NullMaterial + UniformVolumeEmitter on the device (k_render_trace_vol): frames bit-identical to the reference's SerialEngine,
-    incl. the accumulate pass; Philox mode equals the oracle; a ray through more emitting segments than the build keeps fails loudly."""
+    """NullMaterial + UniformVolumeEmitter on the device (k_render_trace_path): frames bit-identical to the reference's SerialEngine,
+    incl. the accumulate pass; Philox mode equals the oracle; more overlapping emitters than the build keeps fails loudly."""
     g = golden("f12_volumes")
     world, prims = scenes.build_volumes(ns)
     cam, pipe = scenes.volumes_camera(ns, world)
@@ -548,7 +548,7 @@ def test_frames_volume_emitters_stream_parity(orc, ns, golden):
     ns.Sphere(0.8, single, ns.translate(0, 0, 2), ns.NullMaterial())
     spectrum = ns.Ray(ns.Point3D(0, 0, 0), ns.Vector3D(0, 0, 1), bins=4).trace(single)
     assert np.allclose(spectrum.samples, 1.0, rtol=0, atol=1e-8) and (spectrum.samples < 1.0).all()
-    # forty nested emitting shells: more volume terms per ray than the build stores -> RSX_EUNSUPPORTED, not a silently wrong frame
+    # forty nested emitting shells: more emitters overlap at a point than the build tracks -> RSX_EUNSUPPORTED, not a silently wrong frame
     from source_amd._lib import RsxError
     deep = ns.World()
     for k in range(40):
@@ -557,6 +557,66 @@ def test_frames_volume_emitters_stream_parity(orc, ns, golden):
     cam3.render_engine = ns.HipEngine(rng="philox", seed=1)
     with pytest.raises(RsxError):
         cam3.observe()
+
+
+def test_frames_lambert_against_oracle(orc, ns):
+    """Lambert scattering on the device (RSX_MAT_LAMBERT, k_render_trace_path): Philox-keyed paths, term lists replayed per bin in
+    the reference's order. The oracle — pinned bit for bit to the reference's SerialEngine frames by fixture F13 on the CPU side —
+    renders the same Philox paths; frames must be identical: observer defaults (roulette 0.01 from depth 3, depth limit 500: long
+    paths that chain arena blocks), an aggressive roulette with a shallow depth limit, and spectral slices."""
+    world, prims = scenes.build_lambert(ns)
+    for pixels, spp, bins, ext, rays in (((96, 80), 8, 5, (0.01, 3, 500), 1), ((64, 48), 6, 6, (0.3, 1, 4), 2), ((40, 40), 3, 4, (0.1, 2, 12), 1)):
+        cam, pipe = scenes.lambert_camera(ns, world, pixels, spp, bins, ext)
+        cam.spectral_rays = rays
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=77)
+        cam.observe()
+        w, h = pixels
+        ref_m, ref_v = np.zeros((w, h, bins)), np.zeros((w, h, bins))
+        for sl in cam._slice_spectrum():
+            keep = []
+            desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+            om, ov, _ = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            ref_m[:, :, sl.offset:sl.offset + sl.bins] = om.reshape(h, w, sl.bins).transpose(1, 0, 2)
+            ref_v[:, :, sl.offset:sl.offset + sl.bins] = ov.reshape(h, w, sl.bins).transpose(1, 0, 2)
+        assert eq(pipe.frame.mean, ref_m) and eq(pipe.frame.variance, ref_v), (pixels, ext)
+        if ext[2] == 500:
+            assert (pipe.frame.mean > 0).mean() > 0.5              # light reaches most pixels only through diffuse bounces
+    # the reference's stream engine cannot drive scattering paths in parallel: loud error, no silent substitute
+    from source_amd._lib import RsxError
+    cam, pipe = scenes.lambert_camera(ns, world, (8, 8), 1, 2)
+    cam.render_engine = ns.SerialEngine()
+    with pytest.raises(RsxError):
+        cam.observe()
+
+
+def test_lambert_furnace_full_size(ns):
+    """Size-independent property at 1024 x 1024: inside a closed furnace — every surface either a unit-reflectivity Lambert wall or
+    an emitter of radiance L — with roulette off (probability 0: normalisation exactly 1) every path ends on an emitter and carries
+    L * prod(pdf * (1 / pdf)), so every pixel's mean is L within a few ulp per bounce and its variance vanishes, however long the path
+    (paths here average tens of bounces and chain arena blocks)."""
+    world = ns.World()
+    P = ns.Point3D
+    ns.Box(P(-1, -1, -1), P(1, 1, 1), world, material=ns.Lambert(ns.ConstantSF(1.0)))
+    ns.Sphere(0.35, world, ns.translate(0.2, -0.3, 0.4), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 3.0))
+    ns.Sphere(0.25, world, ns.translate(-0.5, 0.4, 0.1), ns.Lambert(ns.ConstantSF(1.0)))
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 2, 3, (0.0, 1, 30000))
+    cam.transform = ns.translate(0, 0, -0.9)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=5)
+    cam.observe()
+    m, v = pipe.frame.mean, pipe.frame.variance
+    weight = None
+    # radiance pipeline: sample = L * projection weight (cos of the pixel's ray to the optical axis), which varies by < 1e-6 inside a pixel
+    assert np.isfinite(m).all() and (m > 0).all()
+    desc_cam = cam.device_camera()
+    ix, iy = np.meshgrid(np.arange(1024), np.arange(1024), indexing="ij")
+    x = desc_cam.image_start_x - desc_cam.image_delta * (ix + 0.5)
+    y = desc_cam.image_start_y - desc_cam.image_delta * (iy + 0.5)
+    w_centre = 1.0 / np.sqrt(x * x + y * y + 1.0)
+    assert np.abs(m / (3.0 * w_centre[:, :, None]) - 1.0).max() < 2e-3          # jitter moves the weight inside the pixel
+    assert np.abs(m[:, :, 0] - m[:, :, 2]).max() <= 1e-12 * 3.0               # the bins of a pixel see the same paths
+    assert v.max() < 1e-5
 
 
 def test_pipelining_does_not_change_frames():

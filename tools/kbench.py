@@ -29,6 +29,9 @@ elif config == "c3s100":                  # the reference's default pixel_sample
 elif config == "c3s24":
     world = scenes.build_c3(ns, n=132)[0]
     cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=24, bins=15)
+elif config == "lambert":                 # diffuse inter-reflection room (fixture F13's scene), observer-default roulette
+    world = scenes.build_lambert(ns)[0]
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
 elif config == "flat":
     world = scenes.build_flat(ns, n=512)[0]
     cam, pipe = scenes.c2_camera(ns, world, (2048, 2048), spp=64, bins=15)
