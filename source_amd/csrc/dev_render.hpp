@@ -284,6 +284,10 @@ struct PathStore {
     unsigned int *flags;       // bit 0: arena exhausted, bit 1: segment guard, bit 2: more than PATH_VOL_OVERLAP emitters at a point
 };
 
+// Lanes are refilled: a lane whose path has ended takes the next ray of the wave's current 64-ray unit (a new unit when that one is
+// used up), so a wave keeps all its lanes on live paths instead of waiting for the longest of 64 (path lengths are geometric: the
+// longest of 64 is several times the mean). Which lane renders which ray never shows in the result — random numbers, sample record
+// and term list are keyed by (pixel, sample).
 template <bool CSG>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
@@ -295,72 +299,97 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
     (void)rp;
     const int my_xcd = xcc_id();
     int victim = -1;
+    long long unit = -1;                                   // wave-uniform: the unit rays are being taken from, and how many are gone
+    int cursor = WAVE;
+    bool exhausted = false;
+    // per-lane path state
+    bool active = false;
+    Ray r;
+    Sample smp;
+    long long record = 0, blk = 0;
+    uint64_t rng_pixel = 0, rng_sample = 0;
+    int pos = 0, depth = 0, segments = 0;
+    unsigned long long spawned = 0;                        // rays this lane traced or spawned (the reference's ray_count statistic)
+    uint32_t work = 0;
+    r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
+    smp.a = 0; smp.weight = 0; smp.table = -1; smp.pad = 0;
+    auto push = [&](double a, double b, int32_t table, int32_t kind) {
+        if (pos == PATH_BLOCK) {
+            const unsigned int nb = atomicAdd(ps.arena_next, 1u);
+            if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
+            PathTerm link;
+            link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
+            blk = ps.n_records + nb;
+            ps.pool[blk * PATH_BLOCK] = link;
+            pos = 1;
+        }
+        PathTerm t;
+        t.a = a; t.b = b; t.table = table; t.kind = kind;
+        ps.pool[blk * PATH_BLOCK + pos] = t;
+        ++pos;
+    };
     for (;;) {
-        long long tk = -1;
-        while (victim < 8) {
-            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
-            const long long begin = q->seg[list], end = q->seg[list + 1];
-            unsigned long long mine = 0;
-            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
-            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
-                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
-            if (got < end) { tk = got; break; }
-            ++victim;
-        }
-        if (tk < 0) break;
-        const int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
-        const UnitPixel px = unit_pixel(q, unit, lane);
-        const uint64_t rng_pixel = (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, rng_sample = q->sample_offset + (uint64_t)px.s;
-        double u1, u2;
-        if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
-        else philox2(q->seed, rng_pixel, rng_sample, u1, u2);
-        const double delta = q->cam.image_delta, half = 0.5 * delta;
-        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
-        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
-        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
-        normalise3(dx, dy, dz);
-        Ray r;
-        {
-            const RSX_CONST_AS double *m = q->cam.to_root;
-            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
-            wq = 1.0 / wq;
-            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
-            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
-            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
-            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
-            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
-            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
-        }
-        r.maxd = INFINITY;
-        Sample smp;
-        smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
-        const long long record = px.slot * q->spp + px.s;
-        // the ray's term list: current block and the next free slot in it
-        long long blk = record;
-        int pos = 0;
-        auto push = [&](double a, double b, int32_t table, int32_t kind) {
-            if (pos == PATH_BLOCK) {
-                const unsigned int nb = atomicAdd(ps.arena_next, 1u);
-                if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
-                PathTerm link;
-                link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
-                blk = ps.n_records + nb;
-                ps.pool[blk * PATH_BLOCK] = link;
-                pos = 1;
+        // ---- refill idle lanes ----
+        unsigned long long idle = __ballot(!active);
+        while (idle && !exhausted) {
+            if (cursor >= WAVE) {
+                long long tk = -1;
+                while (victim < 8) {
+                    const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+                    const long long begin = q->seg[list], end = q->seg[list + 1];
+                    unsigned long long mine = 0;
+                    if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+                    const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
+                    if (got < end) { tk = got; break; }
+                    ++victim;
+                }
+                if (tk < 0) { exhausted = true; break; }
+                unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
+                cursor = 0;
             }
-            PathTerm t;
-            t.a = a; t.b = b; t.table = table; t.kind = kind;
-            ps.pool[blk * PATH_BLOCK + pos] = t;
-            ++pos;
-        };
-        int depth = 0;
-        bool active = px.valid;
-        uint32_t work = 0;
-        for (int seg = 0; __any(active); ++seg) {
-            Hit hit;
-            const bool got = world_trace_wave<CSG>(active, sc, r, st, ms, csg_state, hit, work);
-            if (!active) continue;
-            if (!got) { active = false; continue; }                         // new_spectrum(): no volume pass for a segment that hits nothing
+            const int n_idle = __popcll(idle);
+            const int take = n_idle < WAVE - cursor ? n_idle : WAVE - cursor;
+            const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
+            if (!active && rank < take) {
+                const UnitPixel px = unit_pixel(q, unit, cursor + rank);
+                if (px.valid) {
+                    rng_pixel = (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy; rng_sample = q->sample_offset + (uint64_t)px.s;
+                    double u1, u2;
+                    if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
+                    else philox2(q->seed, rng_pixel, rng_sample, u1, u2);
+                    const double delta = q->cam.image_delta, half = 0.5 * delta;
+                    const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
+                    const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
+                    double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+                    normalise3(dx, dy, dz);
+                    const RSX_CONST_AS double *m = q->cam.to_root;
+                    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+                    wq = 1.0 / wq;
+                    r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+                    r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+                    r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+                    r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
+                    r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
+                    r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
+                    r.maxd = INFINITY;
+                    smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
+                    record = px.slot * q->spp + px.s;
+                    blk = record; pos = 0; depth = 0; segments = 0;
+                    ++spawned;
+                    active = true;
+                }
+            }
+            cursor += take;
+            idle = __ballot(!active);
+        }
+        if (!__any(active)) break;
+        // ---- one segment of every live path ----
+        const bool was_active = active;
+        Hit hit;
+        const bool got = world_trace_wave<CSG>(active, sc, r, st, ms, csg_state, hit, work);
+        if (active && !got) active = false;                               // new_spectrum(): no volume pass for a segment that hits nothing
+        if (active) {
             const rsx_primitive &p = sc.prims[hit.prim];
             const rsx_material mat = q->materials[p.material];
             Geom g;
@@ -390,13 +419,13 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
             });
 #pragma unroll
             for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], TERM_VOL);
-            if (seg + 1 >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; continue; }
-            if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
+            ++segments;
+            if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
+            else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
                 const double *from = g.exiting ? g.outside : g.inside;
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
-                continue;
-            }
-            if (mat.type == RSX_MAT_LAMBERT) {
+                ++spawned;
+            } else if (mat.type == RSX_MAT_LAMBERT) {
                 // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
                 // normal.pyx:346-370); the normal faces the incident side
                 const double *from = g.exiting ? g.inside : g.outside;
@@ -420,49 +449,56 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                 const double sz = sqrt(sz2 > 0 ? sz2 : 0);
                 const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;
                 const double rcp = 1.0 / pdf;                                 // div_scalar (spectrum.pyx:459-467)
-                if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; continue; }   // zero spectrum, then * (1 / 0)
-                // direction = s_outgoing.transform(primitive_to_world.mul(surface_to_primitive)), affinematrix.pyx:255-273
-                const double *a = p.to_root;
-                double stw[9];
+                if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }   // zero spectrum, then * (1 / 0)
+                else {
+                    // direction = s_outgoing.transform(primitive_to_world.mul(surface_to_primitive)), affinematrix.pyx:255-273
+                    const double *a = p.to_root;
+                    double stw[9];
 #pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
-                    stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
-                    stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
-                }
-                xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
-                r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                ++depth;
-                // Russian roulette of the daughter (ray.pyx:382-388)
-                int32_t kind = TERM_LAMBERT;
-                if (depth >= q->ray_min_depth) {
-                    if (depth >= q->ray_max_depth) active = false;
-                    else {
-                        double k1, k2;
-                        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
-                        if (k1 < q->ray_extinction_prob) active = false; else kind = TERM_LAMBERT_NORM;
+                    for (int i = 0; i < 3; ++i) {
+                        stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
+                        stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
+                        stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
                     }
+                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                    r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                    r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                    r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                    ++depth;
+                    ++spawned;
+                    // Russian roulette of the daughter (ray.pyx:382-388)
+                    int32_t kind = TERM_LAMBERT;
+                    if (depth >= q->ray_min_depth) {
+                        if (depth >= q->ray_max_depth) active = false;
+                        else {
+                            double k1, k2;
+                            philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
+                            if (k1 < q->ray_extinction_prob) active = false; else kind = TERM_LAMBERT_NORM;
+                        }
+                    }
+                    push(pdf, rcp, mat.table, kind);
                 }
-                push(pdf, rcp, mat.table, kind);
-                continue;
+            } else {
+                if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
+                else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
+                    double lx, ly, lz;
+                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                    smp.a = mat.scale * (dot > 0 ? dot : 0.0);
+                    smp.table = mat.table;
+                }
+                active = false;
             }
-            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
-            else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
-                double lx, ly, lz;
-                xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
-                const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
-                smp.a = mat.scale * (dot > 0 ? dot : 0.0);
-                smp.table = mat.table;
-            }
-            active = false;
         }
-        if (!px.valid) continue;
-        smp.pad = pos;
-        samples[record] = smp;
-        ps.tail[record] = (int32_t)blk;
+        if (was_active && !active) {                                          // path over: its record is complete
+            smp.pad = pos;
+            samples[record] = smp;
+            ps.tail[record] = (int32_t)blk;
+        }
     }
+    // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
+    for (int o = 32; o > 0; o >>= 1) spawned += __shfl_xor(spawned, o);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ps.flags) + 1, spawned);
 }
 
 // Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.

@@ -1077,6 +1077,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         unsigned int flags = 0;
         HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ray_count) {
+            unsigned long long spawned = 0;
+            HIP_TRY(hipMemcpy(&spawned, reinterpret_cast<unsigned long long *>(lane.overflow) + 1, sizeof(spawned), hipMemcpyDeviceToHost));
+            *ray_count = spawned;
+        }
         if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: the path-term arena (%zu blocks of %d terms) ran out; render fewer rays per call or raise RSX_PATH_ARENA", arena_blocks, PATH_BLOCK - 1);
         if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a path crossed more than %d surfaces (limit of this build)", PATH_MAX_SEGMENTS);
         if (flags & 4u) return rsx_fail(RSX_EUNSUPPORTED, "render: more than %d volume emitters overlap at one point (limit of this build)", PATH_VOL_OVERLAP);

@@ -573,13 +573,16 @@ def test_frames_lambert_against_oracle(orc, ns):
         cam.observe()
         w, h = pixels
         ref_m, ref_v = np.zeros((w, h, bins)), np.zeros((w, h, bins))
+        ref_rays = 0
         for sl in cam._slice_spectrum():
             keep = []
             desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
-            om, ov, _ = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            ref_rays += n_rays
             ref_m[:, :, sl.offset:sl.offset + sl.bins] = om.reshape(h, w, sl.bins).transpose(1, 0, 2)
             ref_v[:, :, sl.offset:sl.offset + sl.bins] = ov.reshape(h, w, sl.bins).transpose(1, 0, 2)
         assert eq(pipe.frame.mean, ref_m) and eq(pipe.frame.variance, ref_v), (pixels, ext)
+        assert cam.stats["rays"] == ref_rays                      # Ray.ray_count: primary rays + every daughter spawned
         if ext[2] == 500:
             assert (pipe.frame.mean > 0).mean() > 0.5              # light reaches most pixels only through diffuse bounces
     # the reference's stream engine cannot drive scattering paths in parallel: loud error, no silent substitute

@@ -294,7 +294,7 @@ def _observe_oracle(orc, ns, cam, pipe, seed, frame=None):
         desc = cam.render_desc(world, tasks, sl, eng, keep)
         desc.power = 1 if pipe.power else 0
         mean, var, rays = orc.render_pinhole(flat, desc)
-        assert rays == len(tasks) * cam.pixel_samples
+        assert rays >= len(tasks) * cam.pixel_samples          # + one per daughter ray (null surfaces, scattering)
         z = slice(sl.offset, sl.offset + sl.bins)
         sub = [f[t[:, 0], t[:, 1], z] for f in frame]
         m, v, n = orc.frame_combine(sub[0], sub[1], sub[2], mean, np.maximum(var, 0), np.full(mean.shape, cam.pixel_samples, dtype=np.int32))

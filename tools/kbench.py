@@ -64,4 +64,5 @@ mean = pipe.frame.mean
 digest = hashlib.sha256(np.ascontiguousarray(mean).tobytes()).hexdigest()[:16]
 print(json.dumps({"lib": os.path.basename(os.environ.get("RSX_LIB", "librsx.so")), "config": config,
                   "trace_ms": round(float(np.mean(tr)), 4), "trace_min": round(float(np.min(tr)), 4), "trace_max": round(float(np.max(tr)), 4),
-                  "accum_ms": round(float(np.mean(ac)), 4), "wall_ms": round(wall * 1e3, 4), "rays_per_s": round(rays / wall, 1), "digest": digest}))
+                  "accum_ms": round(float(np.mean(ac)), 4), "wall_ms": round(wall * 1e3, 4), "rays_per_s": round(rays / wall, 1),
+                  "all_rays_per_pass": int(cam.stats.get("rays", 0)), "all_rays_per_s": round(cam.stats.get("rays", 0) / wall, 1), "digest": digest}))
