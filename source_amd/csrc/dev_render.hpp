@@ -39,6 +39,7 @@ struct RenderParams {
     uint64_t seed, sample_offset;
     int32_t ray_max_depth, ray_min_depth;      // Ray.max_depth / extinction_min_depth / extinction_prob: path kernel only
     double ray_extinction_prob;
+    int32_t n_vol_emitters, pad_path;          // materials with a volume contribution (0: the per-segment world.contains() pass is skipped)
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
@@ -255,9 +256,10 @@ __device__ __forceinline__ void portable_sincos(double phi, double &sn, double &
 }
 
 // world.contains(point) in leaf order (kdtree3d.pyx:736-792, kdtree.pyx:126-162): calls f(primitive index) for every world
-// primitive whose bounding box and surface contain the point
-template <bool CSG, typename F>
-__device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, F f) {
+// primitive that passes `want` (a side-effect-free filter evaluated BEFORE the containment test, which for a mesh is a ray cast) and
+// whose bounding box and surface contain the point
+template <bool CSG, typename W, typename F>
+__device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, W want, F f) {
     if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) return;
     int32_t node = 0;
     rsx_kdnode nd = load_node(sc.wnodes, node);
@@ -268,6 +270,7 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
     for (int32_t k = 0; k < nd.count; ++k) {
         const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
         const rsx_primitive &p = sc.prims[idx];
+        if (!want(idx)) continue;
         bool in;
         if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
         else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
@@ -401,10 +404,11 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
             double v_len[PATH_VOL_OVERLAP], v_scale[PATH_VOL_OVERLAP];
             int32_t v_table[PATH_VOL_OVERLAP];
             int n_vol = 0;
-            world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
+            if (q->n_vol_emitters) world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
+                return q->materials[sc.prims[idx].material].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;   // every other evaluate_volume leaves the spectrum unchanged
+            }, [&](int32_t idx) {
                 const rsx_primitive &vp = sc.prims[idx];
                 const rsx_material vm = q->materials[vp.material];
-                if (vm.type != RSX_MAT_UNIFORM_VOLUME_EMITTER) return;        // NullVolume.evaluate_volume: unchanged
                 double sx, sy, sz, ex, ey, ez;
                 xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
                 xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);

@@ -937,6 +937,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.rng_mode = desc->rng_mode;
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
+    rp.n_vol_emitters = 0; rp.pad_path = 0;
+    for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured

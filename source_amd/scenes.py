@@ -330,7 +330,7 @@ def volumes_camera(ns, world, pixels=(48, 40), spp=3, bins=6):
     return cam, pipe
 
 
-def build_lambert(ns, with_volume=True):
+def build_lambert(ns, with_volume=True, csg=True):
     """Diffuse inter-reflection scene (fixture F13): an open-fronted room of Lambert walls with spectrally different reflectivities,
     an emitting ceiling panel, a Lambert sphere, a smooth-shaded Lambert mesh, a Lambert CSG solid, and — so that scattering,
     transparent boundaries and volume emission meet on one path — a glowing volume and a NullMaterial shell."""
@@ -347,9 +347,12 @@ def build_lambert(ns, with_volume=True):
         ns.Box(P(1.0, -1.0, 0.0), P(1.05, 1.0, 2.0), world, material=ns.Lambert(green)),          # right
         ns.Box(P(-0.4, 0.98, 0.6), P(0.4, 0.999, 1.4), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 8.0)),   # light
         ns.Sphere(0.3, world, ns.translate(-0.45, -0.7, 1.3), ns.Lambert(ns.ConstantSF(0.9))),
-        ns.Subtract(ns.Box(P(-0.25, -0.25, -0.25), P(0.25, 0.25, 0.25)), ns.Sphere(0.3, transform=ns.translate(0.2, 0.2, -0.2)), world,
-                    ns.translate(0.45, -0.75, 0.9) * ns.rotate(25, 0, 0), ns.Lambert(green)),
     ]
+    if csg:
+        prims.append(ns.Subtract(ns.Box(P(-0.25, -0.25, -0.25), P(0.25, 0.25, 0.25)), ns.Sphere(0.3, transform=ns.translate(0.2, 0.2, -0.2)), world,
+                                 ns.translate(0.45, -0.75, 0.9) * ns.rotate(25, 0, 0), ns.Lambert(green)))
+    else:
+        prims.append(ns.Box(P(-0.25, -0.25, -0.25), P(0.25, 0.25, 0.25), world, ns.translate(0.45, -0.75, 0.9) * ns.rotate(25, 0, 0), ns.Lambert(green)))
     v, t = displaced_sphere(10, radius=0.25)
     nv = vertex_normals(v, t)
     prims.append(ns.Mesh(v, np.concatenate([t, t], axis=1), normals=nv, smoothing=True, parent=world, transform=ns.translate(0.1, -0.2, 1.5), material=ns.Lambert(red)))

@@ -32,6 +32,9 @@ elif config == "c3s24":
 elif config == "lambert":                 # diffuse inter-reflection room (fixture F13's scene), observer-default roulette
     world = scenes.build_lambert(ns)[0]
     cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+elif config == "lambert_plain":           # the same room without the CSG solid and without volumes
+    world = scenes.build_lambert(ns, with_volume=False, csg=False)[0]
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
 elif config == "flat":
     world = scenes.build_flat(ns, n=512)[0]
     cam, pipe = scenes.c2_camera(ns, world, (2048, 2048), spp=64, bins=15)
