@@ -54,7 +54,13 @@ enum {
      * primitives): one cosine-weighted daughter ray (HemisphereCosineSampler, core/math/sampler/solidangle.pyx:208-238) from the
      * incident side, depth + 1, Russian roulette per Ray.trace (optical/ray.pyx:382-388);
      * spectrum = trace(daughter) * table[bin] * pdf / pdf. Stochastic: RSX_RNG_PHILOX only. */
-    RSX_MAT_LAMBERT = 5
+    RSX_MAT_LAMBERT = 5,
+    /* Dielectric (optical/material/dielectric.pyx:125-328): scale = refractive index inside, light_dir[0] = index outside (both
+     * SpectralFunction.average over the slice's wavelength range), light_dir[1] != 0 = transmission_only, table = transmission per
+     * metre. Surface: refracted or reflected daughter chosen with probability(transmission) (Fresnel, unpolarised), total internal
+     * reflection when 1 - (n1/n2)^2 (1 - cos^2) <= 0; depth + 1, Russian roulette. Volume: every segment starting inside the
+     * primitive scales the spectrum by pow(table[bin], world-space segment length). Stochastic: RSX_RNG_PHILOX only. */
+    RSX_MAT_DIELECTRIC = 6
 };
 
 /* ---- flattened KD-tree (raysect/core/math/spatial/kdtree3d.pxd:38-43 `kdnode`, 32 B -> 16 B) -- */

@@ -79,7 +79,7 @@ class MT(C.Structure):
 
 
 PRIM_SPHERE, PRIM_BOX, PRIM_CYLINDER, PRIM_MESH, PRIM_UNION, PRIM_INTERSECT, PRIM_SUBTRACT, PRIM_NULL = range(8)
-MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT, MAT_NULL, MAT_UNIFORM_VOLUME_EMITTER, MAT_LAMBERT = range(6)
+MAT_ABSORBER, MAT_UNIFORM_EMITTER, MAT_DEBUG_LIGHT, MAT_NULL, MAT_UNIFORM_VOLUME_EMITTER, MAT_LAMBERT, MAT_DIELECTRIC = range(7)
 RNG_STREAM, RNG_PHILOX = 0, 1
 
 # every symbol include/rsx.h declares: (name, restype, argtypes)

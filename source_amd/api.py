@@ -3,7 +3,7 @@ from .core import (AffineMatrix3D, Normal3D, Point3D, Vector3D, rotate, rotate_v
                    Node, Intersection, BoundingBox3D)
 from .core.scenegraph import Ray as CoreRay  # noqa: F401
 from .optical import World, Ray, Spectrum, ConstantSF, InterpolatedSF  # noqa: F401
-from .optical.material import AbsorbingSurface, UniformSurfaceEmitter, Light, NullMaterial, UniformVolumeEmitter, Lambert  # noqa: F401
+from .optical.material import AbsorbingSurface, UniformSurfaceEmitter, Light, NullMaterial, UniformVolumeEmitter, Lambert, Dielectric, Sellmeier  # noqa: F401
 from .optical.observer import (PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D,  # noqa: F401
                                HipEngine, RenderEngine, SerialEngine, MulticoreEngine, RectFrameSampler2D, RectTasks)
 from .primitive import Sphere, Box, Cylinder, Mesh, Union, Intersect, Subtract  # noqa: F401

@@ -12,7 +12,9 @@
 // trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
 // ---------------------------------------------------------------------------------------------------
 #define CSG_MAX_SLOTS 16
+#ifndef CSG_MAX_DEPTH
 #define CSG_MAX_DEPTH 4
+#endif
 #define F_VALID 1u
 #define F_EXIT 2u
 #define F_FLIP 4u

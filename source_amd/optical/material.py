@@ -11,7 +11,7 @@ Mirrors raysect/optical/material/{material,absorber,debug}.pyx and emitter/unifo
 """
 from ..core.scenegraph import Material as CoreMaterial
 from .. import _lib
-from .spectral import ConstantSF
+from .spectral import ConstantSF, NumericallyIntegratedSF
 
 
 class Material(CoreMaterial):
@@ -166,6 +166,40 @@ class Lambert(NullVolume):
     def device_material(self, tables, min_wavelength, max_wavelength, bins):
         tables.append(self.reflectivity.sample(min_wavelength, max_wavelength, bins))
         return _record(_lib.MAT_LAMBERT, len(tables) - 1, 1.0)
+
+
+class Sellmeier(NumericallyIntegratedSF):
+    """dielectric.pyx:40-122 — three-term Sellmeier refractive index; wavelength in nm (the equation's is in micrometres)."""
+
+    def __init__(self, b1, b2, b3, c1, c2, c3, sample_resolution=10):
+        super().__init__(sample_resolution)
+        self.b1, self.b2, self.b3, self.c1, self.c2, self.c3 = float(b1), float(b2), float(b3), float(c1), float(c2), float(c3)
+
+    def function(self, wavelength):
+        import math
+        w2 = wavelength * wavelength * 1e-6
+        return math.sqrt(1 + (self.b1 * w2) / (w2 - self.c1) + (self.b2 * w2) / (w2 - self.c2) + (self.b3 * w2) / (w2 - self.c3))
+
+
+class Dielectric(Material):
+    """dielectric.pyx:125-328 — ideal dielectric: Fresnel-weighted stochastic choice between the refracted and the reflected ray
+    (total internal reflection handled), refractive indices averaged over the ray's spectral range (one index per spectral slice:
+    dispersion comes from spectral_rays), Beer-Lambert attenuation transmission ** path_length inside the primitive.
+    Rendered on the device (RSX_MAT_DIELECTRIC) with Philox-keyed paths."""
+
+    def __init__(self, index, transmission, external_index=None, transmission_only=False):
+        super().__init__()
+        self.index = index
+        self.transmission = transmission
+        self.transmission_only = bool(transmission_only)
+        self.external_index = ConstantSF(1.0) if external_index is None else external_index
+        self.importance = 1.0
+
+    def device_material(self, tables, min_wavelength, max_wavelength, bins):
+        tables.append(self.transmission.sample(min_wavelength, max_wavelength, bins))
+        internal = self.index.average(min_wavelength, max_wavelength)
+        external = self.external_index.average(min_wavelength, max_wavelength)
+        return _record(_lib.MAT_DIELECTRIC, len(tables) - 1, internal, (external, 1.0 if self.transmission_only else 0.0, 0.0))
 
 
 # convenience used by scene builders

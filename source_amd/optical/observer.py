@@ -577,8 +577,8 @@ class PinholeCamera(Observer2D):
             # band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
             # and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut.
             limit = self.MAX_RAYS_PER_CALL
-            from .material import NullSurface, Lambert
-            if any(isinstance(p.material, (NullSurface, Lambert)) for p in world._primitives):
+            from .material import NullSurface, Lambert, Dielectric
+            if any(isinstance(p.material, (NullSurface, Lambert, Dielectric)) for p in world._primitives):
                 limit = min(limit, 1 << 24)                 # the volume path also keeps 768 B of emission terms per ray
             per_call = max(1, limit // self._pixel_samples)
             if isinstance(tasks, RectTasks):

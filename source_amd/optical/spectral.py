@@ -116,6 +116,32 @@ class ConstantSF(SpectralFunction):
         return np.full(bins, self.value, dtype=np.float64)
 
 
+class NumericallyIntegratedSF(SpectralFunction):
+    """spectralfunction.pyx:330-413 — midpoint-rule integration of function() at sample_resolution nm."""
+
+    def __init__(self, sample_resolution=1.0):
+        super().__init__()
+        if sample_resolution <= 0:
+            raise ValueError("Sampling resolution must be greater than zero.")
+        self.sample_resolution = float(sample_resolution)
+
+    def evaluate(self, wavelength):
+        return self.function(wavelength)
+
+    def integrate(self, min_wavelength, max_wavelength):
+        import math
+        samples = max(int(math.ceil((max_wavelength - min_wavelength) / self.sample_resolution)), 1)
+        total = 0.0
+        delta = (max_wavelength - min_wavelength) / samples
+        for i in range(samples):
+            centre = min_wavelength + (0.5 + i) * delta
+            total += self.function(centre) * delta
+        return total
+
+    def function(self, wavelength):
+        raise NotImplementedError("Virtual method function() not implemented.")
+
+
 class InterpolatedSF(SpectralFunction):
     """spectralfunction.pyx:383-470 — linear interpolation, nearest-neighbour extrapolation."""
 

@@ -369,3 +369,38 @@ def lambert_camera(ns, world, pixels=(24, 20), spp=4, bins=5, extinction=(0.1, 2
     cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = extinction
     cam.ray_importance_sampling = False                     # multiple importance sampling is the next scope row
     return cam, pipe
+
+
+def build_glass(ns, unit_transmission=False):
+    """Refraction scene (fixture F14): dispersive glass (Sellmeier index, absorbing transmission) as a sphere, a rotated block, a CSG
+    lens and a small smooth mesh, over a Lambert floor, lit by an emitting panel and a striped back wall so that refraction is visible.
+    ``unit_transmission`` makes every glass perfectly clear: no pow() in the volume pass, so device frames can be compared bit for bit."""
+    world = ns.World()
+    P = ns.Point3D
+    bk7 = ns.Sellmeier(1.03961212, 0.231792344, 1.01046945, 6.00069867e-3, 2.00179144e-2, 1.03560653e2)
+    tint = ns.ConstantSF(1.0) if unit_transmission else ns.InterpolatedSF([300, 450, 550, 650, 800], np.array([0.35, 0.6, 0.9, 0.7, 0.4]))
+    clear = ns.ConstantSF(1.0) if unit_transmission else ns.ConstantSF(0.8)
+    stripes = ns.InterpolatedSF([300, 480, 500, 600, 620, 800], np.array([0.1, 0.15, 1.0, 0.9, 0.2, 0.1]))
+    prims = [
+        ns.Box(P(-2.0, -1.05, -0.5), P(2.0, -1.0, 3.0), world, material=ns.Lambert(ns.ConstantSF(0.6))),               # floor
+        ns.Box(P(-2.0, -1.0, 3.0), P(2.0, 2.0, 3.05), world, material=ns.UniformSurfaceEmitter(stripes, 0.8)),          # back wall, emitting
+        ns.Box(P(-0.6, 1.6, 0.6), P(0.6, 1.62, 1.8), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 6.0)),   # panel
+        ns.Sphere(0.4, world, ns.translate(-0.7, -0.6, 1.4), ns.Dielectric(bk7, tint)),
+        ns.Box(P(-0.3, -0.3, -0.3), P(0.3, 0.3, 0.3), world, ns.translate(0.75, -0.7, 1.6) * ns.rotate(30, 10, 0), ns.Dielectric(ns.ConstantSF(1.5), clear)),
+        ns.Intersect(ns.Sphere(0.6, transform=ns.translate(0, 0, 0.45)), ns.Sphere(0.6, transform=ns.translate(0, 0, -0.45)), world,
+                     ns.translate(0.0, 0.1, 1.0), ns.Dielectric(bk7, clear, transmission_only=True)),
+        ns.Sphere(0.25, world, ns.translate(0.1, -0.75, 0.7), ns.Dielectric(ns.ConstantSF(1.33), tint, external_index=ns.ConstantSF(1.0))),
+    ]
+    v, t = displaced_sphere(8, radius=0.22)
+    prims.append(ns.Mesh(v, np.concatenate([t, t], axis=1), normals=vertex_normals(v, t), smoothing=True, parent=world,
+                         transform=ns.translate(-0.2, -0.75, 2.1), material=ns.Dielectric(ns.ConstantSF(1.7), clear)))
+    return world, prims
+
+
+def glass_camera(ns, world, pixels=(24, 20), spp=4, bins=6, spectral_rays=3, extinction=(0.1, 2, 20)):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=50, parent=world, pipelines=[pipe], frame_sampler=ns.FullFrameSampler2D(), transform=ns.translate(0.0, -0.2, -1.6))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, spectral_rays, True
+    cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = extinction
+    cam.ray_importance_sampling = False
+    return cam, pipe

@@ -34,7 +34,7 @@ from raysect.core.math import random as rsrandom  # noqa: E402
 from raysect.core.acceleration.kdtree import _PrimitiveKDTree  # noqa: E402
 from raysect.primitive import Mesh, Sphere, Box, Cylinder, Union, Intersect, Subtract  # noqa: E402
 from raysect.optical import World, ConstantSF, InterpolatedSF, Ray as OpticalRay  # noqa: E402
-from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial, Lambert  # noqa: E402
+from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial, Lambert, Dielectric, Sellmeier  # noqa: E402
 from raysect.optical.material.debug import Light  # noqa: E402
 from raysect.optical.observer import PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D  # noqa: E402
 
@@ -45,7 +45,7 @@ NS = types.SimpleNamespace(
     World=World, Mesh=Mesh, Sphere=Sphere, Box=Box, Cylinder=Cylinder, Union=Union, Intersect=Intersect,
     Subtract=Subtract, Point3D=Point3D, Vector3D=Vector3D, translate=translate, rotate=rotate,
     ConstantSF=ConstantSF, InterpolatedSF=InterpolatedSF, AbsorbingSurface=AbsorbingSurface,
-    UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light, Lambert=Lambert,
+    UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light, Lambert=Lambert, Dielectric=Dielectric, Sellmeier=Sellmeier,
     PinholeCamera=PinholeCamera,
     FullFrameSampler2D=FullFrameSampler2D, SpectralRadiancePipeline2D=SpectralRadiancePipeline2D,
     SpectralPowerPipeline2D=SpectralPowerPipeline2D)
@@ -487,6 +487,24 @@ def f13_lambert():
     save("f13_lambert", **out)
 
 
+def f14_glass():
+    """Dielectric (dielectric.pyx:125-328): Fresnel-weighted refraction / reflection, total internal reflection, transmission_only,
+    Sellmeier index averaged per spectral slice, Beer-Lambert attenuation in the volume pass; mixed with Lambert and emitters."""
+    out = {}
+    world, prims = scenes.build_glass(NS)
+    cam, pipe = scenes.glass_camera(NS, world)
+    out["mean"], out["var"], out["n"] = observe_frame(cam, pipe, 51)
+    pyrandom.seed(52); rsrandom.seed(52); cam.observe()
+    out["mean2"], out["var2"], out["n2"] = np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples)
+    world, prims = scenes.build_glass(NS, unit_transmission=True)
+    cam, pipe = scenes.glass_camera(NS, world, pixels=(16, 12), spp=3, bins=4, spectral_rays=2, extinction=(0.01, 3, 500))
+    out["clear_mean"], out["clear_var"], out["clear_n"] = observe_frame(cam, pipe, 53)
+    bk7 = Sellmeier(1.03961212, 0.231792344, 1.01046945, 6.00069867e-3, 2.00179144e-2, 1.03560653e2)
+    out["sellmeier_avg"] = np.array([bk7.average(375.0, 740.0), bk7.average(375.0, 496.0), bk7.average(700.0, 703.5), bk7.evaluate(589.3)])
+    out["sellmeier_sample"] = bk7.sample(375.0, 740.0, 7)
+    save("f14_glass", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -507,3 +525,4 @@ if __name__ == "__main__":
     if run("f11"): f11_edges()
     if run("f12"): f12_volumes()
     if run("f13"): f13_lambert()
+    if run("f14"): f14_glass()

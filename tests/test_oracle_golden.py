@@ -434,3 +434,23 @@ def test_frames_lambert(orc, ns, golden):
     cam.spectral_rays = 2
     f = _observe_oracle_mt(orc, ns, cam, pipe, 44)
     assert eq(f[0], g["rr0_mean"]) and eq(f[1], g["rr0_var"]) and eq(f[2], g["rr0_n"])
+
+
+# ---------------------------------------------------------------------------------------- F14 Dielectric
+def test_frames_dielectric(orc, ns, golden):
+    """Dielectric: refraction / reflection choice, total internal reflection, transmission_only, per-slice Sellmeier index and the
+    Beer-Lambert volume pass, bit for bit against the reference's SerialEngine frames (the oracle calls the same libm pow)."""
+    g = golden("f14_glass")
+    bk7 = ns.Sellmeier(1.03961212, 0.231792344, 1.01046945, 6.00069867e-3, 2.00179144e-2, 1.03560653e2)
+    assert eq(np.array([bk7.average(375.0, 740.0), bk7.average(375.0, 496.0), bk7.average(700.0, 703.5), bk7.evaluate(589.3)]), g["sellmeier_avg"])
+    assert eq(bk7.sample(375.0, 740.0, 7), g["sellmeier_sample"])
+    world, prims = scenes.build_glass(ns)
+    cam, pipe = scenes.glass_camera(ns, world)
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 51)
+    assert eq(f[0], g["mean"]) and eq(f[1], g["var"]) and eq(f[2], g["n"])
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 52, f)
+    assert eq(f[0], g["mean2"]) and eq(f[1], g["var2"]) and eq(f[2], g["n2"])
+    world, prims = scenes.build_glass(ns, unit_transmission=True)
+    cam, pipe = scenes.glass_camera(ns, world, pixels=(16, 12), spp=3, bins=4, spectral_rays=2, extinction=(0.01, 3, 500))
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 53)
+    assert eq(f[0], g["clear_mean"]) and eq(f[1], g["clear_var"]) and eq(f[2], g["clear_n"])
