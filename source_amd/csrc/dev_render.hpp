@@ -225,11 +225,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
 // from a shared arena (one atomic per 15 terms), each linked back to its predecessor through slot 0. Scenes without such
 // materials never run this kernel (k_render_trace is untouched).
 struct PathTerm {
-    double a, b;               // VOL: segment length, emitter scale.  LAMBERT: pdf, 1 / pdf
+    double a, b;               // VOL: segment length, emitter scale.  LAMBERT: pdf, 1 / pdf.  ATTEN: segment length
     int32_t table;             // spectral table row (emission / reflectivity).  LINK: id of the previous block
     int32_t kind;
 };
-enum { TERM_VOL = 0, TERM_LAMBERT = 1, TERM_LAMBERT_NORM = 2, TERM_LINK = 3 };   // _NORM: the daughter survived roulette, its result is scaled first
+enum { TERM_VOL = 0, TERM_LAMBERT = 1, TERM_LAMBERT_NORM = 2, TERM_LINK = 3, TERM_NORM = 4, TERM_ATTEN = 5 };
+// LAMBERT_NORM: the daughter survived roulette, its result is scaled first.  NORM: roulette scaling alone (daughter of a dielectric
+// surface, which itself leaves the spectrum unchanged).  ATTEN: a = world-space segment length inside a dielectric, table = transmission
 #define PATH_BLOCK 16
 #define PATH_MAX_SEGMENTS (1 << 20)        // guard against a path that never ends (each Lambert bounce and each null surface is a segment)
 #define PATH_VOL_OVERLAP 4                 // volume emitters that may contain one point
@@ -331,6 +333,15 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
         ps.pool[blk * PATH_BLOCK + pos] = t;
         ++pos;
     };
+    // Russian roulette of a freshly spawned daughter (ray.pyx:382-388): 0 = extinguished, 1 = alive, 2 = alive and its result is
+    // scaled by 1 / (1 - extinction_prob)
+    auto roulette = [&]() -> int {
+        if (depth < q->ray_min_depth) return 1;
+        if (depth >= q->ray_max_depth) return 0;
+        double k1, k2;
+        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
+        return k1 < q->ray_extinction_prob ? 0 : 2;
+    };
     for (;;) {
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(!active);
@@ -402,27 +413,34 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
             // volume emitters containing this segment's origin: found in world.contains() order, pushed newest first because the
             // list is replayed backwards
             double v_len[PATH_VOL_OVERLAP], v_scale[PATH_VOL_OVERLAP];
-            int32_t v_table[PATH_VOL_OVERLAP];
+            int32_t v_table[PATH_VOL_OVERLAP], v_kind[PATH_VOL_OVERLAP];
             int n_vol = 0;
             if (q->n_vol_emitters) world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
-                return q->materials[sc.prims[idx].material].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;   // every other evaluate_volume leaves the spectrum unchanged
+                const int32_t vt = q->materials[sc.prims[idx].material].type;         // every other evaluate_volume leaves the spectrum unchanged
+                return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || vt == RSX_MAT_DIELECTRIC;
             }, [&](int32_t idx) {
                 const rsx_primitive &vp = sc.prims[idx];
                 const rsx_material vm = q->materials[vp.material];
-                double sx, sy, sz, ex, ey, ez;
-                xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
-                xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
-                const double vx = sx - ex, vy = sy - ey, vz = sz - ez;        // end.vector_to(start)
-                const double length = sqrt(vx * vx + vy * vy + vz * vz);
-                if (length == 0) return;
+                double length;
+                if (vm.type == RSX_MAT_DIELECTRIC) {                          // dielectric.pyx:300-328: world-space length
+                    const double vx = r.ox - hx, vy = r.oy - hy, vz = r.oz - hz;  // start_point.vector_to(end_point)
+                    length = sqrt(vx * vx + vy * vy + vz * vz);
+                } else {
+                    double sx, sy, sz, ex, ey, ez;
+                    xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
+                    xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
+                    const double vx = sx - ex, vy = sy - ey, vz = sz - ez;    // end.vector_to(start)
+                    length = sqrt(vx * vx + vy * vy + vz * vz);
+                    if (length == 0) return;
+                }
                 if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u);
 #pragma unroll
-                for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; }
-                v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table;
+                for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
+                v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
                 ++n_vol;
             });
 #pragma unroll
-            for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], TERM_VOL);
+            for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
             ++segments;
             if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
             else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
@@ -470,17 +488,53 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                     r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
                     ++depth;
                     ++spawned;
-                    // Russian roulette of the daughter (ray.pyx:382-388)
-                    int32_t kind = TERM_LAMBERT;
-                    if (depth >= q->ray_min_depth) {
-                        if (depth >= q->ray_max_depth) active = false;
-                        else {
-                            double k1, k2;
-                            philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
-                            if (k1 < q->ray_extinction_prob) active = false; else kind = TERM_LAMBERT_NORM;
-                        }
+                    const int alive = roulette();
+                    if (!alive) active = false;
+                    push(pdf, rcp, mat.table, alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
+                }
+            } else if (mat.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:159-262
+                double ix, iy, iz;
+                xform_vector(p.to_local, r.dx, r.dy, r.dz, ix, iy, iz);
+                normalise3(ix, iy, iz);
+                double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
+                normalise3(nx, ny, nz);
+                const double c1 = -(nx * ix + ny * iy + nz * iz);
+                const bool inside = c1 < 0.0;
+                const double n1 = inside ? mat.scale : mat.light_dir[0], n2 = inside ? mat.light_dir[0] : mat.scale;
+                const bool transmission_only = mat.light_dir[1] != 0.0;
+                const double gamma = n1 / n2;
+                const double c2s = 1 - (gamma * gamma) * (1 - c1 * c1);
+                bool reflect = true;
+                double ox = 0, oy = 0, oz = 0;
+                if (c2s > 0) {
+                    const double temp = inside ? gamma * c1 + sqrt(c2s) : gamma * c1 - sqrt(c2s);
+                    ox = gamma * ix + temp * nx; oy = gamma * iy + temp * ny; oz = gamma * iz + temp * nz;
+                    const double ci = c1, ct = -(nx * ox + ny * oy + nz * oz);
+                    const double ra = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct), rb = (n1 * ct - n2 * ci) / (n1 * ct + n2 * ci);
+                    const double reflectivity = 0.5 * (ra * ra + rb * rb);
+                    const double transmission = 1 - reflectivity;
+                    if (transmission_only) reflect = false;
+                    else {
+                        double k1, k2;
+                        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), k1, k2);
+                        reflect = !(k1 < transmission);
                     }
-                    push(pdf, rcp, mat.table, kind);
+                }
+                if (reflect && transmission_only) active = false;             // total internal reflection without a reflected ray: zero spectrum
+                else {
+                    const double *from;
+                    if (reflect) {
+                        const double temp = 2 * c1;
+                        ox = ix + temp * nx; oy = iy + temp * ny; oz = iz + temp * nz;
+                        from = inside ? g.inside : g.outside;
+                    } else from = inside ? g.outside : g.inside;
+                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                    xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
+                    ++depth;
+                    ++spawned;
+                    const int alive = roulette();
+                    if (!alive) active = false;
+                    else if (alive == 2) push(0.0, 0.0, mat.table, TERM_NORM);
                 }
             } else {
                 if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
@@ -724,7 +778,9 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                     if (tm.kind == TERM_VOL) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;
-                    } else {
+                    } else if (tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);  // dielectric.pyx:325-326
+                    else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
+                    else {
                         if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;
                         x = x * tv;
                         x = x * tm.a;

@@ -856,8 +856,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     bool has_vol = false, has_scatter = false;
     for (int32_t i = 0; i < desc->n_materials; ++i) {
         const int32_t mt = desc->materials[i].type;
-        has_vol = has_vol || mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT;
-        has_scatter = has_scatter || mt == RSX_MAT_LAMBERT;
+        has_vol = has_vol || mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC;
+        has_scatter = has_scatter || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC;
     }
     if (has_scatter) {
         if (desc->rng_mode != RSX_RNG_PHILOX)
@@ -938,7 +938,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.n_vol_emitters = 0; rp.pad_path = 0;
-    for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER;
+    for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured

@@ -593,6 +593,35 @@ def test_frames_lambert_against_oracle(orc, ns):
         cam.observe()
 
 
+def test_frames_dielectric_against_oracle(orc, ns):
+    """Dielectric on the device (RSX_MAT_DIELECTRIC): refraction / reflection choice, total internal reflection, transmission_only,
+    per-slice Sellmeier index, Beer-Lambert attenuation. The oracle is pinned bit for bit to the reference by fixture F14. Perfectly
+    clear glass (pow(1, length) == 1 on any libm): frames and ray statistics identical. Tinted glass: the volume pass calls the
+    device's pow(), which may differ from glibc's in the last bit per attenuated segment — radiance within 1e-12 relative."""
+    for clear, tol in ((True, 0.0), (False, 1e-12)):
+        world, prims = scenes.build_glass(ns, unit_transmission=clear)
+        cam, pipe = scenes.glass_camera(ns, world, (96, 72), 6, 6, 3, (0.01, 3, 500) if clear else (0.1, 2, 20))
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=123)
+        cam.observe()
+        w, h, bins = 96, 72, 6
+        ref_m, ref_v = np.zeros((w, h, bins)), np.zeros((w, h, bins))
+        ref_rays = 0
+        for sl in cam._slice_spectrum():
+            keep = []
+            desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+            om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            ref_rays += n_rays
+            ref_m[:, :, sl.offset:sl.offset + sl.bins] = om.reshape(h, w, sl.bins).transpose(1, 0, 2)
+            ref_v[:, :, sl.offset:sl.offset + sl.bins] = ov.reshape(h, w, sl.bins).transpose(1, 0, 2)
+        assert cam.stats["rays"] == ref_rays
+        if tol == 0.0:
+            assert eq(pipe.frame.mean, ref_m) and eq(pipe.frame.variance, ref_v)
+        else:
+            assert np.allclose(pipe.frame.mean, ref_m, rtol=tol, atol=0) and np.allclose(pipe.frame.variance, ref_v, rtol=64 * tol, atol=1e-300)
+        assert (pipe.frame.mean > 0).mean() > 0.7
+
+
 def test_lambert_furnace_full_size(ns):
     """Size-independent property at 1024 x 1024: inside a closed furnace — every surface either a unit-reflectivity Lambert wall or
     an emitter of radiance L — with roulette off (probability 0: normalisation exactly 1) every path ends on an emitter and carries

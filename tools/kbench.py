@@ -35,6 +35,9 @@ elif config == "lambert":                 # diffuse inter-reflection room (fixtu
 elif config == "lambert_plain":           # the same room without the CSG solid and without volumes
     world = scenes.build_lambert(ns, with_volume=False, csg=False)[0]
     cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+elif config == "glass":                   # refraction scene (fixture F14's), 3 spectral slices
+    world = scenes.build_glass(ns)[0]
+    cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 15, 3, (0.01, 3, 500))
 elif config == "flat":
     world = scenes.build_flat(ns, n=512)[0]
     cam, pipe = scenes.c2_camera(ns, world, (2048, 2048), spp=64, bins=15)
