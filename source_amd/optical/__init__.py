@@ -9,4 +9,4 @@ from .material import AbsorbingSurface, Light, Material, NullVolume, UniformSurf
 
 
 class World(_CoreWorld):
-    """raysect/optical/scenegraph/world.pyx — the optical world (importance sampling manager is out of scope)."""
+    """raysect/optical/scenegraph/world.pyx — the optical world (the importance-sampling manager, SURVEY.md §8f row 2, is not built yet)."""

@@ -531,6 +531,13 @@ class PinholeCamera(Observer2D):
     def render_desc(self, world, tasks, slice_, engine, keep, rect=None):
         """Builds the rsx_render_desc for one spectral slice. ``keep`` collects arrays that must outlive the call."""
         tables = []
+        from .material import Lambert
+        if self.ray_importance_sampling and any(isinstance(p.material, Lambert) for p in world._primitives) \
+                and any(getattr(p.material, "importance", 0.0) > 0 for p in world._primitives):
+            # ContinuousBSDF.evaluate_surface would mix in world.important_direction_sample (material.pyx:327-352): not lowered yet
+            raise NotImplementedError("multiple importance sampling (SURVEY.md §8f row 2) is not lowered to the device yet: this world has "
+                                      "important primitives (emitters default to importance 1) and a Lambert surface — set "
+                                      "observer.ray_importance_sampling = False, as the reference's unweighted path does")
         mats = [p.material.device_material(tables, slice_.min_wavelength, slice_.max_wavelength, slice_.bins) for p in world._primitives]
         desc = _lib.RenderDesc()
         desc.camera = self.device_camera()
