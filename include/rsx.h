@@ -148,6 +148,15 @@ typedef struct rsx_material {
  * Russian-roulette uniform and draw 2d + 1 the pair of uniforms of the scattering event that spawns the depth d + 1 ray (draw 1
  * for the primary ray's). Paths therefore reproduce whatever wave, GPU or rank renders them. */
 
+/* One important primitive of the world's ImportanceManager (optical/scenegraph/world.pyx:47-230): world-space bounding sphere
+ * (primitive.bounding_sphere()), cumulative selection probability (_calculate_cdf) and importance / total_importance. */
+typedef struct rsx_important_sphere {
+    double centre[3];
+    double radius;
+    double cdf;
+    double weight;
+} rsx_important_sphere;
+
 typedef struct rsx_render_desc {
     rsx_camera camera;
     const rsx_material *materials;  /* one per world primitive material id */
@@ -168,6 +177,13 @@ typedef struct rsx_render_desc {
     int32_t ray_max_depth;            /* Ray.max_depth */
     int32_t ray_extinction_min_depth; /* Ray.extinction_min_depth */
     double ray_extinction_prob;       /* Ray.extinction_prob */
+    /* multiple importance sampling of ContinuousBSDF materials (material.pyx:327-352): active when n_important > 0, i.e. when
+     * ray.importance_sampling and world.has_important_primitives(). Philox draws of a scattering event at depth d: block 2d+1 =
+     * (probability(important_path_weight), sphere selection), the same block with bit 63 of the pixel word set = the direction pair. */
+    const rsx_important_sphere *important;
+    int32_t n_important;
+    int32_t pad_important;
+    double important_path_weight;     /* Ray.important_path_weight */
 } rsx_render_desc;
 
 typedef struct rsx_ctx rsx_ctx;

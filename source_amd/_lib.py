@@ -66,12 +66,18 @@ class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("table", C.c_int32), ("scale", C.c_double), ("light_dir", C.c_double * 3)]
 
 
+class ImportantSphere(C.Structure):
+    _fields_ = [("centre", C.c_double * 3), ("radius", C.c_double), ("cdf", C.c_double), ("weight", C.c_double)]
+
+
 class RenderDesc(C.Structure):
     _fields_ = [("camera", Camera), ("materials", C.POINTER(Material)), ("tables", C.c_void_p), ("tasks", C.c_void_p),
                 ("uniforms", C.c_void_p), ("n_tasks", C.c_int64), ("rect", C.c_int32 * 4), ("n_materials", C.c_int32),
                 ("n_tables", C.c_int32), ("bins", C.c_int32), ("spp", C.c_int32), ("power", C.c_int32),
                 ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
-                ("ray_max_depth", C.c_int32), ("ray_extinction_min_depth", C.c_int32), ("ray_extinction_prob", C.c_double)]
+                ("ray_max_depth", C.c_int32), ("ray_extinction_min_depth", C.c_int32), ("ray_extinction_prob", C.c_double),
+                ("important", C.POINTER(ImportantSphere)), ("n_important", C.c_int32), ("pad_important", C.c_int32),
+                ("important_path_weight", C.c_double)]
 
 
 class MT(C.Structure):

@@ -531,13 +531,6 @@ class PinholeCamera(Observer2D):
     def render_desc(self, world, tasks, slice_, engine, keep, rect=None):
         """Builds the rsx_render_desc for one spectral slice. ``keep`` collects arrays that must outlive the call."""
         tables = []
-        from .material import Lambert
-        if self.ray_importance_sampling and any(isinstance(p.material, Lambert) for p in world._primitives) \
-                and any(getattr(p.material, "importance", 0.0) > 0 for p in world._primitives):
-            # ContinuousBSDF.evaluate_surface would mix in world.important_direction_sample (material.pyx:327-352): not lowered yet
-            raise NotImplementedError("multiple importance sampling (SURVEY.md §8f row 2) is not lowered to the device yet: this world has "
-                                      "important primitives (emitters default to importance 1) and a Lambert surface — set "
-                                      "observer.ray_importance_sampling = False, as the reference's unweighted path does")
         mats = [p.material.device_material(tables, slice_.min_wavelength, slice_.max_wavelength, slice_.bins) for p in world._primitives]
         desc = _lib.RenderDesc()
         desc.camera = self.device_camera()
@@ -549,6 +542,16 @@ class PinholeCamera(Observer2D):
         desc.bins, desc.spp = slice_.bins, self._pixel_samples
         desc.ray_max_depth, desc.ray_extinction_min_depth = int(self.ray_max_depth), int(self.ray_extinction_min_depth)
         desc.ray_extinction_prob = float(self.ray_extinction_prob)
+        # multiple importance sampling (material.pyx:327: ray.importance_sampling and world.has_important_primitives())
+        spheres = world.important_spheres() if self.ray_importance_sampling else []
+        desc.n_important, desc.important_path_weight = len(spheres), float(self.ray_important_path_weight)
+        if spheres:
+            arr = (_lib.ImportantSphere * len(spheres))()
+            for rec, (centre, radius, cdf, weight) in zip(arr, spheres):
+                rec.centre[0], rec.centre[1], rec.centre[2] = centre
+                rec.radius, rec.cdf, rec.weight = radius, cdf, weight
+            keep.append(arr)
+            desc.important = arr
         if rect is not None:
             desc.tasks = None
             for i in range(4):

@@ -505,6 +505,39 @@ def f14_glass():
     save("f14_glass", **out)
 
 
+def f15_importance():
+    """Multiple importance sampling (ContinuousBSDF.evaluate_surface, material.pyx:327-352; ImportanceManager, world.pyx:47-230):
+    emitters carry importance 1 by default, a second emitter gets importance 3, the camera starts inside one bounding sphere's reach."""
+    out = {}
+    world, prims = scenes.build_lambert(NS)
+    prims[5].material.importance = 3.0
+    world2_light = NS.Sphere(0.12, world, NS.translate(-0.6, 0.5, 1.2), NS.UniformSurfaceEmitter(NS.ConstantSF(1.0), 4.0))
+    cam, pipe = scenes.lambert_camera(NS, world)
+    cam.ray_importance_sampling = True
+    cam.ray_important_path_weight = 0.25
+    out["mean"], out["var"], out["n"] = observe_frame(cam, pipe, 61)
+    pyrandom.seed(62); rsrandom.seed(62); cam.observe()
+    out["mean2"], out["var2"], out["n2"] = np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples)
+    cam.ray_important_path_weight = 0.9                                        # mostly light-directed samples, many below the surface
+    cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = 0.01, 3, 500
+    pipe2 = SpectralRadiancePipeline2D(); cam.pipelines = [pipe2]
+    out["heavy_mean"], out["heavy_var"], out["heavy_n"] = observe_frame(cam, pipe2, 63)
+    # ImportanceManager.sample / pdf on their own (world.pyx:150-230): 40 origins (the first inside a bounding sphere), seeded stream
+    rng = np.random.RandomState(5)
+    pts = rng.uniform(-0.9, 0.9, (40, 3)); pts[:, 2] += 1.0
+    pts[0] = [0.3, 0.3, 1.05]
+    dirs = rng.normal(size=(40, 3)); dirs /= np.linalg.norm(dirs, axis=1)[:, None]
+    out["im_pts"], out["im_dirs"] = pts, dirs
+    out["im_pdf"] = np.array([world.important_direction_pdf(Point3D(*p), Vector3D(*d)) for p, d in zip(pts, dirs)])
+    rsrandom.seed(99)
+    samples, pdf2 = [], []
+    for p in pts:
+        v = world.important_direction_sample(Point3D(*p))
+        samples.append([v.x, v.y, v.z]); pdf2.append(world.important_direction_pdf(Point3D(*p), v))
+    out["im_samples"], out["im_pdf2"] = np.array(samples), np.array(pdf2)
+    save("f15_importance", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -526,3 +559,4 @@ if __name__ == "__main__":
     if run("f12"): f12_volumes()
     if run("f13"): f13_lambert()
     if run("f14"): f14_glass()
+    if run("f15"): f15_importance()

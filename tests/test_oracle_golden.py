@@ -454,3 +454,46 @@ def test_frames_dielectric(orc, ns, golden):
     cam, pipe = scenes.glass_camera(ns, world, pixels=(16, 12), spp=3, bins=4, spectral_rays=2, extinction=(0.01, 3, 500))
     f = _observe_oracle_mt(orc, ns, cam, pipe, 53)
     assert eq(f[0], g["clear_mean"]) and eq(f[1], g["clear_var"]) and eq(f[2], g["clear_n"])
+
+
+# ---------------------------------------------------------------------------------------- F15 multiple importance sampling
+def _importance_scene(ns):
+    world, prims = scenes.build_lambert(ns)
+    prims[5].material.importance = 3.0
+    ns.Sphere(0.12, world, ns.translate(-0.6, 0.5, 1.2), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 4.0))
+    cam, pipe = scenes.lambert_camera(ns, world)
+    cam.ray_importance_sampling = True
+    cam.ray_important_path_weight = 0.25
+    return world, cam, pipe
+
+
+def test_frames_importance_sampling(orc, ns, golden):
+    """ContinuousBSDF multiple importance sampling against the reference's SerialEngine frames: bounding spheres and selection CDF
+    of the important primitives (host), sphere selection, cone / full-sphere sampling, the combined pdf."""
+    g = golden("f15_importance")
+    world, cam, pipe = _importance_scene(ns)
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 61)
+    assert eq(f[0], g["mean"]) and eq(f[1], g["var"]) and eq(f[2], g["n"])
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 62, f)
+    assert eq(f[0], g["mean2"]) and eq(f[1], g["var2"]) and eq(f[2], g["n2"])
+    cam.ray_important_path_weight = 0.9
+    cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = 0.01, 3, 500
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 63)
+    assert eq(f[0], g["heavy_mean"]) and eq(f[1], g["heavy_var"]) and eq(f[2], g["heavy_n"])
+    # ImportanceManager.sample / pdf on their own: selection by CDF, cone and full-sphere sampling, the cimported rotate_basis
+    import ctypes as C
+    from source_amd.optical.observer import HipEngine
+    keep = []
+    desc = cam.render_desc(world, [(0, 0)], cam._slice_spectrum()[0], HipEngine(), keep)
+    L = orc.lib()
+    L.orc_important_pdf.restype = C.c_double
+    L.orc_important_pdf.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.orc_important_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_void_p]
+    u = orc.mt_uniform(99, 3 * 40)
+    for i, (p, d) in enumerate(zip(g["im_pts"], g["im_dirs"])):
+        p, d = np.ascontiguousarray(p), np.ascontiguousarray(d)
+        assert L.orc_important_pdf(C.byref(desc), orc.p(p), orc.p(d)) == g["im_pdf"][i]
+        out = np.zeros(3)
+        L.orc_important_sample(C.byref(desc), orc.p(p), u[3 * i], u[3 * i + 1], u[3 * i + 2], 1, orc.p(out))
+        assert eq(out, g["im_samples"][i])
+        assert L.orc_important_pdf(C.byref(desc), orc.p(p), orc.p(out)) == g["im_pdf2"][i]
