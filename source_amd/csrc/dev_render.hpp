@@ -39,6 +39,9 @@ struct RenderParams {
     uint64_t seed, sample_offset;
     int32_t ray_max_depth, ray_min_depth;      // Ray.max_depth / extinction_min_depth / extinction_prob: path kernel only
     double ray_extinction_prob;
+    const rsx_important_sphere *important;     // ImportanceManager spheres (world.pyx:47-128) or n_important == 0
+    int32_t n_important, pad_important;
+    double important_path_weight;
     int32_t n_vol_emitters, pad_path;          // materials with a volume contribution (0: the per-segment world.contains() pass is skipped)
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
@@ -257,6 +260,105 @@ __device__ __forceinline__ void portable_sincos(double phi, double &sn, double &
     }
 }
 
+// asin on [0, 1]: the oracle's portable_asin operation for operation (rational approximation below 0.5, half-angle identity with a
+// split square root above).
+__device__ __forceinline__ double portable_asin(double x) {
+    const double PIO2_HI = 1.57079632679489655800e+00, PIO2_LO = 6.12323399573676603587e-17, PIO4_HI = 7.85398163397448278999e-01;
+    const double P0 = 1.66666666666666657415e-01, P1 = -3.25565818622400915405e-01, P2 = 2.01212532134862925881e-01,
+                 P3 = -4.00555345006794114027e-02, P4 = 7.91534994289814532176e-04, P5 = 3.47933107596021167570e-05;
+    const double Q1 = -2.40339491173441421878e+00, Q2 = 2.02094576023350569471e+00, Q3 = -6.88283971605453293030e-01,
+                 Q4 = 7.70381505559019352791e-02;
+    if (x >= 1.0) return x * PIO2_HI + x * PIO2_LO;
+    if (x < 0.5) {
+        if (x < 7.450580596923828e-09) return x;
+        const double t = x * x;
+        const double p = t * (P0 + t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5)))));
+        const double q = 1.0 + t * (Q1 + t * (Q2 + t * (Q3 + t * Q4)));
+        return x + x * (p / q);
+    }
+    double w = 1.0 - x;
+    double t = w * 0.5;
+    double p = t * (P0 + t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5)))));
+    double q = 1.0 + t * (Q1 + t * (Q2 + t * (Q3 + t * Q4)));
+    const double s = sqrt(t);
+    if (x >= 0.975) {
+        w = p / q;
+        t = PIO2_HI - (2.0 * (s + s * w) - PIO2_LO);
+    } else {
+        w = __longlong_as_double(__double_as_longlong(s) & (long long)0xFFFFFFFF00000000ULL);
+        const double c = (t - w * w) / (s + w);
+        const double r = p / q;
+        p = 2.0 * s * r - (PIO2_LO - 2.0 * c);
+        q = PIO4_HI - 2.0 * w;
+        t = PIO4_HI - (p - q);
+    }
+    return t;
+}
+
+// ImportanceManager.sample (world.pyx:150-188): pick = the selection uniform, (ua, ub) = the direction pair in the reference's draw order
+__device__ void important_sample(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double pick, double ua, double ub,
+                                 double &wx, double &wy, double &wz) {
+    int index = 0;
+    while (index < n - 1 && !(pick < spheres[index].cdf)) ++index;            // find_index(cdf, u) + 1
+    const rsx_important_sphere sp = spheres[index];
+    double dx = sp.centre[0] - ox, dy = sp.centre[1] - oy, dz = sp.centre[2] - oz;
+    const double distance = sqrt(dx * dx + dy * dy + dz * dz);
+    double sn, cs;
+    if (distance == 0 || distance < sp.radius) {                              // vector_sphere
+        const double z = 1.0 - 2.0 * ua;
+        const double r2 = 1.0 - z * z;
+        const double r = sqrt(r2 > 0 ? r2 : 0);
+        portable_sincos(2.0 * M_PI * ub, sn, cs);
+        wx = r * cs; wy = r * sn; wz = z;
+        return;
+    }
+    const double angular_radius = portable_asin(sp.radius / distance);
+    double theta = angular_radius * 180 / M_PI;                               // vector_cone_uniform(degrees)
+    theta *= 0.017453292519943295;
+    const double phi = 2.0 * M_PI * ua;
+    double cos_theta, unused;
+    portable_sincos(theta, unused, cos_theta);
+    const double z = ub * (1 - cos_theta) + cos_theta;
+    const double r2 = 1.0 - z * z;
+    const double r = sqrt(r2 > 0 ? r2 : 0);
+    portable_sincos(phi, sn, cs);
+    const double sx = r * cs, sy = r * sn, sz = z;
+    normalise3(dx, dy, dz);
+    double nx = dx, ny = dy, nz = dz;                                         // direction.orthogonal()
+    normalise3(nx, ny, nz);
+    double vx = 1, vy = 0, vz = 0;
+    if (fabs(nx * vx + ny * vy + nz * vz) > 0.5) { vx = 0; vy = 1; }
+    const double m = nx * vx + ny * vy + nz * vz;
+    double ux = vx - m * nx, uy = vy - m * ny, uz = vz - m * nz;
+    normalise3(ux, uy, uz);
+    const double rx = uy * dz - dy * uz, ry = uz * dx - dz * ux, rz = ux * dy - dx * uy;   // the cimported rotate_basis: up.cross(forward)
+    wx = rx * sx + ux * sy + dx * sz;
+    wy = ry * sx + uy * sy + dy * sz;
+    wz = rz * sx + uz * sy + dz * sz;
+}
+
+// ImportanceManager.pdf (world.pyx:190-230)
+__device__ double important_pdf(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double wx, double wy, double wz) {
+    double pdf_all = 0;
+    for (int i = 0; i < n; ++i) {
+        const rsx_important_sphere sp = spheres[i];
+        double ax = sp.centre[0] - ox, ay = sp.centre[1] - oy, az = sp.centre[2] - oz;
+        const double distance = sqrt(ax * ax + ay * ay + az * az);
+        double solid_angle;
+        if (distance == 0 || distance < sp.radius) solid_angle = 4 * M_PI;
+        else {
+            const double t = sp.radius / distance;
+            const double angular_radius_cos = sqrt(1 - t * t);
+            normalise3(ax, ay, az);
+            if (wx * ax + wy * ay + wz * az < angular_radius_cos) continue;
+            solid_angle = 2 * M_PI * (1 - angular_radius_cos);
+        }
+        const double pdf_sphere = 1 / solid_angle;
+        pdf_all += sp.weight * pdf_sphere;
+    }
+    return pdf_all;
+}
+
 // world.contains(point) in leaf order (kdtree3d.pyx:736-792, kdtree.pyx:126-162): calls f(primitive index) for every world
 // primitive that passes `want` (a side-effect-free filter evaluated BEFORE the containment test, which for a mesh is a ray cast) and
 // whose bounding box and surface contain the point
@@ -461,27 +563,68 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                 double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
                 normalise3(tx, ty, tz);
                 const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
-                // HemisphereCosineSampler.sample / pdf (solidangle.pyx:223-233)
-                double h1, h2, sn, cs;
-                philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
-                const double rad = sqrt(h1);
-                portable_sincos(2.0 * M_PI * h2, sn, cs);
-                const double sx = rad * cs, sy = rad * sn;
-                const double sz2 = 1.0 - sx * sx - sy * sy;
-                const double sz = sqrt(sz2 > 0 ? sz2 : 0);
-                const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;
-                const double rcp = 1.0 / pdf;                                 // div_scalar (spectrum.pyx:459-467)
+                // surface_to_world = primitive_to_world.mul(surface_to_primitive) (affinematrix.pyx:255-273), rotation part
+                const double *a = p.to_root;
+                double stw[9];
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
+                    stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
+                    stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
+                }
+                // outgoing direction: HemisphereCosineSampler.sample (solidangle.pyx:228-233) or, in a world with important primitives,
+                // the important-path / BSDF mixture of ContinuousBSDF.evaluate_surface (material.pyx:327-352)
+                const bool mis = q->n_important > 0;
+                double h1, h2, sx, sy, sz, pdf_important = 0.0;
+                bool from_important = false;
+                if (mis) {
+                    double choose, pick;
+                    philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), choose, pick);
+                    philox2(q->seed, rng_pixel | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                    from_important = choose < q->important_path_weight;
+                    double wx, wy, wz;
+                    if (from_important) {
+                        important_sample(q->important, q->n_important, hx, hy, hz, pick, h1, h2, wx, wy, wz);
+                        // s_outgoing = w_outgoing.transform(primitive_to_surface.mul(world_to_primitive))
+                        const double *wtp = p.to_local;
+                        double wts[9];
+#pragma unroll
+                        for (int j = 0; j < 3; ++j) {
+                            wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                            wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                            wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                        }
+                        sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
+                        sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
+                        sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
+                    }
+                    if (!from_important) {
+                        double sn, cs;
+                        const double rad = sqrt(h1);
+                        portable_sincos(2.0 * M_PI * h2, sn, cs);
+                        sx = rad * cs; sy = rad * sn;
+                        const double sz2 = 1.0 - sx * sx - sy * sy;
+                        sz = sqrt(sz2 > 0 ? sz2 : 0);
+                        wx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                        wy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                        wz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                    }
+                    pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
+                } else {
+                    double sn, cs;
+                    philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                    const double rad = sqrt(h1);
+                    portable_sincos(2.0 * M_PI * h2, sn, cs);
+                    sx = rad * cs; sy = rad * sn;
+                    const double sz2 = 1.0 - sx * sx - sy * sy;
+                    sz = sqrt(sz2 > 0 ? sz2 : 0);
+                }
+                const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;             // HemisphereCosineSampler.pdf
+                const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
+                const double rcp = 1.0 / pdf_all;                             // div_scalar (spectrum.pyx:459-467)
                 if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }   // zero spectrum, then * (1 / 0)
                 else {
-                    // direction = s_outgoing.transform(primitive_to_world.mul(surface_to_primitive)), affinematrix.pyx:255-273
-                    const double *a = p.to_root;
-                    double stw[9];
-#pragma unroll
-                    for (int i = 0; i < 3; ++i) {
-                        stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
-                        stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
-                        stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
-                    }
+                    // direction = s_outgoing.transform(surface_to_world)
                     xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
                     r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
                     r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;

@@ -865,13 +865,21 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (desc->ray_extinction_min_depth < 1) return rsx_fail(RSX_EINVAL, "render: the minimum extinction depth cannot be less than 1");   // ray.pyx:276
         if (desc->ray_max_depth < desc->ray_extinction_min_depth) return rsx_fail(RSX_EINVAL, "render: the maximum depth cannot be less than the minimum extinction depth");
         if (!(desc->ray_extinction_prob >= 0.0 && desc->ray_extinction_prob <= 1.0)) return rsx_fail(RSX_EINVAL, "render: the extinction probability must lie in [0, 1]");
+        if (desc->n_important > 0 && !(desc->important_path_weight >= 0.0 && desc->important_path_weight <= 1.0))
+            return rsx_fail(RSX_EINVAL, "render: the important path weight must lie in [0, 1]");               // ray.pyx:107
         if (desc->ray_max_depth >= (1 << 15)) return rsx_fail(RSX_EUNSUPPORTED, "render: ray_max_depth %d exceeds the Philox draw counter's range (32767)", desc->ray_max_depth);
     }
     const bool pipelined = !h_mean && !has_vol && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
 
-    if ((rc = pool_get(ctx, POOL_MATERIALS, sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials), &d_mat)) ||
+    // materials and the importance manager's spheres share one small buffer: [materials][spheres]
+    const int n_important = has_scatter && desc->important ? std::max(0, desc->n_important) : 0;
+    const size_t mat_bytes = sizeof(rsx_material) * (size_t)std::max(1, desc->n_materials), imp_bytes = sizeof(rsx_important_sphere) * (size_t)n_important;
+    std::vector<unsigned char> mat_blob(mat_bytes + imp_bytes, 0);
+    if (desc->n_materials) std::memcpy(mat_blob.data(), desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials);
+    if (n_important) std::memcpy(mat_blob.data() + mat_bytes, desc->important, imp_bytes);
+    if ((rc = pool_get(ctx, POOL_MATERIALS, mat_blob.size(), &d_mat)) ||
         (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)std::max(1, desc->n_tables), &d_tab))) return rc;
     // small per-call inputs are uploaded only when they differ from what the device already holds (steady-state
     // passes of one observe() loop re-send identical materials / tables / task lists); a change drains the pipeline first
@@ -885,7 +893,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return RSX_OK;
     };
-    if (desc->n_materials && (rc = upload_if_changed(0, d_mat, desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials))) return rc;
+    if (desc->n_materials && (rc = upload_if_changed(0, d_mat, mat_blob.data(), mat_blob.size()))) return rc;
     if (desc->n_tables && (rc = upload_if_changed(1, d_tab, desc->tables, 8 * B * (size_t)desc->n_tables))) return rc;
     if (desc->tasks) {
         if ((rc = pool_get(ctx, POOL_TASKS, T * 8, &d_tasks))) return rc;
@@ -937,6 +945,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.rng_mode = desc->rng_mode;
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
+    rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
+    rp.n_important = n_important; rp.pad_important = 0; rp.important_path_weight = desc->important_path_weight;
     rp.n_vol_emitters = 0; rp.pad_path = 0;
     for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;

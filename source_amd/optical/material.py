@@ -157,7 +157,8 @@ class UniformVolumeEmitter(NullSurface):
 class Lambert(NullVolume):
     """lambert.pyx:40-112 under ContinuousBSDF.evaluate_surface (material.pyx:286-361) — ideal diffuse reflector: one cosine-weighted
     daughter ray per hit, spectrum = trace(daughter) * reflectivity * pdf / pdf. Rendered on the device with Philox-keyed scattering
-    (RSX_MAT_LAMBERT); worlds with important primitives (multiple importance sampling) are not lowered yet."""
+    (RSX_MAT_LAMBERT); in a world with important primitives and ray_importance_sampling on, the outgoing direction is the reference's
+    important-path / BSDF mixture (material.pyx:327-352), also on the device."""
 
     def __init__(self, reflectivity=None):
         super().__init__()

@@ -622,6 +622,29 @@ def test_frames_dielectric_against_oracle(orc, ns):
         assert (pipe.frame.mean > 0).mean() > 0.7
 
 
+def test_frames_importance_sampling_against_oracle(orc, ns):
+    """Multiple importance sampling on the device: the oracle — pinned bit for bit to the reference's frames and
+    to ImportanceManager.sample()/pdf() vectors by fixture F15 — and the device draw the same Philox numbers; frames and ray counts
+    must be identical for the reference's default weight, for a light-dominated mixture and with the camera's defaults."""
+    world, prims = scenes.build_lambert(ns)
+    prims[5].material.importance = 3.0
+    ns.Sphere(0.12, world, ns.translate(-0.6, 0.5, 1.2), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 4.0))
+    for weight, ext in ((0.25, (0.01, 3, 500)), (0.9, (0.1, 2, 12)), (0.0, (0.1, 2, 12)), (1.0, (0.1, 2, 12))):
+        w, h, bins = 80, 64, 5
+        cam, pipe = scenes.lambert_camera(ns, world, (w, h), 6, bins, ext)
+        cam.ray_importance_sampling = True
+        cam.ray_important_path_weight = weight
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=31)
+        cam.observe()
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, w, h))
+        assert desc.n_important == 3
+        om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+        assert eq(pipe.frame.mean, om.reshape(h, w, bins).transpose(1, 0, 2)) and eq(pipe.frame.variance, ov.reshape(h, w, bins).transpose(1, 0, 2)), weight
+        assert cam.stats["rays"] == n_rays
+
+
 def test_lambert_furnace_full_size(ns):
     """Size-independent property at 1024 x 1024: inside a closed furnace — every surface either a unit-reflectivity Lambert wall or
     an emitter of radiance L — with roulette off (probability 0: normalisation exactly 1) every path ends on an emitter and carries
