@@ -294,6 +294,14 @@ int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, doub
                              double *frame_variance, int32_t *frame_samples, int32_t frame_bins,
                              int32_t slice_offset, uint64_t *ray_count);
 
+/* XYZPixelProcessor (optical/observer/pipeline/rgb.pyx:534-562) for one spectral slice: every sample's spectrum (times its
+ * projection weight) is projected on the CIE XYZ curves resampled over the slice (spectrum_to_ciexyz, optical/colour.pyx:158-187:
+ * sum over bins of delta_wavelength * sample[bin] * resampled_xyz[bin, c]), times camera.sensitivity, and the three channels go
+ * through the Welford accumulator. resampled_xyz: host [desc->bins, 3]; mean / variance: host [n_tasks, 3] — what
+ * XYZPixelProcessor.pack_results() returns per pixel; RGBPipeline2D.update/finalise (rgb.pyx:249-289) stay on the host. */
+int rsx_render_pinhole_xyz(rsx_scene *scene, const rsx_render_desc *desc, const double *resampled_xyz, double delta_wavelength,
+                           double *mean, double *variance, uint64_t *ray_count);
+
 /* StatsArray3D.combine_samples applied elementwise to two frames resident on the device
  * (statsarray.pyx:780-859): a <- combine(a, b). Used to merge passes / sample-sharded ranks. */
 int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, double *var_a, int32_t *n_a,

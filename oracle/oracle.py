@@ -54,6 +54,7 @@ def lib():
         L.orc_render_pinhole.argtypes = [C.POINTER(S.SceneDesc), C.POINTER(S.RenderDesc), vp, vp, C.POINTER(C.c_uint64), C.c_int]
         L.orc_render_pinhole_mt.argtypes = [C.POINTER(S.SceneDesc), C.POINTER(S.RenderDesc), vp, vp, vp, C.POINTER(C.c_uint64)]
         L.orc_set_libm_trig.argtypes = [C.c_int]
+        L.orc_render_pinhole_xyz.argtypes = [C.POINTER(S.SceneDesc), C.POINTER(S.RenderDesc), vp, vp, C.c_double, vp, vp, C.POINTER(C.c_uint64), C.c_int]
         L.orc_pinhole_rays.argtypes = [C.POINTER(S.RenderDesc), vp]
         L.orc_max_threads.restype = C.c_int
         _lib = L
@@ -101,6 +102,17 @@ def render_pinhole_mt(flat, desc, state):
     var = np.zeros((desc.n_tasks, desc.bins))
     rays = C.c_uint64(0)
     lib().orc_render_pinhole_mt(C.byref(flat.desc), C.byref(desc), p(state), p(mean), p(var), C.byref(rays))
+    return mean, var, int(rays.value)
+
+
+def render_pinhole_xyz(flat, desc, xyz, delta_wavelength, state=None, threads=1):
+    """XYZPixelProcessor results per task: (mean[n_tasks,3], variance[n_tasks,3], ray_count); state = MT stream or None."""
+    mean = np.zeros((desc.n_tasks, 3))
+    var = np.zeros((desc.n_tasks, 3))
+    rays = C.c_uint64(0)
+    xyz = np.ascontiguousarray(xyz, dtype=np.float64)
+    lib().orc_render_pinhole_xyz(C.byref(flat.desc), C.byref(desc), p(state) if state is not None else None, p(xyz), float(delta_wavelength),
+                                 p(mean), p(var), C.byref(rays), threads)
     return mean, var, int(rays.value)
 
 

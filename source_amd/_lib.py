@@ -126,6 +126,7 @@ SYMBOLS = [
     ("rsx_contains_batch", C.c_int, [_vp, C.c_int64, _vp, _vp]),
     ("rsx_render_pinhole", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rsx_render_pinhole_frame", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
+    ("rsx_render_pinhole_xyz", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, C.c_double, _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rsx_frame_combine_dev", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
 ]
 

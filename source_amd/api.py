@@ -5,6 +5,7 @@ from .core.scenegraph import Ray as CoreRay  # noqa: F401
 from .optical import World, Ray, Spectrum, ConstantSF, InterpolatedSF  # noqa: F401
 from .optical.material import AbsorbingSurface, UniformSurfaceEmitter, Light, NullMaterial, UniformVolumeEmitter, Lambert, Dielectric, Sellmeier  # noqa: F401
 from .optical.observer import (PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D,  # noqa: F401
-                               HipEngine, RenderEngine, SerialEngine, MulticoreEngine, RectFrameSampler2D, RectTasks)
+                               HipEngine, RenderEngine, SerialEngine, MulticoreEngine, RectFrameSampler2D, RectTasks,
+                               RGBPipeline2D, RGBAdaptiveSampler2D)
 from .primitive import Sphere, Box, Cylinder, Mesh, Union, Intersect, Subtract  # noqa: F401
 from .primitive.obj import import_obj, export_obj  # noqa: F401

@@ -973,6 +973,71 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     }
 }
 
+// XYZPixelProcessor (rgb.pyx:534-562): one thread per (task, channel). Every sample's spectrum, times its projection weight, is
+// projected on the channel's resampled CIE curve in bin order (spectrum_to_ciexyz, colour.pyx:176-186: x += delta * sample * curve),
+// scaled by the pixel sensitivity and fed to the same Welford recurrence as k_accumulate. The curves are rows xyz_table0 + channel of
+// the spectral tables. Outputs are per task: RGBPipeline2D sums them over the spectral slices on the host.
+template <bool VOL>
+__global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_table0, double delta) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = ap.n_tasks * 3;
+    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;
+    if (gid >= total) return;
+    const long long p = gid / 3;
+    const int c = (int)(gid % 3);
+    long long k = p;
+    if (!ap.tasks) {
+        const int w = ap.rect[2] - ap.rect[0], h = ap.rect[3] - ap.rect[1];
+        const int lx = (int)(p / h), ly = (int)(p % h);
+        k = (long long)ly * w + lx;
+    }
+    const Sample *s = ap.samples + p * ap.spp;
+    const double *curve = ap.tables + (size_t)(xyz_table0 + c) * ap.bins;
+    auto value = [&](const Sample &smp, long long record) {
+        double acc = 0;
+        for (int b = 0; b < ap.bins; ++b) {
+            double x = smp.table < 0 ? 0.0 : smp.a * ap.tables[smp.table * ap.bins + b];
+            if (VOL) {
+                long long blk = ap.tail[record];
+                int n = smp.pad;
+                for (;;) {
+                    const PathTerm *t = ap.pool + blk * PATH_BLOCK;
+                    const int first = blk < ap.n_records ? 0 : 1;
+                    for (int j = n - 1; j >= first; --j) {
+                        const PathTerm tm = t[j];
+                        const double tv = ap.tables[tm.table * ap.bins + b];
+                        if (tm.kind == TERM_VOL) { const double emission = 0.0 + tv * tm.b; x = x + emission * tm.a; }
+                        else if (tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);
+                        else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
+                        else {
+                            if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;
+                            x = x * tv; x = x * tm.a; x = x * tm.b;
+                        }
+                    }
+                    if (first == 0) break;
+                    blk = t[0].table;
+                    n = PATH_BLOCK;
+                }
+            }
+            x = x * smp.weight;
+            acc += delta * x * curve[b];
+        }
+        return acc * ap.sensitivity;
+    };
+    const long long rec0 = p * ap.spp;
+    double m = value(s[0], rec0), v = 0;
+    double dm = 1.0;
+    for (int i = 1; i < ap.spp; ++i) {
+        const double x = value(s[i], rec0 + i);
+        const double dn = dm + 1.0, cc = i == 1 ? 1.0 : dm - 1.0;
+        const double pm = m, pv = v;
+        m = pm + exact_div(x - pm, dn, refine_rcp(dn), true);
+        v = exact_div(pv * cc + (x - pm) * (x - m), dm, refine_rcp(dm), true);
+        dm = dn;
+    }
+    ap.mean[k * 3 + c] = m; ap.variance[k * 3 + c] = v;
+}
+
 __global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, double *va, int32_t *na, const double *mb,
                                                        const double *vb, const int32_t *nb) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

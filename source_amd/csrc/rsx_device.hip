@@ -826,7 +826,7 @@ namespace {
 
 // shared body of rsx_render_pinhole / rsx_render_pinhole_frame
 int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double *h_var, double *fmean, double *fvar, int32_t *fn,
-           int32_t frame_bins, int32_t slice_offset, uint64_t *ray_count) {
+           int32_t frame_bins, int32_t slice_offset, uint64_t *ray_count, const double *h_xyz = nullptr, double delta_wavelength = 0.0) {
     if (!scene || !desc) return rsx_fail(RSX_EINVAL, "render: null argument");
     if (desc->n_tasks < 0 || desc->spp < 1 || desc->bins < 1) return rsx_fail(RSX_EINVAL, "render: n_tasks/spp/bins out of range");
     if (desc->rng_mode == RSX_RNG_STREAM && !desc->uniforms) return rsx_fail(RSX_EINVAL, "render: RSX_RNG_STREAM needs uniforms");
@@ -880,7 +880,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (desc->n_materials) std::memcpy(mat_blob.data(), desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials);
     if (n_important) std::memcpy(mat_blob.data() + mat_bytes, desc->important, imp_bytes);
     if ((rc = pool_get(ctx, POOL_MATERIALS, mat_blob.size(), &d_mat)) ||
-        (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)std::max(1, desc->n_tables), &d_tab))) return rc;
+        (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)(std::max(1, desc->n_tables) + 3), &d_tab))) return rc;
     // small per-call inputs are uploaded only when they differ from what the device already holds (steady-state
     // passes of one observe() loop re-send identical materials / tables / task lists); a change drains the pipeline first
     auto upload_if_changed = [&](int slot, void *dst, const void *src, size_t bytes) -> int {
@@ -894,13 +894,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if (desc->n_materials && (rc = upload_if_changed(0, d_mat, mat_blob.data(), mat_blob.size()))) return rc;
-    if (desc->n_tables && (rc = upload_if_changed(1, d_tab, desc->tables, 8 * B * (size_t)desc->n_tables))) return rc;
+    // spectral tables; the XYZ form appends the three resampled CIE curves as rows n_tables .. n_tables + 2 ([channel][bin])
+    std::vector<double> tab_blob((size_t)(desc->n_tables + (h_xyz ? 3 : 0)) * B);
+    if (desc->n_tables) std::memcpy(tab_blob.data(), desc->tables, 8 * B * (size_t)desc->n_tables);
+    if (h_xyz) for (size_t b = 0; b < B; ++b) for (int c = 0; c < 3; ++c) tab_blob[((size_t)desc->n_tables + c) * B + b] = h_xyz[3 * b + c];
+    if (!tab_blob.empty() && (rc = upload_if_changed(1, d_tab, tab_blob.data(), 8 * tab_blob.size()))) return rc;
     if (desc->tasks) {
         if ((rc = pool_get(ctx, POOL_TASKS, T * 8, &d_tasks))) return rc;
         if ((rc = upload_if_changed(2, d_tasks, desc->tasks, T * 8))) return rc;
     }
     if (h_mean) {
-        if ((rc = pool_get(ctx, POOL_MEAN, T * B * 8, &d_mean)) || (rc = pool_get(ctx, POOL_VAR, T * B * 8, &d_var))) return rc;
+        const size_t out_channels = h_xyz ? 3 : B;
+        if ((rc = pool_get(ctx, POOL_MEAN, T * out_channels * 8, &d_mean)) || (rc = pool_get(ctx, POOL_VAR, T * out_channels * 8, &d_var))) return rc;
     }
     // the lane's previous pass must have been merged before its sample buffer (and scheduling state) is reused
     if (pipelined && lane.in_flight) HIP_TRY(hipStreamWaitEvent(lane.stream, lane.merged, 0));
@@ -1067,7 +1072,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
     if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
     const dim3 acc_grid((unsigned)((total + 255) / 256));
-    if (has_vol) {
+    if (h_xyz) {
+        const dim3 xyz_grid((unsigned)(((long long)T * 3 + 255) / 256));
+        if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<true>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
+        else hipLaunchKernelGGL((k_accumulate_xyz<false>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
+    } else if (has_vol) {
         if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, true>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
         else hipLaunchKernelGGL((k_accumulate<false, true>), acc_grid, dim3(256), 0, ctx->stream, ap);
     } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, false>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
@@ -1081,8 +1090,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     HP_MARK(3)
     if (g_hp_on) ++g_hp_calls;
     if (h_mean) {
-        HIP_TRY(hipMemcpyAsync(h_mean, d_mean, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(h_var, d_var, T * B * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_mean, d_mean, T * (h_xyz ? 3 : B) * 8, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(h_var, d_var, T * (h_xyz ? 3 : B) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
     if (has_vol) {                                          // a ray that ran out of term slots or segments must not go unnoticed
@@ -1107,6 +1116,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 extern "C" int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *mean, double *variance, uint64_t *ray_count) {
     if (!mean || !variance) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole: null output");
     return render(scene, desc, mean, variance, nullptr, nullptr, nullptr, 0, 0, ray_count);
+}
+
+extern "C" int rsx_render_pinhole_xyz(rsx_scene *scene, const rsx_render_desc *desc, const double *resampled_xyz, double delta_wavelength,
+                                      double *mean, double *variance, uint64_t *ray_count) {
+    if (!mean || !variance || !resampled_xyz) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole_xyz: null argument");
+    return render(scene, desc, mean, variance, nullptr, nullptr, nullptr, 0, 0, ray_count, resampled_xyz, delta_wavelength);
 }
 
 extern "C" int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, double *frame_mean, double *frame_variance,

@@ -217,3 +217,38 @@ def combine_scalar(mx, vx, nx, my, vy, ny):
         v = (pv * (pn - 1) + (my - pm) * (my - m)) / (n - 1)
         return m, v, n
     return mx, vx, nx
+
+
+def combine_arrays(mx, vx, nx, my, vy, ny):
+    """combine_scalar over arrays (same operations element by element, so the same bits): returns (mean, variance, samples)."""
+    mx, vx, my, vy = (np.array(a, dtype=np.float64) for a in (mx, vx, my, vy))
+    nx, ny = np.array(nx, dtype=np.int64), np.array(ny, dtype=np.int64)
+    swap = nx < ny
+    mx, my = np.where(swap, my, mx), np.where(swap, mx, my)
+    vx, vy = np.where(swap, vy, vx), np.where(swap, vx, vy)
+    nx, ny = np.where(swap, ny, nx), np.where(swap, nx, ny)
+    mt, vt, nt = mx.copy(), vx.copy(), nx.copy()                # default: (mx, vx, nx)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        a = (nx > 1) & (ny > 1)
+        n_sum = (nx + ny).astype(np.float64)
+        fx, fy = nx.astype(np.float64), ny.astype(np.float64)
+        m_a = (fx * mx + fy * my) / n_sum
+        vxa = (fx - 1) * vx / fx
+        vya = (fy - 1) * vy / fy
+        v_a = (fx * (mx * mx + vxa) + fy * (my * my + vya)) / n_sum - m_a * m_a
+        v_a = n_sum * v_a / (n_sum - 1)
+        mt, vt, nt = np.where(a, m_a, mt), np.where(a, v_a, vt), np.where(a, nx + ny, nt)
+        z = (nx == 0) & (ny == 0)
+        mt, vt, nt = np.where(z, 0.0, mt), np.where(z, 0.0, vt), np.where(z, 0, nt)
+        c = (nx == 1) & (ny == 0)
+        vt = np.where(c, 0.0, vt)
+        d = (nx == 1) & (ny == 1)
+        m_d = 0.5 * (mx + my)
+        t_d = mx - m_d
+        mt, vt, nt = np.where(d, m_d, mt), np.where(d, 2 * t_d * t_d, vt), np.where(d, 2, nt)
+        e = (nx > 1) & (ny == 1)
+        n_e = fx + 1
+        m_e = mx + (my - mx) / n_e
+        v_e = (vx * (fx - 1) + (my - mx) * (my - m_e)) / (n_e - 1)
+        mt, vt, nt = np.where(e, m_e, mt), np.where(e, v_e, vt), np.where(e, nx + 1, nt)
+    return mt, vt, nt.astype(np.int32)

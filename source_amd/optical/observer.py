@@ -292,6 +292,126 @@ class SpectralRadiancePipeline2D(SpectralPowerPipeline2D):
     power = False
 
 
+class RGBPipeline2D(Pipeline2D):
+    """pipeline/rgb.pyx:48-289 — CIE XYZ per pixel (the sRGB image is a view of it). Per spectral slice every sample's spectrum is
+    projected on the slice's resampled XYZ curves and the three channels go through a Welford accumulator (XYZPixelProcessor, on the
+    device: rsx_render_pinhole_xyz); update() sums the slices' means and variances into working frames, finalise() merges the working
+    frame into xyz_frame with combine_samples. The display / auto-exposure machinery of the reference is not mirrored; the
+    display_* keyword arguments are accepted so that existing scripts construct the pipeline unchanged."""
+    power = True
+
+    def __init__(self, display_progress=False, display_update_time=15, accumulate=True, display_auto_exposure=True,
+                 display_sensitivity=1.0, display_unsaturated_fraction=1.0, name=None):
+        self.name = name or "RGB Pipeline 2D"
+        self.accumulate = accumulate
+        self.display_sensitivity = display_sensitivity
+        self.xyz_frame = None
+        self._pixels, self._samples = None, 0
+        self._resampled = []
+        self._working_mean = self._working_variance = self._working_touched = None
+
+    def initialise(self, pixels, pixel_samples, min_wavelength, max_wavelength, spectral_bins, spectral_slices, quiet):
+        from .colour import resample_ciexyz
+        nx, ny = pixels
+        self._pixels, self._samples = pixels, pixel_samples
+        if not self.accumulate or self.xyz_frame is None or self.xyz_frame.shape != (nx, ny, 3):
+            self.xyz_frame = StatsArray3D(nx, ny, 3)
+        self._working_mean = np.zeros((nx, ny, 3))
+        self._working_variance = np.zeros((nx, ny, 3))
+        self._working_touched = np.zeros((nx, ny), dtype=np.int8)
+        self._resampled = [np.ascontiguousarray(resample_ciexyz(sl.min_wavelength, sl.max_wavelength, sl.bins)) for sl in spectral_slices]
+        self._deltas = [(sl.max_wavelength - sl.min_wavelength) / sl.bins for sl in spectral_slices]
+
+    def update(self, x, y, slice_id, packed_result):        # rgb.pyx:249-271
+        mean, variance = packed_result
+        for c in range(3):
+            self._working_mean[x, y, c] += mean[c]
+            self._working_variance[x, y, c] += variance[c]
+        self._working_touched[x, y] = 1
+
+    def update_block(self, xs, ys, mean, variance):
+        """update() for a whole block of pixels of one slice (pixels of a block are distinct)."""
+        self._working_mean[xs, ys, :] += mean
+        self._working_variance[xs, ys, :] += variance
+        self._working_touched[xs, ys] = 1
+
+    def finalise(self):                                     # rgb.pyx:276-289
+        from ..device import combine_arrays
+        f = self.xyz_frame
+        f._sync_host()
+        t = self._working_touched == 1
+        if t.any():
+            m, v, n = combine_arrays(f._host[0][t], f._host[1][t], f._host[2][t], self._working_mean[t],
+                                     np.maximum(self._working_variance[t], 0.0), np.full(self._working_mean[t].shape, self._samples))
+            f._host[0][t], f._host[1][t], f._host[2][t] = m, v, n
+
+    @property
+    def rgb_frame(self):
+        """[nx, ny, 3] sRGB image of xyz_frame.mean * display_sensitivity (colour.pyx:235-266)."""
+        from .colour import ciexyz_to_srgb
+        xyz = self.xyz_frame.mean * self.display_sensitivity
+        out = np.zeros_like(xyz)
+        for x in range(xyz.shape[0]):
+            for y in range(xyz.shape[1]):
+                out[x, y] = ciexyz_to_srgb(*xyz[x, y])
+        return out
+
+
+class RGBAdaptiveSampler2D(FrameSampler2D):
+    """sampler2d.pyx:697-896 — re-samples the pixels whose normalised standard error (worst of X, Y, Z) lies in the top `fraction`
+    of the image or above `cutoff`, and every pixel that has fewer than max(min_samples, max_samples / ratio) samples."""
+
+    def __init__(self, pipeline, fraction=0.2, ratio=10.0, min_samples=1000, cutoff=0.0, mask=None):
+        if not isinstance(pipeline, RGBPipeline2D):
+            raise TypeError("Sampler only compatible with RGBPipeline2D pipeline.")
+        if fraction <= 0 or fraction > 1.0:
+            raise ValueError("Attribute 'fraction' must be in the range (0, 1].")
+        if ratio < 1.0:
+            raise ValueError("Attribute 'ratio' must be >= 1.")
+        if min_samples < 1:
+            raise ValueError("Attribute 'min_samples' must be >= 1.")
+        if cutoff < 0 or cutoff > 1.0:
+            raise ValueError("Attribute 'cutoff' must be in the range [0, 1].")
+        self.pipeline, self.fraction, self.ratio, self.min_samples, self.cutoff = pipeline, float(fraction), float(ratio), int(min_samples), float(cutoff)
+        if mask is not None and np.asarray(mask).ndim != 2:
+            raise ValueError("Mask must be a 2D array.")
+        self.mask = None if mask is None else np.asarray(mask).astype(bool)
+
+    def generate_tasks(self, pixels):
+        pixels = tuple(pixels)
+        if self.mask is None:
+            self.mask = np.ones(pixels, dtype=bool)
+        if pixels != self.mask.shape:
+            if self.mask.all():
+                self.mask = np.ones(pixels, dtype=bool)
+            else:
+                raise ValueError("The pixel geometry passed to the frame sampler is inconsistent with the mask shape.")
+        frame = self.pipeline.xyz_frame
+        if frame is None:
+            return self._full_frame(pixels)
+        if (pixels[0], pixels[1], 3) != frame.shape:
+            raise ValueError("The number of pixels passed to the frame sampler are inconsistent with the pipeline frame size.")
+        mask = self.mask
+        samples, mean = frame.samples, frame.mean
+        min_samples = max(self.min_samples, int(samples[mask].max() / self.ratio))
+        error = frame.errors()
+        with np.errstate(divide="ignore", invalid="ignore"):
+            per_channel = np.where(mean > 0, error / mean, 0.0)
+        normalised = np.where(mask, per_channel.max(axis=2), 0.0)
+        percentile_error = np.percentile(normalised[mask], (1 - self.fraction) * 100)
+        cutoff = max(self.cutoff, percentile_error)
+        need = mask & ((samples.min(axis=2) < min_samples) | (normalised > cutoff))
+        tasks = [(int(x), int(y)) for x, y in zip(*np.nonzero(need))]    # x outer, y inner
+        pyrandom.shuffle(tasks)
+        return tasks
+
+    def _full_frame(self, pixels):
+        nx, ny = pixels
+        tasks = [(x, y) for x in range(nx) for y in range(ny) if self.mask[x, y]]
+        pyrandom.shuffle(tasks)
+        return tasks
+
+
 # ---------------------------------------------------------------------------------------------------
 # observers
 # ---------------------------------------------------------------------------------------------------
@@ -575,6 +695,22 @@ class PinholeCamera(Observer2D):
             desc.sample_offset = engine.sample_offset
         return desc
 
+    def _render_xyz(self, scene, desc, pipe, slice_id, tasks, rect, rays):
+        """One slice of one block of pixels for an RGBPipeline2D: XYZPixelProcessor results from the device, summed into the
+        pipeline's working frames (RGBPipeline2D.update)."""
+        n = desc.n_tasks
+        mean, var = np.zeros((n, 3)), np.zeros((n, 3))
+        _lib.check(_lib.lib().rsx_render_pinhole_xyz(scene.handle, C.byref(desc), _lib.ptr(pipe._resampled[slice_id]), pipe._deltas[slice_id],
+                                                     _lib.ptr(mean), _lib.ptr(var), C.byref(rays)))
+        if rect is not None:                                # row-major over the rect: k = ly * w + lx
+            x0, y0, x1, y1 = rect
+            xs, ys = np.meshgrid(np.arange(x0, x1), np.arange(y0, y1), indexing="xy")
+            xs, ys = xs.reshape(-1), ys.reshape(-1)
+        else:
+            t = np.array(tasks, dtype=np.int64).reshape(-1, 2)
+            xs, ys = t[:, 0], t[:, 1]
+        pipe.update_block(xs, ys, mean, var)
+
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
         world = self.root
         scene = world.build_accelerator()
@@ -600,6 +736,9 @@ class PinholeCamera(Observer2D):
             for piece in pieces:
                 desc = self.render_desc(world, piece.get("tasks"), sl, engine, keep, rect=piece.get("rect"))
                 for pipe in self._pipelines:
+                    if isinstance(pipe, RGBPipeline2D):
+                        self._render_xyz(scene, desc, pipe, slice_id, piece.get("tasks"), piece.get("rect"), rays)
+                        continue
                     desc.power = 1 if pipe.power else 0
                     fm, fv, fn = pipe.frame._device(scene.context)
                     _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
@@ -618,6 +757,12 @@ class PinholeCamera(Observer2D):
             n = desc.n_tasks
             results = []
             for pipe in self._pipelines:
+                if isinstance(pipe, RGBPipeline2D):
+                    mean, var = np.zeros((n, 3)), np.zeros((n, 3))
+                    _lib.check(L.rsx_render_pinhole_xyz(scene.handle, C.byref(desc), _lib.ptr(pipe._resampled[slice_id]), pipe._deltas[slice_id],
+                                                        _lib.ptr(mean), _lib.ptr(var), C.byref(rays)))
+                    results.append((mean, var))
+                    continue
                 desc.power = 1 if pipe.power else 0
                 mean, var = np.zeros((n, sl.bins)), np.zeros((n, sl.bins))
                 _lib.check(L.rsx_render_pinhole(scene.handle, C.byref(desc), _lib.ptr(mean), _lib.ptr(var), C.byref(rays)))

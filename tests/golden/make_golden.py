@@ -37,6 +37,7 @@ from raysect.optical import World, ConstantSF, InterpolatedSF, Ray as OpticalRay
 from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, UniformVolumeEmitter, NullMaterial, Lambert, Dielectric, Sellmeier  # noqa: E402
 from raysect.optical.material.debug import Light  # noqa: E402
 from raysect.optical.observer import PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D  # noqa: E402
+from raysect.optical.observer import RGBPipeline2D, RGBAdaptiveSampler2D  # noqa: E402
 
 from source_amd import scenes  # noqa: E402
 import raysets  # noqa: E402
@@ -48,7 +49,7 @@ NS = types.SimpleNamespace(
     UniformSurfaceEmitter=UniformSurfaceEmitter, UniformVolumeEmitter=UniformVolumeEmitter, NullMaterial=NullMaterial, Light=Light, Lambert=Lambert, Dielectric=Dielectric, Sellmeier=Sellmeier,
     PinholeCamera=PinholeCamera,
     FullFrameSampler2D=FullFrameSampler2D, SpectralRadiancePipeline2D=SpectralRadiancePipeline2D,
-    SpectralPowerPipeline2D=SpectralPowerPipeline2D)
+    SpectralPowerPipeline2D=SpectralPowerPipeline2D, RGBPipeline2D=RGBPipeline2D, RGBAdaptiveSampler2D=RGBAdaptiveSampler2D)
 
 
 def save(name, **arrays):
@@ -538,6 +539,35 @@ def f15_importance():
     save("f15_importance", **out)
 
 
+def f16_rgb():
+    """RGBPipeline2D / XYZPixelProcessor (rgb.pyx:48-289, 534-562; colour.pyx:123-187) next to a spectral pipeline on the same
+    rays, three spectral slices, sensitivity, two accumulating passes; and RGBAdaptiveSampler2D's task lists (sampler2d.pyx:697-896)
+    for the resulting frames."""
+    from raysect.optical.colour import resample_ciexyz, ciexyz_to_srgb
+    out = {}
+    out["xyz_7"] = np.array(resample_ciexyz(375.0, 740.0, 7))
+    out["xyz_slice"] = np.array(resample_ciexyz(496.0, 618.0, 5))
+    out["srgb"] = np.array([ciexyz_to_srgb(*v) for v in ((0.2, 0.3, 0.1), (0.001, 0.002, 0.0005), (0.9, 1.0, 1.2), (0.0, 0.0, 0.0))])
+    world, mesh, box = scenes.build_c2(NS, n=48, smoothing=True, with_normals=True)
+    rgb = RGBPipeline2D(display_progress=False)
+    spectral = SpectralPowerPipeline2D(display_progress=False) if "display_progress" in SpectralPowerPipeline2D.__init__.__doc__ else SpectralPowerPipeline2D()
+    cam = PinholeCamera((20, 16), fov=45, sensitivity=2.5, parent=world, pipelines=[rgb, spectral], frame_sampler=FullFrameSampler2D(),
+                        transform=translate(0, 0.16, -0.4) * rotate(0, -12, 0))
+    cam.pixel_samples = 3; cam.spectral_bins = 9; cam.spectral_rays = 3; cam.quiet = True
+    cam.min_wavelength = 400.0; cam.max_wavelength = 700.0
+    pyrandom.seed(71); rsrandom.seed(71); cam.render_engine = SerialEngine(); cam.observe()
+    f = rgb.xyz_frame
+    out["xyz_mean"], out["xyz_var"], out["xyz_n"] = np.array(f.mean), np.array(f.variance), np.array(f.samples)
+    out["spec_mean"] = np.array(spectral.frame.mean)
+    sampler = RGBAdaptiveSampler2D(rgb, ratio=2, fraction=0.3, min_samples=5, cutoff=0.05)
+    pyrandom.seed(72); out["tasks1"] = np.array(sampler.generate_tasks((20, 16)))
+    cam.frame_sampler = sampler
+    pyrandom.seed(73); rsrandom.seed(73); cam.observe()
+    out["xyz_mean2"], out["xyz_var2"], out["xyz_n2"] = np.array(f.mean), np.array(f.variance), np.array(f.samples)
+    pyrandom.seed(74); out["tasks2"] = np.array(sampler.generate_tasks((20, 16)))
+    save("f16_rgb", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -560,3 +590,4 @@ if __name__ == "__main__":
     if run("f13"): f13_lambert()
     if run("f14"): f14_glass()
     if run("f15"): f15_importance()
+    if run("f16"): f16_rgb()
