@@ -28,10 +28,25 @@ struct DScene {
     int32_t wlds, mlds;        // how many of those levels are held in LDS (the rest spill)
     char *spill;               // per-wave global spill regions
     const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
+    const struct CsgFast *csgfast;   // per primitive: flattened operand tree of a top-level CSG node whose leaves are all analytic (n_leaves = 0: none)
 };
 
 struct CsgInfo {
     int32_t parent, slot, is_b, top;
+};
+
+// A top-level CSG primitive whose operand tree has only sphere / box / cylinder leaves, flattened on the host (rsx_scene_create):
+// leaves in depth-first order with the chain of nodes that leads to each, the parity of Subtract-b ancestors (how often
+// _modify_intersection flips the root, csg.pyx:551-568), and the tree as a postfix program over "inside leaf k" bits.
+#define CSGF_MAX_LEAVES 8
+#define CSGF_MAX_CHAIN 6
+struct CsgFast {
+    int32_t n_leaves, n_ops;
+    int32_t leaf[CSGF_MAX_LEAVES];
+    int32_t parity[CSGF_MAX_LEAVES];
+    int32_t chain_len[CSGF_MAX_LEAVES];
+    int32_t chain[CSGF_MAX_LEAVES][CSGF_MAX_CHAIN];   // primitive ids from the top node's operand down to the leaf (inclusive)
+    int8_t ops[2 * CSGF_MAX_LEAVES];                  // >= 0: push inside(leaf slot); -1 union, -2 intersect, -3 subtract
 };
 
 struct Ray {

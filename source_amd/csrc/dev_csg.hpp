@@ -203,6 +203,106 @@ __device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Fast first hit of a CSG tree of analytic leaves.
+//
+// The stream merge above keeps ~260 B of cached state per operand node per lane in scratch: on demos/csg.py's tree that is 150 KB
+// of scattered state per wave, and the kernel waits on it 77 % of the time. For hit() — the only entry the world traversal needs
+// — of a tree whose leaves are convex analytic solids, the streams can be merged without any state: every leaf has at most two
+// roots (enter, exit); walking all leaf roots in increasing t, the first root across which "inside the solid" flips is the first
+// root the reference's merge accepts: csg_valid() is the truth table of exactly that flip, with "inside operand" read off the
+// exit flag of the operand's next root, and a nested node's stream is by induction the list of its own flips. The two orders can
+// differ only when two roots tie exactly (the merge prefers operand b, csg.pyx:231-234) or a leaf reports an inconsistent
+// enter/exit pattern (grazing): both are detected and sent to the stream merge, so results stay bit-identical.
+// Leaf roots live in the (idle) mesh-stack LDS levels: t in the f64 array, (face, axis, exit) packed in the i32 array.
+// Returns 1 = hit (cand filled), 0 = no hit, -1 = use the stream merge.
+__device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const Stack &ms, Hit &cand) {
+    const CsgFast &P = sc.csgfast[idx];
+    const int lane = threadIdx.x % WAVE;
+    double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
+    int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
+    Ray l0 = to_local(sc.prims[idx], r);
+    l0.maxd = INFINITY;
+    uint32_t nroots = 0;                                     // 2 bits per leaf
+    for (int k = 0; k < P.n_leaves; ++k) {
+        Ray cur = l0;
+        bool alive = true;
+        for (int j = 0; j < P.chain_len[k]; ++j) {           // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
+            const rsx_primitive &node = sc.prims[P.chain[k][j]];
+            double f, b;
+            if (!aabb(node.box_lower, node.box_upper, cur, f, b)) { alive = false; break; }
+            if (j + 1 < P.chain_len[k]) cur = to_local(node, cur);   // csg_first: the operands see the ray in the node's space
+        }
+        if (!alive) continue;
+        const rsx_primitive &leaf = sc.prims[P.leaf[k]];
+        const Ray ll = to_local(leaf, cur);
+        Roots roots;
+        roots.n = 0;
+        if (leaf.type == RSX_PRIM_SPHERE) sphere_roots(leaf, ll, roots);
+        else if (leaf.type == RSX_PRIM_BOX) box_roots(leaf, ll, roots);
+        else cylinder_roots(leaf, ll, roots);
+        for (int j = 0; j < roots.n; ++j) {
+            Geom g;
+            analytic_geom(leaf, ll, roots.t[j], roots.a0[j], roots.a1[j], g);
+            if (!(roots.t[j] == roots.t[j])) return -1;
+            if (g.exiting != (j == roots.n - 1)) return -1;  // convex solid: (enter, exit) or a lone exit; anything else: stream merge
+            lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
+            lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((g.exiting ? 1 : 0) << 16);
+        }
+        nroots |= (uint32_t)roots.n << (2 * k);
+    }
+    auto inside_solid = [&](uint32_t consumed) {
+        uint32_t stack = 0;
+        int sp = 0;
+        for (int o = 0; o < P.n_ops; ++o) {
+            const int op = P.ops[o];
+            if (op >= 0) {
+                const uint32_t c = (consumed >> (2 * op)) & 3u, n = (nroots >> (2 * op)) & 3u;
+                const uint32_t in = (c < n) && ((lds_m[(2 * op + (int)c) * WAVE + lane] >> 16) & 1);   // the next root is an exit
+                stack |= in << sp;
+                ++sp;
+            } else {
+                const uint32_t b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
+                const uint32_t res = op == -1 ? (a | b) : op == -2 ? (a & b) : (a & (b ^ 1u));
+                sp -= 2;
+                stack = (stack & ~(3u << sp)) | (res << sp);
+                ++sp;
+            }
+        }
+        return stack & 1u;
+    };
+    uint32_t consumed = 0;
+    for (int step = 0; step <= 2 * P.n_leaves; ++step) {
+        int best = -1;
+        double best_t = INFINITY;
+        bool tie = false;
+        for (int k = 0; k < P.n_leaves; ++k) {
+            const uint32_t c = (consumed >> (2 * k)) & 3u, n = (nroots >> (2 * k)) & 3u;
+            if (c >= n) continue;
+            const double t = lds_t[(2 * k + (int)c) * WAVE + lane];
+            if (best < 0 || t < best_t) { best = k; best_t = t; tie = false; }
+            else if (t == best_t) tie = true;
+        }
+        if (best < 0) return 0;
+        if (tie) return -1;
+        const uint32_t before = inside_solid(consumed);
+        const uint32_t c = (consumed >> (2 * best)) & 3u;
+        consumed += 1u << (2 * best);
+        if (inside_solid(consumed) == before) continue;      // not a surface of the solid: csg_valid() rejects it, next root
+        if (!(best_t <= r.maxd)) return 0;                   // csg_identify: accepted only within the ray's reach
+        const int32_t m = lds_m[(2 * best + (int)c) * WAVE + lane];
+        const uint32_t exiting = (uint32_t)(m >> 16) & 1u, parity = (uint32_t)P.parity[best] & 1u;
+        cand.prim = idx; cand.t = best_t;
+        cand.a0 = (int32_t)(int8_t)(m & 0xff); cand.a1 = (int32_t)(int8_t)((m >> 8) & 0xff);
+        cand.u = cand.v = cand.w = 0.0f;
+        cand.leaf = P.leaf[best];
+        cand.flags = F_VALID | ((exiting ^ parity) ? F_EXIT : 0u) | (parity ? F_FLIP : 0u);
+        cand.hx = cand.hy = cand.hz = 0.0;
+        return 1;
+    }
+    return -1;
+}
+
 // contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
 __device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
     double qx, qy, qz;

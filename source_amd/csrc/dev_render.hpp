@@ -43,6 +43,7 @@ struct RenderParams {
     int32_t n_important, pad_important;
     double important_path_weight;
     int32_t n_vol_emitters, pad_path;          // materials with a volume contribution (0: the per-segment world.contains() pass is skipped)
+    unsigned long long *redo_mask;    // [n_units] CSG scenes: lanes of each unit the fast pass could not finish (ties -> stream merge), or null
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
@@ -101,12 +102,20 @@ __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams 
     return px;
 }
 
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+// MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
+// it fits several waves per SIMD; rays it cannot finish (exact ties between operand roots, operands with mesh leaves) are listed in
+// redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
+#ifndef RSX_CSGFAST_MIN_WAVES
+#define RSX_CSGFAST_MIN_WAVES 2
+#endif
+template <bool CSG, int MODE = 0>
+__global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
+void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
+    NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
+    long long redo_unit = (long long)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // MODE 2: units are strided over the waves
     // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
     // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
     const int my_xcd = xcc_id();
@@ -121,18 +130,29 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
         asm volatile("" : "+s"(rp_bits));
         const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
         long long tk = -1;
-        while (victim < 8) {
-            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
-            const long long begin = q->seg[list], end = q->seg[list + 1];
-            unsigned long long mine = 0;
-            if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
-            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
-                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
-            if (got < end) { tk = got; break; }
-            ++victim;
+        unsigned long long redo_lanes = ~0ULL;
+        int unit;
+        if constexpr (MODE == 2) {
+            const long long n_units = q->seg[9];
+            while (redo_unit < n_units && q->redo_mask[redo_unit] == 0ULL) redo_unit += (long long)gridDim.x * (WG_THREADS / WAVE);
+            if (redo_unit >= n_units) break;
+            unit = __builtin_amdgcn_readfirstlane((int)redo_unit);
+            redo_lanes = q->redo_mask[unit];
+            redo_unit += (long long)gridDim.x * (WG_THREADS / WAVE);
+        } else {
+            while (victim < 8) {
+                const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+                const long long begin = q->seg[list], end = q->seg[list + 1];
+                unsigned long long mine = 0;
+                if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+                const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                          (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
+                if (got < end) { tk = got; break; }
+                ++victim;
+            }
+            if (tk < 0) break;
+            unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
         }
-        if (tk < 0) break;
-        int unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
         const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF
         unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -142,7 +162,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
         unsigned long long *phase_acc = nullptr;
 #endif
         const UnitPixel px = unit_pixel(q, unit, lane);
-        const bool valid = px.valid;
+        const bool valid = px.valid && ((redo_lanes >> lane) & 1ULL);
         // PinholeCamera._generate_rays, pinhole.pyx:169-204 + RectangleSampler3D.sample, surface3d.pyx:197-198
         double u1, u2;
         if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
@@ -169,13 +189,15 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
         r.maxd = INFINITY;
         Hit hit;
         uint32_t work = 0;
-        const bool got = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
         // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
         // compiler cannot merge this with the computation above)
         asm volatile("" : "+s"(unit));
         asm volatile("" : "+s"(rp_bits));
         const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
-        if (q2->measure_cost && lane == 0) {
+        const bool redo = MODE == 1 && (work >> 31) != 0;
+        work &= 0x7fffffffu;
+        if (q2->measure_cost && MODE != 2 && lane == 0) {
             unsigned long long c = (unsigned long long)work;
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
             q2->unit_cost[unit] = (uint32_t)c;
@@ -189,6 +211,12 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
 #endif
         }
         const UnitPixel px2 = unit_pixel(q2, unit, lane);
+        if constexpr (MODE == 1) {
+            const unsigned long long again = __ballot(redo && px2.valid);
+            if (lane == 0) q2->redo_mask[unit] = again;
+            if (redo) continue;
+        }
+        if constexpr (MODE == 2) { if (!((q2->redo_mask[unit] >> lane) & 1ULL)) continue; }
         if (!px2.valid) continue;
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;

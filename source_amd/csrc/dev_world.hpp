@@ -6,12 +6,33 @@
 // World.hit — core/scenegraph/world.pyx:125-146, core/acceleration/kdtree.pyx:73-122,170-175,
 //             boundprimitive.pyx:42-51
 // ---------------------------------------------------------------------------------------------------
-template <bool CSG>
+#ifdef CSGF_COUNT
+__device__ unsigned long long g_csgf[3];      // [fallback, miss, hit] counts of csg_fast_hit (diagnostic builds only)
+#endif
+// FASTONLY (k_render_trace<true, 1>): the stream merge is not compiled in; a ray that would need it raises `needs_stream`, the
+// primitive counts as missed, and the ray is traced again by the redo pass (k_render_trace<true, 2>), which has the merge.
+template <bool CSG, bool FASTONLY = false>
 __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t idx, const rsx_primitive &p, const Ray &r, Stack mesh_stack,
-                                                    NodeSt *csg_state, Hit &cand) {
+                                                    NodeSt *csg_state, Hit &cand, bool &needs_stream) {
     cand.prim = -1;
     if constexpr (CSG) {
         if (is_csg(p.type)) {
+            if constexpr (FASTONLY) {
+                int fast = -1;
+                if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * CSGF_MAX_LEAVES) fast = csg_fast_hit(sc, idx, r, mesh_stack, cand);
+                if (fast <= 0) cand.prim = -1;
+                if (fast < 0) needs_stream = true;
+                return;
+            }
+            if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * CSGF_MAX_LEAVES) {
+                const int fast = csg_fast_hit(sc, idx, r, mesh_stack, cand);
+#ifdef CSGF_COUNT
+                atomicAdd(&g_csgf[fast + 1], 1ULL);
+#endif
+                if (fast == 0) cand.prim = -1;
+                if (fast >= 0) return;
+                cand.prim = -1;
+            }
             CsgEval e;
             e.sc = &sc; e.st = csg_state; e.mesh_stack = mesh_stack;
             Rec rec;
@@ -42,7 +63,7 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 // World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
 // that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
 // the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
-template <bool CSG>
+template <bool CSG, bool FASTONLY = false>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
@@ -93,7 +114,11 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                 }
             }
-            if (gate && !is_mesh) primitive_first_hit<CSG>(sc, idx, p, r, mesh_stack, csg_state, cand);
+            if (gate && !is_mesh) {
+                bool needs_stream = false;
+                primitive_first_hit<CSG, FASTONLY>(sc, idx, p, r, mesh_stack, csg_state, cand, needs_stream);
+                if (FASTONLY && needs_stream) work |= 0x80000000u;            // top bit of the cost counter: trace this ray again with the stream merge
+            }
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
         if (active) {

@@ -31,6 +31,7 @@
 #include <string>
 #include <tuple>
 #include <vector>
+#include <functional>
 
 #include "../../include/rsx.h"
 #include "rsx_internal.h"
@@ -145,6 +146,8 @@ struct TraceLane {
     long long cost_units = 0;          // number of units unit_cost currently describes (0 = none)
     long long order_units = 0;         // number of units unit_order was sorted for (0 = no valid work list)
     uint64_t cost_signature = 0;       // (scene, camera, tasks) the costs were measured on
+    void *redo = nullptr;              // CSG scenes: per-unit lane masks handed from the fast pass to the redo pass
+    size_t redo_bytes = 0;
     void *samples = nullptr, *uniforms = nullptr, *terms = nullptr, *tail = nullptr;   // terms / tail: PathTerm blocks of the path kernel
     size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0, tail_bytes = 0;
     unsigned int *overflow = nullptr;
@@ -260,7 +263,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, (void *)ln->overflow})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, (void *)ln->overflow})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -282,6 +285,10 @@ extern "C" int rsx_set_stream(rsx_ctx *ctx, void *hip_stream) {
 }
 
 extern "C" int rsx_synchronize(rsx_ctx *ctx) {
+#ifdef CSGF_COUNT
+    { unsigned long long c[3] = {0, 0, 0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_csgf), sizeof(c));
+      std::fprintf(stderr, "csg_fast_hit: fallback %llu miss %llu hit %llu\n", c[0], c[1], c[2]); }
+#endif
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     if (g_hp_on && g_hp_calls) {
         fprintf(stderr, "[rsx host prof] %ld render calls: throttle %.3f ms/call, setup+trace launch %.3f, events/order/wait %.3f, merge launch %.3f\n",
@@ -511,9 +518,45 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         }
         if (slots > CSG_MAX_SLOTS) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG tree with %d nodes (limit %d)", top, slots, CSG_MAX_SLOTS); }
     }
+    // flattened operand trees for the state-free first-hit evaluator (csg_fast_hit): analytic leaves only
+    std::vector<CsgFast> fast;
+    bool any_fast = false;
+    if (sc->has_csg) {
+        fast.assign((size_t)desc->n_primitives, CsgFast{});
+        for (int32_t top = 0; top < desc->n_primitives; ++top) {
+            if (info[(size_t)top].top != top) continue;
+            CsgFast f{};
+            bool ok = true;
+            std::vector<int32_t> chain;
+            std::function<void(int32_t, int)> visit = [&](int32_t i, int parity) {
+                if (!ok) return;
+                const rsx_primitive &q = desc->primitives[i];
+                const bool inner = q.type == RSX_PRIM_UNION || q.type == RSX_PRIM_INTERSECT || q.type == RSX_PRIM_SUBTRACT;
+                if (i != top) chain.push_back(i);
+                if (!inner) {
+                    const bool analytic = q.type == RSX_PRIM_SPHERE || q.type == RSX_PRIM_BOX || q.type == RSX_PRIM_CYLINDER;
+                    if (!analytic || f.n_leaves >= CSGF_MAX_LEAVES || (int)chain.size() > CSGF_MAX_CHAIN) ok = false;
+                    else {
+                        const int k = f.n_leaves++;
+                        f.leaf[k] = i; f.parity[k] = parity & 1; f.chain_len[k] = (int32_t)chain.size();
+                        for (size_t j = 0; j < chain.size(); ++j) f.chain[k][j] = chain[j];
+                        f.ops[f.n_ops++] = (int8_t)k;
+                    }
+                } else {
+                    visit(q.child_a, parity);
+                    visit(q.child_b, parity + (q.type == RSX_PRIM_SUBTRACT ? 1 : 0));
+                    if (ok) f.ops[f.n_ops++] = q.type == RSX_PRIM_UNION ? (int8_t)-1 : q.type == RSX_PRIM_INTERSECT ? (int8_t)-2 : (int8_t)-3;
+                }
+                if (i != top) chain.pop_back();
+            };
+            visit(top, 0);
+            if (ok && f.n_leaves > 0) { fast[(size_t)top] = f; any_fast = true; }
+        }
+    }
 #define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
     UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
     if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
+    if (any_fast) UP(upload(sc, fast.data(), fast.size(), &d.csgfast));
     UP(upload(sc, desc->world_kd.nodes, (size_t)desc->world_kd.n_nodes, &d.wnodes));
     UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
     std::memcpy(d.wlower, desc->world_kd.lower, 24);
@@ -572,8 +615,9 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
+    if (any_fast) d.mdepth = std::max(d.mdepth, 2 * CSGF_MAX_LEAVES);   // csg_fast_hit keeps the leaf roots in the mesh-stack LDS levels
     d.wlds = std::min(d.wdepth, RSX_WORLD_LDS_LEVELS);
-    d.mlds = std::min(d.mdepth, RSX_MESH_LDS_LEVELS);
+    d.mlds = std::min(d.mdepth, std::max(RSX_MESH_LDS_LEVELS, any_fast ? 2 * CSGF_MAX_LEAVES : 0));
     if (const char *env = std::getenv("RSX_WORLD_LDS")) d.wlds = std::max(0, std::min(d.wdepth, std::atoi(env)));   // tuning aids
     if (const char *env = std::getenv("RSX_MESH_LDS")) d.mlds = std::max(0, std::min(d.mdepth, std::atoi(env)));
 #undef UP
@@ -919,6 +963,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
+    const bool two_pass_csg = scene->has_csg && !has_vol && scene->d.csgfast != nullptr;
+    if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;
     if (has_vol) {
@@ -948,6 +994,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     std::memcpy(rp.rect, desc->rect, sizeof(rp.rect));
     rp.spp = desc->spp;
     rp.rng_mode = desc->rng_mode;
+    rp.redo_mask = two_pass_csg ? static_cast<unsigned long long *>(lane.redo) : nullptr;
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
@@ -1033,6 +1080,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_path<true>) : reinterpret_cast<const void *>(k_render_trace_path<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
         else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+    } else if (two_pass_csg) {
+        // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+        hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
