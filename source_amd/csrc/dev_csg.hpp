@@ -224,17 +224,34 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     Ray l0 = to_local(sc.prims[idx], r);
     l0.maxd = INFINITY;
     uint32_t nroots = 0;                                     // 2 bits per leaf
+    // The chain of a leaf is walked from the top unless it only differs from the previous leaf's in its last entry (siblings):
+    // then the parent-space ray, its reciprocals and the verdict of the gates above are kept. The reciprocals 1 / d are shared by
+    // every box tested in one space (aabb_rcp: bit-identical to aabb).
+    const double l0rx = 1.0 / l0.dx, l0ry = 1.0 / l0.dy, l0rz = 1.0 / l0.dz;
+    Ray cur = l0;
+    double crx = l0rx, cry = l0ry, crz = l0rz;
+    bool prefix_alive = true;
     for (int k = 0; k < P.n_leaves; ++k) {
-        Ray cur = l0;
-        bool alive = true;
-        for (int j = 0; j < P.chain_len[k]; ++j) {           // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
-            const rsx_primitive &node = sc.prims[P.chain[k][j]];
-            double f, b;
-            if (!aabb(node.box_lower, node.box_upper, cur, f, b)) { alive = false; break; }
-            if (j + 1 < P.chain_len[k]) cur = to_local(node, cur);   // csg_first: the operands see the ray in the node's space
+        const int len = P.chain_len[k];
+        bool sibling = k > 0 && P.chain_len[k - 1] == len;
+        for (int j = 0; sibling && j + 1 < len; ++j) sibling = P.chain[k][j] == P.chain[k - 1][j];
+        if (!sibling) {
+            cur = l0; crx = l0rx; cry = l0ry; crz = l0rz;
+            prefix_alive = true;
+            for (int j = 0; j + 1 < len; ++j) {              // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
+                const rsx_primitive &node = sc.prims[P.chain[k][j]];
+                double f, b;
+                if (!aabb_rcp(node.box_lower, node.box_upper, cur, crx, cry, crz, f, b)) { prefix_alive = false; break; }
+                cur = to_local(node, cur);                   // csg_first: the operands see the ray in the node's space
+                crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz;
+            }
         }
-        if (!alive) continue;
+        if (!prefix_alive) continue;
         const rsx_primitive &leaf = sc.prims[P.leaf[k]];
+        {
+            double f, b;
+            if (!aabb_rcp(leaf.box_lower, leaf.box_upper, cur, crx, cry, crz, f, b)) continue;
+        }
         const Ray ll = to_local(leaf, cur);
         Roots roots;
         roots.n = 0;
@@ -242,12 +259,11 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
         else if (leaf.type == RSX_PRIM_BOX) box_roots(leaf, ll, roots);
         else cylinder_roots(leaf, ll, roots);
         for (int j = 0; j < roots.n; ++j) {
-            Geom g;
-            analytic_geom(leaf, ll, roots.t[j], roots.a0[j], roots.a1[j], g);
+            const bool exiting = analytic_exiting(leaf, ll, roots.t[j], roots.a0[j], roots.a1[j]);
             if (!(roots.t[j] == roots.t[j])) return -1;
-            if (g.exiting != (j == roots.n - 1)) return -1;  // convex solid: (enter, exit) or a lone exit; anything else: stream merge
+            if (exiting != (j == roots.n - 1)) return -1;    // convex solid: (enter, exit) or a lone exit; anything else: stream merge
             lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
-            lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((g.exiting ? 1 : 0) << 16);
+            lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((exiting ? 1 : 0) << 16);
         }
         nroots |= (uint32_t)roots.n << (2 * k);
     }

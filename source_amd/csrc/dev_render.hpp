@@ -423,12 +423,18 @@ struct PathStore {
 // used up), so a wave keeps all its lanes on live paths instead of waiting for the longest of 64 (path lengths are geometric: the
 // longest of 64 is several times the mean). Which lane renders which ray never shows in the result — random numbers, sample record
 // and term list are keyed by (pixel, sample).
-template <bool CSG>
+// CSG scenes run it twice like k_render_trace: MODE 1 carries only the state-free CSG evaluator; a path that meets a ray it cannot
+// finish (exact tie between operand roots, operand with mesh leaves) is abandoned and its (unit, slot) bit set in redo_mask; MODE 2,
+// with the reference's stream merge, then traces the abandoned paths from their primary ray again (their term lists restart in the
+// ray's own block; arena blocks of the abandoned attempt are simply not linked any more).
+template <bool CSG, int MODE = 0>
 __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
+    NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
+    int ray_unit = 0, ray_slot = 0;                        // where the lane's current ray came from (MODE 1: to flag it for the redo pass)
+    unsigned long long path_spawned = 0;
     const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
     const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
     (void)rp;
@@ -491,13 +497,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                 if (tk < 0) { exhausted = true; break; }
                 unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
                 cursor = 0;
+                if constexpr (MODE == 2) { if (q->redo_mask[unit] == 0ULL) { cursor = WAVE; continue; } }
             }
             const int n_idle = __popcll(idle);
             const int take = n_idle < WAVE - cursor ? n_idle : WAVE - cursor;
             const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
             if (!active && rank < take) {
                 const UnitPixel px = unit_pixel(q, unit, cursor + rank);
-                if (px.valid) {
+                bool wanted = px.valid;
+                if constexpr (MODE == 2) wanted = wanted && ((q->redo_mask[unit] >> (cursor + rank)) & 1ULL);
+                if (wanted) {
+                    ray_unit = (int)unit; ray_slot = cursor + rank; path_spawned = 0;
                     rng_pixel = (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy; rng_sample = q->sample_offset + (uint64_t)px.s;
                     double u1, u2;
                     if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
@@ -520,7 +530,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                     smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
                     record = px.slot * q->spp + px.s;
                     blk = record; pos = 0; depth = 0; segments = 0;
-                    ++spawned;
+                    ++spawned; ++path_spawned;
                     active = true;
                 }
             }
@@ -531,7 +541,17 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
         // ---- one segment of every live path ----
         const bool was_active = active;
         Hit hit;
-        const bool got = world_trace_wave<CSG>(active, sc, r, st, ms, csg_state, hit, work);
+        work = 0;
+        const bool got = world_trace_wave<CSG, MODE == 1>(active, sc, r, st, ms, csg_state, hit, work);
+        bool abandoned = false;
+        if constexpr (MODE == 1) {
+            if (active && (work >> 31)) {                                     // this path needs the stream merge: hand it to the redo pass
+                atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
+                spawned -= path_spawned;
+                abandoned = true;
+                active = false;
+            }
+        }
         if (active && !got) active = false;                               // new_spectrum(): no volume pass for a segment that hits nothing
         if (active) {
             const rsx_primitive &p = sc.prims[hit.prim];
@@ -576,7 +596,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
             else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
                 const double *from = g.exiting ? g.outside : g.inside;
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
-                ++spawned;
+                ++spawned; ++path_spawned;
             } else if (mat.type == RSX_MAT_LAMBERT) {
                 // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
                 // normal.pyx:346-370); the normal faces the incident side
@@ -658,7 +678,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                     r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
                     r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
                     ++depth;
-                    ++spawned;
+                    ++spawned; ++path_spawned;
                     const int alive = roulette();
                     if (!alive) active = false;
                     push(pdf, rcp, mat.table, alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
@@ -702,7 +722,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                     xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
                     xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
                     ++depth;
-                    ++spawned;
+                    ++spawned; ++path_spawned;
                     const int alive = roulette();
                     if (!alive) active = false;
                     else if (alive == 2) push(0.0, 0.0, mat.table, TERM_NORM);
@@ -719,7 +739,7 @@ __global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, 
                 active = false;
             }
         }
-        if (was_active && !active) {                                          // path over: its record is complete
+        if (was_active && !active && !abandoned) {                            // path over: its record is complete
             smp.pad = pos;
             samples[record] = smp;
             ps.tail[record] = (int32_t)blk;

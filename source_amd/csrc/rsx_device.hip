@@ -963,7 +963,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
-    const bool two_pass_csg = scene->has_csg && !has_vol && scene->d.csgfast != nullptr;
+    const bool two_pass_csg = scene->has_csg && scene->d.csgfast != nullptr;
     if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;
@@ -1078,7 +1078,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
         ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
         HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_path<true>) : reinterpret_cast<const void *>(k_render_trace_path<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+        if (two_pass_csg) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
+            hipLaunchKernelGGL((k_render_trace_path<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            if ((rc = reset_ticket(lane))) return rc;                          // the redo pass walks the same work lists
+            hipLaunchKernelGGL((k_render_trace_path<true, 2>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+        } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
         else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
     } else if (two_pass_csg) {
         // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish

@@ -32,6 +32,12 @@ elif config == "c3s24":
 elif config == "lambert":                 # diffuse inter-reflection room (fixture F13's scene), observer-default roulette
     world = scenes.build_lambert(ns)[0]
     cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+elif config == "lambert_csg":             # ... with the CSG solid, without volumes
+    world = scenes.build_lambert(ns, with_volume=False, csg=True)[0]
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+elif config == "lambert_vol":             # ... with the volumes, without the CSG solid
+    world = scenes.build_lambert(ns, with_volume=True, csg=False)[0]
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
 elif config == "lambert_plain":           # the same room without the CSG solid and without volumes
     world = scenes.build_lambert(ns, with_volume=False, csg=False)[0]
     cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
