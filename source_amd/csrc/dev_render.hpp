@@ -427,8 +427,11 @@ struct PathStore {
 // finish (exact tie between operand roots, operand with mesh leaves) is abandoned and its (unit, slot) bit set in redo_mask; MODE 2,
 // with the reference's stream merge, then traces the abandoned paths from their primary ray again (their term lists restart in the
 // ray's own block; arena blocks of the abandoned attempt are simply not linked any more).
+#ifndef RSX_PATH_MIN_WAVES
+#define RSX_PATH_MIN_WAVES 2
+#endif
 template <bool CSG, int MODE = 0>
-__global__ __launch_bounds__(WG_THREADS, 1) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -917,8 +920,8 @@ struct AccumParams {
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
 
-template <bool STAGED, bool VOL>        // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
-                                        // VOL = samples carry path terms (k_render_trace_path)
+template <bool STAGED, int VOL>         // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
+                                        // VOL = samples carry path terms (k_render_trace_path): 1 = without, 2 = with dielectric attenuation (pow() costs 60 registers)
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
     extern __shared__ __attribute__((aligned(16))) double acc_lds[];
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                     if (tm.kind == TERM_VOL) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;
-                    } else if (tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);  // dielectric.pyx:325-326
+                    } else if (VOL == 2 && tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);  // dielectric.pyx:325-326
                     else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                     else {
                         if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;

@@ -1137,10 +1137,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<true>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
         else hipLaunchKernelGGL((k_accumulate_xyz<false>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
     } else if (has_vol) {
-        if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, true>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
-        else hipLaunchKernelGGL((k_accumulate<false, true>), acc_grid, dim3(256), 0, ctx->stream, ap);
-    } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, false>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
-    else hipLaunchKernelGGL((k_accumulate<false, false>), acc_grid, dim3(256), 0, ctx->stream, ap);
+        bool has_dielectric = false;                        // only then do the terms need pow() (60 more registers in the kernel)
+        for (int32_t i = 0; i < desc->n_materials; ++i) has_dielectric = has_dielectric || desc->materials[i].type == RSX_MAT_DIELECTRIC;
+        if (has_dielectric) {
+            if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 2>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
+            else hipLaunchKernelGGL((k_accumulate<false, 2>), acc_grid, dim3(256), 0, ctx->stream, ap);
+        } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 1>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
+        else hipLaunchKernelGGL((k_accumulate<false, 1>), acc_grid, dim3(256), 0, ctx->stream, ap);
+    } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 0>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
+    else hipLaunchKernelGGL((k_accumulate<false, 0>), acc_grid, dim3(256), 0, ctx->stream, ap);
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
