@@ -913,7 +913,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             return rsx_fail(RSX_EINVAL, "render: the important path weight must lie in [0, 1]");               // ray.pyx:107
         if (desc->ray_max_depth >= (1 << 15)) return rsx_fail(RSX_EUNSUPPORTED, "render: ray_max_depth %d exceeds the Philox draw counter's range (32767)", desc->ray_max_depth);
     }
-    const bool pipelined = !h_mean && !has_vol && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // CSG scenes render in two passes (state-free evaluator, then the stream merge for the rays that need it); their passes are not pipelined
+    const bool two_pass_csg = scene->has_csg && scene->d.csgfast != nullptr;
+    const bool pipelined = !h_mean && !has_vol && !two_pass_csg && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
 
@@ -963,7 +965,6 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         return RSX_OK;
     };
     if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
-    const bool two_pass_csg = scene->has_csg && scene->d.csgfast != nullptr;
     if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;

@@ -21,7 +21,7 @@ for line in open(os.path.join(src, "trace.log")):
 counters = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in sorted(glob.glob(os.path.join(src, "pmc_*", "k_counter_collection.csv"))):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("<false, 0>", "").replace("<true, 0>", "")
         if "rocclr" not in k:
             counters[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 avg = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in counters.items()}
