@@ -337,6 +337,43 @@ __device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double p
     return false;
 }
 
+// contains() of a flattened analytic operand tree (csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains): the point is
+// taken down each leaf's chain (box gate in the parent's space, then into the node's space), the leaf tests give one bit each and
+// the postfix program combines them. A gate that fails anywhere leaves the bits below it clear, and any union / intersection /
+// difference of all-clear operands is clear — which is what the reference's early `return False` yields for that node.
+__device__ bool csg_fast_contains(const DScene &sc, int32_t idx, double px, double py, double pz, const Stack &ms) {
+    const CsgFast &P = sc.csgfast[idx];
+    const rsx_primitive &top = sc.prims[idx];
+    if (!aabb_contains(top.box_lower, top.box_upper, px, py, pz)) return false;
+    double tx, ty, tz;
+    xform_point(top.to_local, px, py, pz, tx, ty, tz);
+    uint32_t inside = 0;
+    for (int k = 0; k < P.n_leaves; ++k) {
+        double x = tx, y = ty, z = tz;
+        bool alive = true;
+        for (int j = 0; j < P.chain_len[k]; ++j) {
+            const rsx_primitive &node = sc.prims[P.chain[k][j]];
+            if (!aabb_contains(node.box_lower, node.box_upper, x, y, z)) { alive = false; break; }
+            if (j + 1 < P.chain_len[k]) { double nx, ny, nz; xform_point(node.to_local, x, y, z, nx, ny, nz); x = nx; y = ny; z = nz; }
+        }
+        if (alive && leaf_contains(sc, sc.prims[P.leaf[k]], x, y, z, ms)) inside |= 1u << k;
+    }
+    uint32_t stack = 0;
+    int sp = 0;
+    for (int o = 0; o < P.n_ops; ++o) {
+        const int op = P.ops[o];
+        if (op >= 0) { stack |= ((inside >> op) & 1u) << sp; ++sp; }
+        else {
+            const uint32_t b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
+            const uint32_t res = op == -1 ? (a | b) : op == -2 ? (a & b) : (a & (b ^ 1u));
+            sp -= 2;
+            stack = (stack & ~(3u << sp)) | (res << sp);
+            ++sp;
+        }
+    }
+    return (stack & 1u) != 0;
+}
+
 template <int D>
 __device__ bool node_contains(const DScene &sc, int32_t idx, double px, double py, double pz, Stack mesh_stack) {
     const rsx_primitive &p = sc.prims[idx];

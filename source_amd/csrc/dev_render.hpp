@@ -390,8 +390,10 @@ __device__ double important_pdf(const rsx_important_sphere *spheres, int n, doub
 // world.contains(point) in leaf order (kdtree3d.pyx:736-792, kdtree.pyx:126-162): calls f(primitive index) for every world
 // primitive that passes `want` (a side-effect-free filter evaluated BEFORE the containment test, which for a mesh is a ray cast) and
 // whose bounding box and surface contain the point
-template <bool CSG, typename W, typename F>
-__device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, W want, F f) {
+// FASTONLY (fast pass of a CSG scene): CSG primitives are tested with the flattened program; one without a program makes the
+// caller abandon the path to the redo pass (needs_stream).
+template <bool CSG, bool FASTONLY, typename W, typename F>
+__device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, bool &needs_stream, W want, F f) {
     if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) return;
     int32_t node = 0;
     rsx_kdnode nd = load_node(sc.wnodes, node);
@@ -404,7 +406,12 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
         const rsx_primitive &p = sc.prims[idx];
         if (!want(idx)) continue;
         bool in;
-        if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
+        if constexpr (CSG && FASTONLY) {
+            if (is_csg(p.type)) {
+                if (sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);
+                else { in = false; needs_stream = true; }
+            } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+        } else if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
         else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
         if (in) f(idx);
     }
@@ -430,8 +437,10 @@ struct PathStore {
 #ifndef RSX_PATH_MIN_WAVES
 #define RSX_PATH_MIN_WAVES 2
 #endif
-template <bool CSG, int MODE = 0>
-__global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+// VOLS = the scene has materials with a volume contribution (volume emitters, dielectrics): only then is the per-segment
+// world.contains() pass compiled in (its CSG form, a depth-unrolled recursion, costs the CSG instantiation a wave per SIMD).
+template <bool CSG, int MODE = 0, bool VOLS = true>
+__global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -568,7 +577,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_PATH_MIN_WAVES) void k_re
             double v_len[PATH_VOL_OVERLAP], v_scale[PATH_VOL_OVERLAP];
             int32_t v_table[PATH_VOL_OVERLAP], v_kind[PATH_VOL_OVERLAP];
             int n_vol = 0;
-            if (q->n_vol_emitters) world_contains_each<CSG>(sc, r.ox, r.oy, r.oz, ms, [&](int32_t idx) {
+            bool contains_needs_stream = false;
+            if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
                 const int32_t vt = q->materials[sc.prims[idx].material].type;         // every other evaluate_volume leaves the spectrum unchanged
                 return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || vt == RSX_MAT_DIELECTRIC;
             }, [&](int32_t idx) {
@@ -594,8 +604,17 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? 1 : RSX_PATH_MIN_WAVES) void k_re
             });
 #pragma unroll
             for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
+            if constexpr (MODE == 1) {
+                if (contains_needs_stream) {                                  // a CSG volume without a flattened program: redo pass
+                    atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
+                    spawned -= path_spawned;
+                    abandoned = true;
+                    active = false;
+                }
+            }
             ++segments;
-            if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
+            if (abandoned) {}
+            else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
             else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
                 const double *from = g.exiting ? g.outside : g.inside;
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);

@@ -1080,10 +1080,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
         HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_path<true>) : reinterpret_cast<const void *>(k_render_trace_path<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         if (two_pass_csg) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            const bool vols = rp.n_vol_emitters > 0;
+            const void *fast = vols ? reinterpret_cast<const void *>(k_render_trace_path<true, 1, true>) : reinterpret_cast<const void *>(k_render_trace_path<true, 1, false>);
+            HIP_TRY(hipFuncSetAttribute(fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
             HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
-            hipLaunchKernelGGL((k_render_trace_path<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            if (vols) hipLaunchKernelGGL((k_render_trace_path<true, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            else hipLaunchKernelGGL((k_render_trace_path<true, 1, false>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
             if ((rc = reset_ticket(lane))) return rc;                          // the redo pass walks the same work lists
             hipLaunchKernelGGL((k_render_trace_path<true, 2>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
         } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
