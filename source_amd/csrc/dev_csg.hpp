@@ -11,6 +11,9 @@
 // recursion over nested CSG nodes is unrolled by a depth template (CSG_MAX_DEPTH nested levels below the top node; deeper
 // trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
 // ---------------------------------------------------------------------------------------------------
+#ifndef RSX_CSGFAST_MIN_WAVES
+#define RSX_CSGFAST_MIN_WAVES 2             // waves per SIMD of the kernels that carry only the state-free CSG evaluator
+#endif
 #define CSG_MAX_SLOTS 16
 #ifndef CSG_MAX_DEPTH
 #define CSG_MAX_DEPTH 4

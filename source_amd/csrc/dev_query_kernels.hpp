@@ -36,18 +36,25 @@ struct HitOut {
     int32_t *prim; double *t; uint8_t *exiting; int32_t *tri; float *uvw; double *geom;
 };
 
-template <bool CSG>
-__global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction,
-                                                          const double *maxd, HitOut out, unsigned long long *ticket) {
+// CSG scenes run it twice, like the render kernels: MODE 1 has only the state-free CSG evaluator and marks the rays it cannot finish
+// (prim = HIT_REDO), MODE 2 carries the stream merge and traces exactly those again.
+#define HIT_REDO (-2)
+template <bool CSG, int MODE = 0>
+__global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
+void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction, const double *maxd, HitOut out, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
-    NodeSt csg_state[CSG ? CSG_MAX_SLOTS : 1];
+    NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
     for (;;) {
         const long long base = next_batch(ticket);
         if (base >= n) break;
         const long long i = base + lane;
-        const bool valid = i < n;               // lanes without a ray still walk the loops: they help on big mesh leaves
+        bool valid = i < n;                     // lanes without a ray still walk the loops: they help on big mesh leaves
+        if constexpr (MODE == 2) {
+            valid = valid && out.prim[i] == HIT_REDO;
+            if (!__any(valid)) continue;
+        }
         Ray r;
         r.ox = r.oy = r.oz = 0.0; r.dx = r.dy = 0.0; r.dz = 1.0; r.maxd = 0.0;
         if (valid) {
@@ -57,8 +64,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG ? RSX_CSG_MIN_WAVES : RSX_MIN_WAVES
         }
         Hit h;
         uint32_t work = 0;
-        const bool hit = world_trace_wave<CSG>(valid, sc, r, st, ms, csg_state, h, work);
+        const bool hit = world_trace_wave<CSG, MODE == 1>(valid, sc, r, st, ms, csg_state, h, work);
         if (!valid) continue;
+        if constexpr (MODE == 1) { if (work >> 31) { out.prim[i] = HIT_REDO; continue; } }
         out.prim[i] = hit ? h.prim : -1;
         if (out.t) out.t[i] = hit ? h.t : NAN;
         bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;

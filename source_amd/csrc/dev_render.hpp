@@ -105,9 +105,6 @@ __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams 
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
 // it fits several waves per SIMD; rays it cannot finish (exact ties between operand roots, operands with mesh leaves) are listed in
 // redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
-#ifndef RSX_CSGFAST_MIN_WAVES
-#define RSX_CSGFAST_MIN_WAVES 2
-#endif
 template <bool CSG, int MODE = 0>
 __global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {

@@ -758,11 +758,16 @@ extern "C" int rsx_hit_batch_dev(rsx_scene *scene, int64_t n, const double *orig
     int rc = plan(scene, n, ctx->main, l);
     if (rc) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_hit_batch<true>) : reinterpret_cast<const void *>(k_hit_batch<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-    rc = reset_ticket(ctx->main);
-    if (rc) return rc;
+    if ((rc = reset_ticket(ctx->main))) return rc;
     HitOut out = {prim, t, exiting, tri, uvw, geom};
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    if (scene->has_csg) hipLaunchKernelGGL(k_hit_batch<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
+    if (scene->has_csg && scene->d.csgfast) {               // fast pass, then the stream merge for the rays marked HIT_REDO
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hit_batch<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hit_batch<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        hipLaunchKernelGGL((k_hit_batch<true, 1>), l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
+        if ((rc = reset_ticket(ctx->main))) return rc;
+        hipLaunchKernelGGL((k_hit_batch<true, 2>), l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
+    } else if (scene->has_csg) hipLaunchKernelGGL(k_hit_batch<true>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
     else hipLaunchKernelGGL(k_hit_batch<false>, l.grid, dim3(WG_THREADS), l.lds, ctx->stream, scene->d, (long long)n, origin, direction, max_distance, out, ctx->main.ticket);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
