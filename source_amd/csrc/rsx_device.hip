@@ -1047,7 +1047,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         rp.seg = lane.n_work;
         // Longest-first ordering pays when a pass is tail-bound (few units per wave); a pass with thousands of units per wave
         // balances by itself, so it keeps the natural (XCD-blocked) order and the kernel skips the cost bookkeeping.
-        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS;
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && !two_pass_csg;
         rp.measure_cost = want_order ? 1 : 0;
         lane.order_units = want_order ? 0 : n_units;
         order_n = n_units;
