@@ -155,6 +155,10 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {          //
 // tested by all 64 lanes for one ray at a time: 64 triangles per step instead of 1, then a (t, leaf position) lexicographic
 // wave-min, which is exactly what the reference's sequential scan with strict `<` returns (the first item among those with the
 // smallest distance). Idle lanes — rays that already finished, or never needed this mesh — serve as helpers.
+// STAGE_MIN: rays of the wave that must share a big leaf before it is staged through LDS (below that the wave serves one ray at a
+// time). 1 = always stage: the serve-one-ray code is then not compiled in, which is worth 11 % on passes whose waves are coherent
+// (several samples per pixel: -11 % on configs[2], -9 % at 100 spp, -4 % at 4 spp) and loses on 1-spp passes (+45 % on configs[1]).
+template <int STAGE_MIN = RSX_STAGE_MIN>
 __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
     const int lane = threadIdx.x % WAVE;
     PHASE_DECL
@@ -221,7 +225,7 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
             const bool same = active && count >= RSX_COOP_LEAF && first == lfirst;
             const unsigned long long group = __ballot(same);
             big &= ~group;
-            if (__popcll(group) >= RSX_STAGE_MIN) {
+            if (STAGE_MIN <= 1 || __popcll(group) >= STAGE_MIN) {
                 // (a) coherent rays: stage the leaf through LDS 64 triangles at a time; every lane of the group tests them all,
                 //     in leaf order (the reference's own loop), reading each record as an LDS broadcast
                 float4 *rec = st.stage;

@@ -105,7 +105,8 @@ __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams 
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
 // it fits several waves per SIMD; rays it cannot finish (exact ties between operand roots, operands with mesh leaves) are listed in
 // redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
-template <bool CSG, int MODE = 0>
+// STAGE_MIN: see mesh_trace_wave (1 for passes with more than one sample per pixel).
+template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN>
 __global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
     Stack st, ms;
@@ -186,7 +187,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         r.maxd = INFINITY;
         Hit hit;
         uint32_t work = 0;
-        const bool got = world_trace_wave<CSG, MODE == 1>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
         // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
         // compiler cannot merge this with the computation above)
         asm volatile("" : "+s"(unit));

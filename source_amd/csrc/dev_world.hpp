@@ -63,7 +63,7 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 // World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
 // that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
 // the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
-template <bool CSG, bool FASTONLY = false>
+template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
@@ -110,7 +110,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 if (mine) l = to_local_uniform(up, r);
                 const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
                 MeshHit mh;
-                if (mesh_trace_wave(mine, um, l, mesh_stack, mh, work, phase_acc)) {
+                if (mesh_trace_wave<STAGE_MIN>(mine, um, l, mesh_stack, mh, work, phase_acc)) {
                     cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                 }
             }

@@ -1103,7 +1103,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
         hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
-    else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+    else if (desc->spp > 1) {                               // coherent waves (several samples of a pixel side by side): always stage big leaves
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        hipLaunchKernelGGL((k_render_trace<false, 0, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+    } else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     HIP_TRY(hipGetLastError());
     HP_MARK(1)
     if (timed) HIP_TRY(hipEventRecord(re[1], lane.stream));
