@@ -87,6 +87,7 @@ __device__ __forceinline__ void leaf_fetch(const int32_t *items, const float4 *t
 #ifndef RSX_LEAF_BATCH
 #define RSX_LEAF_BATCH 3           // triangles whose loads are issued together before the tests (latency hiding inside a leaf)
 #endif
+#define RSX_LEAF_BATCH_DEFAULT RSX_LEAF_BATCH
 
 __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out) {
     double tmin, tmax;
@@ -161,6 +162,7 @@ __device__ __forceinline__ double readlane_f64(double x, int lane) {          //
 template <int STAGE_MIN = RSX_STAGE_MIN>
 __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work, unsigned long long *phase_acc = nullptr) {
     const int lane = threadIdx.x % WAVE;
+    constexpr int LEAF_BATCH = STAGE_MIN <= 1 ? 2 : RSX_LEAF_BATCH_DEFAULT;   // coherent passes: two records in flight are enough (-3 % on configs[2])
     PHASE_DECL
     const rsx_kdnode *nodes = m->nodes;                     // scalar loads: the bases sit in SGPRs, lanes supply 32-bit offsets
     const float4 *leaf = m->leaf, *tris = m->tris;
@@ -195,15 +197,15 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
             count = nd.count;
             first = nd.u.leaf.first_item;
             if (count < RSX_COOP_LEAF) {
-                for (int32_t k = 0; k < count; k += RSX_LEAF_BATCH) {
+                for (int32_t k = 0; k < count; k += LEAF_BATCH) {
                     UTIL_COUNT(phase_acc, 6)
-                    int32_t tri[RSX_LEAF_BATCH];
-                    float4 t0[RSX_LEAF_BATCH], t1[RSX_LEAF_BATCH], t2[RSX_LEAF_BATCH];
+                    int32_t tri[LEAF_BATCH];
+                    float4 t0[LEAF_BATCH], t1[LEAF_BATCH], t2[LEAF_BATCH];
 #pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j)
+                    for (int j = 0; j < LEAF_BATCH; ++j)
                         leaf_fetch(items, tris, leaf, first + (k + j < count ? k + j : count - 1), tri[j], t0[j], t1[j], t2[j]);
 #pragma unroll
-                    for (int j = 0; j < RSX_LEAF_BATCH; ++j) {
+                    for (int j = 0; j < LEAF_BATCH; ++j) {
                         float ht, hu, hv, hw;
                         if (k + j < count && tri_test(q, t0[j], t1[j], t2[j], ht, hu, hv, hw) && (double)ht < distance) {
                             distance = (double)ht; closest = tri[j]; bu = hu; bv = hv; bw = hw;

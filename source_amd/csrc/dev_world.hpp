@@ -44,14 +44,8 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
             return;
         }
     }
+    // (mesh primitives never come here: world_trace_wave traces them wave-cooperatively, one instance at a time)
     const Ray l = to_local(p, r);
-    if (p.type == RSX_PRIM_MESH) {
-        MeshHit mh;
-        if (mesh_trace(sc.meshes[p.mesh], l, mesh_stack, mh)) {
-            cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
-        }
-        return;
-    }
     Roots roots;
     roots.n = 0;
     if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
