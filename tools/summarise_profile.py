@@ -42,6 +42,6 @@ for k, d in avg.items():
                   "valu_lane_utilisation": d.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64 * d.get("SQ_ACTIVE_INST_VALU", 0)),
                   "waves": d.get("SQ_WAVES")}
 json.dump({"command": "RSX_PIPELINE=1 rocprofv3 --pmc <group> -- python tools/kbench.py 4 <%s>, one counter group per run" % wl, "kernels": out,
-           "hbm_bytes_per_launch": out.get("k_render_trace", {}).get("hbm_bytes_per_launch")},
+           "hbm_bytes_per_launch": next((v.get("hbm_bytes_per_launch") for k, v in sorted(out.items()) if k.startswith("k_render_trace")), None)},
           open(os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)), "w"), indent=1)
 print(json.dumps(out, indent=1))
