@@ -1080,22 +1080,39 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const bool timed = ctx->timing;
     if (timed) HIP_TRY(hipEventRecord(re[0], lane.stream));
     if (has_vol) {
-        PathStore ps;
-        ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
-        ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
         HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace_path<true>) : reinterpret_cast<const void *>(k_render_trace_path<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        if (two_pass_csg) {
-            const bool vols = rp.n_vol_emitters > 0;
-            const void *fast = vols ? reinterpret_cast<const void *>(k_render_trace_path<true, 1, true>) : reinterpret_cast<const void *>(k_render_trace_path<true, 1, false>);
-            HIP_TRY(hipFuncSetAttribute(fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-            HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
-            if (vols) hipLaunchKernelGGL((k_render_trace_path<true, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-            else hipLaunchKernelGGL((k_render_trace_path<true, 1, false>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-            if ((rc = reset_ticket(lane))) return rc;                          // the redo pass walks the same work lists
-            hipLaunchKernelGGL((k_render_trace_path<true, 2>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-        } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-        else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+        // Paths are deterministic (counter-based random numbers), so a pass whose term arena ran out is simply traced again with
+        // a four times larger one — before its records are merged into the frame (one host round trip per path pass, small next
+        // to the pass itself). RSX_PATH_ARENA pins the size instead.
+        for (int attempt = 0;; ++attempt) {
+            PathStore ps;
+            ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
+            ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
+            if (two_pass_csg) {
+                const bool vols = rp.n_vol_emitters > 0;
+                const void *fast = vols ? reinterpret_cast<const void *>(k_render_trace_path<true, 1, true>) : reinterpret_cast<const void *>(k_render_trace_path<true, 1, false>);
+                HIP_TRY(hipFuncSetAttribute(fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+                HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
+                if (vols) hipLaunchKernelGGL((k_render_trace_path<true, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+                else hipLaunchKernelGGL((k_render_trace_path<true, 1, false>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+                if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
+                hipLaunchKernelGGL((k_render_trace_path<true, 2>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+            HIP_TRY(hipGetLastError());
+            if (!has_scatter || std::getenv("RSX_PATH_ARENA")) break;
+            unsigned int flags = 0;
+            HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
+            HIP_TRY(hipStreamSynchronize(lane.stream));
+            if (!(flags & 1u)) break;
+            const size_t bigger = arena_blocks * 4, pool_bytes = (S + bigger) * PATH_BLOCK * sizeof(PathTerm);
+            if (attempt >= 4 || S + bigger >= ((size_t)1 << 31) || pool_bytes > ((size_t)96 << 30)) break;   // reported below
+            arena_blocks = bigger;
+            if ((rc = lane_buffer(lane.terms, lane.terms_bytes, pool_bytes))) return rc;
+            HIP_TRY(hipMemsetAsync(lane.overflow, 0, 64, lane.stream));
+            if ((rc = reset_ticket(lane))) return rc;
+        }
     } else if (two_pass_csg) {
         // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));

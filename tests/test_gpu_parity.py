@@ -721,6 +721,30 @@ def test_lambert_furnace_full_size(ns):
     assert v.max() < 1e-5
 
 
+def test_path_arena_grows_on_demand(ns):
+    """Long paths: a closed furnace with a small emitter and roulette off makes paths hundreds of bounces long, far more terms than the
+    arena a pass starts with (two blocks per ray). The pass is traced again with a larger arena (deterministic Philox paths) until it
+    fits; the furnace property (every pixel = the emitter's radiance) shows that nothing was lost or merged twice on the way."""
+    world = ns.World()
+    P = ns.Point3D
+    ns.Box(P(-1, -1, -1), P(1, 1, 1), world, material=ns.Lambert(ns.ConstantSF(1.0)))
+    ns.Sphere(0.12, world, ns.translate(0.3, -0.2, 0.4), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 2.0))
+    cam, pipe = scenes.lambert_camera(ns, world, (256, 256), 4, 2, (0.0, 1, 30000))
+    cam.transform = ns.translate(0, 0, -0.9)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=11)
+    cam.observe()
+    m = pipe.frame.mean
+    assert cam.stats["rays"] > 50 * 256 * 256 * 4                 # paths really are long (mean > 50 segments)
+    desc_cam = cam.device_camera()
+    ix, iy = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    x = desc_cam.image_start_x - desc_cam.image_delta * (ix + 0.5)
+    y = desc_cam.image_start_y - desc_cam.image_delta * (iy + 0.5)
+    w_centre = 1.0 / np.sqrt(x * x + y * y + 1.0)
+    assert np.isfinite(m).all() and np.abs(m / (2.0 * w_centre[:, :, None]) - 1.0).max() < 5e-3
+    assert (pipe.frame.samples == 4).all()
+
+
 def test_pipelining_does_not_change_frames():
     """Render-pass pipelining (private lanes, longest-first unit order, XCD work lists) only changes which wave renders which unit:
     120 accumulating passes give the same frame digest with 1, 3 and 4 lanes (separate processes: the depth is read at rsx_init)."""
