@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                     if (tm.kind == TERM_VOL) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;
-                    } else if (VOL == 2 && tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);  // dielectric.pyx:325-326
+                    } else if (VOL == 2 && tm.kind == TERM_ATTEN) { if (tv != 1.0) x = x * pow(tv, tm.a); }  // dielectric.pyx:325-326; pow(1, length) = 1 exactly
                     else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                     else {
                         if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_
                         const PathTerm tm = t[j];
                         const double tv = ap.tables[tm.table * ap.bins + b];
                         if (tm.kind == TERM_VOL) { const double emission = 0.0 + tv * tm.b; x = x + emission * tm.a; }
-                        else if (tm.kind == TERM_ATTEN) x = x * pow(tv, tm.a);
+                        else if (tm.kind == TERM_ATTEN) { if (tv != 1.0) x = x * pow(tv, tm.a); }
                         else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                         else {
                             if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;

@@ -404,3 +404,38 @@ def glass_camera(ns, world, pixels=(24, 20), spp=4, bins=6, spectral_rays=3, ext
     cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = extinction
     cam.ray_importance_sampling = False
     return cam, pipe
+
+
+def build_cornell(ns):
+    """A Cornell-box variant after the reference's demos/cornell_box.py (BASELINE.json configs[0]): five Lambert walls (white, red,
+    green; smooth stand-ins for the measured reflectances), a ceiling light, a glass block and a glass sphere (Sellmeier N-BK7
+    coefficients instead of the reference's library entry). The emitter carries importance 1, so with ray_importance_sampling on
+    (the observer default) Lambert surfaces use the important-path / BSDF mixture."""
+    world = ns.World()
+    P = ns.Point3D
+    wl = [400, 450, 500, 550, 600, 650, 700]
+    white = ns.InterpolatedSF(wl, np.array([0.45, 0.74, 0.75, 0.74, 0.75, 0.72, 0.74]))
+    green = ns.InterpolatedSF(wl, np.array([0.09, 0.10, 0.29, 0.37, 0.16, 0.12, 0.16]))
+    red = ns.InterpolatedSF(wl, np.array([0.04, 0.06, 0.06, 0.06, 0.29, 0.61, 0.64]))
+    light = ns.InterpolatedSF([400, 500, 600, 700], np.array([0.0, 8.0, 15.6, 18.4]))
+    bk7 = ns.Sellmeier(1.03961212, 0.231792344, 1.01046945, 6.00069867e-3, 2.00179144e-2, 1.03560653e2)
+    prims = [
+        ns.Box(P(-1, -1, 0), P(1, 1, 0.02), world, ns.translate(0, 0, 1), ns.Lambert(white)),                           # back
+        ns.Box(P(-1, -1, 0), P(1, 1, 0.02), world, ns.translate(0, -1, 0) * ns.rotate(0, -90, 0), ns.Lambert(white)),   # bottom
+        ns.Box(P(-1, -1, 0), P(1, 1, 0.02), world, ns.translate(0, 1, 0) * ns.rotate(0, 90, 0), ns.Lambert(white)),     # top
+        ns.Box(P(-1, -1, 0), P(1, 1, 0.02), world, ns.translate(1, 0, 0) * ns.rotate(-90, 0, 0), ns.Lambert(red)),      # left
+        ns.Box(P(-1, -1, 0), P(1, 1, 0.02), world, ns.translate(-1, 0, 0) * ns.rotate(90, 0, 0), ns.Lambert(green)),    # right
+        ns.Box(P(-0.4, -0.4, -0.01), P(0.4, 0.4, 0.0), world, ns.translate(0, 1, 0) * ns.rotate(0, 90, 0), ns.UniformSurfaceEmitter(light, 2)),
+        ns.Box(P(-0.4, 0, -0.4), P(0.3, 1.4, 0.3), world, ns.translate(0.4, -1 + 1e-6, 0.4) * ns.rotate(30, 0, 0), ns.Dielectric(bk7, ns.ConstantSF(1.0))),
+        ns.Sphere(0.4, world, ns.translate(-0.4, -0.6 + 1e-6, -0.4), ns.Dielectric(bk7, ns.ConstantSF(1.0))),
+    ]
+    return world, prims
+
+
+def cornell_camera(ns, world, pixels=(256, 256), spp=1, bins=15, pipelines=None):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, parent=world, transform=ns.translate(0, 0, -3.3), pipelines=pipelines or [pipe], frame_sampler=ns.FullFrameSampler2D())
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, 1, True
+    cam.ray_importance_sampling, cam.ray_important_path_weight = True, 0.25
+    cam.ray_max_depth, cam.ray_extinction_min_depth, cam.ray_extinction_prob = 500, 3, 0.01
+    return cam, pipe

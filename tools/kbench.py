@@ -41,6 +41,9 @@ elif config == "lambert_vol":             # ... with the volumes, without the CS
 elif config == "lambert_plain":           # the same room without the CSG solid and without volumes
     world = scenes.build_lambert(ns, with_volume=False, csg=False)[0]
     cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+elif config == "cornell":                 # BASELINE configs[0]'s scene (demos/cornell_box.py variant): Lambert + glass, importance sampling
+    world = scenes.build_cornell(ns)[0]
+    cam, pipe = scenes.cornell_camera(ns, world, (1024, 1024), 16, 15)
 elif config == "glass":                   # refraction scene (fixture F14's), 3 spectral slices
     world = scenes.build_glass(ns)[0]
     cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 15, 3, (0.01, 3, 500))
