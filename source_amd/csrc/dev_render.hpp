@@ -989,7 +989,9 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                     if (tm.kind == TERM_VOL) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;
-                    } else if (VOL == 2 && tm.kind == TERM_ATTEN) { if (tv != 1.0) x = x * pow(tv, tm.a); }  // dielectric.pyx:325-326; pow(1, length) = 1 exactly
+                    } else if (tm.kind == TERM_ATTEN) {                       // dielectric.pyx:325-326; pow(1, length) = 1 exactly
+                        if constexpr (VOL == 2) { if (tv != 1.0) x = x * pow(tv, tm.a); }   // VOL == 1: the host saw only unit transmissions
+                    }
                     else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                     else {
                         if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;

@@ -1166,8 +1166,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<true>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
         else hipLaunchKernelGGL((k_accumulate_xyz<false>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
     } else if (has_vol) {
-        bool has_dielectric = false;                        // only then do the terms need pow() (60 more registers in the kernel)
-        for (int32_t i = 0; i < desc->n_materials; ++i) has_dielectric = has_dielectric || desc->materials[i].type == RSX_MAT_DIELECTRIC;
+        bool has_dielectric = false;                        // an absorbing dielectric: only then do the terms need pow() (60 more registers)
+        for (int32_t i = 0; i < desc->n_materials; ++i) {
+            if (desc->materials[i].type != RSX_MAT_DIELECTRIC) continue;
+            const double *row = desc->tables + (size_t)desc->materials[i].table * B;
+            for (size_t b = 0; b < B; ++b) has_dielectric = has_dielectric || row[b] != 1.0;
+        }
         if (has_dielectric) {
             if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 2>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
             else hipLaunchKernelGGL((k_accumulate<false, 2>), acc_grid, dim3(256), 0, ctx->stream, ap);
