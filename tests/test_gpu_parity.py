@@ -721,6 +721,38 @@ def test_lambert_furnace_full_size(ns):
     assert v.max() < 1e-5
 
 
+def test_cornell_box_end_to_end(orc, ns):
+    """BASELINE configs[0]'s scene the way demos/cornell_box.py drives it: Lambert walls, glass, an important light (multiple importance
+    sampling), an RGB pipeline next to a spectral one, and RGBAdaptiveSampler2D deciding what each further pass renders. Pass 1 must
+    equal the oracle (same Philox paths) in both pipelines; the adaptive passes must only add samples where the sampler asked."""
+    world, prims = scenes.build_cornell(ns)
+    rgb, spectral = ns.RGBPipeline2D(), ns.SpectralRadiancePipeline2D()
+    cam, _ = scenes.cornell_camera(ns, world, (48, 48), 4, 6, pipelines=[rgb, spectral])
+    cam.frame_sampler = ns.RGBAdaptiveSampler2D(rgb, ratio=4, fraction=0.3, min_samples=8, cutoff=0.01)
+    cam.render_engine = ns.HipEngine(rng="philox", seed=3)
+    cam.observe()
+    tasks = None
+    import random as pyrandom
+    # oracle for pass 1: the sampler's first task list is the full frame (x outer, y inner, shuffled) — order does not matter in Philox mode
+    keep = []
+    full = [(x, y) for x in range(48) for y in range(48)]
+    desc = cam.render_desc(world, full, cam._slice_spectrum()[0], cam.render_engine, keep)
+    om, ov, _ = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    xm, xv, _ = orc.render_pinhole_xyz(world.flatten(), desc, rgb._resampled[0], rgb._deltas[0], threads=orc.max_threads())
+    assert eq(spectral.frame.mean, om.reshape(48, 48, 6)) and eq(spectral.frame.variance, ov.reshape(48, 48, 6))
+    assert eq(rgb.xyz_frame.mean, xm.reshape(48, 48, 3)) and eq(rgb.xyz_frame.variance, xv.reshape(48, 48, 3))
+    assert (rgb.xyz_frame.samples == 4).all() and (rgb.xyz_frame.mean[:, :, 1] > 0).mean() > 0.4
+    before = rgb.xyz_frame.samples.copy()
+    for step in range(3):                                          # adaptive passes
+        engine_offset = (step + 1) * 4
+        cam.render_engine.sample_offset = engine_offset
+        cam.observe()
+    after = rgb.xyz_frame.samples
+    assert (after >= before).all() and after.max() == 16 and (after % 4 == 0).all()
+    assert after.min() >= 8                                        # min_samples reached everywhere after the second pass
+    assert np.isfinite(rgb.xyz_frame.mean).all() and np.isfinite(rgb.rgb_frame).all()
+
+
 def test_path_arena_grows_on_demand(ns):
     """Long paths: a closed furnace with a small emitter and roulette off makes paths hundreds of bounces long, far more terms than the
     arena a pass starts with (two blocks per ray). The pass is traced again with a larger arena (deterministic Philox paths) until it
