@@ -439,3 +439,49 @@ def cornell_camera(ns, world, pixels=(256, 256), spp=1, bins=15, pipelines=None)
     cam.ray_importance_sampling, cam.ray_important_path_weight = True, 0.25
     cam.ray_max_depth, cam.ray_extinction_min_depth, cam.ray_extinction_prob = 500, 3, 0.01
     return cam, pipe
+
+
+def build_prism(ns):
+    """The dispersive-prism scene after the reference's demos/prism.py (BASELINE.json configs[4]): an equilateral SF11 prism cut from
+    boxes by two Subtracts, a slit light box (CSG) aimed at it, a curved N-BK7 stand with a white Lambert screen parented to it
+    (nested CSG of boxes and cylinders), a Lambert floor and a fill light. Glasses are Sellmeier dielectrics with the published Schott
+    coefficients and unit transmission (the reference takes them, with measured transmission tables, from its data library); the
+    daylight spectrum is a seven-point D65. The prism's importance is 9, so Lambert surfaces aim most of their samples at it."""
+    from math import tan, pi
+    world = ns.World()
+    P = ns.Point3D
+    d65 = ns.InterpolatedSF([400, 450, 500, 550, 600, 650, 700], np.array([0.8275, 1.1701, 1.0935, 1.0405, 0.9001, 0.8003, 0.7161]))
+    sf11 = ns.Sellmeier(1.73759695, 0.313747346, 1.89878101, 0.013188707, 0.0623068142, 155.23629)
+    bk7 = ns.Sellmeier(1.03961212, 0.231792344, 1.01046945, 6.00069867e-3, 2.00179144e-2, 1.03560653e2)
+    width, height = 0.06, 0.15
+    half = width / 2
+    mid = half * tan(60 / 180 * pi) / 2
+    centre = ns.Box(P(-half * 1.001, 0, 0), P(half * 1.001, height, width))
+    left = ns.Box(P(0, -height * 0.001, -width * 0.001), P(width, height * 1.001, 2 * width), transform=ns.translate(half, 0, 0) * ns.rotate(30, 0, 0))
+    right = ns.Box(P(-width, -height * 0.001, -width * 0.001), P(0.0, height * 1.001, 2 * width), transform=ns.translate(-half, 0, 0) * ns.rotate(-30, 0, 0))
+    prism = ns.Subtract(ns.Subtract(centre, left), right, world, ns.translate(0, 1e-6, -0.01) * ns.translate(0, 0, -mid), ns.Dielectric(sf11, ns.ConstantSF(1.0)))
+    prism.material.importance = 9
+    floor = ns.Box(P(-1000, -0.1, -1000), P(1000, 0, 1000), world, material=ns.Lambert())
+    stand = ns.Intersect(ns.Box(P(-10, -10, -10), P(10, 10, 0)),
+                         ns.Subtract(ns.Cylinder(0.21, 0.15), ns.Cylinder(0.20, 0.16, transform=ns.translate(0, 0, -0.005)), transform=ns.rotate(0, 90, 0)),
+                         world, ns.translate(0.0, 1e-6, 0.0), ns.Dielectric(bk7, ns.ConstantSF(1.0)))
+    screen = ns.Intersect(ns.Box(P(-10, -10, -10), P(10, 10, -0.015)),
+                          ns.Subtract(ns.Cylinder(0.1999, 0.12, transform=ns.translate(0, 0, 0.015)), ns.Cylinder(0.1998, 0.13, transform=ns.translate(0, 0, 0.010)),
+                                      transform=ns.rotate(0, 90, 0)),
+                          world, ns.translate(0.0, 1e-6, 0.0), ns.Lambert(ns.ConstantSF(1.0)))
+    box_t = ns.rotate(-35.5, 0, 0) * ns.translate(0.10, 0, 0) * ns.rotate(90, 0, 0)
+    housing = ns.Subtract(ns.Box(P(-0.01, 0, -0.05), P(0.01, 0.15, 0.0)), ns.Box(P(-0.0015, 0.03, -0.045), P(0.0015, 0.12, 0.0001)), world, box_t,
+                          ns.Lambert(ns.ConstantSF(0.1)))
+    slit_light = ns.Box(P(-0.0015, 0.03, -0.045), P(0.0015, 0.12, -0.04), world, box_t, ns.UniformSurfaceEmitter(d65, 250))
+    top_light = ns.Sphere(0.25, world, ns.translate(-1, 2, 1), ns.UniformSurfaceEmitter(d65, 5))
+    return world, [prism, floor, stand, screen, housing, slit_light, top_light]
+
+
+def prism_camera(ns, world, pixels=(1024, 1024), spp=4, bins=32, spectral_rays=32, pipelines=None):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera(pixels, fov=45, parent=world, pipelines=pipelines or [pipe], frame_sampler=ns.FullFrameSampler2D(),
+                           transform=ns.translate(0, 0.075, -0.05) * ns.rotate(180, -45, 0) * ns.translate(0, 0, -0.75))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = spp, bins, spectral_rays, True
+    cam.ray_importance_sampling, cam.ray_important_path_weight = True, 0.75
+    cam.ray_max_depth, cam.ray_extinction_min_depth, cam.ray_extinction_prob = 500, 3, 0.01
+    return cam, pipe

@@ -568,6 +568,20 @@ def f16_rgb():
     save("f16_rgb", **out)
 
 
+def f17_scenes():
+    """Whole demo scenes as the reference renders them (SerialEngine): the dispersive prism (demos/prism.py variant: nested CSG, two
+    Sellmeier glasses, importance 9 on the prism, path weight 0.75, four one-bin spectral slices) and the Cornell box with glass
+    (demos/cornell_box.py variant)."""
+    out = {}
+    world, prims = scenes.build_prism(NS)
+    cam, pipe = scenes.prism_camera(NS, world, (24, 18), 2, 4, 4)
+    out["prism_mean"], out["prism_var"], out["prism_n"] = observe_frame(cam, pipe, 81)
+    world, prims = scenes.build_cornell(NS)
+    cam, pipe = scenes.cornell_camera(NS, world, (20, 20), 3, 5)
+    out["cornell_mean"], out["cornell_var"], out["cornell_n"] = observe_frame(cam, pipe, 82)
+    save("f17_scenes", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -591,3 +605,4 @@ if __name__ == "__main__":
     if run("f14"): f14_glass()
     if run("f15"): f15_importance()
     if run("f16"): f16_rgb()
+    if run("f17"): f17_scenes()

@@ -753,6 +753,29 @@ def test_cornell_box_end_to_end(orc, ns):
     assert np.isfinite(rgb.xyz_frame.mean).all() and np.isfinite(rgb.rgb_frame).all()
 
 
+def test_prism_scene_against_oracle(orc, ns):
+    """BASELINE configs[4]'s scene (dispersive prism: nested analytic CSG through the state-free evaluator and the two-pass path
+    kernel, two Sellmeier glasses, importance sampling towards the prism, one-bin spectral slices): device frame = oracle frame
+    (the oracle reproduces the reference's frame of this scene bit for bit, fixture F17), ray statistics included."""
+    world, prims = scenes.build_prism(ns)
+    w, h, bins = 96, 64, 8
+    cam, pipe = scenes.prism_camera(ns, world, (w, h), 4, bins, bins)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=17)
+    cam.observe()
+    ref_m, ref_v, ref_rays = np.zeros((w, h, bins)), np.zeros((w, h, bins)), 0
+    for sl in cam._slice_spectrum():
+        keep = []
+        desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+        om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+        ref_rays += n_rays
+        ref_m[:, :, sl.offset:sl.offset + sl.bins] = om.reshape(h, w, sl.bins).transpose(1, 0, 2)
+        ref_v[:, :, sl.offset:sl.offset + sl.bins] = ov.reshape(h, w, sl.bins).transpose(1, 0, 2)
+    assert eq(pipe.frame.mean, ref_m) and eq(pipe.frame.variance, ref_v)
+    assert cam.stats["rays"] == ref_rays
+    assert (pipe.frame.mean > 0).mean() > 0.1
+
+
 def test_path_arena_grows_on_demand(ns):
     """Long paths: a closed furnace with a small emitter and roulette off makes paths hundreds of bounces long, far more terms than the
     arena a pass starts with (two blocks per ray). The pass is traced again with a larger arena (deterministic Philox paths) until it

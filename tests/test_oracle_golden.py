@@ -559,3 +559,19 @@ def test_rgb_pipeline_and_adaptive_sampler(orc, ns, golden):
     assert np.array_equal(np.array(sampler.generate_tasks((20, 16))), g["tasks2"])
     with pytest.raises(TypeError):
         ns.RGBAdaptiveSampler2D(ns.SpectralRadiancePipeline2D())
+
+
+# ---------------------------------------------------------------------------------------- F17 whole demo scenes
+def test_frames_demo_scenes(orc, ns, golden):
+    """The prism scene (BASELINE configs[4]: nested CSG + dispersive glass + importance sampling + spectral slices) and the Cornell box
+    with glass (configs[0]) against the reference's SerialEngine frames."""
+    g = golden("f17_scenes")
+    world, prims = scenes.build_prism(ns)
+    cam, pipe = scenes.prism_camera(ns, world, (24, 18), 2, 4, 4)
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 81)
+    assert eq(f[0], g["prism_mean"]) and eq(f[1], g["prism_var"]) and eq(f[2], g["prism_n"])
+    assert (f[0] > 0).mean() > 0.05
+    world, prims = scenes.build_cornell(ns)
+    cam, pipe = scenes.cornell_camera(ns, world, (20, 20), 3, 5)
+    f = _observe_oracle_mt(orc, ns, cam, pipe, 82)
+    assert eq(f[0], g["cornell_mean"]) and eq(f[1], g["cornell_var"]) and eq(f[2], g["cornell_n"])

@@ -44,6 +44,9 @@ elif config == "lambert_plain":           # the same room without the CSG solid 
 elif config == "cornell":                 # BASELINE configs[0]'s scene (demos/cornell_box.py variant): Lambert + glass, importance sampling
     world = scenes.build_cornell(ns)[0]
     cam, pipe = scenes.cornell_camera(ns, world, (1024, 1024), 16, 15)
+elif config == "prism":                   # BASELINE configs[4]'s scene (demos/prism.py variant), 32 one-bin spectral slices per pass
+    world = scenes.build_prism(ns)[0]
+    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), 4, 32, 32)
 elif config == "glass":                   # refraction scene (fixture F14's), 3 spectral slices
     world = scenes.build_glass(ns)[0]
     cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 15, 3, (0.01, 3, 500))
