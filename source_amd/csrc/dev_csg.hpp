@@ -215,10 +215,18 @@ __device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
 // roots (enter, exit); walking all leaf roots in increasing t, the first root across which "inside the solid" flips is the first
 // root the reference's merge accepts: csg_valid() is the truth table of exactly that flip, with "inside operand" read off the
 // exit flag of the operand's next root, and a nested node's stream is by induction the list of its own flips. The two orders can
-// differ only when two roots tie exactly (the merge prefers operand b, csg.pyx:231-234) or a leaf reports an inconsistent
-// enter/exit pattern (grazing): both are detected and sent to the stream merge, so results stay bit-identical.
+// differ only when a leaf reports an inconsistent enter/exit pattern (grazing), which is detected and sent to the stream merge.
+// Exact ties between roots of different leaves (coplanar faces, e.g. the two cutting boxes of demos/prism.py's prism) are taken
+// in the merge's own order: it prefers operand b at every node (csg.pyx:231-234), i.e. the later leaf in depth-first numbering.
 // Leaf roots live in the (idle) mesh-stack LDS levels: t in the f64 array, (face, axis, exit) packed in the i32 array.
 // Returns 1 = hit (cand filled), 0 = no hit, -1 = use the stream merge.
+#ifdef CSGF_COUNT
+__device__ double g_csgf_ex[8];                 // one example of a tie: idx, leaf a, leaf b, t, ray origin
+__device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fast_hit gave up [nan, enter/exit pattern, tie, steps]
+#define CSGF_WHY(k) atomicAdd(&g_csgf_why[k], 1ULL)
+#else
+#define CSGF_WHY(k)
+#endif
 __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const Stack &ms, Hit &cand) {
     const CsgFast &P = sc.csgfast[idx];
     const int lane = threadIdx.x % WAVE;
@@ -263,8 +271,8 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
         else cylinder_roots(leaf, ll, roots);
         for (int j = 0; j < roots.n; ++j) {
             const bool exiting = analytic_exiting(leaf, ll, roots.t[j], roots.a0[j], roots.a1[j]);
-            if (!(roots.t[j] == roots.t[j])) return -1;
-            if (exiting != (j == roots.n - 1)) return -1;    // convex solid: (enter, exit) or a lone exit; anything else: stream merge
+            if (!(roots.t[j] == roots.t[j])) { CSGF_WHY(0); return -1; }
+            if (exiting != (j == roots.n - 1)) { CSGF_WHY(1); return -1; }    // convex solid: (enter, exit) or a lone exit; anything else: stream merge
             lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
             lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((exiting ? 1 : 0) << 16);
         }
@@ -294,16 +302,15 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     for (int step = 0; step <= 2 * P.n_leaves; ++step) {
         int best = -1;
         double best_t = INFINITY;
-        bool tie = false;
         for (int k = 0; k < P.n_leaves; ++k) {
             const uint32_t c = (consumed >> (2 * k)) & 3u, n = (nroots >> (2 * k)) & 3u;
             if (c >= n) continue;
             const double t = lds_t[(2 * k + (int)c) * WAVE + lane];
-            if (best < 0 || t < best_t) { best = k; best_t = t; tie = false; }
-            else if (t == best_t) tie = true;
+            // exact ties go to the LATER leaf: leaves are numbered operand a before operand b at every node, and the reference's
+            // merge takes b's root when the two heads tie (csg.pyx:231-234), level by level
+            if (best < 0 || t <= best_t) { best = k; best_t = t; }
         }
         if (best < 0) return 0;
-        if (tie) return -1;
         const uint32_t before = inside_solid(consumed);
         const uint32_t c = (consumed >> (2 * best)) & 3u;
         consumed += 1u << (2 * best);

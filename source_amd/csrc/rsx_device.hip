@@ -287,7 +287,10 @@ extern "C" int rsx_set_stream(rsx_ctx *ctx, void *hip_stream) {
 extern "C" int rsx_synchronize(rsx_ctx *ctx) {
 #ifdef CSGF_COUNT
     { unsigned long long c[3] = {0, 0, 0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_csgf), sizeof(c));
-      std::fprintf(stderr, "csg_fast_hit: fallback %llu miss %llu hit %llu\n", c[0], c[1], c[2]); }
+      unsigned long long w[4] = {0, 0, 0, 0}; (void)hipMemcpyFromSymbol(w, HIP_SYMBOL(g_csgf_why), sizeof(w));
+      double ex[8]; (void)hipMemcpyFromSymbol(ex, HIP_SYMBOL(g_csgf_ex), sizeof(ex));
+      std::fprintf(stderr, "tie example: prim %g leaves %g %g t %.17g origin %.6f %.6f %.6f dx %.6f\n", ex[0], ex[1], ex[2], ex[3], ex[4], ex[5], ex[6], ex[7]);
+      std::fprintf(stderr, "csg_fast_hit: fallback %llu miss %llu hit %llu | why: nan %llu pattern %llu tie %llu\n", c[0], c[1], c[2], w[0], w[1], w[2]); }
 #endif
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     if (g_hp_on && g_hp_calls) {
