@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
 // projected on the channel's resampled CIE curve in bin order (spectrum_to_ciexyz, colour.pyx:176-186: x += delta * sample * curve),
 // scaled by the pixel sensitivity and fed to the same Welford recurrence as k_accumulate. The curves are rows xyz_table0 + channel of
 // the spectral tables. Outputs are per task: RGBPipeline2D sums them over the spectral slices on the host.
-template <bool VOL>
+template <int VOL>                      // 0 = no path terms, 1 = path terms, 2 = path terms with absorbing dielectrics (pow), as in k_accumulate
 __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_table0, double delta) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * 3;
@@ -1077,7 +1077,7 @@ __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_
                         const PathTerm tm = t[j];
                         const double tv = ap.tables[tm.table * ap.bins + b];
                         if (tm.kind == TERM_VOL) { const double emission = 0.0 + tv * tm.b; x = x + emission * tm.a; }
-                        else if (tm.kind == TERM_ATTEN) { if (tv != 1.0) x = x * pow(tv, tm.a); }
+                        else if (tm.kind == TERM_ATTEN) { if constexpr (VOL == 2) { if (tv != 1.0) x = x * pow(tv, tm.a); } }
                         else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                         else {
                             if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;

@@ -1164,17 +1164,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
     if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
     const dim3 acc_grid((unsigned)((total + 255) / 256));
+    bool has_dielectric = false;                            // an absorbing dielectric: only then do the terms need pow() (60 more registers)
+    for (int32_t i = 0; has_vol && i < desc->n_materials; ++i) {
+        if (desc->materials[i].type != RSX_MAT_DIELECTRIC) continue;
+        const double *row = desc->tables + (size_t)desc->materials[i].table * B;
+        for (size_t b = 0; b < B; ++b) has_dielectric = has_dielectric || row[b] != 1.0;
+    }
     if (h_xyz) {
         const dim3 xyz_grid((unsigned)(((long long)T * 3 + 255) / 256));
-        if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<true>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
-        else hipLaunchKernelGGL((k_accumulate_xyz<false>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
+        if (has_vol && has_dielectric) hipLaunchKernelGGL((k_accumulate_xyz<2>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
+        else if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<1>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
+        else hipLaunchKernelGGL((k_accumulate_xyz<0>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
     } else if (has_vol) {
-        bool has_dielectric = false;                        // an absorbing dielectric: only then do the terms need pow() (60 more registers)
-        for (int32_t i = 0; i < desc->n_materials; ++i) {
-            if (desc->materials[i].type != RSX_MAT_DIELECTRIC) continue;
-            const double *row = desc->tables + (size_t)desc->materials[i].table * B;
-            for (size_t b = 0; b < B; ++b) has_dielectric = has_dielectric || row[b] != 1.0;
-        }
         if (has_dielectric) {
             if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 2>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
             else hipLaunchKernelGGL((k_accumulate<false, 2>), acc_grid, dim3(256), 0, ctx->stream, ap);
