@@ -41,6 +41,9 @@
 #define WG_WAVES 4
 #endif
 #define WG_THREADS (WAVE * WG_WAVES)
+#ifndef RSX_COHERENT_MIN_SPP
+#define RSX_COHERENT_MIN_SPP 1      // passes with more samples per pixel than this run the always-stage instantiation of k_render_trace
+#endif
 #ifndef RSX_WORLD_LDS_LEVELS
 #define RSX_WORLD_LDS_LEVELS 3      // LDS-resident traversal stack entries per lane, world tree. 3 + 10 levels + the staging area are
                                     // 13.0 KB per wave = 52 KB per workgroup: three workgroups (three waves per SIMD) fit the 160 KB LDS
@@ -1123,7 +1126,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
         hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
-    else if (desc->spp > 1) {                               // coherent waves (several samples of a pixel side by side): always stage big leaves
+    else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         hipLaunchKernelGGL((k_render_trace<false, 0, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
     } else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);

@@ -19,7 +19,7 @@ if config == "c2":
     cam, pipe = scenes.c2_camera(ns, world, (1024, 1024), spp=1, bins=15)
 elif config == "c3":
     world = scenes.build_c3(ns, n=132)[0]
-    cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=4, bins=15)
+    cam, pipe = scenes.c3_camera(ns, world, (1024, 1024), spp=int(os.environ.get("KB_SPP", "4")), bins=15)
 elif config == "c3full":
     world = scenes.build_c3(ns, n=132)[0]
     cam, pipe = scenes.c3_camera(ns, world, (2048, 2048), spp=64, bins=15)
