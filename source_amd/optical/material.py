@@ -164,6 +164,10 @@ class Lambert(NullVolume):
         super().__init__()
         self.reflectivity = ConstantSF(0.5) if reflectivity is None else reflectivity
 
+    def evaluate_surface(self, *args, **kwargs):
+        raise NotImplementedError("Lambert is path traced on the device by the observers (observe()); a host-side evaluate_surface for "
+                                  "single Ray.trace() calls is not part of this build (there is no CPU rendering path)")
+
     def device_material(self, tables, min_wavelength, max_wavelength, bins):
         tables.append(self.reflectivity.sample(min_wavelength, max_wavelength, bins))
         return _record(_lib.MAT_LAMBERT, len(tables) - 1, 1.0)
@@ -195,6 +199,10 @@ class Dielectric(Material):
         self.transmission_only = bool(transmission_only)
         self.external_index = ConstantSF(1.0) if external_index is None else external_index
         self.importance = 1.0
+
+    def evaluate_surface(self, *args, **kwargs):
+        raise NotImplementedError("Dielectric is path traced on the device by the observers (observe()); a host-side evaluate_surface "
+                                  "for single Ray.trace() calls is not part of this build (there is no CPU rendering path)")
 
     def device_material(self, tables, min_wavelength, max_wavelength, bins):
         tables.append(self.transmission.sample(min_wavelength, max_wavelength, bins))
