@@ -46,7 +46,7 @@ elif config == "cornell":                 # BASELINE configs[0]'s scene (demos/c
     cam, pipe = scenes.cornell_camera(ns, world, (1024, 1024), 16, 15)
 elif config == "prism":                   # BASELINE configs[4]'s scene (demos/prism.py variant), 32 one-bin spectral slices per pass
     world = scenes.build_prism(ns)[0]
-    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), 4, 32, 32)
+    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), int(os.environ.get("KB_SPP", "4")), 32, 32)
 elif config == "glass":                   # refraction scene (fixture F14's), 3 spectral slices
     world = scenes.build_glass(ns)[0]
     cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 15, 3, (0.01, 3, 500))
