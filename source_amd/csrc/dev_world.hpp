@@ -19,12 +19,12 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
         if (is_csg(p.type)) {
             if constexpr (FASTONLY) {
                 int fast = -1;
-                if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * CSGF_MAX_LEAVES) fast = csg_fast_hit(sc, idx, r, mesh_stack, cand);
+                if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * sc.csgfast[idx].n_leaves) fast = csg_fast_hit(sc, idx, r, mesh_stack, cand);
                 if (fast <= 0) cand.prim = -1;
                 if (fast < 0) needs_stream = true;
                 return;
             }
-            if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * CSGF_MAX_LEAVES) {
+            if (sc.csgfast && sc.csgfast[idx].n_leaves > 0 && mesh_stack.lds_levels >= 2 * sc.csgfast[idx].n_leaves) {
                 const int fast = csg_fast_hit(sc, idx, r, mesh_stack, cand);
 #ifdef CSGF_COUNT
                 atomicAdd(&g_csgf[fast + 1], 1ULL);

@@ -527,6 +527,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     // flattened operand trees for the state-free first-hit evaluator (csg_fast_hit): analytic leaves only
     std::vector<CsgFast> fast;
     bool any_fast = false;
+    int fast_levels = 0;                                    // LDS levels csg_fast_hit needs: two root slots per leaf of the biggest tree
     if (sc->has_csg) {
         fast.assign((size_t)desc->n_primitives, CsgFast{});
         for (int32_t top = 0; top < desc->n_primitives; ++top) {
@@ -556,7 +557,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 if (i != top) chain.pop_back();
             };
             visit(top, 0);
-            if (ok && f.n_leaves > 0) { fast[(size_t)top] = f; any_fast = true; }
+            if (ok && f.n_leaves > 0) { fast[(size_t)top] = f; any_fast = true; fast_levels = std::max(fast_levels, 2 * f.n_leaves); }
         }
     }
 #define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
@@ -621,9 +622,9 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
-    if (any_fast) d.mdepth = std::max(d.mdepth, 2 * CSGF_MAX_LEAVES);   // csg_fast_hit keeps the leaf roots in the mesh-stack LDS levels
+    if (any_fast) d.mdepth = std::max(d.mdepth, fast_levels);           // csg_fast_hit keeps the leaf roots in the mesh-stack LDS levels
     d.wlds = std::min(d.wdepth, RSX_WORLD_LDS_LEVELS);
-    d.mlds = std::min(d.mdepth, std::max(RSX_MESH_LDS_LEVELS, any_fast ? 2 * CSGF_MAX_LEAVES : 0));
+    d.mlds = std::min(d.mdepth, std::max(RSX_MESH_LDS_LEVELS, fast_levels));
     if (const char *env = std::getenv("RSX_WORLD_LDS")) d.wlds = std::max(0, std::min(d.wdepth, std::atoi(env)));   // tuning aids
     if (const char *env = std::getenv("RSX_MESH_LDS")) d.mlds = std::max(0, std::min(d.mdepth, std::atoi(env)));
 #undef UP
