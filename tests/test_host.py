@@ -155,3 +155,21 @@ def test_rsm_reader_and_obj_io(ns, golden, tmp_path):
         f.write("f 1 2 3 4\n")
     with pytest.raises(ValueError):
         ns.import_obj(path)
+
+
+def test_combine_arrays_matches_scalar_law():
+    """The vectorised combine_samples used by RGBPipeline2D.finalise() performs the scalar restatement's operations element by
+    element: identical bits for every branch of the law (empty, single, many samples on either side)."""
+    import numpy as np
+    from source_amd.device import combine_arrays, combine_scalar
+    rng = np.random.RandomState(3)
+    n = 4000
+    mx, my = rng.normal(size=n), rng.normal(size=n)
+    vx, vy = rng.uniform(0, 2, n), rng.uniform(0, 2, n)
+    nx, ny = rng.randint(0, 7, n), rng.randint(0, 7, n)
+    nx[:200], ny[:200] = rng.randint(100, 100000, 200), rng.randint(1, 5, 200)
+    vx, vy = np.where(nx > 1, vx, 0.0), np.where(ny > 1, vy, 0.0)
+    m, v, c = combine_arrays(mx, vx, nx, my, vy, ny)
+    for i in range(n):
+        want = combine_scalar(mx[i], vx[i], int(nx[i]), my[i], vy[i], int(ny[i]))
+        assert (want[0], want[1], want[2]) == (m[i], v[i], c[i]), i
