@@ -42,6 +42,7 @@ struct CsgInfo {
 #define CSGF_MAX_CHAIN 6
 struct CsgFast {
     int32_t n_leaves, n_ops;
+    int32_t top_type, top_a_leaves;                   // the top node's operator and how many leaves its operand a holds (they come first)
     int32_t leaf[CSGF_MAX_LEAVES];
     int32_t parity[CSGF_MAX_LEAVES];
     int32_t chain_len[CSGF_MAX_LEAVES];

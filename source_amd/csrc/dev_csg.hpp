@@ -243,6 +243,9 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     double crx = l0rx, cry = l0ry, crz = l0rz;
     bool prefix_alive = true;
     for (int k = 0; k < P.n_leaves; ++k) {
+        // CSGPrimitive.hit's early exit (csg.pyx:148-150): operand a of an Intersect / Subtract has no root -> no hit, operand b is
+        // not even looked at
+        if (k == P.top_a_leaves && P.top_type != RSX_PRIM_UNION && nroots == 0) return 0;
         const int len = P.chain_len[k];
         bool sibling = k > 0 && P.chain_len[k - 1] == len;
         for (int j = 0; sibling && j + 1 < len; ++j) sibling = P.chain[k][j] == P.chain[k - 1][j];

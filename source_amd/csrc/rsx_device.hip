@@ -556,7 +556,14 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 }
                 if (i != top) chain.pop_back();
             };
-            visit(top, 0);
+            {   // operand a of the top node first: an Intersect / Subtract whose operand a has no root at all has none either (csg.pyx:148-150)
+                const rsx_primitive &tq = desc->primitives[top];
+                f.top_type = tq.type;
+                visit(tq.child_a, 0);
+                f.top_a_leaves = f.n_leaves;
+                visit(tq.child_b, tq.type == RSX_PRIM_SUBTRACT ? 1 : 0);
+                if (ok) f.ops[f.n_ops++] = tq.type == RSX_PRIM_UNION ? (int8_t)-1 : tq.type == RSX_PRIM_INTERSECT ? (int8_t)-2 : (int8_t)-3;
+            }
             if (ok && f.n_leaves > 0) { fast[(size_t)top] = f; any_fast = true; fast_levels = std::max(fast_levels, 2 * f.n_leaves); }
         }
     }
