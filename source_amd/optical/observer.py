@@ -357,6 +357,22 @@ class RGBPipeline2D(Pipeline2D):
         return out
 
 
+    def save(self, filename):
+        """rgb.pyx:517-531 — writes the sRGB image as an 8-bit PNG (row = image y, as the reference's transposed imsave). The
+        reference's auto-exposure is not mirrored: the image is xyz_frame.mean * display_sensitivity."""
+        import struct
+        import zlib
+        img = np.clip(np.transpose(self.rgb_frame, (1, 0, 2)) * 255.0 + 0.5, 0, 255).astype(np.uint8)
+        h, w, _ = img.shape
+        raw = b"".join(b"\x00" + img[y].tobytes() for y in range(h))
+
+        def chunk(tag, data):
+            return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xFFFFFFFF)
+        with open(filename, "wb") as f:
+            f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 8, 2, 0, 0, 0)) +
+                    chunk(b"IDAT", zlib.compress(raw, 6)) + chunk(b"IEND", b""))
+
+
 class RGBAdaptiveSampler2D(FrameSampler2D):
     """sampler2d.pyx:697-896 — re-samples the pixels whose normalised standard error (worst of X, Y, Z) lies in the top `fraction`
     of the image or above `cutoff`, and every pixel that has fewer than max(min_samples, max_samples / ratio) samples."""
