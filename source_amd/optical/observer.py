@@ -493,8 +493,7 @@ class _ObserverBase(Observer):
         for slice_id, template in enumerate(templates):
             self.render_engine.run(tasks, self._render_pixel, self._update_state,
                                    render_args=(slice_id, template), update_args=(slice_id,))
-        self._finalise_pipelines()
-        self.render_complete = True
+        self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
 
     def _slice_spectrum(self):                              # observer.pyx:311-340
         current, start, ranges = 0, 0, []

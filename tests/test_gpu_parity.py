@@ -751,6 +751,16 @@ def test_cornell_box_end_to_end(orc, ns):
     assert (after >= before).all() and after.max() == 16 and (after % 4 == 0).all()
     assert after.min() >= 8                                        # min_samples reached everywhere after the second pass
     assert np.isfinite(rgb.xyz_frame.mean).all() and np.isfinite(rgb.rgb_frame).all()
+    # render_complete (observer.pyx:265-309): False after a pass that rendered something, True once the sampler has nothing left to ask for
+    assert cam.render_complete is False
+    sampler = cam.frame_sampler
+    sampler.cutoff, sampler.min_samples, sampler.ratio = 1.0, 1, 1000.0
+    passes = 0
+    while not cam.render_complete and passes < 50:
+        cam.render_engine.sample_offset = (4 + passes) * 4
+        cam.observe()
+        passes += 1
+    assert cam.render_complete is True and passes < 50
 
 
 def test_prism_scene_against_oracle(orc, ns):
