@@ -235,6 +235,7 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     Ray l0 = to_local(sc.prims[idx], r);
     l0.maxd = INFINITY;
     uint32_t nroots = 0;                                     // 2 bits per leaf
+    uint32_t exitbits = 0;                                   // bit 2k + j: root j of leaf k is an exit
     // The chain of a leaf is walked from the top unless it only differs from the previous leaf's in its last entry (siblings):
     // then the parent-space ray, its reciprocals and the verdict of the gates above are kept. The reciprocals 1 / d are shared by
     // every box tested in one space (aabb_rcp: bit-identical to aabb).
@@ -278,6 +279,7 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             if (exiting != (j == roots.n - 1)) { CSGF_WHY(1); return -1; }    // convex solid: (enter, exit) or a lone exit; anything else: stream merge
             lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
             lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((exiting ? 1 : 0) << 16);
+            exitbits |= (exiting ? 1u : 0u) << (2 * k + j);
         }
         nroots |= (uint32_t)roots.n << (2 * k);
     }
@@ -288,7 +290,7 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             const int op = P.ops[o];
             if (op >= 0) {
                 const uint32_t c = (consumed >> (2 * op)) & 3u, n = (nroots >> (2 * op)) & 3u;
-                const uint32_t in = (c < n) && ((lds_m[(2 * op + (int)c) * WAVE + lane] >> 16) & 1);   // the next root is an exit
+                const uint32_t in = (c < n) && ((exitbits >> (2 * op + (int)c)) & 1u);                  // the next root is an exit
                 stack |= in << sp;
                 ++sp;
             } else {
