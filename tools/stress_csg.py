@@ -1,0 +1,104 @@
+#!/usr/bin/env python3
+"""One-off stress run on the GPU box for the state-free CSG evaluator: random operand trees of spheres, boxes and cylinders — many
+with deliberately coplanar faces and shared centres, so that exact ties between operand roots are common — hit by random, axis-parallel
+and grid-aligned rays; rsx_hit_batch (fast pass + stream-merge redo pass) against the oracle's stream merge: primitive id, distance,
+exiting flag and the full intersection geometry must be identical.   python tools/stress_csg.py [worlds] [rays_per_world]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from oracle import oracle as orc  # noqa: E402
+from source_amd import api as ns  # noqa: E402
+
+n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+rng = np.random.RandomState(12345)
+GRID = [-0.5, -0.25, 0.0, 0.25, 0.5]                         # coordinates snap to a grid: coincident faces and centres
+
+
+def snap():
+    return float(rng.choice(GRID)) if rng.rand() < 0.6 else float(rng.uniform(-0.5, 0.5))
+
+
+def leaf():
+    kind = rng.randint(3)
+    t = ns.translate(snap(), snap(), snap())
+    if rng.rand() < 0.4:
+        t = t * ns.rotate(float(rng.choice([0, 90, 30, 45])), float(rng.choice([0, 90, 30])), float(rng.choice([0, 90])))
+    if kind == 0:
+        return ns.Sphere(float(rng.choice([0.25, 0.5, 0.4])), transform=t)
+    if kind == 1:
+        lo = [float(rng.choice([-0.5, -0.25])) for _ in range(3)]
+        hi = [float(rng.choice([0.25, 0.5])) for _ in range(3)]
+        return ns.Box(ns.Point3D(*lo), ns.Point3D(*hi), transform=t)
+    return ns.Cylinder(float(rng.choice([0.25, 0.5])), float(rng.choice([0.5, 1.0])), transform=t)
+
+
+def tree(depth):
+    if depth == 0 or rng.rand() < 0.3:
+        return leaf()
+    op = [ns.Union, ns.Intersect, ns.Subtract][rng.randint(3)]
+    t = ns.translate(snap(), snap(), snap()) if rng.rand() < 0.5 else None
+    return op(tree(depth - 1), tree(depth - 1), transform=t) if t is not None else op(tree(depth - 1), tree(depth - 1))
+
+
+def count_leaves(p):
+    return count_leaves(p.primitive_a) + count_leaves(p.primitive_b) if hasattr(p, "primitive_a") else 1
+
+
+total = bad = hits = 0
+for wi in range(n_worlds):
+    world = ns.World()
+    made = 0
+    while made < 4:
+        obj = tree(3)
+        if not hasattr(obj, "primitive_a") or count_leaves(obj) > 8:
+            continue
+        obj.parent = world
+        obj.transform = ns.translate(float(rng.choice([-1.5, 0, 1.5])), float(rng.choice([-1.5, 0, 1.5])), 0.0) * (obj.transform or ns.translate(0, 0, 0))
+        obj.material = ns.AbsorbingSurface()
+        made += 1
+    n = n_rays
+    o = rng.uniform(-3, 3, (n, 3))
+    d = rng.normal(size=(n, 3))
+    k = n // 4                                                # a quarter axis-parallel from grid points: ties galore
+    axis = rng.randint(3, size=k)
+    o[:k] = rng.choice(GRID + [1.0, 1.5, 1.75, -1.5, -1.25], size=(k, 3))
+    d[:k] = 0.0
+    d[np.arange(k), axis] = rng.choice([-1.0, 1.0], size=k)
+    o[np.arange(k), axis] = -4.0 * d[np.arange(k), axis]
+    o[k:2 * k] = rng.choice(GRID + [1.5, -1.5], size=(k, 3)) + rng.choice([0.0, 3.0, -3.0], size=(k, 3))   # through grid points
+    d[k:2 * k] = rng.choice(GRID + [1.5, -1.5], size=(k, 3)) - o[k:2 * k] + 1e-300
+    norm = np.linalg.norm(d, axis=1)
+    d[norm < 1e-200] = [0.0, 0.0, 1.0]
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    m = np.where(rng.rand(n) < 0.2, rng.uniform(0.5, 6.0, n), np.inf)
+    scene = world.build_accelerator()
+    dev = scene.hit_batch(o, d, m, geometry=True)
+    ref = orc.hit_batch(world.flatten(), o, d, m, geometry=True, threads=orc.max_threads())
+    same = (dev["prim"] == ref["prim"])
+    hit = ref["prim"] >= 0
+    same &= np.where(hit, dev["t"] == ref["t"], True) & np.where(hit, dev["exiting"] == ref["exiting"], True)
+    geq = (dev["geom"] == ref["geom"]) | (np.isnan(dev["geom"]) & np.isnan(ref["geom"]))     # degenerate rays give NaN points on both sides
+    same &= np.where(hit[:, None], geq, True).all(axis=1)
+    total += n
+    hits += int(hit.sum())
+    bad += int((~same).sum())
+    if not same.all():
+        i = int(np.argmin(same))
+        print("world %d: %d mismatches, first at ray %d: device prim %d t %r, oracle prim %d t %r" %
+              (wi, int((~same).sum()), i, dev["prim"][i], dev["t"][i], ref["prim"][i], ref["t"][i]), flush=True)
+        print("   exiting", dev["exiting"][i], ref["exiting"][i], "\n   dev geom", dev["geom"][i].tolist(), "\n   ref geom", ref["geom"][i].tolist(),
+              "\n   ray", o[i].tolist(), d[i].tolist(), m[i])
+
+        def show(p, ind=0):
+            tr = p.transform
+            print("   " + " " * ind + type(p).__name__, [round(v, 4) for v in (tr.m if tr is not None else [])][3:12:4],
+                  getattr(p, "radius", ""), getattr(p, "height", ""), getattr(p, "lower", ""), getattr(p, "upper", ""))
+            if hasattr(p, "primitive_a"):
+                show(p.primitive_a, ind + 2); show(p.primitive_b, ind + 2)
+        show(world._primitives[int(ref["prim"][i])])
+print("%d worlds, %d rays, %d hits, mismatches: %d" % (n_worlds, total, hits, bad))
+sys.exit(1 if bad else 0)
