@@ -207,7 +207,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n,
             const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
             const rsx_primitive &p = sc.prims[idx];
             bool in;
-            if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);   // BoundPrimitive.contains: box gate first
+            if constexpr (CSG) {                                                                // BoundPrimitive.contains: box gate first
+                if (is_csg(p.type) && sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);   // flattened analytic tree
+                else in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
+            }
             else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
             inside[i * sc.n_world + idx] = in ? 1 : 0;
         }

@@ -48,7 +48,7 @@ def count_leaves(p):
     return count_leaves(p.primitive_a) + count_leaves(p.primitive_b) if hasattr(p, "primitive_a") else 1
 
 
-total = bad = hits = 0
+total = bad = hits = inside = 0
 for wi in range(n_worlds):
     world = ns.World()
     made = 0
@@ -83,6 +83,14 @@ for wi in range(n_worlds):
     same &= np.where(hit, dev["t"] == ref["t"], True) & np.where(hit, dev["exiting"] == ref["exiting"], True)
     geq = (dev["geom"] == ref["geom"]) | (np.isnan(dev["geom"]) & np.isnan(ref["geom"]))     # degenerate rays give NaN points on both sides
     same &= np.where(hit[:, None], geq, True).all(axis=1)
+    # contains(): the flattened operand program against the oracle's recursion, random and grid points (points on faces included)
+    pts = rng.uniform(-2.2, 2.2, (n // 2, 3))
+    pts[: n // 8] = rng.choice(GRID + [1.0, 1.5, 1.75, 2.0, -1.0, -1.5, -1.25, -2.0], size=(n // 8, 3))
+    cd, cr = scene.contains_batch(pts), orc.contains_batch(world.flatten(), pts)
+    if not np.array_equal(cd, cr):
+        print("world %d: contains() differs for %d points" % (wi, int((cd != cr).any(axis=1).sum())), flush=True)
+        bad += int((cd != cr).any(axis=1).sum())
+    inside += int(cr.sum())
     total += n
     hits += int(hit.sum())
     bad += int((~same).sum())
@@ -100,5 +108,5 @@ for wi in range(n_worlds):
             if hasattr(p, "primitive_a"):
                 show(p.primitive_a, ind + 2); show(p.primitive_b, ind + 2)
         show(world._primitives[int(ref["prim"][i])])
-print("%d worlds, %d rays, %d hits, mismatches: %d" % (n_worlds, total, hits, bad))
+print("%d worlds, %d rays, %d hits, %d point-in-solid positives, mismatches: %d" % (n_worlds, total, hits, inside, bad))
 sys.exit(1 if bad else 0)
