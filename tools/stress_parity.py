@@ -56,4 +56,14 @@ bad += run("glass", world, cam, pipe, tol=1e-12)
 world, _ = scenes.build_csg_demo(ns)
 cam, pipe = scenes.csg_camera(ns, world, (512 * K, 512 * K), spp=8, bins=5)
 bad += run("csg", world, cam, pipe)
+# primary-ray mesh scenes through the render kernels (coherent-pass instantiation at 16 spp, 1-spp instantiation), whole frames
+world = scenes.build_c3(ns, n=132)[0]
+cam, pipe = scenes.c3_camera(ns, world, (256 * K, 256 * K), spp=16, bins=3)
+bad += run("c3 16spp", world, cam, pipe)
+world = scenes.build_c2(ns, n=132)[0]
+cam, pipe = scenes.c2_camera(ns, world, (512 * K, 512 * K), spp=1, bins=3)
+bad += run("c2 1spp", world, cam, pipe)
+world = scenes.build_c2(ns, n=132, smoothing=True, with_normals=True)[0]
+cam, pipe = scenes.c2_camera(ns, world, (256 * K, 256 * K), spp=5, bins=3)
+bad += run("c2 smooth", world, cam, pipe)
 sys.exit(1 if bad else 0)
