@@ -48,7 +48,7 @@ def count_leaves(p):
     return count_leaves(p.primitive_a) + count_leaves(p.primitive_b) if hasattr(p, "primitive_a") else 1
 
 
-total = bad = hits = inside = 0
+total = bad = hits = inside = frames = 0
 for wi in range(n_worlds):
     world = ns.World()
     made = 0
@@ -91,6 +91,30 @@ for wi in range(n_worlds):
         print("world %d: contains() differs for %d points" % (wi, int((cd != cr).any(axis=1).sum())), flush=True)
         bad += int((cd != cr).any(axis=1).sum())
     inside += int(cr.sum())
+    # the same solids path traced: random scattering / refracting / emitting materials, an emitting shell around them — the path
+    # kernel's fast pass (state-free hit and contains), its redo pass and the term replay against the oracle, bit for bit
+    if wi % int(os.environ.get("STRESS_FRAME_EVERY", "4")) == 0:
+        mats = [ns.Lambert(ns.ConstantSF(0.8)), ns.Dielectric(ns.ConstantSF(1.5), ns.ConstantSF(1.0)), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.5),
+                ns.Lambert(ns.ConstantSF(0.5)), ns.NullMaterial(), ns.Dielectric(ns.ConstantSF(1.3), ns.ConstantSF(1.0), transmission_only=True)]
+        for prim in list(world._primitives):
+            prim.material = mats[rng.randint(len(mats))]
+        ns.Box(ns.Point3D(-4, -4, -4), ns.Point3D(4, 4, 4), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 1.0))
+        pipe = ns.SpectralRadiancePipeline2D()
+        cam = ns.PinholeCamera((96, 96), fov=60, parent=world, pipelines=[pipe], frame_sampler=ns.RectFrameSampler2D(), transform=ns.translate(0.2, 0.1, -3.5))
+        cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = 4, 3, 1, True
+        cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = 0.05, 2, 60
+        cam.render_engine = ns.HipEngine(rng="philox", seed=wi)
+        cam.observe()
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 96, 96))
+        om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+        fm = np.array(pipe.frame.mean)
+        rm = om.reshape(96, 96, 3).transpose(1, 0, 2)
+        diff = int(((fm != rm) & ~(np.isnan(fm) & np.isnan(rm))).sum())
+        frames += 1
+        if diff or cam.stats["rays"] != rays:
+            print("world %d: path-traced frame differs in %d entries (ray counts %d / %d)" % (wi, diff, cam.stats["rays"], rays), flush=True)
+            bad += max(diff, 1)
     total += n
     hits += int(hit.sum())
     bad += int((~same).sum())
@@ -108,5 +132,5 @@ for wi in range(n_worlds):
             if hasattr(p, "primitive_a"):
                 show(p.primitive_a, ind + 2); show(p.primitive_b, ind + 2)
         show(world._primitives[int(ref["prim"][i])])
-print("%d worlds, %d rays, %d hits, %d point-in-solid positives, mismatches: %d" % (n_worlds, total, hits, inside, bad))
+print("%d worlds, %d rays, %d hits, %d point-in-solid positives, %d path-traced frames, mismatches: %d" % (n_worlds, total, hits, inside, frames, bad))
 sys.exit(1 if bad else 0)
