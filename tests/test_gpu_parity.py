@@ -708,7 +708,6 @@ def test_lambert_furnace_full_size(ns):
     cam.render_engine = ns.HipEngine(rng="philox", seed=5)
     cam.observe()
     m, v = pipe.frame.mean, pipe.frame.variance
-    weight = None
     # radiance pipeline: sample = L * projection weight (cos of the pixel's ray to the optical axis), which varies by < 1e-6 inside a pixel
     assert np.isfinite(m).all() and (m > 0).all()
     desc_cam = cam.device_camera()
@@ -731,8 +730,6 @@ def test_cornell_box_end_to_end(orc, ns):
     cam.frame_sampler = ns.RGBAdaptiveSampler2D(rgb, ratio=4, fraction=0.3, min_samples=8, cutoff=0.01)
     cam.render_engine = ns.HipEngine(rng="philox", seed=3)
     cam.observe()
-    tasks = None
-    import random as pyrandom
     # oracle for pass 1: the sampler's first task list is the full frame (x outer, y inner, shuffled) — order does not matter in Philox mode
     keep = []
     full = [(x, y) for x in range(48) for y in range(48)]
