@@ -173,6 +173,14 @@ class DeviceScene:
 _private_scenes = weakref.WeakKeyDictionary()
 
 
+def _geometry_versions(prim):
+    out = [getattr(prim, "_geometry_version", 0)]
+    for operand in (getattr(prim, "_primitive_a", None), getattr(prim, "_primitive_b", None)):
+        if operand is not None:
+            out.append(_geometry_versions(operand))
+    return tuple(out)
+
+
 def scene_for_primitive(prim):
     """Device scene able to answer Primitive.hit()/contains() for `prim`: the owning world's scene when the primitive
     is registered with a World, otherwise a private one-primitive scene (its own scenegraph root)."""
@@ -183,7 +191,9 @@ def scene_for_primitive(prim):
         scene = root.build_accelerator()
         return scene, scene.flat.index_of[id(prim)]
     cached = _private_scenes.get(prim)
-    key = (tuple(prim.to_root().m), id(root))
+    # geometry edits of an unregistered primitive reach no World (Node._change is a no-op): its own version counter, bumped by
+    # notify_geometry_change(), is part of the key — operands of a CSG primitive report through the CSG root to the CSG primitive
+    key = (tuple(prim.to_root().m), id(root), _geometry_versions(prim))
     if cached is None or cached[0] != key:
         cached = (key, DeviceScene(FlatScene([prim])))
         _private_scenes[prim] = cached

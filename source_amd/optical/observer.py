@@ -54,13 +54,19 @@ class HipEngine(RenderEngine):
     reference's SerialEngine: 2 uniforms per sample in task order) — bit-parity mode for primary-ray scenes.
     ``fused=True`` merges results into the pipelines' device frames; ``fused=False`` follows the RenderEngine
     contract literally (update(packed_result) per task), which is what a stock raysect pipeline needs.
+
+    Philox sample counters: pass p of an observer draws the counters ``sample_offset + p * pixel_samples ...`` — consecutive
+    observe() calls of one observer never reuse a (pixel, sample) counter, like the reference's engines, which draw fresh random
+    numbers every pass. Assigning ``engine.sample_offset`` between passes restarts the count from the assigned value (that is how
+    the multi-GPU shards place their samples, source_amd/distributed.py).
     """
 
-    def __init__(self, rng="philox", seed=0, fused=True, timing=True, sample_offset=0):
+    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
         self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
-        self.timing = bool(timing)          # read back HIP-event kernel times after each slice (forces a sync)
+        self.timing = bool(timing)          # True: read back HIP-event kernel times after each library call (one stream sync per call:
+                                            # a tuning aid, it defeats the pipelined render lanes)
         self.sample_offset = int(sample_offset)
         self.last_kernel_ms = None
 
@@ -452,6 +458,7 @@ class _ObserverBase(Observer):
         self.quiet = quiet or False
         self.render_complete = False
         self.stats = {}
+        self._auto_key, self._auto_offset = None, 0         # Philox counters handed out by earlier passes (see pass_sample_offset)
 
     @property
     def min_wavelength(self):
@@ -490,10 +497,25 @@ class _ObserverBase(Observer):
             return
         self._slices = slices
         self.stats = {"rays": 0, "kernel_ms": 0.0}
+        self._pass_offset = self.pass_sample_offset(self.render_engine)
         for slice_id, template in enumerate(templates):
             self.render_engine.run(tasks, self._render_pixel, self._update_state,
                                    render_args=(slice_id, template), update_args=(slice_id,))
+        self._auto_offset += self._samples_per_pass()
         self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
+
+    def pass_sample_offset(self, engine):
+        """First Philox sample counter of the pass about to be rendered: the engine's sample_offset plus the samples this observer's
+        earlier passes drew with that same setting. The reference's engines draw fresh random numbers every pass (one running
+        MT19937-64 stream, core/math/random.pyx); with counter-based numbers that means: never hand out a counter twice. Assigning
+        engine.sample_offset (or another engine) restarts the count at the assigned value."""
+        key = (id(engine), getattr(engine, "sample_offset", 0), getattr(engine, "seed", 0))
+        if key != self._auto_key:
+            self._auto_key, self._auto_offset = key, 0
+        return getattr(engine, "sample_offset", 0) + self._auto_offset
+
+    def _samples_per_pass(self):
+        return 0
 
     def _slice_spectrum(self):                              # observer.pyx:311-340
         current, start, ranges = 0, 0, []
@@ -583,6 +605,9 @@ class Observer2D(_ObserverBase):
     def _generate_tasks(self):
         return self._frame_sampler.generate_tasks(self._pixels)
 
+    def _samples_per_pass(self):
+        return self._pixel_samples
+
     def _initialise_pipelines(self, min_wavelength, max_wavelength, spectral_bins, slices, quiet):
         for p in self._pipelines:
             p.initialise(self._pixels, self._pixel_samples, min_wavelength, max_wavelength, spectral_bins, slices, quiet)
@@ -663,8 +688,9 @@ class PinholeCamera(Observer2D):
         return cam
 
     # -- the device path --------------------------------------------------------------------------
-    def render_desc(self, world, tasks, slice_, engine, keep, rect=None):
-        """Builds the rsx_render_desc for one spectral slice. ``keep`` collects arrays that must outlive the call."""
+    def render_desc(self, world, tasks, slice_, engine, keep, rect=None, sample_offset=None):
+        """Builds the rsx_render_desc for one spectral slice. ``keep`` collects arrays that must outlive the call.
+        ``sample_offset``: first Philox sample counter (default: the engine's; observe() passes pass_sample_offset())."""
         tables = []
         mats = [p.material.device_material(tables, slice_.min_wavelength, slice_.max_wavelength, slice_.bins) for p in world._primitives]
         desc = _lib.RenderDesc()
@@ -707,7 +733,7 @@ class PinholeCamera(Observer2D):
             # observer.pyx:299-305): the slice offset is folded into the key; slice 0 keeps the engine's seed
             key = (engine.seed + slice_.offset * 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
             desc.uniforms, desc.rng_mode, desc.seed = None, _lib.RNG_PHILOX, key
-            desc.sample_offset = engine.sample_offset
+            desc.sample_offset = engine.sample_offset if sample_offset is None else int(sample_offset)
         return desc
 
     def _render_xyz(self, scene, desc, pipe, slice_id, tasks, rect, rays):
@@ -726,6 +752,21 @@ class PinholeCamera(Observer2D):
             xs, ys = t[:, 0], t[:, 1]
         pipe.update_block(xs, ys, mean, var)
 
+    def _pieces(self, tasks, world):
+        """One library call renders at most MAX_RAYS_PER_CALL rays (its sample-record buffer is 24 B per ray): larger slices go
+        band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
+        and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut."""
+        limit = self.MAX_RAYS_PER_CALL
+        from .material import NullSurface, Lambert, Dielectric
+        if any(isinstance(p.material, (NullSurface, Lambert, Dielectric)) for p in world._primitives):
+            limit = min(limit, 1 << 24)                     # the volume path also keeps 768 B of emission terms per ray
+        per_call = max(1, limit // self._pixel_samples)
+        if isinstance(tasks, RectTasks):
+            x0, y0, x1, y1 = tasks.rect
+            band = max(1, per_call // max(1, y1 - y0))
+            return [dict(rect=(xa, y0, min(xa + band, x1), y1)) for xa in range(x0, x1, band)]
+        return [dict(tasks=tasks[a:a + per_call]) for a in range(0, len(tasks), per_call)]
+
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
         world = self.root
         scene = world.build_accelerator()
@@ -733,23 +774,10 @@ class PinholeCamera(Observer2D):
         keep = []
         L = _lib.lib()
         rays = C.c_uint64(0)
-        if engine.fused:
-            # One library call renders at most MAX_RAYS_PER_CALL rays (its sample-record buffer is 24 B per ray): larger slices go
-            # band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
-            # and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut.
-            limit = self.MAX_RAYS_PER_CALL
-            from .material import NullSurface, Lambert, Dielectric
-            if any(isinstance(p.material, (NullSurface, Lambert, Dielectric)) for p in world._primitives):
-                limit = min(limit, 1 << 24)                 # the volume path also keeps 768 B of emission terms per ray
-            per_call = max(1, limit // self._pixel_samples)
-            if isinstance(tasks, RectTasks):
-                x0, y0, x1, y1 = tasks.rect
-                band = max(1, per_call // max(1, y1 - y0))
-                pieces = [dict(rect=(xa, y0, min(xa + band, x1), y1)) for xa in range(x0, x1, band)]
-            else:
-                pieces = [dict(tasks=tasks[a:a + per_call]) for a in range(0, len(tasks), per_call)]
-            for piece in pieces:
-                desc = self.render_desc(world, piece.get("tasks"), sl, engine, keep, rect=piece.get("rect"))
+        offset = getattr(self, "_pass_offset", None)
+        for piece in self._pieces(tasks, world):
+            desc = self.render_desc(world, piece.get("tasks"), sl, engine, keep, rect=piece.get("rect"), sample_offset=offset)
+            if engine.fused:
                 for pipe in self._pipelines:
                     if isinstance(pipe, RGBPipeline2D):
                         self._render_xyz(scene, desc, pipe, slice_id, piece.get("tasks"), piece.get("rect"), rays)
@@ -764,11 +792,8 @@ class PinholeCamera(Observer2D):
                         self.stats["kernel_ms"] = self.stats.get("kernel_ms", 0.0) + tr
                         self.stats["accumulate_ms"] = self.stats.get("accumulate_ms", 0.0) + ac
                 self.stats["rays"] = self.stats.get("rays", 0) + rays.value
-        else:
-            if isinstance(tasks, RectTasks):
-                desc = self.render_desc(world, None, sl, engine, keep, rect=tasks.rect)
-            else:
-                desc = self.render_desc(world, tasks, sl, engine, keep)
+                continue
+            # RenderEngine contract taken literally (workflow.py:78-91): per-task (mean, variance) blocks, update() once per task
             n = desc.n_tasks
             results = []
             for pipe in self._pipelines:
@@ -782,6 +807,8 @@ class PinholeCamera(Observer2D):
                 mean, var = np.zeros((n, sl.bins)), np.zeros((n, sl.bins))
                 _lib.check(L.rsx_render_pinhole(scene.handle, C.byref(desc), _lib.ptr(mean), _lib.ptr(var), C.byref(rays)))
                 results.append((mean, var))
-            for k, task in enumerate(tasks):
-                packed = (tuple(task), [(m[k], v[k]) for m, v in results], self._pixel_samples)
+            piece_tasks = piece["tasks"] if "tasks" in piece else RectTasks(*piece["rect"])    # rect blocks come back row-major, like RectTasks iterates
+            ray_share, ray_rest = divmod(int(rays.value), max(1, n))
+            for k, task in enumerate(piece_tasks):
+                packed = (tuple(task), [(m[k], v[k]) for m, v in results], ray_share + (1 if k < ray_rest else 0))
                 update(packed, *update_args, **update_kwargs)

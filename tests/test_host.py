@@ -173,3 +173,64 @@ def test_combine_arrays_matches_scalar_law():
     for i in range(n):
         want = combine_scalar(mx[i], vx[i], int(nx[i]), my[i], vy[i], int(ny[i]))
         assert (want[0], want[1], want[2]) == (m[i], v[i], c[i]), i
+
+
+def test_material_primitive_lists_and_world_accelerator(ns):
+    """primitive.pyx:62-96: a material knows the primitives it coats (the setter moves the primitive between the lists);
+    world.pyx:59-70: World.accelerator exists, defaults to the device accelerator and accepts any Accelerator-shaped object."""
+    from source_amd.core.scenegraph import Accelerator, HipAccelerator
+    world = ns.World()
+    a, b = ns.AbsorbingSurface(), ns.AbsorbingSurface()
+    s = ns.Sphere(0.5, world, material=a)
+    assert a.primitives == [s] and b.primitives == []
+    s.material = b
+    assert a.primitives == [] and b.primitives == [s]
+    with pytest.raises(TypeError):
+        s.material = 3
+    assert isinstance(world.accelerator, HipAccelerator)
+    with pytest.raises(TypeError):
+        world.accelerator = object()
+
+    class Recorder(Accelerator):
+        def __init__(self):
+            self.built = None
+
+        def build(self, primitives):
+            self.built = list(primitives)
+
+        def hit(self, ray):
+            return "hit"
+
+        def contains(self, point):
+            return ["contains"]
+    world.accelerator = Recorder()
+    assert world._rebuild_accelerator is True
+    # geometry edits of a primitive without a World bump its private version (device.scene_for_primitive keys its cache on it)
+    free = ns.Sphere(0.5)
+    v0 = free._geometry_version
+    free.radius = 0.75
+    assert free._geometry_version == v0 + 1
+
+
+def test_philox_counters_advance_between_passes(ns):
+    """Consecutive observe() passes of one observer must not reuse Philox (pixel, sample) counters (the reference's engines draw
+    fresh numbers every pass); assigning engine.sample_offset restarts the count from the assigned value."""
+    from source_amd import scenes
+    world = scenes.build_c2(ns, n=8)[0]
+    cam, pipe = scenes.c2_camera(ns, world, (8, 8), spp=5, bins=3)
+    eng = ns.HipEngine(rng="philox", seed=1)
+    seen = []
+    cam._render_slice_device = lambda *a, **k: seen.append(cam._pass_offset)     # no GPU here: record what a pass would draw
+    cam.render_engine = eng
+    world.build_accelerator = lambda force=False: None
+    cam.observe(); cam.observe()
+    cam.pixel_samples = 7
+    cam.observe(); cam.observe()
+    assert seen == [0, 5, 10, 17]
+    eng.sample_offset = 100                                                      # explicit placement (multi-GPU shards): restart there
+    cam.observe(); cam.observe()
+    assert seen[4:] == [100, 107]
+    eng.sample_offset = 100
+    cam.observe()
+    assert seen[6] == 114                                                        # same value re-assigned: the count carries on
+    assert ns.HipEngine().timing is False

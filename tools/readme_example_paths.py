@@ -13,7 +13,6 @@ cam.frame_sampler = rs.RGBAdaptiveSampler2D(rgb, ratio=10, fraction=0.2, min_sam
 cam.render_engine = rs.MulticoreEngine()
 passes = 0
 while not cam.render_complete and passes < 40:
-    cam.render_engine.sample_offset = passes * 16
     cam.observe()
     passes += 1
 out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "cornell.png")
