@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """
-bench.py — primary rays/s of the hot path on MI355X (BASELINE.json metric), with the kernel's roofline position
-and the CPU baseline timed in the same run.
+bench.py — primary rays/s of the hot path on MI355X (BASELINE.json metric), with the dominant kernel located against its
+ceilings (counters collected in this same run) and the CPU baseline timed in the same run.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -9,20 +9,31 @@ and the CPU baseline timed in the same run.
 Workload (default, --workload c3): BASELINE.json configs[2], the configuration the metric is quoted on — the ~1M-triangle
 instanced scene (15 instances of the 69 432-triangle Stanford-bunny stand-in of source_amd/scenes.py + floor box),
 PinholeCamera 2048x2048, 64 samples/pixel/pass, 15 spectral bins, primary rays only (closed-form materials).
-One "step" = one observe() pass over the whole frame = 268 435 456 primary rays: ray generation (Philox jitter) ->
+One "step" = one observe() pass over the frame = 268 435 456 primary rays at N = 1: ray generation (Philox jitter) ->
 two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford over the 64 samples, merged into the
 device-resident spectral frame. Scene, camera tables and the frame are resident in HBM when the timed region starts.
 --workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass); --workload c4 = configs[3] (demos/csg.py
 tree, 1024x1024, 16 spp/pass); --workload flat = one 1M-triangle mesh without instancing (geometry far larger than L2).
 
-N>1: sample sharding — every rank renders the same frame with its own sample counters (weak scaling: per-GPU work is
-fixed); the only collective is one RCCL all_gather of the (mean, variance, samples) frames after the K passes, followed
-by the combine_samples merge on every rank. That collective is inside the timed region.
+N > 1 (one process per GPU; control plane = torch.distributed/gloo for rendezvous and barriers, data plane = RCCL called
+from librsx, include/rsx.h rsx_allgather_frame / rsx_allreduce_frame):
+  --sharding tile (default; BASELINE configs[2] "1->8 MI355X tile-sharded"): rank r renders the column tile
+      tile_rect(r, N) of every pass; after the K passes ONE all-gather of the x-major frame shards, inside the timed region.
+      Total work is fixed ("scaling": "strong"); the gathered frame is bit-identical to a one-GPU render — rank 0 re-renders the
+      whole frame alone after the timed region and compares SHA-256 digests (config.frame_digest_equals_single_gpu).
+  --sharding sample: every rank renders the whole frame with its own Philox sample counters (weak scaling), then ONE
+      combine_samples all-reduce (reduce-scatter + all-gather over point-to-point xGMI links), inside the timed region.
 """
 import argparse
+import csv
+import glob
+import hashlib
 import json
 import os
+import shutil
+import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,22 +41,33 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-PEAK_HBM_GBS = 8000.0       # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+# /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+PEAK_L2_GBS = 34500.0       # aggregate L2 bandwidth (8 XCDs)
+N_CUS, SIMDS_PER_CU, CLOCK_GHZ = 256, 4, 2.4
+PEAK_L1_GBS = N_CUS * 64 * CLOCK_GHZ          # per-CU vector cache: 64 B / clk / CU
+VALU_CYCLES_PER_WAVE_INSTR = 4                # a wave64 VALU instruction occupies its SIMD's 16 lanes for 4 cycles (f64 / integer rate)
 BINS = 15
 WORKLOADS = {
     "c3": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
                name="configs[2]: 1 041 480-triangle instanced scene (15 instances of the 69 432-triangle Stanford-bunny stand-in + floor "
-                    "box), PinholeCamera 2048x2048, 64 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
+                    "box), PinholeCamera 2048x2048, 64 spp/pass, 15 spectral bins, primary rays only"),
     "c2": dict(nx=1024, ny=1024, spp=1, counter_rows=8,
                name="configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera 1024x1024, 1 spp/pass, "
-                    "15 spectral bins, primary rays only, 1 MI355X per rank"),
+                    "15 spectral bins, primary rays only"),
     "flat": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
                  name="HBM stress (SURVEY.md 8d M1M-flat): ONE 1 047 552-triangle displaced-sphere mesh (no instancing), PinholeCamera "
-                      "2048x2048, 64 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
+                      "2048x2048, 64 spp/pass, 15 spectral bins, primary rays only"),
     "c4": dict(nx=1024, ny=1024, spp=16, counter_rows=8,
                name="configs[3]: demos/csg.py Boolean tree (sphere/box/cylinder Union/Intersect/Subtract, 5 CSG objects), PinholeCamera "
-                    "1024x1024, 16 spp/pass, 15 spectral bins, primary rays only, 1 MI355X per rank"),
+                    "1024x1024, 16 spp/pass, 15 spectral bins, primary rays only"),
 }
+PMC_GROUPS = [
+    ["FETCH_SIZE"],                                                               # 3 of the 4 TCC slots
+    ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],                                # 2 + 1 + 1 TCC slots
+    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
+     "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"],                                 # 8 SQ slots + 1 GRBM
+]
 
 
 def build_workload(key, ns, scenes):
@@ -73,11 +95,112 @@ def ray_bytes(counters, n_rays):
     return b, per
 
 
-def _lib_combine(ctx, m, v, n, mb, vb, nb):
-    """combine_samples law applied in place on the device (rsx_frame_combine_dev) to torch tensors."""
-    from source_amd import _lib
-    _lib.check(_lib.lib().rsx_frame_combine_dev(ctx.handle, m.numel(), m.data_ptr(), v.data_ptr(), n.data_ptr(),
-                                                mb.data_ptr(), vb.data_ptr(), nb.data_ptr()))
+def child_main(args):
+    """--child: a few un-timed passes of the workload and nothing else — the command the parent runs under `rocprofv3 --pmc`."""
+    import __graft_entry__ as ge
+    ge.build_librsx()
+    from source_amd import api as ns, scenes
+    from source_amd.device import get_context
+    world, cam, pipe = build_workload(args.workload, ns, scenes)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=20250905)
+    world.build_accelerator()
+    for _ in range(max(1, args.steps)):
+        cam.observe()
+    get_context().synchronize()
+
+
+def collect_pmc(workload, passes, keep_dir=None):
+    """Runs `rocprofv3 --pmc <group> -- python bench.py --child` once per counter group (the HBM counters in their own passes, never
+    together with a trace option: /opt/skills/guides/MI355X_MICROARCH.md) and returns {kernel: {counter: mean per launch}}, or
+    (None, reason)."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    out_root = tempfile.mkdtemp(prefix="rsx_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp", RSX_PIPELINE="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    table, errors = {}, []
+    for gi, group in enumerate(PMC_GROUPS):
+        out = os.path.join(out_root, "g%d" % gi)
+        cmd = [rocprof, "--pmc", *group, "-d", out, "-o", "k", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+               "--child", "--workload", workload, "--steps", str(passes)]
+        try:
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
+        except subprocess.TimeoutExpired:
+            errors.append("group %d timed out" % gi)
+            continue
+        files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+        if r.returncode != 0 or not files:
+            errors.append("group %d: rc %d, %s" % (gi, r.returncode, r.stdout.decode(errors="replace")[-300:].replace("\n", " | ")))
+            continue
+        acc = {}
+        for f in files:
+            for row in csv.DictReader(open(f)):
+                kern = row["Kernel_Name"].split("(")[0].replace("void ", "")
+                if "rocclr" in kern:
+                    continue
+                acc.setdefault((kern, row["Counter_Name"]), []).append(float(row["Counter_Value"]))
+        for (kern, counter), vals in acc.items():
+            table.setdefault(kern, {})[counter] = sum(vals) / len(vals)
+            table[kern]["launches"] = len(vals)
+    if keep_dir:
+        os.makedirs(keep_dir, exist_ok=True)
+        with open(os.path.join(keep_dir, "pmc_%s.json" % workload), "w") as f:
+            json.dump({"command": "rocprofv3 --pmc <group> -- python bench.py --child --workload %s --steps %d (one run per group)" % (workload, passes),
+                       "groups": PMC_GROUPS, "kernels": table, "errors": errors}, f, indent=1, sort_keys=True)
+    shutil.rmtree(out_root, ignore_errors=True)
+    if not table:
+        return None, "; ".join(errors) or "no counters collected"
+    return table, "; ".join(errors)
+
+
+def kernel_counters(table, prefix):
+    """Counters of the kernel whose name starts with `prefix` (the instantiation with the most SIMD time when several ran)."""
+    best = None
+    for kern, c in table.items():
+        if kern.startswith(prefix) and (best is None or c.get("GRBM_GUI_ACTIVE", 0) * c.get("launches", 1) > best[1].get("GRBM_GUI_ACTIVE", 0) * best[1].get("launches", 1)):
+            best = (kern, c)
+    return best
+
+
+def ceilings(c, kernel_ms, algorithmic_gbs):
+    """Locates one kernel against its ceilings from the counters of the profiled run. Returns (dict, name of the binding ceiling)."""
+    out = {}
+    secs = kernel_ms * 1e-3
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        # rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-B reads at 64 B: doubled (guide, §HBM)
+        hbm_bytes = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
+        out["hbm_measured"] = {"bytes_per_launch": int(hbm_bytes), "achieved_gbs": round(hbm_bytes / secs / 1e9, 1), "peak_gbs": PEAK_HBM_GBS,
+                               "frac": round(hbm_bytes / secs / 1e9 / PEAK_HBM_GBS, 4)}
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        req = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
+        out["l2"] = {"hit_rate": round(c["TCC_HIT_sum"] / max(1.0, req), 4), "requests_per_launch": int(req),
+                     "achieved_gbs": round(req * 128 / secs / 1e9, 1), "peak_gbs": PEAK_L2_GBS, "frac": round(req * 128 / secs / 1e9 / PEAK_L2_GBS, 4),
+                     "note": "requests x 128-B lines (upper estimate)"}
+    # the algorithmic bytes (node / triangle / primitive records every ray reads) are served by the per-CU vector caches
+    out["l1_vector_cache"] = {"achieved_gbs": round(algorithmic_gbs, 1), "peak_gbs": PEAK_L1_GBS, "frac": round(algorithmic_gbs / PEAK_L1_GBS, 4),
+                              "note": "algorithmic bytes / (64 B/clk/CU x 256 CUs x 2.4 GHz)"}
+    if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; SQ_* cycle counters tick every 4 cycles (guide: quad-cycles)
+        simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_CUS * SIMDS_PER_CU
+        busy = c["SQ_ACTIVE_INST_VALU"] * 4
+        out["valu_issue"] = {"valu_busy_cycles": int(busy), "simd_cycles": int(simd_cycles), "frac": round(busy / simd_cycles, 4),
+                             "wave_instructions": int(c.get("SQ_INSTS_VALU", 0)),
+                             "issue_model_frac": round(c.get("SQ_INSTS_VALU", 0) * VALU_CYCLES_PER_WAVE_INSTR / simd_cycles, 4),
+                             "lane_utilisation": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
+                             "wave_wait_frac": round(c.get("SQ_WAIT_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4),
+                             "effective_clock_ghz": round(c["GRBM_GUI_ACTIVE"] / 8.0 / secs / 1e9, 3)}
+    binding = max(out, key=lambda k: out[k]["frac"]) if out else None
+    return out, binding
+
+
+def frame_digest(frame):
+    h = hashlib.sha256()
+    for a in (frame.mean, frame.variance, frame.samples):
+        h.update(np.ascontiguousarray(a).tobytes())
+    return h.hexdigest()[:32]
 
 
 def main():
@@ -88,39 +211,79 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--sharding", choices=["auto", "tile", "sample"], default="auto", help="N > 1: tile (strong scaling, default) or sample (weak)")
+    ap.add_argument("--collective", choices=["rsx", "torch"], default="rsx", help="N > 1 data plane: RCCL from librsx (default) or torch.distributed")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
+    ap.add_argument("--pmc-keep", default=None, help="directory that receives the PMC summary of this run (e.g. profiles/r02)")
+    ap.add_argument("--no-verify", action="store_true", help="tile sharding: skip the one-GPU re-render digest check")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.child:
+        return child_main(args)
     W = WORKLOADS[args.workload]
     NX, NY, SPP = W["nx"], W["ny"], W["spp"]
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
-    dist = None
-    torch = None
-    if args.gpus > 1 or world_size > 1 or "RANK" in os.environ:      # launched by torch.distributed.run: take the collective path even for 1 rank
+    dist = torch = None
+    distributed = args.gpus > 1 or world_size > 1 or "RANK" in os.environ     # launched by torch.distributed.run: take the collective path even for 1 rank
+    collective = args.collective if distributed else "none"
+    if distributed:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if collective == "torch":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")                   # control plane only: rendezvous, barriers, the RCCL unique id
         world_size = dist.get_world_size()
+    sharding = "none" if world_size == 1 and not distributed else ("tile" if args.sharding == "auto" else args.sharding)
     os.environ["RSX_DEVICE"] = str(local_rank)
 
     import __graft_entry__ as ge
     ge.build_librsx()                                      # no-op when the in-tree .so is fresh
     from source_amd import api as ns, scenes
+    from source_amd import distributed as D
     from source_amd.device import get_context
-    from source_amd.distributed import rank_sample_offset
 
     world, cam, pipe = build_workload(args.workload, ns, scenes)
-    cam.frame_sampler = ns.RectFrameSampler2D()
-    engine = ns.HipEngine(rng="philox", seed=20250905, timing=False)
+    my_rect = D.tile_rect(rank, world_size, NX, NY) if sharding == "tile" else (0, 0, NX, NY)
+    cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
+    engine = ns.HipEngine(rng="philox", seed=20250905)
     cam.render_engine = engine
     ctx = get_context()
     scene = world.build_accelerator()                      # flatten + KD build (host) + upload: outside the timed region
 
+    def all_agree(ok):
+        if dist is None:
+            return ok
+        t = torch.tensor([1 if ok else 0], dtype=torch.int32, device="cuda" if collective == "torch" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        return bool(t.item())
+
+    comm, comm_note = None, None
+    if collective == "rsx":
+        def exchange(payload):
+            box = [payload]
+            dist.broadcast_object_list(box, src=0)
+            return box[0]
+        try:
+            comm = D.FrameComm(ctx, rank, world_size, exchange)
+            ok = True
+        except Exception as e:                              # librccl missing / communicator refused: say so and take the torch path
+            comm_note, ok = "rsx_comm unavailable (%s)" % e, False
+        if not all_agree(ok):
+            if comm is not None:
+                comm.close()
+            comm, collective = None, "torch"
+            comm_note = comm_note or "rsx_comm unavailable on another rank"
+            dist.destroy_process_group()
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
     frames = None
-    if dist is not None:
-        # frame storage = torch tensors so RCCL can move them; librsx writes through the raw device pointers
+    if collective == "torch":
+        # frame storage = torch tensors so torch.distributed can move them; librsx writes through the raw device pointers
         ctx.set_stream(torch.cuda.current_stream().cuda_stream)
         frames = [torch.zeros((NX, NY, BINS), dtype=torch.float64, device="cuda"),
                   torch.zeros((NX, NY, BINS), dtype=torch.float64, device="cuda"),
@@ -133,7 +296,8 @@ def main():
     step_counter = [0]
 
     def step():
-        engine.sample_offset = rank_sample_offset(step_counter[0], rank, world_size, SPP)
+        # tile sharding: the counters of a one-GPU render (pass p draws samples p*spp ...); sample sharding: rank-private counters
+        engine.sample_offset = step_counter[0] * SPP if sharding != "sample" else D.rank_sample_offset(step_counter[0], rank, world_size, SPP)
         step_counter[0] += 1
         cam.observe()
         bind()
@@ -147,12 +311,29 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def combine_torch(m, v, n, mb, vb, nb):
+        from source_amd import _lib
+        _lib.check(_lib.lib().rsx_frame_combine_dev(ctx.handle, m.numel(), m.data_ptr(), v.data_ptr(), n.data_ptr(), mb.data_ptr(), vb.data_ptr(), nb.data_ptr()))
+
+    def exchange_frames():
+        """The one exchange step of a multi-GPU render. Returns the frame arrays rank 0 reports on (torch path) or None (in place)."""
+        if comm is not None:
+            if sharding == "tile":
+                comm.allgather_tiles(pipe.frame, NX, NY)
+            else:
+                comm.allreduce_samples(pipe.frame)
+            return None
+        if sharding == "tile":
+            return D.gather_tile_sharded(frames[0], frames[1], frames[2], rank, dist)
+        return D.merge_sample_sharded(frames[0], frames[1], frames[2], dist, combine_torch)
+
     # first observe() creates the pipeline frame; bind external storage before anything is rendered into it
     pipe.initialise((NX, NY), SPP, cam.min_wavelength, cam.max_wavelength, BINS, cam._slice_spectrum(), True)
     bind()
     # Pre-warm: a freshly loaded MI355X takes one ~75 ms hit some tens of ms after sustained work starts (clock / power-state
     # transition; measured as a single stalled kernel in otherwise 0.6 ms passes). Run ~0.4 s of untimed passes so that it lands
-    # here and not inside the W warmup or K timed steps. These passes are ordinary passes into the same accumulating frame.
+    # here and not inside the W warmup or K timed steps. These passes are ordinary passes into the same accumulating frame; every
+    # rank runs the same number of them (tile shards of one frame must hold the same passes).
     prewarm = 0
     t_pre = time.perf_counter()
     burst = 16 if NX * NY * SPP < (1 << 24) else 1
@@ -161,16 +342,28 @@ def main():
             step()
         sync()
         prewarm += burst
+    if dist is not None:
+        t = torch.tensor([prewarm], dtype=torch.int64, device="cuda" if collective == "torch" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        for _ in range(int(t.item()) - prewarm):
+            step()
+        prewarm = int(t.item())
     for _ in range(args.warmup):
         step()
     if dist is not None:
-        # untimed: the first all_to_all / all_gather of a process group sets up its RCCL channels and peer connections (tens of
-        # ms); run the frame merge once on small dummy tensors so that this one-time cost is not charged to the timed steps
-        from source_amd import distributed as D0
-        tiny = [torch.zeros(4096, dtype=torch.float64, device="cuda"), torch.zeros(4096, dtype=torch.float64, device="cuda"),
-                torch.ones(4096, dtype=torch.int32, device="cuda")]
-        D0.merge_sample_sharded(tiny[0], tiny[1], tiny[2], dist,
-                                lambda m, v, n, mb, vb, nb: _lib_combine(ctx, m, v, n, mb, vb, nb))
+        # untimed: the first collective of a communicator sets up its RCCL channels and peer connections (tens of ms); run the
+        # exchange once on a throw-away frame so that this one-time cost is not charged to the timed steps
+        if comm is not None:
+            from source_amd.optical.observer import StatsArray3D
+            tiny = StatsArray3D(world_size * 8, 8, 4)
+            tiny._host[2][:] = 1
+            (comm.allgather_tiles(tiny, world_size * 8, 8) if sharding == "tile" else comm.allreduce_samples(tiny))
+            ctx.synchronize()
+            tiny.release()
+        else:
+            tiny = [torch.zeros(4096, dtype=torch.float64, device="cuda"), torch.zeros(4096, dtype=torch.float64, device="cuda"),
+                    torch.ones(4096, dtype=torch.int32, device="cuda")]
+            D.merge_sample_sharded(tiny[0], tiny[1], tiny[2], dist, combine_torch)
     sync()
     barrier()
     sync()
@@ -178,12 +371,11 @@ def main():
     for _ in range(args.steps):
         step()
     collective_ms = 0.0
+    merged = None
     if dist is not None:
         sync()
         tc = time.perf_counter()
-        from source_amd import distributed as D
-        merged = D.merge_sample_sharded(frames[0], frames[1], frames[2], dist,
-                                        lambda m, v, n, mb, vb, nb: _lib_combine(ctx, m, v, n, mb, vb, nb))
+        merged = exchange_frames()
         sync()
         collective_ms = (time.perf_counter() - tc) * 1e3
     sync()
@@ -191,13 +383,13 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed, collective_ms], dtype=torch.float64, device="cuda" if collective == "torch" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+        elapsed, collective_ms = float(tmax[0].item()), float(tmax[1].item())
 
-    rays_per_step = NX * NY * SPP
-    total_rays = rays_per_step * args.steps * world_size
-    value = total_rays / elapsed
+    rays_per_step_rank = (my_rect[2] - my_rect[0]) * (my_rect[3] - my_rect[1]) * SPP
+    rays_per_step_job = NX * NY * SPP * (world_size if sharding == "sample" else 1)
+    value = rays_per_step_job * args.steps / elapsed
 
     # per-launch kernel durations of the timed steps (HIP events recorded by librsx on its launch stream)
     n_hist = min(args.steps, 512)
@@ -206,11 +398,35 @@ def main():
 
     out = None
     if rank == 0:
-        # sanity of the rendered frame (rank 0's own frame)
-        samples = pipe.frame.samples
-        mean = pipe.frame.mean
-        assert int(samples.min()) == int(samples.max()) == (prewarm + args.warmup + args.steps) * SPP, "frame sample count mismatch"
+        # sanity of the rendered frame
+        passes = prewarm + args.warmup + args.steps
+        if merged is not None:
+            mean, samples = merged[0].cpu().numpy(), merged[2].cpu().numpy()
+        else:
+            mean, samples = pipe.frame.mean, pipe.frame.samples
+        expect = passes * SPP * (world_size if sharding == "sample" else 1)
+        assert int(samples.min()) == int(samples.max()) == expect, "frame sample count mismatch (%d..%d, expected %d)" % (samples.min(), samples.max(), expect)
         assert np.isfinite(mean).all() and mean.max() > 0
+        digest_ok = None
+        if sharding == "tile" and world_size > 1 and not args.no_verify:
+            # the gathered frame must equal a one-GPU render of the same passes bit for bit: render it alone, compare digests
+            if merged is not None:
+                h = hashlib.sha256()
+                for t in merged:
+                    h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
+                got = h.hexdigest()[:32]
+            else:
+                got = frame_digest(pipe.frame)
+            world1, cam1, pipe1 = build_workload(args.workload, ns, scenes)
+            cam1.frame_sampler = ns.RectFrameSampler2D()
+            eng1 = ns.HipEngine(rng="philox", seed=20250905)
+            cam1.render_engine = eng1
+            for p in range(passes):
+                eng1.sample_offset = p * SPP
+                cam1.observe()
+            digest_ok = frame_digest(pipe1.frame) == got
+            pipe1.frame.release()
+            assert digest_ok, "tile-sharded frame differs from the one-GPU render"
 
         from oracle import oracle as orc
         flat = scene.flat
@@ -226,16 +442,41 @@ def main():
         nthreads = orc.max_threads()
         cnt = orc.hit_batch(flat, rays[:, 0:3], rays[:, 3:6], None, threads=nthreads, counters=True)["counters"]
         b_ray, per_ray = ray_bytes(cnt, len(tasks))
-        achieved = b_ray * rays_per_step / (trace_avg * 1e-3) / 1e9
-        traffic = None
-        import glob
-        pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_%s.json" % args.workload)))   # latest committed rocprofv3 --pmc summary
-        if pmcs:
-            traffic = json.load(open(pmcs[-1])).get("hbm_bytes_per_launch")
+        achieved = b_ray * rays_per_step_rank / (trace_avg * 1e-3) / 1e9
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": traffic, "kernel": "k_render_trace",
+                    "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None, "kernel": "k_render_trace",
                     "kernel_ms": round(trace_avg, 4), "accumulate_kernel_ms": round(accum_avg, 4),
-                    "bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()}}
+                    "bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
+                    "line": "achieved/peak/frac = the contract's HBM line: SURVEY 8d algorithmic bytes per ray x rays per launch / kernel time against the "
+                            "8 TB/s HBM peak. The bytes are node / triangle / primitive records that the caches serve, so it can exceed 1; "
+                            "`ceilings` prices the kernel against what it is actually bound by (counters of this run), `bound` names the highest."}
+        if not args.no_pmc and world_size == 1:
+            table, note = collect_pmc(args.workload, 3, args.pmc_keep)
+            if table is None:
+                roofline["pmc_error"] = note
+            else:
+                if note:
+                    roofline["pmc_error"] = note
+                tr = kernel_counters(table, "k_render_trace")
+                if tr is not None:
+                    c = tr[1]
+                    ceil, binding = ceilings(c, trace_avg, achieved)
+                    roofline["kernel"] = tr[0]
+                    roofline["ceilings"] = ceil
+                    if "hbm_measured" in ceil:
+                        roofline["traffic"] = ceil["hbm_measured"]["bytes_per_launch"]
+                        roofline["hbm_measured_gbs"] = ceil["hbm_measured"]["achieved_gbs"]
+                        roofline["hbm_measured_frac"] = ceil["hbm_measured"]["frac"]
+                    if "l2" in ceil:
+                        roofline["l2_hit_rate"] = ceil["l2"]["hit_rate"]
+                    if binding:
+                        roofline["bound"] = binding
+                        roofline["bound_frac"] = ceil[binding]["frac"]
+                ac = kernel_counters(table, "k_accumulate")
+                if ac is not None and accum_avg > 1e-3:
+                    bytes_acc = (24.0 * SPP + 40.0 * BINS) * NX * NY
+                    ceil_a, bind_a = ceilings(ac[1], accum_avg, bytes_acc / (accum_avg * 1e-3) / 1e9)
+                    roofline["accumulate"] = {"kernel": ac[0], "algorithmic_gbs": round(bytes_acc / (accum_avg * 1e-3) / 1e9, 1), "ceilings": ceil_a, "bound": bind_a}
 
         cpu = None
         if not args.no_cpu_baseline and world_size == 1:       # the CPU baseline is timed at N = 1 only (the other ranks would idle at the barrier)
@@ -252,11 +493,11 @@ def main():
             rate = nr / (time.perf_counter() - tcal)
             target = rate * args.cpu_seconds
             saved = cam.pixel_samples
-            if target >= rays_per_step:
-                passes = int(min(2048, max(1, round(target / rays_per_step))))
-                cam.pixel_samples = SPP * passes
+            if target >= NX * NY * SPP:
+                n_pass = int(min(2048, max(1, round(target / (NX * NY * SPP)))))
+                cam.pixel_samples = SPP * n_pass
                 rect = (0, 0, NX, NY)
-                what = "%d full %dx%d passes of %d spp" % (passes, NX, NY, SPP)
+                what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, SPP)
             else:
                 nrows = int(max(16, min(NY, target // (NX * SPP))))
                 rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
@@ -270,16 +511,33 @@ def main():
             cpu = {"value": round(nr / tcpu, 1), "unit": "primary rays/s", "cores": nthreads, "kind": "port",
                    "sample": "%s of the same workload (%d rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
                              "with OpenMP on %d host threads, %.1f s" % (what, nr, nthreads, tcpu)}
+            # the compiled Cython reference itself, measured where it can run (development container; tests/golden/time_reference.py)
+            ref_path = os.path.join(ROOT, "tests", "golden", "reference_timing.json")
+            if os.path.exists(ref_path):
+                table = json.load(open(ref_path))
+                r = table.get(args.workload if args.workload in table else "c2")
+                if r:
+                    cpu["reference"] = {"rays_s": r["reference_multicore_8_rays_per_s"], "rays_s_serial": r["reference_serial_rays_per_s"], "cores": 8,
+                                        "where": r["where"] + ", MulticoreEngine(processes=8), %s scene %dx%d px %d spp" % (r["workload"], r["pixels"], r["pixels"], r["spp"]),
+                                        "port_rays_s_same_cores": r["oracle_8_threads_rays_per_s"],
+                                        "port_over_reference": r["oracle_8_over_reference_multicore_8"],
+                                        "port_over_reference_one_core": r["oracle_1_over_reference_serial"],
+                                        "note": "cpu_baseline.value is the C port; a Raysect user's CPU rate is lower by port_over_reference"}
 
         out = {
             "metric": "primary rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": W["name"], "rays_per_step_per_gpu": rays_per_step, "rng": "philox4x32-10", "sharding": "sample" if world_size > 1 else "none",
-                       "collective_ms": round(collective_ms, 3)},
+            "higher_is_better": True, "scaling": "weak" if sharding == "sample" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": W["name"] + (", %d MI355X" % world_size), "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
+                       "rng": "philox4x32-10", "sharding": sharding,
+                       "collective": {"none": "none", "rsx": "RCCL from librsx (rsx_allgather_frame / rsx_allreduce_frame)",
+                                      "torch": "torch.distributed nccl"}[collective] + ("; " + comm_note if comm_note else ""),
+                       "collective_ms": round(collective_ms, 3), "frame_digest_equals_single_gpu": digest_ok},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
+    if comm is not None:
+        comm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -307,6 +307,29 @@ int rsx_render_pinhole_xyz(rsx_scene *scene, const rsx_render_desc *desc, const 
 int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, double *var_a, int32_t *n_a,
                           const double *mean_b, const double *var_b, const int32_t *n_b);
 
+/* ---- multi-GPU: the spectral framebuffer over RCCL / xGMI (one process per GPU) ---------------------------------------------
+ * Replaces the result queue of MulticoreEngine (raysect/core/workflow.py:201-251: workers send per-task (mean, variance) blocks, the
+ * parent folds them into the frame, pipeline/spectral/power.pyx:424-437). Rays never cross GPUs; the frames meet once per render.
+ * librccl is dlopen'ed by the first rsx_comm_* call (RSX_EUNSUPPORTED if it cannot be loaded); nothing else in librsx needs it.
+ * Bootstrap: rank 0 calls rsx_comm_unique_id and hands the 128 bytes to every rank by any means (file, socket, MPI, a
+ * torch.distributed store); then every rank calls rsx_comm_create (collective, blocks until all ranks arrive). All calls run on the
+ * ctx stream; frame pointers are DEVICE pointers (the frames rsx_render_pinhole_frame accumulates into). */
+typedef struct rsx_comm rsx_comm;
+#define RSX_COMM_ID_BYTES 128
+int rsx_comm_unique_id(void *id128);
+int rsx_comm_create(rsx_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id128, rsx_comm **out);
+void rsx_comm_free(rsx_comm *comm);
+int rsx_comm_barrier(rsx_comm *comm);                       /* all ranks' ctx streams have drained up to here */
+int rsx_comm_max_f64(rsx_comm *comm, double *value);        /* in place: max over ranks of a host double (step timing) */
+/* Tile sharding (SURVEY.md 8e default): rank r rendered frame elements [shard_begin[r], shard_begin[r+1]) of the x-major arrays — a
+ * column tile [x0, x1) x [0, ny) is the contiguous run [x0 * ny * bins, x1 * ny * bins). In place; afterwards every rank holds the
+ * whole frame, bit-identical to a one-GPU render (no arithmetic in the collective). shard_begin: host [n_ranks + 1]. */
+int rsx_allgather_frame(rsx_comm *comm, double *frame_mean, double *frame_variance, int32_t *frame_samples, const int64_t *shard_begin);
+/* Sample sharding: every rank rendered the whole n-element frame with its own samples; afterwards every rank holds the
+ * StatsArray3D.combine_samples fold (statsarray.pyx:780-859) of the ranks' frames in rank order — deterministic and identical on
+ * every rank. Routed as reduce-scatter + all-gather (xGMI is point to point: 2 (W-1)/W frames per rank instead of W-1). */
+int rsx_allreduce_frame(rsx_comm *comm, double *frame_mean, double *frame_variance, int32_t *frame_samples, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,229 @@
+// rsx_comm.hpp — part of librsx's device translation unit (included by rsx_device.hip after the host API).
+// Multi-GPU exchange of the spectral framebuffer over RCCL (xGMI), one process per GPU.
+//
+// The reference's counterpart is the result queue of MulticoreEngine (raysect/core/workflow.py:201-251): workers push
+// (task, [(mean, variance) per pipeline], ray_count) messages and the parent folds them into the frame with
+// StatsArray3D.combine_samples (pipeline/spectral/power.pyx:424-437). Here every rank renders into its own device-resident frame with
+// no traffic during traversal, and the frames meet once:
+//   * tile sharding   — ranks own disjoint runs of the x-major frame: rsx_allgather_frame moves the runs, no arithmetic;
+//   * sample sharding — every rank holds a full frame of its own samples: rsx_allreduce_frame folds them with the combine_samples
+//     law in rank order (deterministic, same result on every rank), routed as reduce-scatter + all-gather because xGMI links are
+//     point to point: each rank receives 2 (W-1)/W frames instead of W-1.
+// librccl is opened with dlopen at the first rsx_comm_* call: single-GPU users never load it, and a process that already holds
+// an RCCL (PyTorch bundles one) shares that copy instead of getting a second set of global symbols.
+#pragma once
+
+#include <dlfcn.h>
+
+namespace rccl {
+
+// the handful of RCCL types the calls below need (rccl/rccl.h, ABI-stable across RCCL 2.x)
+typedef struct ncclComm *ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccess = 0 };
+enum { ncclInt32 = 2, ncclUint8 = 1, ncclFloat64 = 8 };
+enum { ncclSum = 0, ncclMax = 2 };
+
+struct Api {
+    void *handle = nullptr;
+    int (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    int (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    int (*CommDestroy)(ncclComm_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    std::string error;
+};
+
+static Api &api() {
+    static Api a;
+    if (a.handle || !a.error.empty()) return a;
+    const char *names[] = {std::getenv("RSX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char *n : names) {
+        if (!n || !*n) continue;
+        a.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        if (a.handle) break;
+    }
+    if (!a.handle) { a.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found"); return a; }
+    auto sym = [&](const char *name) -> void * {
+        void *p = dlsym(a.handle, name);
+        if (!p && a.error.empty()) a.error = std::string("librccl lacks ") + name;
+        return p;
+    };
+    a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(sym("ncclGetUniqueId"));
+    a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(sym("ncclCommInitRank"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(sym("ncclCommDestroy"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(sym("ncclGetErrorString"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(sym("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(sym("ncclGroupEnd"));
+    a.Send = reinterpret_cast<decltype(a.Send)>(sym("ncclSend"));
+    a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
+    a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
+    a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    if (!a.error.empty()) { dlclose(a.handle); a.handle = nullptr; }
+    return a;
+}
+
+}  // namespace rccl
+
+struct rsx_comm {
+    rsx_ctx *ctx;
+    rccl::ncclComm_t comm;
+    int32_t n_ranks, rank;
+    void *scratch;             // sample sharding: the ranks' copies of this rank's frame segment
+    size_t scratch_bytes;
+    double *word;              // one device double for barrier / max
+};
+
+#define RCCL_TRY(expr)                                                                                         \
+    do {                                                                                                       \
+        const int r_ = (expr);                                                                                 \
+        if (r_ != rccl::ncclSuccess) return rsx_fail(RSX_EHIP, "%s: %s", #expr, rccl::api().GetErrorString ? rccl::api().GetErrorString(r_) : "RCCL error"); \
+    } while (0)
+
+extern "C" int rsx_comm_unique_id(void *id128) {
+    if (!id128) return rsx_fail(RSX_EINVAL, "rsx_comm_unique_id: null buffer");
+    rccl::Api &a = rccl::api();
+    if (!a.handle) return rsx_fail(RSX_EUNSUPPORTED, "%s", a.error.c_str());
+    rccl::ncclUniqueId id;
+    RCCL_TRY(a.GetUniqueId(&id));
+    std::memcpy(id128, id.internal, sizeof(id.internal));
+    return RSX_OK;
+}
+
+extern "C" int rsx_comm_create(rsx_ctx *ctx, int32_t n_ranks, int32_t rank, const void *id128, rsx_comm **out) {
+    if (!ctx || !id128 || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return rsx_fail(RSX_EINVAL, "rsx_comm_create: bad arguments");
+    rccl::Api &a = rccl::api();
+    if (!a.handle) return rsx_fail(RSX_EUNSUPPORTED, "%s", a.error.c_str());
+    HIP_TRY(hipSetDevice(ctx->device));
+    rccl::ncclUniqueId id;
+    std::memcpy(id.internal, id128, sizeof(id.internal));
+    rsx_comm *c = new (std::nothrow) rsx_comm();
+    if (!c) return rsx_fail(RSX_ENOMEM, "out of host memory");
+    c->ctx = ctx; c->comm = nullptr; c->n_ranks = n_ranks; c->rank = rank; c->scratch = nullptr; c->scratch_bytes = 0; c->word = nullptr;
+    const int r = a.CommInitRank(&c->comm, n_ranks, id, rank);
+    if (r != rccl::ncclSuccess) { delete c; return rsx_fail(RSX_EHIP, "ncclCommInitRank(rank %d of %d): %s", rank, n_ranks, a.GetErrorString(r)); }
+    if (hipMalloc(&c->word, 64) != hipSuccess) { a.CommDestroy(c->comm); delete c; return rsx_fail(RSX_ENOMEM, "rsx_comm_create: out of device memory"); }
+    *out = c;
+    return RSX_OK;
+}
+
+extern "C" void rsx_comm_free(rsx_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->ctx->stream);
+    if (c->comm) rccl::api().CommDestroy(c->comm);
+    if (c->scratch) (void)hipFree(c->scratch);
+    if (c->word) (void)hipFree(c->word);
+    delete c;
+}
+
+// max over the ranks of one host double (bench timing: the slowest rank defines the step); doubles as a barrier
+extern "C" int rsx_comm_max_f64(rsx_comm *c, double *value) {
+    if (!c || !value) return rsx_fail(RSX_EINVAL, "rsx_comm_max_f64: null argument");
+    rsx_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemcpyAsync(c->word, value, sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    RCCL_TRY(rccl::api().AllReduce(c->word, c->word, 1, rccl::ncclFloat64, rccl::ncclMax, c->comm, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(value, c->word, sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_comm_barrier(rsx_comm *c) {
+    double zero = 0.0;
+    return rsx_comm_max_f64(c, &zero);
+}
+
+// Tile sharding: rank r owns frame elements [shard_begin[r], shard_begin[r+1]) of the x-major (mean, variance, samples) arrays
+// (column tiles of a frame are contiguous runs). After the call every rank holds the whole frame. In place, no arithmetic: the
+// result is bit-identical to a single-GPU render (Philox counters are per pixel).
+extern "C" int rsx_allgather_frame(rsx_comm *c, double *mean, double *variance, int32_t *samples, const int64_t *shard_begin) {
+    if (!c || !mean || !variance || !samples || !shard_begin) return rsx_fail(RSX_EINVAL, "rsx_allgather_frame: null argument");
+    for (int r = 0; r < c->n_ranks; ++r) if (shard_begin[r] < 0 || shard_begin[r + 1] < shard_begin[r]) return rsx_fail(RSX_EINVAL, "rsx_allgather_frame: shard offsets must be non-decreasing");
+    rsx_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    rccl::Api &a = rccl::api();
+    RCCL_TRY(a.GroupStart());
+    for (int r = 0; r < c->n_ranks; ++r) {
+        const size_t off = (size_t)shard_begin[r], len = (size_t)(shard_begin[r + 1] - shard_begin[r]);
+        if (!len) continue;
+        RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+        RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+        RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+    }
+    RCCL_TRY(a.GroupEnd());
+    return RSX_OK;
+}
+
+// Sample sharding: every rank holds a full n-element frame of its own samples; afterwards every rank holds
+// combine(...combine(combine(rank 0, rank 1), rank 2)..., rank W-1) — StatsArray3D.combine_samples (statsarray.pyx:780-859) folded in
+// rank order, element by element, whatever the routing. Reduce-scatter (point-to-point sends of 1/W segments, fold on the owner)
+// followed by an all-gather of the merged segments.
+extern "C" int rsx_allreduce_frame(rsx_comm *c, double *mean, double *variance, int32_t *samples, int64_t n) {
+    if (!c || !mean || !variance || !samples || n < 0) return rsx_fail(RSX_EINVAL, "rsx_allreduce_frame: bad arguments");
+    if (n == 0 || c->n_ranks == 1) return RSX_OK;
+    rsx_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    const int W = c->n_ranks, me = c->rank;
+    const size_t N = (size_t)n, seg = (N + W - 1) / W;
+    auto seg_off = [&](int r) { return std::min(N, seg * (size_t)r); };
+    auto seg_len = [&](int r) { return std::min(N, seg * (size_t)(r + 1)) - seg_off(r); };
+    const size_t mine = seg_len(me);
+    // scratch: W copies of my segment, as [W][mine] doubles (mean), [W][mine] doubles (variance), [W][mine] int32 (samples)
+    const size_t need = (size_t)W * mine * 20 + 256;
+    if (need > c->scratch_bytes) {
+        if (c->scratch) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+        HIP_TRY(hipMalloc(&c->scratch, need));
+        c->scratch_bytes = need;
+    }
+    double *sm = static_cast<double *>(c->scratch), *sv = sm + (size_t)W * mine;
+    int32_t *sn = reinterpret_cast<int32_t *>(sv + (size_t)W * mine);
+    rccl::Api &a = rccl::api();
+    RCCL_TRY(a.GroupStart());
+    for (int r = 0; r < W; ++r) {
+        if (r == me) continue;
+        const size_t off = seg_off(r), len = seg_len(r);
+        if (len) {
+            RCCL_TRY(a.Send(mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Send(variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Send(samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+        }
+        if (mine) {
+            RCCL_TRY(a.Recv(sm + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Recv(sv + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Recv(sn + (size_t)r * mine, mine, rccl::ncclInt32, r, c->comm, ctx->stream));
+        }
+    }
+    RCCL_TRY(a.GroupEnd());
+    if (mine) {
+        const size_t off = seg_off(me);
+        HIP_TRY(hipMemcpyAsync(sm + (size_t)me * mine, mean + off, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(sv + (size_t)me * mine, variance + off, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(sn + (size_t)me * mine, samples + off, mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        for (int r = 1; r < W; ++r) {                       // fold in rank order into rank 0's copy
+            hipLaunchKernelGGL(k_frame_combine, dim3((unsigned)((mine + 255) / 256)), dim3(256), 0, ctx->stream, (long long)mine, sm, sv, sn,
+                               sm + (size_t)r * mine, sv + (size_t)r * mine, sn + (size_t)r * mine);
+            HIP_TRY(hipGetLastError());
+        }
+        HIP_TRY(hipMemcpyAsync(mean + off, sm, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(variance + off, sv, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(samples + off, sn, mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    RCCL_TRY(a.GroupStart());
+    for (int r = 0; r < W; ++r) {
+        const size_t off = seg_off(r), len = seg_len(r);
+        if (!len) continue;
+        RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+        RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+        RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+    }
+    RCCL_TRY(a.GroupEnd());
+    return RSX_OK;
+}

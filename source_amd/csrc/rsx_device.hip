@@ -1255,3 +1255,8 @@ extern "C" int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, do
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
     return RSX_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------
+// multi-GPU frame exchange (RCCL over xGMI)
+// ---------------------------------------------------------------------------------------------------
+#include "rsx_comm.hpp"

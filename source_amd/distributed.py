@@ -108,6 +108,26 @@ def merge_sample_sharded(mean, variance, samples, dist, combine=None, mode="scat
     return tuple(out)
 
 
+def gather_tile_sharded(mean, variance, samples, rank, dist):
+    """Tile sharding on torch tensors (bench.py --collective torch, and the gloo tests): every rank holds full-size x-major frame
+    tensors of which it rendered the column tile tile_rect(rank); returns the assembled (mean, variance, samples). Tiles of unequal
+    width (nx not divisible by the world size) are padded to the widest one for the all_gather and cut back afterwards."""
+    import torch
+    world = dist.get_world_size()
+    nx, ny = mean.shape[0], mean.shape[1]
+    rects = [tile_rect(r, world, nx, ny) for r in range(world)]
+    widest = max(r[2] - r[0] for r in rects)
+    x0, _, x1, _ = rects[rank]
+    out = []
+    for t in (mean, variance, samples):
+        tile = torch.zeros((widest,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        tile[:x1 - x0] = t[x0:x1]
+        parts = [torch.empty_like(tile) for _ in range(world)]
+        dist.all_gather(parts, tile)
+        out.append(torch.cat([p[:r[2] - r[0]] for p, r in zip(parts, rects)], dim=0))
+    return tuple(out)
+
+
 def gather_tiles(tile, dist):
     """All-gather equally sized column tiles [x0:x1, :, :] of an x-major frame tensor into the full frame."""
     import torch
@@ -115,3 +135,54 @@ def gather_tiles(tile, dist):
     parts = [torch.empty_like(tile) for _ in range(world)]
     dist.all_gather(parts, tile.contiguous())
     return torch.cat(parts, dim=0)
+
+
+class FrameComm:
+    """rsx_comm wrapper: the framebuffer exchange of a multi-GPU render over RCCL, called straight from librsx (no PyTorch in the
+    data path). ``exchange(payload)`` is any callable that returns rank 0's payload on every rank (a torch.distributed
+    broadcast_object_list over gloo, an MPI bcast, a shared file ...): it carries the 128-byte RCCL unique id."""
+
+    def __init__(self, context, rank, world_size, exchange):
+        import ctypes as C
+        from . import _lib
+        self.context, self.rank, self.world_size = context, int(rank), int(world_size)
+        L = _lib.lib()
+        ident = (C.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(L.rsx_comm_unique_id(ident))
+        payload = exchange(bytes(ident.raw) if self.rank == 0 else None)
+        ident = (C.c_char * 128).from_buffer_copy(payload)
+        self._h = C.c_void_p()
+        _lib.check(L.rsx_comm_create(context.handle, self.world_size, self.rank, ident, C.byref(self._h)))
+
+    def barrier(self):
+        from . import _lib
+        _lib.check(_lib.lib().rsx_comm_barrier(self._h))
+
+    def max(self, value):
+        import ctypes as C
+        from . import _lib
+        v = C.c_double(float(value))
+        _lib.check(_lib.lib().rsx_comm_max_f64(self._h, C.byref(v)))
+        return float(v.value)
+
+    def allgather_tiles(self, frame, nx, ny):
+        """frame: StatsArray3D whose column tile tile_rect(rank) this rank rendered; afterwards the whole frame on every rank."""
+        from . import _lib
+        begin = np.array([tile_rect(r, self.world_size, nx, ny)[0] * ny * frame.nz for r in range(self.world_size)] + [nx * ny * frame.nz], dtype=np.int64)
+        fm, fv, fn = frame._device(self.context)
+        _lib.check(_lib.lib().rsx_allgather_frame(self._h, fm, fv, fn, _lib.ptr(begin)))
+        frame._mark_device_written()
+
+    def allreduce_samples(self, frame):
+        """frame: StatsArray3D holding this rank's samples of every pixel; afterwards the combine_samples fold over the ranks."""
+        from . import _lib
+        fm, fv, fn = frame._device(self.context)
+        _lib.check(_lib.lib().rsx_allreduce_frame(self._h, fm, fv, fn, frame.length))
+        frame._mark_device_written()
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.lib().rsx_comm_free(self._h)
+            self._h = None

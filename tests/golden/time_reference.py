@@ -3,9 +3,11 @@
 Development-container only: times the COMPILED REFERENCE (built by build_reference.sh) and the CPU oracle on the same scene, so that
 the oracle's rays/s measured on the GPU box (bench.py cpu_baseline, kind "port") can be related to the reference's own speed.
 
-    bash tests/golden/build_reference.sh && python tests/golden/time_reference.py [pixels]
+    bash tests/golden/build_reference.sh && python tests/golden/time_reference.py [pixels] [c2|c3] [spp]
 
-Scene: BASELINE configs[1] (69 432-triangle mesh, pinhole camera), `pixels` x `pixels`, 1 sample / pixel, 15 bins.
+Scene: BASELINE configs[1] (c2: 69 432-triangle mesh) or configs[2] (c3: 15 instances of it + floor box), pinhole camera,
+`pixels` x `pixels`, `spp` samples / pixel, 15 bins. The result is merged into tests/golden/reference_timing.json (committed:
+bench.py reports it as cpu_baseline.reference next to the oracle's rate on the GPU box).
 """
 import json
 import os
@@ -40,19 +42,28 @@ REFNS = types.SimpleNamespace(
     SpectralPowerPipeline2D=SpectralPowerPipeline2D)
 
 px = int(sys.argv[1]) if len(sys.argv) > 1 else 256
-out = {"pixels": px, "host_cpus": os.cpu_count()}
+wl = sys.argv[2] if len(sys.argv) > 2 else "c2"
+spp = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+out = {"workload": wl, "pixels": px, "spp": spp, "host_cpus": os.cpu_count(), "where": "development container (8 vCPU Xeon 2.1 GHz), compiled Cython reference"}
 
-world, mesh, box = scenes.build_c2(REFNS, n=132)
-cam, pipe = scenes.c2_camera(REFNS, world, (px, px), spp=1, bins=15)
+
+def build(api):
+    if wl == "c3":
+        world = scenes.build_c3(api, n=132)[0]
+        return world, scenes.c3_camera(api, world, (px, px), spp=spp, bins=15)
+    world = scenes.build_c2(api, n=132)[0]
+    return world, scenes.c2_camera(api, world, (px, px), spp=spp, bins=15)
+
+
+world, (cam, pipe) = build(REFNS)
 world.build_accelerator()
 for name, engine in (("reference_serial", SerialEngine()), ("reference_multicore_8", MulticoreEngine(processes=8))):
     cam.render_engine = engine
     t0 = time.perf_counter()
     cam.observe()
-    out[name + "_rays_per_s"] = round(px * px / (time.perf_counter() - t0), 1)
+    out[name + "_rays_per_s"] = round(px * px * spp / (time.perf_counter() - t0), 1)
 
-world, mesh, box = scenes.build_c2(ns, n=132)
-cam, pipe = scenes.c2_camera(ns, world, (px, px), spp=1, bins=15)
+world, (cam, pipe) = build(ns)
 flat = world.flatten()
 keep = []
 desc = cam.render_desc(world, None, cam._slice_spectrum()[0], ns.HipEngine(rng="philox", seed=1), keep, rect=(0, 0, px, px))
@@ -62,4 +73,9 @@ for threads in (1, 8):
     m, v, rays = orc.render_pinhole(flat, desc, threads=threads)
     out["oracle_%d_threads_rays_per_s" % threads] = round(rays / (time.perf_counter() - t0), 1)
 out["oracle_1_over_reference_serial"] = round(out["oracle_1_threads_rays_per_s"] / out["reference_serial_rays_per_s"], 2)
+out["oracle_8_over_reference_multicore_8"] = round(out["oracle_8_threads_rays_per_s"] / out["reference_multicore_8_rays_per_s"], 2)
 print(json.dumps(out))
+path = os.path.join(HERE, "reference_timing.json")
+table = json.load(open(path)) if os.path.exists(path) else {}
+table[wl] = out
+json.dump(table, open(path, "w"), indent=1, sort_keys=True)

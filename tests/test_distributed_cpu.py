@@ -45,6 +45,19 @@ def _worker(rank, world_size, port, out):
     w = rect[2] - rect[0]
     tile = np.ascontiguousarray(tm.reshape(ny, w, bins).transpose(1, 0, 2))
     full = D.gather_tiles(torch.from_numpy(tile), dist)
+    # bench.py's tile path (--collective torch): full-size frames of which each rank filled its own tile; 25 columns over 2 ranks
+    # would be uneven, so also exercise the padded gather on a 5-column crop
+    fr = [np.zeros((nx, ny, bins)), np.zeros((nx, ny, bins)), np.zeros((nx, ny, bins), dtype=np.int32)]
+    fr[0][rect[0]:rect[2]] = tile
+    fr[1][rect[0]:rect[2]] = np.ascontiguousarray(tv.reshape(ny, w, bins).transpose(1, 0, 2))
+    fr[2][rect[0]:rect[2]] = spp
+    tm_, tv_, tn_ = D.gather_tile_sharded(*(torch.from_numpy(a) for a in fr), rank, dist)
+    assert torch.equal(tm_, full) and int(tn_.min()) == int(tn_.max()) == spp
+    r5 = D.tile_rect(rank, world_size, 5, ny)
+    odd = np.zeros((5, ny, bins))
+    odd[r5[0]:r5[2]] = rank + 1.0
+    o5 = D.gather_tile_sharded(torch.from_numpy(odd), torch.from_numpy(odd.copy()), torch.from_numpy(odd.astype(np.int32)), rank, dist)[0].numpy()
+    assert (o5[:2] == 1.0).all() and (o5[2:] == 2.0).all()
     np.savez(out % rank, M=M.numpy(), V=V.numpy(), N=N.numpy(), fm=fm, fv=fv, full=full.numpy())
     dist.barrier()
     dist.destroy_process_group()
