@@ -173,7 +173,7 @@ def test_mesh_files_on_device(orc, ns, golden, tmp_path):
     assert (dev["prim"] >= 0).sum() > 2000
     # ... and through World.hit(), the single-ray API
     first = int(np.nonzero(dev["prim"] >= 0)[0][0])
-    hit = world.hit(ns.Ray(ns.Point3D(*o[first]), ns.Vector3D(*d[first]), float(m[first])))
+    hit = world.hit(ns.Ray(ns.Point3D(*o[first]), ns.Vector3D(*d[first]), max_distance=float(m[first])))
     assert hit is not None and hit.primitive is back and hit.triangle == dev["tri"][first] and hit.ray_distance == dev["t"][first]
 
 
