@@ -45,6 +45,22 @@ class _Vec3:
         return math.sqrt(self.x * self.x + self.y * self.y + self.z * self.z)
 
 
+def _orthogonal(vec):
+    """An arbitrary unit vector orthogonal to `vec` (vector.pyx:440-472 / normal.pyx:346-370): Gram-Schmidt of the x axis (the y axis
+    when `vec` lies within 60 degrees of x) against the normalised vector."""
+    t = vec.x * vec.x + vec.y * vec.y + vec.z * vec.z
+    t = 1.0 / math.sqrt(t)
+    nx, ny, nz = vec.x * t, vec.y * t, vec.z * t
+    vx, vy, vz = 1.0, 0.0, 0.0
+    if abs(nx * vx + ny * vy + nz * vz) > 0.5:
+        vx, vy = 0.0, 1.0
+    m = nx * vx + ny * vy + nz * vz
+    ux, uy, uz = vx - m * nx, vy - m * ny, vz - m * nz
+    t = ux * ux + uy * uy + uz * uz
+    t = 1.0 / math.sqrt(t)
+    return ux * t, uy * t, uz * t
+
+
 class Vector3D(_Vec3):
     """raysect/core/math/vector.pyx"""
     __slots__ = ()
@@ -85,6 +101,12 @@ class Vector3D(_Vec3):
     def copy(self):
         return Vector3D(self.x, self.y, self.z)
 
+    def neg(self):
+        return Vector3D(-self.x, -self.y, -self.z)
+
+    def orthogonal(self):                                   # vector.pyx:440-472
+        return Vector3D(*_orthogonal(self))
+
 
 class Normal3D(_Vec3):
     """raysect/core/math/normal.pyx"""
@@ -117,6 +139,15 @@ class Normal3D(_Vec3):
 
     def copy(self):
         return Normal3D(self.x, self.y, self.z)
+
+    def neg(self):
+        return Normal3D(-self.x, -self.y, -self.z)
+
+    def cross(self, v):                                     # normal.pyx:200-204
+        return Vector3D(self.y * v.z - v.y * self.z, self.z * v.x - v.z * self.x, self.x * v.y - v.x * self.y)
+
+    def orthogonal(self):                                   # normal.pyx:346-370
+        return Vector3D(*_orthogonal(self))
 
 
 class Point3D(_Vec3):

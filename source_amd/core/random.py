@@ -37,7 +37,19 @@ def uniform_block(n):
     return out
 
 
+_override = None      # a stream object with next(): while set, uniform() draws from it (source_amd/optical/hybrid.py: per-path Philox streams)
+
+
+def set_stream(stream):
+    """Routes uniform()/probability() to `stream.next()` (None restores the process-global MT19937-64 state). Returns the previous one."""
+    global _override
+    previous, _override = _override, stream
+    return previous
+
+
 def uniform():
+    if _override is not None:
+        return _override.next()
     return float(uniform_block(1)[0])
 
 

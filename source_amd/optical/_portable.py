@@ -1,0 +1,94 @@
+"""
+Host restatements (plain Python floats: IEEE f64, no FMA) of the arithmetic the device render kernels use for stochastic paths, so
+that a path evaluated on the host (source_amd/optical/hybrid.py, Ray.trace of a single ray) takes the same turns as the same path
+on the device: Philox4x32-10 with librsx's counter convention (include/rsx.h), the portable sin / cos / asin of
+source_amd/csrc/dev_render.hpp (Cody-Waite reduction + minimax polynomials; oracle/rsx_oracle.c holds the C form).
+"""
+import math
+import struct
+
+import numpy as np
+
+M32 = 0xFFFFFFFF
+TWO_PI = 2.0 * math.pi
+
+
+def philox2(seed, pixel, sample):
+    """Two uniforms in [0, 1) from counter (pixel, sample) under key seed — dev_render.hpp philox2."""
+    c0, c1, c2, c3 = pixel & M32, (pixel >> 32) & M32, sample & M32, (sample >> 32) & M32
+    k0, k1 = seed & M32, (seed >> 32) & M32
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M32, p1 & M32, ((p0 >> 32) ^ c3 ^ k1) & M32, p0 & M32
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    a, b = (c1 << 32) | c0, (c3 << 32) | c2
+    return (a >> 11) * (1.0 / 9007199254740992.0), (b >> 11) * (1.0 / 9007199254740992.0)
+
+
+def philox2_array(seed, pixel, sample):
+    """philox2 over numpy uint64 arrays `pixel`, `sample` (primary-ray jitter of a whole block of pixels)."""
+    pixel, sample = np.asarray(pixel, dtype=np.uint64), np.asarray(sample, dtype=np.uint64)
+    m = np.uint64(M32)
+    s32 = np.uint64(32)
+    c0, c1, c2, c3 = pixel & m, (pixel >> s32) & m, sample & m, (sample >> s32) & m
+    k0, k1 = int(seed) & M32, (int(seed) >> 32) & M32
+    for _ in range(10):
+        p0, p1 = np.uint64(0xD2511F53) * c0, np.uint64(0xCD9E8D57) * c2
+        c0, c1, c2, c3 = ((p1 >> s32) ^ c1 ^ np.uint64(k0)) & m, p1 & m, ((p0 >> s32) ^ c3 ^ np.uint64(k1)) & m, p0 & m
+        k0, k1 = (k0 + 0x9E3779B9) & M32, (k1 + 0xBB67AE85) & M32
+    a, b = (c1 << s32) | c0, (c3 << s32) | c2
+    scale = 1.0 / 9007199254740992.0
+    return (a >> np.uint64(11)).astype(np.float64) * scale, (b >> np.uint64(11)).astype(np.float64) * scale
+
+
+def sincos(phi):
+    """(sin, cos) of phi in [0, 2 pi] — portable_sincos."""
+    PIO2_HI, PIO2_LO, TWO_OVER_PI = 1.57079632673412561417e+00, 6.07710050650619224932e-11, 6.36619772367581382433e-01
+    S1, S2, S3, S4, S5, S6 = (-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                              2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10)
+    C1, C2, C3, C4, C5, C6 = (4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                              -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11)
+    kf = math.floor(phi * TWO_OVER_PI + 0.5)
+    r = (phi - kf * PIO2_HI) - kf * PIO2_LO
+    z = r * r
+    ps = r + (r * z) * (S1 + z * (S2 + z * (S3 + z * (S4 + z * (S5 + z * S6)))))
+    pc = (1.0 - 0.5 * z) + (z * z) * (C1 + z * (C2 + z * (C3 + z * (C4 + z * (C5 + z * C6)))))
+    q = int(kf) & 3
+    if q == 0:
+        return ps, pc
+    if q == 1:
+        return pc, -ps
+    if q == 2:
+        return -ps, -pc
+    return -pc, ps
+
+
+def asin(x):
+    """asin on [0, 1] — portable_asin."""
+    PIO2_HI, PIO2_LO, PIO4_HI = 1.57079632679489655800e+00, 6.12323399573676603587e-17, 7.85398163397448278999e-01
+    P0, P1, P2, P3, P4, P5 = (1.66666666666666657415e-01, -3.25565818622400915405e-01, 2.01212532134862925881e-01,
+                              -4.00555345006794114027e-02, 7.91534994289814532176e-04, 3.47933107596021167570e-05)
+    Q1, Q2, Q3, Q4 = -2.40339491173441421878e+00, 2.02094576023350569471e+00, -6.88283971605453293030e-01, 7.70381505559019352791e-02
+    if x >= 1.0:
+        return x * PIO2_HI + x * PIO2_LO
+    if x < 0.5:
+        if x < 7.450580596923828e-09:
+            return x
+        t = x * x
+        p = t * (P0 + t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5)))))
+        q = 1.0 + t * (Q1 + t * (Q2 + t * (Q3 + t * Q4)))
+        return x + x * (p / q)
+    w = 1.0 - x
+    t = w * 0.5
+    p = t * (P0 + t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5)))))
+    q = 1.0 + t * (Q1 + t * (Q2 + t * (Q3 + t * Q4)))
+    s = math.sqrt(t)
+    if x >= 0.975:
+        w = p / q
+        return PIO2_HI - (2.0 * (s + s * w) - PIO2_LO)
+    w = struct.unpack("<d", struct.pack("<Q", struct.unpack("<Q", struct.pack("<d", s))[0] & 0xFFFFFFFF00000000))[0]
+    c = (t - w * w) / (s + w)
+    r = p / q
+    p = 2.0 * s * r - (PIO2_LO - 2.0 * c)
+    q = PIO4_HI - 2.0 * w
+    return PIO4_HI - (p - q)

@@ -61,10 +61,12 @@ class HipEngine(RenderEngine):
     the multi-GPU shards place their samples, source_amd/distributed.py).
     """
 
-    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0):
+    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
         self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
+        self.host_materials = bool(host_materials)    # True: evaluate every material on the host (source_amd/optical/hybrid.py) even when
+                                                      # all of them have device lowerings — scenes with a user-written material always do
         self.timing = bool(timing)          # True: read back HIP-event kernel times after each library call (one stream sync per call:
                                             # a tuning aid, it defeats the pipelined render lanes)
         self.sample_offset = int(sample_offset)
@@ -193,6 +195,14 @@ class StatsArray3D:
 
     def _mark_device_written(self):
         self._dev_dirty = True
+
+    def _host_written(self):
+        """The host arrays were modified (host-callback render path): bring the device copy, if there is one, up to date."""
+        if self._dev is not None:
+            ctx = self._dev[0]
+            for p, a in zip(self._dev[1:], self._host):
+                ctx.upload(p, a)
+            self._dev_dirty = False
 
     @property
     def mean(self):
@@ -752,11 +762,22 @@ class PinholeCamera(Observer2D):
             xs, ys = t[:, 0], t[:, 1]
         pipe.update_block(xs, ys, mean, var)
 
-    def _pieces(self, tasks, world):
+    def _needs_host_materials(self, world, engine):
+        """True when the slice must go through the host-callback path: a material without a device lowering (a user-written
+        Material subclass), or an engine that asks for it."""
+        if getattr(engine, "host_materials", False):
+            return True
+        from .material import has_device_lowering
+        return not all(has_device_lowering(p.material) for p in world._primitives)
+
+    HOST_RAYS_PER_PIECE = 1 << 16     # primary rays per scheduler run of the host-callback path (bounds the Python objects alive at once)
+
+    def _pieces(self, tasks, world, limit=None):
         """One library call renders at most MAX_RAYS_PER_CALL rays (its sample-record buffer is 24 B per ray): larger slices go
         band by band (rect) or run by run (task list, which keeps the MT stream's consumption order). Pixels are independent
         and the Philox counters are per (pixel, sample), so the frame does not depend on how a slice is cut."""
-        limit = self.MAX_RAYS_PER_CALL
+        if limit is None:
+            limit = self.MAX_RAYS_PER_CALL
         from .material import NullSurface, Lambert, Dielectric
         if any(isinstance(p.material, (NullSurface, Lambert, Dielectric)) for p in world._primitives):
             limit = min(limit, 1 << 24)                     # the volume path also keeps 768 B of emission terms per ray
@@ -769,6 +790,10 @@ class PinholeCamera(Observer2D):
 
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
         world = self.root
+        if self._needs_host_materials(world, engine):
+            from . import hybrid
+            hybrid.render_slice(self, tasks, slice_id, template, engine, self._pieces(tasks, world, self.HOST_RAYS_PER_PIECE))
+            return
         scene = world.build_accelerator()
         sl = self._slices[slice_id]
         keep = []

@@ -80,6 +80,9 @@ class SpectralFunction:
     def average(self, min_wavelength, max_wavelength):
         return self.integrate(min_wavelength, max_wavelength) / (max_wavelength - min_wavelength)
 
+    def sample_mv(self, min_wavelength, max_wavelength, bins):
+        return self.sample(min_wavelength, max_wavelength, bins)
+
     def sample(self, min_wavelength, max_wavelength, bins):  # :171-217 (bin average = integral / bin width)
         key = (float(min_wavelength), float(max_wavelength), int(bins))
         if self._sample_key == key:
@@ -193,6 +196,52 @@ class Spectrum(SpectralFunction):
 
     def mul_scalar(self, value):                            # spectrum.pyx:449-453
         self.samples *= value
+
+    def div_scalar(self, value):                            # spectrum.pyx:459-467: multiplies by the reciprocal
+        self.samples *= 1.0 / value if value != 0.0 else float("inf")
+
+    def add_array(self, array):
+        self.samples += array
+
+    def sub_array(self, array):
+        self.samples -= array
+
+    def mul_array(self, array):                             # spectrum.pyx:429-437
+        self.samples *= array
+
+    def mad_scalar(self, scalar, array):                    # spectrum.pyx:479-487: samples += scalar * array
+        self.samples += scalar * np.asarray(array)
+
+    def clear(self):
+        self.samples[:] = 0.0
+
+    def is_zero(self):
+        return not self.samples.any()
+
+    def is_compatible(self, min_wavelength, max_wavelength, bins):
+        return self.min_wavelength == min_wavelength and self.max_wavelength == max_wavelength and self.bins == bins
+
+    def new_spectrum(self):
+        return Spectrum(self.min_wavelength, self.max_wavelength, self.bins)
+
+    def copy(self):
+        s = Spectrum(self.min_wavelength, self.max_wavelength, self.bins)
+        s.samples[:] = self.samples
+        return s
+
+    def evaluate(self, wavelength):                         # spectrum.pyx: piecewise constant over the bins, nearest outside
+        i = int((wavelength - self.min_wavelength) / self.delta_wavelength)
+        return float(self.samples[min(max(i, 0), self.bins - 1)])
+
+    def integrate(self, min_wavelength, max_wavelength):
+        lo, hi = max(min_wavelength, self.min_wavelength), min(max_wavelength, self.max_wavelength)
+        total = 0.0
+        for i in range(self.bins):
+            a = self.min_wavelength + i * self.delta_wavelength
+            overlap = min(hi, a + self.delta_wavelength) - max(lo, a)
+            if overlap > 0:
+                total += self.samples[i] * overlap
+        return total
 
     def total(self):
         return float(self.samples.sum() * self.delta_wavelength)

@@ -883,3 +883,94 @@ def test_pipelining_does_not_change_frames():
         digests.append(json.loads(out.stdout.strip().splitlines()[-1])["digest"])
     assert len(set(digests)) == 1, digests
 
+
+
+def test_host_callback_path_equals_device_path(ns):
+    """The host-callback render path (source_amd/optical/hybrid.py: rays traced on the device wave by wave, every material's
+    evaluate_surface / evaluate_volume called on the host) against the on-device path tracer on the same scenes and Philox counters:
+    frames and ray statistics bit-identical. Diffuse room (Lambert, roulette, CSG solid, smooth mesh, volume emitter, null shell)
+    and the Cornell box (multiple importance sampling, clear dielectrics)."""
+    for build, camera in ((lambda: scenes.build_lambert(ns), lambda w: scenes.lambert_camera(ns, w, (40, 32), spp=3, bins=4, extinction=(0.2, 2, 9))),
+                          (lambda: scenes.build_cornell(ns), lambda w: scenes.cornell_camera(ns, w, (28, 24), 2, 5))):
+        frames = []
+        for host in (False, True):
+            world, prims = build()
+            cam, pipe = camera(world)
+            cam.frame_sampler = ns.RectFrameSampler2D()
+            cam.render_engine = ns.HipEngine(rng="philox", seed=31, host_materials=host)
+            cam.observe()
+            cam.observe()                                                       # two accumulating passes
+            frames.append((pipe.frame.mean.copy(), pipe.frame.variance.copy(), pipe.frame.samples.copy(), cam.stats["rays"]))
+        assert eq(frames[0][0], frames[1][0]) and eq(frames[0][1], frames[1][1]) and eq(frames[0][2], frames[1][2])
+        assert frames[0][3] == frames[1][3] and (frames[0][0] > 0).mean() > 0.2
+
+
+def test_user_written_material_through_observe(orc, ns):
+    """A Material subclass the library has never seen renders through observe() (SURVEY.md §8b plug-point #3: the material plugin API
+    stays untouched). (1) A user re-implementation of Lambert's shading goes through the host-callback path and reproduces the
+    device-lowered Lambert's frame bit for bit (and so, by test_frames_lambert_against_oracle, the oracle's). (2) A material that
+    traces two daughters per hit and adds a volume term renders, finite and non-trivial. (3) The single-ray API: Ray.trace()."""
+    from source_amd.optical.material import Material, has_device_lowering, hemisphere_cosine_pdf
+
+    class MyLambert(ns.Lambert):
+        def evaluate_shading(self, world, ray, s_in, s_out, w_refl, w_trans, back_face, w2s, s2w, intersection):
+            pdf = hemisphere_cosine_pdf(s_out)
+            if pdf == 0.0:
+                return ray.new_spectrum()
+            spectrum = ray.spawn_daughter(w_refl, s_out.transform(s2w)).trace(world)
+            spectrum.mul_array(self.reflectivity.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins))
+            spectrum.mul_scalar(pdf)
+            return spectrum
+
+    class Splitter(Material):
+        def evaluate_surface(self, world, ray, primitive, hit_point, exiting, inside_point, outside_point, normal, w2p, p2w, intersection):
+            n = normal.transform_with_inverse(w2p).normalise()
+            d = ray.direction
+            k = 2 * (d.x * n.x + d.y * n.y + d.z * n.z)
+            a = ray.spawn_daughter((inside_point if exiting else outside_point).transform(p2w), ns.Vector3D(d.x - k * n.x, d.y - k * n.y, d.z - k * n.z)).trace(world)
+            b = ray.spawn_daughter((outside_point if exiting else inside_point).transform(p2w), d).trace(world)
+            a.mul_scalar(0.5)
+            a.mad_scalar(0.5, b.samples)
+            return a
+
+        def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, w2p, p2w):
+            spectrum.samples[:] = spectrum.samples + 0.05 * start_point.vector_to(end_point).length
+            return spectrum
+
+    assert not has_device_lowering(MyLambert()) and has_device_lowering(ns.Lambert())
+    frames = []
+    for lambert in (ns.Lambert, MyLambert):
+        world, prims = scenes.build_lambert(ns)
+        for p in prims:
+            if isinstance(p.material, ns.Lambert):
+                p.material = lambert(p.material.reflectivity)
+        cam, pipe = scenes.lambert_camera(ns, world, (36, 28), spp=3, bins=4, extinction=(0.2, 2, 9))
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=77)
+        cam.observe()
+        frames.append((pipe.frame.mean.copy(), pipe.frame.variance.copy(), cam.stats["rays"]))
+    assert eq(frames[0][0], frames[1][0]) and eq(frames[0][1], frames[1][1]) and frames[0][2] == frames[1][2]
+    # the lowered frame is the oracle's frame (same check as test_frames_lambert_against_oracle, restated for this camera)
+    keep = []
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 36, 28))
+    for p, lam in zip(world.primitives, [type(q.material) for q in world.primitives]):
+        if lam is MyLambert:
+            p.material = ns.Lambert(p.material.reflectivity)
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 36, 28))
+    om, ov, _ = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    assert eq(frames[1][0], om.reshape(28, 36, 4).transpose(1, 0, 2)) and eq(frames[1][1], ov.reshape(28, 36, 4).transpose(1, 0, 2))
+    # (2) two daughters per hit + a volume term
+    world, prims = scenes.build_lambert(ns, with_volume=False, csg=False)
+    ns.Sphere(0.25, world, ns.translate(0.35, 0.1, 0.9), Splitter())
+    cam, pipe = scenes.lambert_camera(ns, world, (32, 24), spp=4, bins=3, extinction=(0.2, 2, 8))
+    cam.render_engine = ns.HipEngine(rng="philox", seed=5)
+    cam.observe()
+    assert np.isfinite(pipe.frame.mean).all() and (pipe.frame.samples == 4).all() and (pipe.frame.mean > 0).mean() > 0.3
+    assert cam.stats["rays"] > 32 * 24 * 4 * 2
+    # (3) single rays through the same plugin API (host MT stream for the stochastic choices)
+    from source_amd.core import random as rsrandom
+    rsrandom.seed(3)
+    ray = ns.Ray(ns.Point3D(0, 0, -1.9), ns.Vector3D(0.05, -0.1, 1).normalise(), min_wavelength=400, max_wavelength=700, bins=6,
+                 extinction_prob=0.2, extinction_min_depth=2, max_depth=12)
+    total = ray.sample(world, 24)
+    assert total.samples.shape == (6,) and np.isfinite(total.samples).all() and total.samples.max() > 0 and ray.ray_count > 1
