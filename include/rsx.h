@@ -307,6 +307,23 @@ int rsx_render_pinhole_xyz(rsx_scene *scene, const rsx_render_desc *desc, const 
 int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, double *var_a, int32_t *n_a,
                           const double *mean_b, const double *var_b, const int32_t *n_b);
 
+/* ---- device-side known-answer entry points -----------------------------------------------------------------------------------
+ * Each runs the device functions / kernels of the render path on caller-supplied operands so that the reference's golden vectors can
+ * be checked against the DEVICE directly (tests/test_gpu_parity.py::test_device_known_answers), not only through rendered frames.
+ * BoundingBox3D.intersect (core/boundingbox.pyx:180-245): result[n,3] = hit, front, back; *mismatches counts rays on which the
+ * hoisted-reciprocal form the traversal uses and the plain form disagree (must be 0). */
+int rsx_selftest_aabb(rsx_ctx *ctx, int64_t n, const double *lower, const double *upper, const double *origin, const double *direction,
+                      double *result, uint64_t *mismatches);
+/* PinholeCamera._generate_rays + the observer's transform to world space (pinhole.pyx:169-204, observer.pyx:403-404) as the render
+ * kernels perform them: rays[n_tasks * spp, 7] = origin, direction, projection weight. desc: camera, tasks (required), spp, rng. */
+int rsx_selftest_camera_rays(rsx_ctx *ctx, const rsx_render_desc *desc, double *rays);
+/* StatsArray _add_sample (statsarray.pyx:743-776) through k_accumulate: x[n_chains, spp] -> (mean, variance)[n_chains] after the
+ * spp samples; both instantiations of the kernel run and must agree. */
+int rsx_selftest_welford(rsx_ctx *ctx, int64_t n_chains, int32_t spp, const double *x, double *mean, double *variance);
+/* The portable math of the path kernels: op 0 = pow(a, b) -> out0 (Beer-Lambert attenuation, dielectric.pyx:325-326),
+ * op 1 = (sin a, cos a) -> (out0, out1), op 2 = asin(a) -> out0 (solidangle.pyx:228-233, world.pyx:150-188). */
+int rsx_selftest_math(rsx_ctx *ctx, int32_t op, int64_t n, const double *a, const double *b, double *out0, double *out1);
+
 /* ---- multi-GPU: the spectral framebuffer over RCCL / xGMI (one process per GPU) ---------------------------------------------
  * Replaces the result queue of MulticoreEngine (raysect/core/workflow.py:201-251: workers send per-task (mean, variance) blocks, the
  * parent folds them into the frame, pipeline/spectral/power.pyx:424-437). Rays never cross GPUs; the frames meet once per render.

@@ -247,5 +247,27 @@ def pinhole_rays(desc):
     return out
 
 
+def _portable(op, a, b=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+    o0, o1 = np.zeros(len(a)), np.zeros(len(a))
+    f = lib().orc_portable_math
+    f.restype, f.argtypes = None, [C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    f(op, len(a), p(a), p(b), p(o0), p(o1))
+    return o0, o1
+
+
+def portable_pow(a, b):
+    return _portable(0, a, b)[0]
+
+
+def portable_sincos(phi):
+    return _portable(1, phi)
+
+
+def portable_asin(x):
+    return _portable(2, x)[0]
+
+
 def max_threads():
     return int(lib().orc_max_threads())

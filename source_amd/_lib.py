@@ -128,6 +128,10 @@ SYMBOLS = [
     ("rsx_render_pinhole_frame", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     ("rsx_render_pinhole_xyz", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, C.c_double, _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rsx_frame_combine_dev", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rsx_selftest_aabb", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_uint64)]),
+    ("rsx_selftest_camera_rays", C.c_int, [_vp, C.POINTER(RenderDesc), _vp]),
+    ("rsx_selftest_welford", C.c_int, [_vp, C.c_int64, C.c_int32, _vp, _vp, _vp]),
+    ("rsx_selftest_math", C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, _vp, _vp]),
     ("rsx_comm_unique_id", C.c_int, [_vp]),
     ("rsx_comm_create", C.c_int, [_vp, C.c_int32, C.c_int32, _vp, C.POINTER(_vp)]),
     ("rsx_comm_free", None, [_vp]),

@@ -102,6 +102,28 @@ __device__ __forceinline__ UnitPixel unit_pixel(const RSX_CONST_AS RenderParams 
     return px;
 }
 
+// PinholeCamera._generate_rays (pinhole.pyx:169-204) + RectangleSampler3D.sample (surface3d.pyx:197-198) + the observer's transform to
+// world space (observer.pyx:403-404: origin (0,0,0) and the direction through camera.to_root). u1 is the FIRST draw of the sample:
+// the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc).
+__device__ __forceinline__ void camera_ray(const RSX_CONST_AS RenderParams *q, int ix, int iy, double u1, double u2, Ray &r, double &weight) {
+    const double delta = q->cam.image_delta, half = 0.5 * delta;
+    const double pixel_x = q->cam.image_start_x - delta * ((double)ix + 0.5);
+    const double pixel_y = q->cam.image_start_y - delta * ((double)iy + 0.5);
+    double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
+    normalise3(dx, dy, dz);
+    weight = dz;
+    const RSX_CONST_AS double *m = q->cam.to_root;
+    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+    wq = 1.0 / wq;
+    r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+    r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+    r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+    r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
+    r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
+    r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
+    r.maxd = INFINITY;
+}
+
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
 // it fits several waves per SIMD; rays it cannot finish (exact ties between operand roots, operands with mesh leaves) are listed in
 // redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
@@ -165,26 +187,9 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         double u1, u2;
         if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
         else philox2(q->seed, (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy, q->sample_offset + (uint64_t)px.s, u1, u2);
-        const double delta = q->cam.image_delta, half = 0.5 * delta;
-        const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
-        const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
-        // the reference build draws the y jitter first, then x (C argument evaluation order of new_point3d(...) under gcc)
-        double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
-        normalise3(dx, dy, dz);
-        const double weight = dz;
         Ray r;
-        {
-            const RSX_CONST_AS double *m = q->cam.to_root;                    // observer.pyx:403-404: origin (0,0,0) and direction to world
-            double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
-            wq = 1.0 / wq;
-            r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
-            r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
-            r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
-            r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
-            r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
-            r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
-        }
-        r.maxd = INFINITY;
+        double weight;
+        camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
         Hit hit;
         uint32_t work = 0;
         const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
@@ -319,6 +324,69 @@ __device__ __forceinline__ double portable_asin(double x) {
         t = PIO4_HI - (p - q);
     }
     return t;
+}
+
+// x ** y for x > 0: the oracle's portable_pow (oracle/rsx_oracle.c) operation for operation — IEEE + - * / only, double-double
+// logarithm (2 atanh((m - 1) / (m + 1)) + e ln 2), Dekker product with y, Cody-Waite reduction and a degree-14 Taylor polynomial for
+// the exponential. The Beer-Lambert attenuation of a tinted dielectric (dielectric.pyx:325-326) is therefore the same bits on both
+// sides; against a correctly rounded pow it is good to about one unit in the last place.
+__device__ __forceinline__ void dd_two_sum(double a, double b, double &s, double &e) { const double t = a + b; const double bb = t - a; e = (a - (t - bb)) + (b - bb); s = t; }
+__device__ __forceinline__ void dd_split(double a, double &hi, double &lo) { const double c = 134217729.0 * a; const double h = c - (c - a); hi = h; lo = a - h; }
+__device__ __forceinline__ void dd_two_prod(double a, double b, double &p, double &e) {
+    double ah, al, bh, bl;
+    dd_split(a, ah, al); dd_split(b, bh, bl);
+    const double pr = a * b;
+    e = ((ah * bh - pr) + ah * bl + al * bh) + al * bl; p = pr;
+}
+__device__ __noinline__ double portable_pow(double x, double y) {
+    if (!(x > 0.0) || !(x < INFINITY) || !(y == y) || !(fabs(y) < INFINITY)) return pow(x, y);
+    if (y == 0.0 || x == 1.0) return 1.0;
+    unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+    int e = (int)((bits >> 52) & 0x7ff);
+    if (e == 0) { const double xs = x * 18014398509481984.0; bits = (unsigned long long)__double_as_longlong(xs); e = (int)((bits >> 52) & 0x7ff) - 54; }
+    e -= 1023;
+    bits = (bits & 0x000fffffffffffffULL) | 0x3ff0000000000000ULL;
+    double m = __longlong_as_double((long long)bits);
+    if (m > 1.4142135623730951) { m *= 0.5; e += 1; }
+    const double num = m - 1.0;
+    double den_h, den_l; dd_two_sum(m, 1.0, den_h, den_l);
+    const double s_h = num / den_h;
+    double ph, pl; dd_two_prod(s_h, den_h, ph, pl);
+    const double s_l = (((num - ph) - pl) - s_h * den_l) / den_h;
+    double z_h, z_l; dd_two_prod(s_h, s_h, z_h, z_l);
+    z_l += 2.0 * s_h * s_l;
+    double c_h, c_l; dd_two_prod(s_h, z_h, c_h, c_l);
+    c_l += s_h * z_l + s_l * z_h;
+    const double THIRD_H = 3.33333333333333314830e-01, THIRD_L = 1.85037170770859413132e-17;
+    double q_h, q_l; dd_two_prod(c_h, THIRD_H, q_h, q_l);
+    q_l += c_h * THIRD_L + c_l * THIRD_H;
+    const double z = z_h;
+    const double poly = 1.0 / 5.0 + z * (1.0 / 7.0 + z * (1.0 / 9.0 + z * (1.0 / 11.0 + z * (1.0 / 13.0 + z * (1.0 / 15.0 + z * (1.0 / 17.0
+                        + z * (1.0 / 19.0 + z * (1.0 / 21.0 + z * (1.0 / 23.0)))))))));
+    const double tail = 2.0 * ((c_h * z) * poly) + 2.0 * (q_l + s_l);
+    double a_h, a_l; dd_two_sum(2.0 * s_h, 2.0 * q_h, a_h, a_l);
+    double l_h, l_l; dd_two_sum(a_h, a_l + tail, l_h, l_l);
+    const double LN2_H = 6.93147180559945286227e-01, LN2_L = 2.31904681384629955842e-17;
+    double eh, el; dd_two_prod((double)e, LN2_H, eh, el);
+    el += (double)e * LN2_L;
+    double t_h, t_l; dd_two_sum(eh, l_h, t_h, t_l);
+    t_l += el + l_l;
+    double L_h, L_l; dd_two_sum(t_h, t_l, L_h, L_l);
+    double p_h, p_l; dd_two_prod(y, L_h, p_h, p_l);
+    p_l += y * L_l;
+    if (p_h > 709.8) return INFINITY;
+    if (p_h < -745.2) return 0.0;
+    const double LN2_CW_H = 6.93147180369123816490e-01, LN2_CW_L = 1.90821492927058770002e-10;
+    const double kf = floor(p_h * 1.44269504088896338700e+00 + 0.5);
+    const double r = ((p_h - kf * LN2_CW_H) - kf * LN2_CW_L) + p_l;
+    const double ex = 1.0 + r * (1.0 + r * (1.0 / 2.0 + r * (1.0 / 6.0 + r * (1.0 / 24.0 + r * (1.0 / 120.0 + r * (1.0 / 720.0 + r * (1.0 / 5040.0
+                      + r * (1.0 / 40320.0 + r * (1.0 / 362880.0 + r * (1.0 / 3628800.0 + r * (1.0 / 39916800.0 + r * (1.0 / 479001600.0
+                      + r * (1.0 / 6227020800.0 + r * (1.0 / 87178291200.0))))))))))))));
+    const int k = (int)kf;
+    const int k1 = k / 2, k2 = k - k1;
+    const double f1 = __longlong_as_double((long long)((unsigned long long)(k1 + 1023) << 52));
+    const double f2 = __longlong_as_double((long long)((unsigned long long)(k2 + 1023) << 52));
+    return (ex * f1) * f2;
 }
 
 // ImportanceManager.sample (world.pyx:150-188): pick = the selection uniform, (ua, ub) = the direction pair in the reference's draw order
@@ -522,22 +590,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     double u1, u2;
                     if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
                     else philox2(q->seed, rng_pixel, rng_sample, u1, u2);
-                    const double delta = q->cam.image_delta, half = 0.5 * delta;
-                    const double pixel_x = q->cam.image_start_x - delta * ((double)px.ix + 0.5);
-                    const double pixel_y = q->cam.image_start_y - delta * ((double)px.iy + 0.5);
-                    double dx = (u2 * delta - half) + pixel_x, dy = (u1 * delta - half) + pixel_y, dz = 0.0 + 1.0;
-                    normalise3(dx, dy, dz);
-                    const RSX_CONST_AS double *m = q->cam.to_root;
-                    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
-                    wq = 1.0 / wq;
-                    r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
-                    r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
-                    r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
-                    r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
-                    r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
-                    r.dz = m[8] * dx + m[9] * dy + m[10] * dz;
-                    r.maxd = INFINITY;
-                    smp.a = 0.0; smp.weight = dz; smp.table = -1; smp.pad = 0;
+                    double weight;
+                    camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
+                    smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
                     record = px.slot * q->spp + px.s;
                     blk = record; pos = 0; depth = 0; segments = 0;
                     ++spawned; ++path_spawned;
@@ -990,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;
                     } else if (tm.kind == TERM_ATTEN) {                       // dielectric.pyx:325-326; pow(1, length) = 1 exactly
-                        if constexpr (VOL == 2) { if (tv != 1.0) x = x * pow(tv, tm.a); }   // VOL == 1: the host saw only unit transmissions
+                        if constexpr (VOL == 2) { if (tv != 1.0) x = x * portable_pow(tv, tm.a); }   // VOL == 1: the host saw only unit transmissions
                     }
                     else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                     else {
@@ -1077,7 +1132,7 @@ __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_
                         const PathTerm tm = t[j];
                         const double tv = ap.tables[tm.table * ap.bins + b];
                         if (tm.kind == TERM_VOL) { const double emission = 0.0 + tv * tm.b; x = x + emission * tm.a; }
-                        else if (tm.kind == TERM_ATTEN) { if constexpr (VOL == 2) { if (tv != 1.0) x = x * pow(tv, tm.a); } }
+                        else if (tm.kind == TERM_ATTEN) { if constexpr (VOL == 2) { if (tv != 1.0) x = x * portable_pow(tv, tm.a); } }
                         else if (tm.kind == TERM_NORM) x = x * ap.roulette_norm;
                         else {
                             if (tm.kind == TERM_LAMBERT_NORM) x = x * ap.roulette_norm;

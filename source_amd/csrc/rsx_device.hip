@@ -127,6 +127,7 @@ extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
 #include "dev_world.hpp"
 #include "dev_query_kernels.hpp"
 #include "dev_render.hpp"
+#include "dev_selftest.hpp"
 
 // ---------------------------------------------------------------------------------------------------
 // host API
@@ -1253,6 +1254,125 @@ extern "C" int rsx_frame_combine_dev(rsx_ctx *ctx, int64_t n, double *mean_a, do
     hipLaunchKernelGGL(k_frame_combine, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, mean_a, var_a, n_a, mean_b, var_b, n_b);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    return RSX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// device-side known-answer entry points (dev_selftest.hpp)
+// ---------------------------------------------------------------------------------------------------
+namespace {
+struct DevBuf {                        // small RAII device buffer for the selftests (not on any hot path)
+    void *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    int alloc(size_t bytes) { return hipMalloc(&p, bytes ? bytes : 16) == hipSuccess ? RSX_OK : rsx_fail(RSX_ENOMEM, "selftest: out of device memory"); }
+    template <typename T> T *as() { return static_cast<T *>(p); }
+};
+}  // namespace
+
+extern "C" int rsx_selftest_aabb(rsx_ctx *ctx, int64_t n, const double *lower, const double *upper, const double *origin, const double *direction,
+                                 double *result, uint64_t *mismatches) {
+    if (!ctx || n < 0 || !lower || !upper || !origin || !direction || !result || !mismatches) return rsx_fail(RSX_EINVAL, "rsx_selftest_aabb: bad arguments");
+    *mismatches = 0;
+    if (n == 0) return RSX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    DevBuf in, out, mm;
+    int rc;
+    if ((rc = in.alloc(N * 96)) || (rc = out.alloc(N * 24)) || (rc = mm.alloc(8))) return rc;
+    double *d = in.as<double>();
+    const double *src[4] = {lower, upper, origin, direction};
+    for (int k = 0; k < 4; ++k) HIP_TRY(hipMemcpyAsync(d + 3 * N * k, src[k], N * 24, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipMemsetAsync(mm.p, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_aabb, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (long long)n, d, d + 3 * N, d + 6 * N, d + 9 * N,
+                       out.as<double>(), mm.as<unsigned long long>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(result, out.p, N * 24, hipMemcpyDeviceToHost, ctx->stream));
+    unsigned long long m = 0;
+    HIP_TRY(hipMemcpyAsync(&m, mm.p, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    *mismatches = m;
+    return RSX_OK;
+}
+
+extern "C" int rsx_selftest_camera_rays(rsx_ctx *ctx, const rsx_render_desc *desc, double *rays) {
+    if (!ctx || !desc || !rays || desc->n_tasks < 0 || desc->spp < 1) return rsx_fail(RSX_EINVAL, "rsx_selftest_camera_rays: bad arguments");
+    if (desc->rng_mode == RSX_RNG_STREAM && !desc->uniforms) return rsx_fail(RSX_EINVAL, "rsx_selftest_camera_rays: RSX_RNG_STREAM needs uniforms");
+    if (!desc->tasks) return rsx_fail(RSX_EINVAL, "rsx_selftest_camera_rays: needs an explicit task list");
+    if (desc->n_tasks == 0) return RSX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t T = (size_t)desc->n_tasks, S = T * (size_t)desc->spp;
+    DevBuf tasks, uni, out;
+    int rc;
+    if ((rc = tasks.alloc(T * 8)) || (rc = uni.alloc(S * 16)) || (rc = out.alloc(S * 56))) return rc;
+    HIP_TRY(hipMemcpyAsync(tasks.p, desc->tasks, T * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (desc->rng_mode == RSX_RNG_STREAM) HIP_TRY(hipMemcpyAsync(uni.p, desc->uniforms, S * 16, hipMemcpyHostToDevice, ctx->stream));
+    RenderParams rp;
+    std::memset(&rp, 0, sizeof(rp));
+    rp.cam = desc->camera;
+    rp.tasks = tasks.as<int32_t>();
+    rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? uni.as<double>() : nullptr;
+    rp.n_tasks = desc->n_tasks;
+    rp.spp = desc->spp; rp.rng_mode = desc->rng_mode; rp.seed = desc->seed; rp.sample_offset = desc->sample_offset;
+    hipLaunchKernelGGL(k_selftest_camera, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, rp, out.as<double>());
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(rays, out.p, S * 56, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RSX_OK;
+}
+
+extern "C" int rsx_selftest_welford(rsx_ctx *ctx, int64_t n_chains, int32_t spp, const double *x, double *mean, double *variance) {
+    if (!ctx || n_chains < 0 || spp < 1 || !x || !mean || !variance) return rsx_fail(RSX_EINVAL, "rsx_selftest_welford: bad arguments");
+    if (n_chains == 0) return RSX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n_chains, S = N * (size_t)spp;
+    DevBuf dx, ds, dm, dv, one;
+    int rc;
+    if ((rc = dx.alloc(S * 8)) || (rc = ds.alloc(S * sizeof(Sample))) || (rc = dm.alloc(N * 16)) || (rc = dv.alloc(N * 16)) || (rc = one.alloc(8))) return rc;
+    HIP_TRY(hipMemcpyAsync(dx.p, x, S * 8, hipMemcpyHostToDevice, ctx->stream));
+    const double unit = 1.0;
+    HIP_TRY(hipMemcpyAsync(one.p, &unit, 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_fill_samples, dim3((unsigned)((S + 255) / 256)), dim3(256), 0, ctx->stream, (long long)S, dx.as<double>(), ds.as<Sample>());
+    AccumParams ap;
+    std::memset(&ap, 0, sizeof(ap));
+    ap.samples = ds.as<Sample>(); ap.tables = one.as<double>(); ap.n_tasks = n_chains;
+    ap.rect[0] = 0; ap.rect[1] = 0; ap.rect[2] = 1; ap.rect[3] = (int32_t)n_chains;      // one column of n_chains pixels: slot order = task order
+    ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.n_tables = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
+    // both instantiations the render path uses: the lean one (few samples per pixel) and the staged one (LDS tables, batched loads)
+    for (int staged = 0; staged < 2; ++staged) {
+        ap.mean = dm.as<double>() + (staged ? N : 0); ap.variance = dv.as<double>() + (staged ? N : 0);
+        const dim3 grid((unsigned)((N + 255) / 256));
+        if (staged) hipLaunchKernelGGL((k_accumulate<true, 0>), grid, dim3(256), ((size_t)std::min(spp, ACC_RCP_TABLE_MAX) + 2 + 1) * 8, ctx->stream, ap);
+        else hipLaunchKernelGGL((k_accumulate<false, 0>), grid, dim3(256), 0, ctx->stream, ap);
+        HIP_TRY(hipGetLastError());
+    }
+    std::vector<double> hm(2 * N), hv(2 * N);
+    HIP_TRY(hipMemcpyAsync(hm.data(), dm.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(hv.data(), dv.p, N * 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < N; ++i)
+        if (std::memcmp(&hm[i], &hm[N + i], 8) || std::memcmp(&hv[i], &hv[N + i], 8))
+            return rsx_fail(RSX_EHIP, "rsx_selftest_welford: the two k_accumulate instantiations disagree on chain %zu", i);
+    std::memcpy(mean, hm.data(), N * 8);
+    std::memcpy(variance, hv.data(), N * 8);
+    return RSX_OK;
+}
+
+extern "C" int rsx_selftest_math(rsx_ctx *ctx, int32_t op, int64_t n, const double *a, const double *b, double *out0, double *out1) {
+    if (!ctx || n < 0 || op < 0 || op > 2 || !a || !out0 || (op == 0 && !b) || (op == 1 && !out1)) return rsx_fail(RSX_EINVAL, "rsx_selftest_math: bad arguments");
+    if (n == 0) return RSX_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t N = (size_t)n;
+    DevBuf buf;
+    int rc;
+    if ((rc = buf.alloc(N * 32))) return rc;
+    double *d = buf.as<double>();
+    HIP_TRY(hipMemcpyAsync(d, a, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    if (b) HIP_TRY(hipMemcpyAsync(d + N, b, N * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_selftest_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, (int)op, (long long)n, d, d + N, d + 2 * N, d + 3 * N);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out0, d + 2 * N, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (out1) HIP_TRY(hipMemcpyAsync(out1, d + 3 * N, N * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     return RSX_OK;
 }
 

@@ -92,3 +92,88 @@ def asin(x):
     p = 2.0 * s * r - (PIO2_LO - 2.0 * c)
     q = PIO4_HI - 2.0 * w
     return PIO4_HI - (p - q)
+
+
+def _two_sum(a, b):
+    t = a + b
+    bb = t - a
+    return t, (a - (t - bb)) + (b - bb)
+
+
+def _split(a):
+    c = 134217729.0 * a
+    h = c - (c - a)
+    return h, a - h
+
+
+def _two_prod(a, b):
+    ah, al = _split(a)
+    bh, bl = _split(b)
+    p = a * b
+    return p, ((ah * bh - p) + ah * bl + al * bh) + al * bl
+
+
+def _bits(x):
+    return struct.unpack("<Q", struct.pack("<d", x))[0]
+
+
+def _from_bits(b):
+    return struct.unpack("<d", struct.pack("<Q", b))[0]
+
+
+def pow(x, y):                                              # noqa: A001 (mirrors the C name)
+    """x ** y for x > 0 — portable_pow of oracle/rsx_oracle.c and dev_render.hpp, operation for operation."""
+    if not (x > 0.0) or not (x < math.inf) or y != y or not (abs(y) < math.inf):
+        return math.pow(x, y)
+    if y == 0.0 or x == 1.0:
+        return 1.0
+    bits = _bits(x)
+    e = (bits >> 52) & 0x7FF
+    if e == 0:
+        bits = _bits(x * 18014398509481984.0)
+        e = ((bits >> 52) & 0x7FF) - 54
+    e -= 1023
+    m = _from_bits((bits & 0x000FFFFFFFFFFFFF) | 0x3FF0000000000000)
+    if m > 1.4142135623730951:
+        m *= 0.5
+        e += 1
+    num = m - 1.0
+    den_h, den_l = _two_sum(m, 1.0)
+    s_h = num / den_h
+    ph, pl = _two_prod(s_h, den_h)
+    s_l = (((num - ph) - pl) - s_h * den_l) / den_h
+    z_h, z_l = _two_prod(s_h, s_h)
+    z_l += 2.0 * s_h * s_l
+    c_h, c_l = _two_prod(s_h, z_h)
+    c_l += s_h * z_l + s_l * z_h
+    THIRD_H, THIRD_L = 3.33333333333333314830e-01, 1.85037170770859413132e-17
+    q_h, q_l = _two_prod(c_h, THIRD_H)
+    q_l += c_h * THIRD_L + c_l * THIRD_H
+    z = z_h
+    poly = 1.0 / 5.0 + z * (1.0 / 7.0 + z * (1.0 / 9.0 + z * (1.0 / 11.0 + z * (1.0 / 13.0 + z * (1.0 / 15.0 + z * (1.0 / 17.0
+           + z * (1.0 / 19.0 + z * (1.0 / 21.0 + z * (1.0 / 23.0)))))))))
+    tail = 2.0 * ((c_h * z) * poly) + 2.0 * (q_l + s_l)
+    a_h, a_l = _two_sum(2.0 * s_h, 2.0 * q_h)
+    l_h, l_l = _two_sum(a_h, a_l + tail)
+    LN2_H, LN2_L = 6.93147180559945286227e-01, 2.31904681384629955842e-17
+    eh, el = _two_prod(float(e), LN2_H)
+    el += float(e) * LN2_L
+    t_h, t_l = _two_sum(eh, l_h)
+    t_l += el + l_l
+    L_h, L_l = _two_sum(t_h, t_l)
+    p_h, p_l = _two_prod(y, L_h)
+    p_l += y * L_l
+    if p_h > 709.8:
+        return math.inf
+    if p_h < -745.2:
+        return 0.0
+    LN2_CW_H, LN2_CW_L = 6.93147180369123816490e-01, 1.90821492927058770002e-10
+    kf = math.floor(p_h * 1.44269504088896338700e+00 + 0.5)
+    r = ((p_h - kf * LN2_CW_H) - kf * LN2_CW_L) + p_l
+    ex = 1.0 + r * (1.0 + r * (1.0 / 2.0 + r * (1.0 / 6.0 + r * (1.0 / 24.0 + r * (1.0 / 120.0 + r * (1.0 / 720.0 + r * (1.0 / 5040.0
+         + r * (1.0 / 40320.0 + r * (1.0 / 362880.0 + r * (1.0 / 3628800.0 + r * (1.0 / 39916800.0 + r * (1.0 / 479001600.0
+         + r * (1.0 / 6227020800.0 + r * (1.0 / 87178291200.0))))))))))))))
+    k = int(kf)
+    k1 = int(k / 2)                                         # C integer division truncates towards zero
+    k2 = k - k1
+    return (ex * _from_bits((k1 + 1023) << 52)) * _from_bits((k2 + 1023) << 52)

@@ -374,7 +374,12 @@ class Dielectric(Material):
     def evaluate_volume(self, spectrum, world, ray, primitive, start_point, end_point, world_to_primitive, primitive_to_world):
         length = start_point.vector_to(end_point).length
         transmission = self.transmission.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins)
-        spectrum.samples[:] = spectrum.samples * transmission ** length
+        if rsrandom._override is not None:                  # host-callback render: the device's portable pow, bit for bit
+            for i in range(spectrum.bins):
+                if transmission[i] != 1.0:
+                    spectrum.samples[i] = spectrum.samples[i] * _portable.pow(float(transmission[i]), length)
+        else:
+            spectrum.samples[:] = spectrum.samples * transmission ** length
         return spectrum
 
     def device_material(self, tables, min_wavelength, max_wavelength, bins):

@@ -575,3 +575,30 @@ def test_frames_demo_scenes(orc, ns, golden):
     cam, pipe = scenes.cornell_camera(ns, world, (20, 20), 3, 5)
     f = _observe_oracle_mt(orc, ns, cam, pipe, 82)
     assert eq(f[0], g["cornell_mean"]) and eq(f[1], g["cornell_var"]) and eq(f[2], g["cornell_n"])
+
+
+def test_portable_pow(orc):
+    """The portable pow the oracle (counter mode), the device and the host-callback path share: against libm's pow (what the reference
+    calls, correctly rounded to well under one unit in the last place) it stays within 2 ulp over the attenuation range and the
+    whole exponent range; the Python restatement gives the C one's bits."""
+    import math
+    from source_amd.optical import _portable as P
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(0, 1, 30000) ** rng.choice([1, 3, 8], 30000), rng.uniform(0.5, 2.5, 5000), 2.0 ** rng.randint(-1000, 1000, 5000) * rng.uniform(1, 2, 5000)])
+    y = np.concatenate([rng.uniform(0, 50, 30000) ** rng.choice([1, 2], 30000), rng.uniform(-300, 300, 5000), rng.uniform(-1, 1, 5000)])
+    x = np.where(x > 0, x, 0.25)
+    got = orc.portable_pow(x, y)
+    with np.errstate(over="ignore", under="ignore"):
+        want = np.power(x, y)
+    ok = np.isfinite(want) & (want > 2.3e-308) & np.isfinite(got)
+    ulp = np.abs(got[ok] - want[ok]) / np.spacing(want[ok])
+    assert ok.sum() > 30000 and ulp.max() <= 2.0, ulp.max()
+    assert (got[ok] == want[ok]).mean() > 0.85
+    assert orc.portable_pow(np.array([1.0, 0.3, 0.0]), np.array([7.5, 0.0, 2.0])).tolist() == [1.0, 1.0, 0.0]
+    for i in range(0, len(x), 17):
+        assert P.pow(float(x[i]), float(y[i])) == got[i] or (math.isnan(got[i]))
+    phi = rng.uniform(0, 2 * np.pi, 2000)
+    sn, cs = orc.portable_sincos(phi)
+    assert all(P.sincos(float(a)) == (float(s), float(c)) for a, s, c in zip(phi[:300], sn, cs))
+    t = rng.uniform(0, 1, 300)
+    assert all(P.asin(float(a)) == float(b) for a, b in zip(t, orc.portable_asin(t)))
