@@ -469,6 +469,40 @@ def test_c5_shape_512_spectral_slices(orc, ns):
     f.release()
 
 
+def test_c5_prism_512_slices_full_size(orc, ns):
+    """BASELINE configs[4] as the combination it names: the dispersive-prism scene (demos/prism.py geometry: nested analytic CSG, two
+    Sellmeier glasses, Lambert screen, importance sampling towards the prism) at 1024x1024 with 512 spectral bins rendered as 512
+    one-bin slices — every slice bends through its own refractive index — 1 sample per pixel per pass: 537 M paths into a 10.7 GB
+    device-resident frame. Strips of three slices against the oracle (mean; the variance of a 1-sample pass is 0), sample counts over
+    the whole frame, and the dispersion itself (the far slices light different screen pixels)."""
+    import time
+    world, prims = scenes.build_prism(ns)
+    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), 1, 512, 512)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=29)
+    t0 = time.perf_counter()
+    cam.observe()
+    f = pipe.frame
+    assert f.shape == (1024, 1024, 512)
+    assert (f.samples == 1).all()
+    elapsed = time.perf_counter() - t0
+    mean = f.mean
+    assert np.isfinite(mean).all() and (f.variance == 0).all()
+    flat = world.flatten()
+    slices = cam._slice_spectrum()
+    assert len(slices) == 512 and all(s.bins == 1 and s.offset == k for k, s in enumerate(slices))
+    lit = []
+    for k in (3, 256, 508):
+        keep = []
+        desc = cam.render_desc(world, None, slices[k], cam.render_engine, keep, rect=(0, 600, 1024, 606))
+        m, v, rays = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+        assert eq(mean[:, 600:606, k], m.reshape(6, 1024).T), k
+        lit.append(mean[:, :, k] > 0)
+    assert lit[0].sum() > 1000 and lit[2].sum() > 1000 and (lit[0] != lit[2]).sum() > 1000     # dispersion: blue and red land apart
+    print("configs[4] combination: 512 slices x 1024^2 x 1 spp in %.1f s (%.3g paths/s, %d rays)" % (elapsed, 512 * 1024 * 1024 / elapsed, cam.stats["rays"]))
+    f.release()
+
+
 def test_edge_semantics_on_device(orc, ns, golden):
     """Fixture F11 on the device: empty world, coincident primitives, t == max_distance, surface origins, axis-parallel grazing
     rays, zero-length batches, and 1x2 / 3x5x1 / masked (ragged task list) frames — all bit-exact against the compiled reference."""
