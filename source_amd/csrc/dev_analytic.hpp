@@ -82,6 +82,48 @@ __device__ void box_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
     pick_roots(near_t, far_t, nf, na, ff, fa, l.maxd, out);
 }
 
+// The same three functions for a wave-uniform primitive (world_trace_wave): the parameters come in as scalars, and a box whose
+// to_local rotation block is the identity (floors, walls, enclosing emitters: translate-only transforms) divides by the world
+// ray's own direction components, for which the caller already holds 1.0 / d (identity_rcp: the same quotients, not recomputed).
+__device__ __forceinline__ void box_slab_rcp(int axis, double o, double d, double rcp, double lo, double hi, double &near_t, double &far_t,
+                                             int &nf, int &ff, int &na, int &fa) {
+    double tmin, tmax;
+    int fmin, fmax;
+    const double inf = INFINITY;
+    if (d != 0.0) {
+        if (d > 0) { tmin = (lo - o) * rcp; tmax = (hi - o) * rcp; fmin = LOWER_FACE; fmax = UPPER_FACE; }
+        else       { tmin = (hi - o) * rcp; tmax = (lo - o) * rcp; fmin = UPPER_FACE; fmax = LOWER_FACE; }
+    } else {
+        if (o < lo)      { tmin = -inf; tmax = -inf; }
+        else if (o > hi) { tmin = inf;  tmax = inf; }
+        else             { tmin = -inf; tmax = inf; }
+        fmin = NO_FACE; fmax = NO_FACE;
+    }
+    if (tmin > near_t) { near_t = tmin; nf = fmin; na = axis; }
+    if (tmax < far_t)  { far_t = tmax;  ff = fmax; fa = axis; }
+}
+
+__device__ __forceinline__ void box_roots_uniform(const double (&prm)[6], const Ray &l, bool identity_rcp, double rx, double ry, double rz, Roots &out) {
+    double near_t = -INFINITY, far_t = INFINITY;
+    int nf = NO_FACE, ff = NO_FACE, na = -1, fa = -1;
+    if (!identity_rcp) { rx = 1.0 / l.dx; ry = 1.0 / l.dy; rz = 1.0 / l.dz; }          // (wave-uniform branch)
+    box_slab_rcp(0, l.ox, l.dx, rx, prm[0], prm[3], near_t, far_t, nf, ff, na, fa);
+    box_slab_rcp(1, l.oy, l.dy, ry, prm[1], prm[4], near_t, far_t, nf, ff, na, fa);
+    box_slab_rcp(2, l.oz, l.dz, rz, prm[2], prm[5], near_t, far_t, nf, ff, na, fa);
+    pick_roots(near_t, far_t, nf, na, ff, fa, l.maxd, out);
+}
+
+__device__ __forceinline__ void sphere_roots_uniform(double radius, const Ray &l, Roots &out) {
+    out.n = 0;
+    const double a = l.dx * l.dx + l.dy * l.dy + l.dz * l.dz;
+    const double b = 2 * (l.dx * l.ox + l.dy * l.oy + l.dz * l.oz);
+    const double c = l.ox * l.ox + l.oy * l.oy + l.oz * l.oz - radius * radius;
+    double t0, t1;
+    if (!solve_quadratic(a, b, c, t0, t1)) return;
+    if (t0 > t1) { const double tmp = t0; t0 = t1; t1 = tmp; }
+    pick_roots(t0, t1, 0, 0, 0, 0, l.maxd, out);
+}
+
 __device__ void cylinder_roots(const rsx_primitive &p, const Ray &l, Roots &out) {
     out.n = 0;
     const double radius = p.params[0], height = p.params[1];

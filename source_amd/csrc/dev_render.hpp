@@ -174,6 +174,9 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
         }
         const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
+#if RSX_PHASE_PROF == 2
+        const unsigned long long ph2_u0 = clock64();
+#endif
 #if RSX_PHASE_PROF
         unsigned long long phase_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #elif RSX_UTIL_PROF
@@ -192,7 +195,15 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
         Hit hit;
         uint32_t work = 0;
+#if RSX_PHASE_PROF == 2
+        const unsigned long long ph2_w0 = clock64();
+        phase_acc[0] = ph2_w0 - ph2_u0;
+#endif
         const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+#if RSX_PHASE_PROF == 2
+        const unsigned long long ph2_w1 = clock64();
+        phase_acc[1] = ph2_w1 - ph2_w0;
+#endif
         // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
         // compiler cannot merge this with the computation above)
         asm volatile("" : "+s"(unit));
@@ -210,6 +221,9 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             q2->unit_times[12 * unit + 1] = wall_clock64();
             q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
 #if RSX_PHASE_PROF
+#if RSX_PHASE_PROF == 2
+            phase_acc[6] = clock64() - ph2_u0;                 // (the store of the sample record follows: not included)
+#endif
             for (int ph = 0; ph < 8; ++ph) q2->unit_times[12 * unit + 3 + ph] = phase_acc[ph];
 #endif
         }
@@ -850,6 +864,9 @@ __global__ void k_selftest_division(unsigned long long n, unsigned long long see
         const double want = num / den;
         const double got = exact_div(num, den, refine_rcp(den), div_operand_safe(den));
         if (__double_as_longlong(want) != __double_as_longlong(got)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
+        // the world-level branch steps use the ray's own 1.0 / d (kept for the box gates) as the reciprocal
+        const double got2 = exact_div(num, den, 1.0 / den, div_operand_safe(den));
+        if (__double_as_longlong(want) != __double_as_longlong(got2)) { ++bad; atomicAdd(mismatches + 1 + (i & 7), 1ULL); }
     }
     if (bad) atomicAdd(mismatches, bad);
 }

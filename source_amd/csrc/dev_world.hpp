@@ -57,6 +57,9 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 // World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
 // that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
 // the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
+#ifndef RSX_WORLD_FAST_DIV
+#define RSX_WORLD_FAST_DIV 0
+#endif
 template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
@@ -64,10 +67,17 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
     bool active = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
-    // the world tree is a handful of nodes per ray: its branch steps use the plain division, which keeps three refined
-    // reciprocals out of the registers that stay live across the mesh traversal
+    // The world tree's branch steps use the plain division. Feeding exact_div with the gates' own 1.0 / d (the correctly rounded
+    // reciprocal satisfies the same correction step as the refined one: rsx_selftest_exact_division checks both forms against `/`)
+    // was measured: 41.1 -> 43.5 ms on configs[2] — the hardware division is ~11 instructions, the shortcut with its operand-range
+    // tests is no shorter and costs registers.
     AxisDiv ad;
+#if RSX_WORLD_FAST_DIV
+    ad.yx = rx; ad.yy = ry; ad.yz = rz;
+    ad.safe = (div_operand_safe(r.dx) ? 1 : 0) | (div_operand_safe(r.dy) ? 2 : 0) | (div_operand_safe(r.dz) ? 4 : 0);
+#else
     ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
+#endif
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
@@ -75,43 +85,81 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         const int32_t *items = sc.witems;
         if (active) { UTIL_COUNT(phase_acc, 0) }
         if (active) {
+#if RSX_UTIL_PROF == 2
+            const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
+#else
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
+#endif
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;
             count = nd.count;
         }
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
+#if RSX_UTIL_PROF == 2
+            if (have) { UTIL_COUNT(phase_acc, 2) }
+#endif
             const int32_t idx = have ? items[k] : 0;
-            const rsx_primitive &p = sc.prims[idx];
-            double f, b;
-            const bool gate = have && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
-            const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
             Hit cand;
             cand.prim = -1;
             work += CSG ? 16 : 4;
-            // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
-            // descriptor, array bases: scalar loads, SGPRs). Coherent waves meet one instance per leaf item; a wave that straddles
-            // several instances takes one turn per instance.
-            unsigned long long todo = __ballot(is_mesh);
+            // Leaf items are processed one PRIMITIVE at a time with everything about the primitive wave-uniform: bounding box,
+            // type, matrix, parameters and mesh descriptor come in over the scalar data path (SGPRs, no vector loads of the 300-byte
+            // record per lane). Coherent waves meet one primitive per leaf item; a wave that straddles several takes one turn each.
+            unsigned long long todo = __ballot(have);
             while (todo) {
                 const int leader = __ffsll((long long)todo) - 1;
                 const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
-                const bool mine = is_mesh && idx == uidx;
+                const bool mine = have && idx == uidx;
                 todo &= ~__ballot(mine);
                 const UPrim up = uniform_prim(sc.prims, uidx);
-                Ray l = r;
-                if (mine) l = to_local_uniform(up, r);
-                const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
-                MeshHit mh;
-                if (mesh_trace_wave<STAGE_MIN>(mine, um, l, mesh_stack, mh, work, phase_acc)) {
-                    cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
+                const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+                double f, b;
+                const bool gate = mine && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                const int32_t type = up->type;
+                if (!__any(gate)) continue;
+                if (type == RSX_PRIM_MESH) {
+#if RSX_PHASE_PROF == 2
+                    const unsigned long long ph2_m0 = clock64();
+#endif
+                    Ray l = r;
+                    if (gate) l = to_local_uniform(up, r);
+                    const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
+                    MeshHit mh;
+                    if (mesh_trace_wave<STAGE_MIN>(gate, um, l, mesh_stack, mh, work, phase_acc)) {
+                        cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
+                    }
+#if RSX_PHASE_PROF == 2
+                    phase_acc[2] += clock64() - ph2_m0; phase_acc[5] += 1;
+#endif
+                    continue;
                 }
-            }
-            if (gate && !is_mesh) {
-                bool needs_stream = false;
-                primitive_first_hit<CSG, FASTONLY>(sc, idx, p, r, mesh_stack, csg_state, cand, needs_stream);
-                if (FASTONLY && needs_stream) work |= 0x80000000u;            // top bit of the cost counter: trace this ray again with the stream merge
+#if RSX_UTIL_PROF == 2
+                if (gate) { UTIL_COUNT(phase_acc, 6) }
+#endif
+                if (CSG && is_csg(type)) {
+                    if (gate) {
+                        bool needs_stream = false;
+                        primitive_first_hit<CSG, FASTONLY>(sc, idx, sc.prims[idx], r, mesh_stack, csg_state, cand, needs_stream);
+                        if (FASTONLY && needs_stream) work |= 0x80000000u;        // top bit of the cost counter: trace this ray again with the stream merge
+                    }
+                    continue;
+                }
+                if (gate) {                                                         // sphere / box / cylinder: Primitive.hit, first root
+                    const Ray l = to_local_uniform(up, r);
+                    Roots roots;
+                    roots.n = 0;
+                    if (type == RSX_PRIM_BOX) {
+                        const RSX_CONST_AS double *m = up->to_local;
+                        const bool identity = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 &&
+                                              m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
+                        // identity rotation: l.d == r.d wherever a component is non-zero (1 * x + 0 * y + 0 * z), so the gates' 1.0 / d are the box's own
+                        const double prm[6] = {up->params[0], up->params[1], up->params[2], up->params[3], up->params[4], up->params[5]};
+                        box_roots_uniform(prm, l, identity, rx, ry, rz, roots);
+                    } else if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(up->params[0], l, roots);
+                    else if (type == RSX_PRIM_CYLINDER) cylinder_roots(sc.prims[idx], l, roots);
+                    if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
+                }
             }
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
