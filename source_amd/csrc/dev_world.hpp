@@ -57,6 +57,34 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 // World.hit for the 64 rays of a wave: every lane calls it together (`valid` = lane has a ray) and all loops are wave-uniform, so
 // that mesh primitives can be traced with mesh_trace_wave (idle lanes help on big leaves). Leaf items are tested in leaf order and
 // the closest kept with `<=` (later item wins ties, kdtree.pyx:113); a hit inside the leaf's range ends the traversal.
+// Primitive.hit of a wave-uniform sphere / box / cylinder (BoundPrimitive gate included): first root t >= 0 and its (face, axis | type)
+// packed as (a0 + 1) | (a1 + 1) << 4, or t = -1 when the ray misses. A box under a translate-only transform divides by the world ray's
+// own direction components: l.d == r.d wherever a component is non-zero (1 * x + 0 * y + 0 * z), so the gates' 1.0 / d are the box's own.
+__device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, int32_t uidx, bool want, const Ray &r, double rx, double ry, double rz,
+                                                    double &t, int32_t &faces) {
+    t = -1.0; faces = 0;
+    const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+    double f, b;
+    const bool gate = want && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);            // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+#if RSX_UTIL_PROF == 2
+    (void)f;
+#endif
+    if (!gate) return;
+    const int32_t type = up->type;
+    const Ray l = to_local_uniform(up, r);
+    Roots roots;
+    roots.n = 0;
+    if (type == RSX_PRIM_BOX) {
+        const RSX_CONST_AS double *m = up->to_local;
+        const bool identity = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 &&
+                              m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
+        const double prm[6] = {up->params[0], up->params[1], up->params[2], up->params[3], up->params[4], up->params[5]};
+        box_roots_uniform(prm, l, identity, rx, ry, rz, roots);
+    } else if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(up->params[0], l, roots);
+    else if (type == RSX_PRIM_CYLINDER) cylinder_roots(sc.prims[uidx], l, roots);
+    if (roots.n > 0) { t = roots.t[0]; faces = (roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4); }
+}
+
 #ifndef RSX_WORLD_FAST_DIV
 #define RSX_WORLD_FAST_DIV 0
 #endif
@@ -78,6 +106,17 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
 #else
     ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
 #endif
+    // Primitives that sit in several world leaves (the reference tests a primitive again in every leaf the ray visits,
+    // kdtree.pyx:99-116; the answer is the same each time): their first root is computed once, here. configs[2]: the floor box and
+    // the enclosing emitter are met 4.4 times per primary ray.
+    double wide_t0 = -1.0, wide_t1 = -1.0;
+    int32_t wide_faces = 0;
+    if (sc.wide[0] >= 0) {
+        int32_t f0 = 0, f1 = 0;
+        analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[0]), sc.wide[0], active, r, rx, ry, rz, wide_t0, f0);
+        if (sc.wide[1] >= 0) analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[1]), sc.wide[1], active, r, rx, ry, rz, wide_t1, f1);
+        wide_faces = f0 | (f1 << 8);
+    }
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
@@ -112,12 +151,23 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
                 const bool mine = have && idx == uidx;
                 todo &= ~__ballot(mine);
+                if (uidx == sc.wide[0] || uidx == sc.wide[1]) {                     // answered before the traversal began
+                    const bool first = uidx == sc.wide[0];
+                    const double t = first ? wide_t0 : wide_t1;
+                    const int32_t faces = first ? wide_faces & 255 : wide_faces >> 8;
+                    if (mine && t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
+                    continue;
+                }
                 const UPrim up = uniform_prim(sc.prims, uidx);
-                const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
-                double f, b;
-                const bool gate = mine && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
                 const int32_t type = up->type;
-                if (!__any(gate)) continue;
+                const bool analytic = type != RSX_PRIM_MESH && !(CSG && is_csg(type));
+                bool gate = mine;
+                if (!analytic) {
+                    const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+                    double f, b;
+                    gate = mine && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);           // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                    if (!__any(gate)) continue;
+                }
                 if (type == RSX_PRIM_MESH) {
 #if RSX_PHASE_PROF == 2
                     const unsigned long long ph2_m0 = clock64();
@@ -145,20 +195,11 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     }
                     continue;
                 }
-                if (gate) {                                                         // sphere / box / cylinder: Primitive.hit, first root
-                    const Ray l = to_local_uniform(up, r);
-                    Roots roots;
-                    roots.n = 0;
-                    if (type == RSX_PRIM_BOX) {
-                        const RSX_CONST_AS double *m = up->to_local;
-                        const bool identity = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 &&
-                                              m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
-                        // identity rotation: l.d == r.d wherever a component is non-zero (1 * x + 0 * y + 0 * z), so the gates' 1.0 / d are the box's own
-                        const double prm[6] = {up->params[0], up->params[1], up->params[2], up->params[3], up->params[4], up->params[5]};
-                        box_roots_uniform(prm, l, identity, rx, ry, rz, roots);
-                    } else if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(up->params[0], l, roots);
-                    else if (type == RSX_PRIM_CYLINDER) cylinder_roots(sc.prims[idx], l, roots);
-                    if (roots.n > 0) { cand.prim = idx; cand.t = roots.t[0]; cand.a0 = roots.a0[0]; cand.a1 = roots.a1[0]; cand.u = cand.v = cand.w = 0.0f; }
+                {                                                                   // sphere / box / cylinder: Primitive.hit, first root
+                    double t;
+                    int32_t faces;
+                    analytic_first_root(sc, up, uidx, gate, r, rx, ry, rz, t, faces);
+                    if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                 }
             }
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties

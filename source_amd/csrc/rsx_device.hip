@@ -581,6 +581,26 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     d.n_meshes = desc->n_meshes;
     d.wdepth = tree_depth(desc->world_kd) + 1;
     d.mdepth = 1;
+    {
+        // the two analytic world primitives that occur in the most world leaves (at least two): see DScene::wide
+        std::vector<int32_t> leaves((size_t)std::max(1, desc->n_world), 0);
+        for (int32_t n = 0; n < desc->world_kd.n_nodes; ++n) {
+            const rsx_kdnode &nd = desc->world_kd.nodes[n];
+            if (nd.type >= 0) continue;
+            for (int32_t k = 0; k < nd.count; ++k) {
+                const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
+                if (idx >= 0 && idx < desc->n_world) leaves[(size_t)idx]++;
+            }
+        }
+        d.wide[0] = d.wide[1] = -1;
+        if (!std::getenv("RSX_NO_WIDE"))
+            for (int32_t i = 0; i < desc->n_world; ++i) {
+                const int32_t t = desc->primitives[i].type;
+                if ((t != RSX_PRIM_SPHERE && t != RSX_PRIM_BOX && t != RSX_PRIM_CYLINDER) || leaves[(size_t)i] < 2) continue;
+                if (d.wide[0] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[0]]) { d.wide[1] = d.wide[0]; d.wide[0] = i; }
+                else if (d.wide[1] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[1]]) d.wide[1] = i;
+            }
+    }
     std::vector<DMesh> meshes((size_t)desc->n_meshes);
     for (int32_t i = 0; i < desc->n_meshes; ++i) {
         const rsx_meshdata &m = desc->meshes[i];
