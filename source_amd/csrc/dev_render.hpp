@@ -124,16 +124,153 @@ __device__ __forceinline__ void camera_ray(const RSX_CONST_AS RenderParams *q, i
     r.maxd = INFINITY;
 }
 
+// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859.
+// Every division here is by a small positive integer whose refined reciprocal is shared by the two divisions of consecutive
+// Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
+// rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
+// (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
+struct IntRcp {
+    double d, y;
+    __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
+    __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
+};
+
+// n -> n + 1 samples; `by_n` = IntRcp(n + 1), `by_nm1` = IntRcp(n) (the divisors of the update)
+__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n, const IntRcp &by_n, const IntRcp &by_nm1) {
+    if (n == 0) { n = 1; m = x; v = 0; return; }
+    const double pm = m, pv = v;
+    const int pn = n > 1 ? n : 2;
+    n += 1;
+    m = pm + by_n.div(x - pm);
+    v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
+}
+
+__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
+    if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
+    if (nx > 1 && ny > 1) {
+        nt = nx + ny;
+        const IntRcp by_nt(nt);
+        mt = by_nt.div(nx * mx + ny * my);
+        vx = IntRcp(nx).div((nx - 1) * vx);
+        vy = IntRcp(ny).div((ny - 1) * vy);
+        vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
+        vt = IntRcp(nt - 1).div(nt * vt);
+        return;
+    }
+    if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
+    else if (nx == 1) {
+        if (ny == 0) { nt = 1; mt = mx; vt = 0; }
+        else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
+    } else if (nx > 1) {
+        nt = nx; mt = mx; vt = vx;
+        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
+    } else { nt = 0; mt = 0; vt = 0; }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Welford in the trace kernel (fused passes)
+// ---------------------------------------------------------------------------------------------------
+// Passes that run alone on the context stream, whose 64-ray units hold whole pixels (64 % spp == 0) and whose materials are the
+// closed-form ones, do not hand their sample records to k_accumulate: every wave keeps the records of its last FUSE_UNITS units in a
+// private global ring (L2-resident: 6 KB per wave, rewritten every four units), and after the fourth unit runs the per-(pixel, bin)
+// Welford recurrence and the frame merge itself — the chains of four units fill the wave (4 pixels x 15 bins = 60 lanes at 64 spp).
+// The records are staged through the wave's own LDS region (idle between units: the traversal stacks are empty), as
+// a[256] | weight[256] | table[256] | reciprocals[spp + 2] | spectral tables. Same operations in the same order as k_accumulate
+// (statsarray.pyx:743-776 per sample, then combine_samples into the frame): frames are bit-identical to the two-kernel form.
+// What it buys: the 6.4 GB sample-record round trip through HBM and the 5.8 ms accumulate kernel of a 2048^2 x 64 spp pass go. What
+// it costs: the recurrence (34 instructions per sample and bin) moves into a kernel that is already bound by instruction issue —
+// measured 41.9 ms against 34.9 + 5.8 = 40.8 ms for the two kernels, so the form is opt-in (RSX_FUSE=1, rsx_device.hip).
+#define FUSE_UNITS 4
+struct FuseParams {
+    Sample *ring;                       // [n_waves][FUSE_UNITS * WAVE]
+    const double *tables;               // [n_tables, bins]
+    double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins]
+    double sensitivity;
+    int32_t n_tables, bins, power, ny, frame_bins, slice_offset;
+    int32_t lds_bytes, tables_in_lds;   // per-wave LDS region size; 1: the spectral tables fit behind the staged records
+};
+
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
 // it fits several waves per SIMD; rays it cannot finish (exact ties between operand roots, operands with mesh leaves) are listed in
 // redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
 // STAGE_MIN: see mesh_trace_wave (1 for passes with more than one sample per pixel).
-template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN>
+// The chains of the units a wave has gathered in its ring: Welford over each pixel's spp samples per bin, merged into the frame.
+template <bool TABLES_IN_LDS>
+__device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q, const FuseParams &fz, int u0, int u1, int u2, int u3, int n_units, uint32_t lds_base) {
+    const int lane = threadIdx.x % WAVE;
+    const int spp = q->spp, bins = fz.bins, ppu = WAVE / spp;             // pixels per unit
+    const double *l_a = reinterpret_cast<const double *>(smem + lds_base), *l_w = l_a + FUSE_UNITS * WAVE;
+    const int32_t *l_tab = reinterpret_cast<const int32_t *>(l_w + FUSE_UNITS * WAVE);
+    const double *l_rcp = reinterpret_cast<const double *>(l_tab + FUSE_UNITS * WAVE), *l_tables = l_rcp + (spp + 2);
+    const double scale = fz.power ? fz.sensitivity : 1.0;                 // x * 1.0 is x, bit for bit: one multiply instead of a branch per sample
+    const double *tables = TABLES_IN_LDS ? l_tables : fz.tables;
+    const int chains = n_units * ppu * bins;
+    for (int c = lane; c < chains; c += WAVE) {
+        const int pix = (int)((uint32_t)c / (uint32_t)bins), b = c - pix * bins;
+        const int u = (int)((uint32_t)pix / (uint32_t)ppu), within = pix - u * ppu;
+        const int unit_u = u == 0 ? u0 : u == 1 ? u1 : u == 2 ? u2 : u3;
+        const UnitPixel px = unit_pixel(q, unit_u, within * spp);
+        if (!px.valid) continue;
+        const int base = u * WAVE + within * spp;
+        // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
+        auto value = [&](int i) {
+            const int32_t table = l_tab[base + i];
+            double x = table < 0 ? 0.0 : l_a[base + i] * tables[(table < 0 ? 0 : table) * bins + b];
+            x = x * l_w[base + i];
+            return x * scale;
+        };
+        double m = value(0), v = 0, dm = 1.0;
+        for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step()
+            const double x = value(i);
+            const double dn = dm + 1.0, cc = i == 1 ? 1.0 : dm - 1.0;
+            const double pm = m, pv = v;
+            m = pm + exact_div(x - pm, dn, l_rcp[i + 1], true);
+            v = exact_div(pv * cc + (x - pm) * (x - m), dm, l_rcp[i], true);
+            dm = dn;
+        }
+        const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
+        if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
+        double mt, vt;
+        int nt;
+        combine_samples(fz.fmean[f], fz.fvar[f], fz.fn[f], m, v, spp, mt, vt, nt);
+        fz.fmean[f] = mt; fz.fvar[f] = vt; fz.fn[f] = nt;
+    }
+}
+
+__device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, const FuseParams &fz, const Sample *ring, int u0, int u1, int u2, int u3, int n_units,
+                                            uint32_t lds_base) {
+    const int lane = threadIdx.x % WAVE;
+    const int spp = q->spp;
+    double *l_a = reinterpret_cast<double *>(smem + lds_base), *l_w = l_a + FUSE_UNITS * WAVE;
+    int32_t *l_tab = reinterpret_cast<int32_t *>(l_w + FUSE_UNITS * WAVE);
+    double *l_rcp = reinterpret_cast<double *>(l_tab + FUSE_UNITS * WAVE), *l_tables = l_rcp + (spp + 2);
+    // the ring was written by this wave's own lanes (earlier units): same CU, same vector L1 — workgroup-scope ordering is enough
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    for (int u = 0; u < n_units; ++u) {
+        const Sample smp = ring[u * WAVE + lane];
+        l_a[u * WAVE + lane] = smp.a; l_w[u * WAVE + lane] = smp.weight; l_tab[u * WAVE + lane] = smp.table;
+    }
+    for (int d = lane + 1; d < spp + 2; d += WAVE) l_rcp[d] = refine_rcp((double)d);
+    if (fz.tables_in_lds) for (int e = lane; e < fz.n_tables * fz.bins; e += WAVE) l_tables[e] = fz.tables[e];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (fz.tables_in_lds) fused_chains<true>(q, fz, u0, u1, u2, u3, n_units, lds_base);
+    else fused_chains<false>(q, fz, u0, u1, u2, u3, n_units, lds_base);
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = false>
 __global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
-void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket) {
+void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, FuseParams fz) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
+    int fuse_u0 = 0, fuse_u1 = 0, fuse_u2 = 0, fuse_u3 = 0, fuse_n = 0;           // wave-uniform: the units whose records wait in the ring
+    Sample *fuse_ring = nullptr;
+    if constexpr (FUSED) fuse_ring = fz.ring + ((size_t)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE))) * (FUSE_UNITS * WAVE);
     NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
     long long redo_unit = (long long)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // MODE 2: units are strided over the waves
     // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
@@ -234,7 +371,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             if (redo) continue;
         }
         if constexpr (MODE == 2) { if (!((q2->redo_mask[unit] >> lane) & 1ULL)) continue; }
-        if (!px2.valid) continue;
+        if (!FUSED && !px2.valid) continue;
         Sample smp;
         smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
         if (got) {                                                                 // optical/ray.pyx:391-393
@@ -253,7 +390,17 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
                 }
             }
         }
-        samples[px2.slot * q2->spp + px2.s] = smp;
+        if constexpr (FUSED) {
+            fuse_ring[fuse_n * WAVE + lane] = smp;                         // (lanes of pixels outside the frame write a record nobody reads)
+            if (fuse_n == 0) fuse_u0 = unit; else if (fuse_n == 1) fuse_u1 = unit; else if (fuse_n == 2) fuse_u2 = unit; else fuse_u3 = unit;
+            if (++fuse_n == FUSE_UNITS) { fused_flush(q2, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t); fuse_n = 0; }
+        } else samples[px2.slot * q2->spp + px2.s] = smp;
+    }
+    if constexpr (FUSED) {
+        if (fuse_n) {
+            const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
+            fused_flush((const RSX_CONST_AS RenderParams *)rp_bits, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
+        }
     }
 }
 
@@ -934,49 +1081,6 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
         const uint32_t c = cost[i];
         order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
     }
-}
-
-// StatsArray _add_sample / _combine_samples — core/math/statsarray.pyx:743-859.
-// Every division here is by a small positive integer whose refined reciprocal is shared by the two divisions of consecutive
-// Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
-// rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
-// (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
-struct IntRcp {
-    double d, y;
-    __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
-    __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
-};
-
-// n -> n + 1 samples; `by_n` = IntRcp(n + 1), `by_nm1` = IntRcp(n) (the divisors of the update)
-__device__ __forceinline__ void add_sample(double x, double &m, double &v, int &n, const IntRcp &by_n, const IntRcp &by_nm1) {
-    if (n == 0) { n = 1; m = x; v = 0; return; }
-    const double pm = m, pv = v;
-    const int pn = n > 1 ? n : 2;
-    n += 1;
-    m = pm + by_n.div(x - pm);
-    v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
-}
-
-__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
-    if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
-    if (nx > 1 && ny > 1) {
-        nt = nx + ny;
-        const IntRcp by_nt(nt);
-        mt = by_nt.div(nx * mx + ny * my);
-        vx = IntRcp(nx).div((nx - 1) * vx);
-        vy = IntRcp(ny).div((ny - 1) * vy);
-        vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
-        vt = IntRcp(nt - 1).div(nt * vt);
-        return;
-    }
-    if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
-    else if (nx == 1) {
-        if (ny == 0) { nt = 1; mt = mx; vt = 0; }
-        else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
-    } else if (nx > 1) {
-        nt = nx; mt = mx; vt = vx;
-        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
-    } else { nt = 0; mt = 0; vt = 0; }
 }
 
 // One thread per (task, bin): sequential Welford over the task's spp samples in sample order

@@ -154,6 +154,8 @@ struct TraceLane {
     size_t redo_bytes = 0;
     void *samples = nullptr, *uniforms = nullptr, *terms = nullptr, *tail = nullptr;   // terms / tail: PathTerm blocks of the path kernel
     size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0, tail_bytes = 0;
+    void *ring = nullptr;              // fused passes: FUSE_UNITS x 64 sample records per wave of the grid
+    size_t ring_bytes = 0;
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
@@ -267,7 +269,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, (void *)ln->overflow})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -1004,7 +1006,17 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         }
         return RSX_OK;
     };
-    if ((rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
+    // Fused form (dev_render.hpp, "Welford in the trace kernel"): a pass that runs alone on the context stream, merges into a frame,
+    // has closed-form materials only and whole pixels per 64-ray unit keeps its sample records in per-wave rings
+    // — opt-in (RSX_FUSE=1): measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. The
+    // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
+    // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
+    static const bool fuse_enabled = [] { const char *e = std::getenv("RSX_FUSE"); return e && std::atoi(e) != 0; }();
+    const size_t wave_lds = (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
+    const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
+    const bool fused = fuse_enabled && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
+                       !ctx->unit_times && wave_lds >= fuse_fixed;
+    if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
     if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;
@@ -1099,6 +1111,20 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
+    FuseParams fz;
+    std::memset(&fz, 0, sizeof(fz));
+    if (fused) {
+        const size_t n_waves = (size_t)l.grid.x * WG_WAVES;
+        if ((rc = lane_buffer(lane.ring, lane.ring_bytes, n_waves * FUSE_UNITS * WAVE * sizeof(Sample)))) return rc;
+        fz.ring = static_cast<Sample *>(lane.ring);
+        fz.tables = static_cast<const double *>(d_tab);
+        fz.fmean = fmean; fz.fvar = fvar; fz.fn = fn;
+        fz.sensitivity = desc->camera.sensitivity;
+        fz.n_tables = desc->n_tables; fz.bins = desc->bins; fz.power = desc->power; fz.ny = desc->camera.ny;
+        fz.frame_bins = frame_bins; fz.slice_offset = slice_offset;
+        fz.lds_bytes = (int32_t)wave_lds;
+        fz.tables_in_lds = fuse_fixed + (size_t)std::max(1, desc->n_tables) * B * 8 <= wave_lds ? 1 : 0;
+    }
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
     while (ctx->ring.size() < (size_t)(slot + 1) * 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
     hipEvent_t *re = &ctx->ring[(size_t)slot * 4];
@@ -1152,13 +1178,22 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
-        hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
-    } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+        hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+        hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+    } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+    else if (fused) {
+        if (desc->spp > RSX_COHERENT_MIN_SPP) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            hipLaunchKernelGGL((k_render_trace<false, 0, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
+        } else {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, RSX_STAGE_MIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            hipLaunchKernelGGL((k_render_trace<false, 0, RSX_STAGE_MIN, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
+        }
+    }
     else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        hipLaunchKernelGGL((k_render_trace<false, 0, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
-    } else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket);
+        hipLaunchKernelGGL((k_render_trace<false, 0, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+    } else hipLaunchKernelGGL(k_render_trace<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     HIP_TRY(hipGetLastError());
     HP_MARK(1)
     if (timed) HIP_TRY(hipEventRecord(re[1], lane.stream));
@@ -1196,6 +1231,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
     if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
     const dim3 acc_grid((unsigned)((total + 255) / 256));
+    if (fused) {                                            // the trace kernel merged its own samples; its tickets are re-armed by the next launch
+        lane.ticket_armed = false;
+        if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
+        HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
+        ctx->render_calls++;
+        ctx->have_accum = true;
+        if (g_hp_on) ++g_hp_calls;
+        return RSX_OK;
+    }
     bool has_dielectric = false;                            // an absorbing dielectric: only then do the terms need pow() (60 more registers)
     for (int32_t i = 0; has_vol && i < desc->n_materials; ++i) {
         if (desc->materials[i].type != RSX_MAT_DIELECTRIC) continue;

@@ -1087,3 +1087,41 @@ def test_user_written_material_through_observe(orc, ns):
                  extinction_prob=0.2, extinction_min_depth=2, max_depth=12)
     total = ray.sample(world, 24)
     assert total.samples.shape == (6,) and np.isfinite(total.samples).all() and total.samples.max() > 0 and ray.ray_count > 1
+
+
+def test_fused_welford_form_gives_the_same_frames(ns):
+    """The opt-in fused form (RSX_FUSE=1: per-pixel Welford and frame merge inside the trace kernel, sample records in per-wave
+    rings instead of one HBM buffer) against the two-kernel form: frames bit-identical, for whole-pixel units at 64, 16 and 1 samples
+    per pixel, a frame whose size is not a multiple of the 8x8 unit tiles, the power pipeline, and two accumulating passes."""
+    import os
+    import subprocess
+    import sys
+    code = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from source_amd import api as ns, scenes
+world = scenes.build_c3(ns, n=24)[0]
+out = []
+for (nx, ny, spp, power) in ((72, 44, 64, False), (100, 61, 16, True), (64, 64, 1, False)):
+    pipe = ns.SpectralPowerPipeline2D() if power else ns.SpectralRadiancePipeline2D()
+    cam, _ = scenes.c3_camera(ns, world, (nx, ny), spp=spp, bins=7)
+    cam.pipelines = [pipe]
+    cam.sensitivity = 2.5
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=8)
+    cam.observe(); cam.observe()
+    h = hashlib.sha256()
+    for a in (pipe.frame.mean, pipe.frame.variance, pipe.frame.samples):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert (pipe.frame.samples == 2 * spp).all() and pipe.frame.mean.max() > 0
+    out.append(h.hexdigest())
+print(" ".join(out))
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digests = []
+    for fuse in ("0", "1"):
+        env = dict(os.environ, RSX_FUSE=fuse, RSX_PIPELINE="1")       # un-pipelined: the fused form only serves passes that run alone
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        digests.append(r.stdout.strip().splitlines()[-1])
+    assert digests[0] == digests[1] and len(digests[0].split()) == 3
