@@ -335,3 +335,43 @@ __device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &
     return nd;
 }
 
+
+// The world tree seen by a coherent wave (the samples of one pixel, the rays of a small tile): the lanes sit on the same node nearly
+// always (utilisation 0.997 of the world-level loops on configs[2]), so the node comes in over the scalar data path, the split axis
+// is a scalar branch instead of twelve per-lane selects, and the child ids are scalars. The arithmetic per lane is the reference's
+// (kdtree3d.pyx:626-700: plane = (split - origin[axis]) / direction[axis], the plain division). The moment the lanes part, the walk
+// continues per lane (descend).
+__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double tmin, double &tmax, const Stack &st, int32_t &sp) {
+    if (__builtin_expect(__any(d == 0), 0)) {
+        if (d == 0) return o < split ? lower : upper;
+    }
+    const double plane = (split - o) / d;
+    const bool below = o < split || (o == split && d < 0);
+    const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
+    if (plane > tmax || plane <= 0) return near_id;
+    if (plane < tmin) return far_id;
+    stack_push(st, sp, far_id, tmax);
+    ++sp;
+    tmax = plane;
+    return near_id;
+}
+
+__device__ __forceinline__ rsx_kdnode descend_coherent(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
+                                                       const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
+    for (;;) {
+        const int32_t unode = __builtin_amdgcn_readfirstlane(node);
+        if (__builtin_expect(!__all(node == unode), 0)) return descend(nodes, node, r, ad, tmin, tmax, st, sp, util);
+        const RSX_CONST_AS rsx_kdnode *sn = (const RSX_CONST_AS rsx_kdnode *)(unsigned long long)(nodes + unode);
+        const int32_t type = sn->type, count = sn->count;
+        if (type < 0) {
+            rsx_kdnode nd;
+            nd.type = type; nd.count = count; nd.u.leaf.first_item = sn->u.leaf.first_item; nd.u.leaf.pad = 0;
+            return nd;
+        }
+        UTIL_COUNT(util, 4)
+        const double split = sn->u.split;
+        if (type == 0) node = world_step(split, unode + 1, count, r.ox, r.dx, tmin, tmax, st, sp);
+        else if (type == 1) node = world_step(split, unode + 1, count, r.oy, r.dy, tmin, tmax, st, sp);
+        else node = world_step(split, unode + 1, count, r.oz, r.dz, tmin, tmax, st, sp);
+    }
+}

@@ -336,7 +336,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         const unsigned long long ph2_w0 = clock64();
         phase_acc[0] = ph2_w0 - ph2_u0;
 #endif
-        const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_w1 = clock64();
         phase_acc[1] = ph2_w1 - ph2_w0;

@@ -85,10 +85,17 @@ __device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, 
     if (roots.n > 0) { t = roots.t[0]; faces = (roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4); }
 }
 
+#ifndef RSX_WORLD_COHERENT
+#define RSX_WORLD_COHERENT 0            // 1: scalar-node walk of the world tree while the lanes agree (descend_coherent) — measured neutral on configs[2] (34.9 vs 35.0 ms), slower on configs[3]
+#endif
 #ifndef RSX_WORLD_FAST_DIV
 #define RSX_WORLD_FAST_DIV 0
 #endif
-template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN>
+// UNIFORM_ITEMS: the leaf items are walked one wave-uniform primitive at a time (primary rays: the lanes of a wave sit in the same
+// world leaf, so a leaf item is one primitive for all of them and its record comes in over the scalar data path). Scattered rays —
+// the daughters of the path kernel, arbitrary query batches — meet a different primitive in every lane: there each lane tests its
+// own item and only the meshes are grouped (measured with the uniform walk on the path kernel: Cornell box 59 -> 76 ms per pass).
+template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
@@ -126,6 +133,8 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         if (active) {
 #if RSX_UTIL_PROF == 2
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
+#elif RSX_WORLD_COHERENT
+            const rsx_kdnode nd = descend_coherent(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
 #else
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
 #endif
@@ -133,6 +142,49 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             items += nd.u.leaf.first_item;
             count = nd.count;
         }
+        if constexpr (!UNIFORM_ITEMS) {
+        for (int32_t k = 0; __any(k < count); ++k) {
+            const bool have = k < count;
+            const int32_t idx = have ? items[k] : 0;
+            const rsx_primitive &p = sc.prims[idx];
+            Hit cand;
+            cand.prim = -1;
+            work += CSG ? 16 : 4;
+            const bool wide = idx == sc.wide[0] || idx == sc.wide[1];         // answered before the traversal began
+            if (have && wide) {
+                const bool first = idx == sc.wide[0];
+                const double t = first ? wide_t0 : wide_t1;
+                const int32_t faces = first ? wide_faces & 255 : wide_faces >> 8;
+                if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
+            }
+            double f, b;
+            const bool gate = have && !wide && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
+            // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
+            // descriptor, array bases: scalar loads, SGPRs): a wave that straddles several instances takes one turn per instance.
+            unsigned long long todo = __ballot(is_mesh);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
+                const bool mine = is_mesh && idx == uidx;
+                todo &= ~__ballot(mine);
+                const UPrim up = uniform_prim(sc.prims, uidx);
+                Ray l = r;
+                if (mine) l = to_local_uniform(up, r);
+                const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
+                MeshHit mh;
+                if (mesh_trace_wave<STAGE_MIN>(mine, um, l, mesh_stack, mh, work, phase_acc)) {
+                    cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
+                }
+            }
+            if (gate && !is_mesh) {
+                bool needs_stream = false;
+                primitive_first_hit<CSG, FASTONLY>(sc, idx, p, r, mesh_stack, csg_state, cand, needs_stream);
+                if (FASTONLY && needs_stream) work |= 0x80000000u;            // top bit of the cost counter: trace this ray again with the stream merge
+            }
+            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
+        }
+        } else {
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
 #if RSX_UTIL_PROF == 2
@@ -203,6 +255,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 }
             }
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
+        }
         }
         if (active) {
             if (best.prim >= 0 || sp == 0) active = false;
