@@ -788,8 +788,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
             // volume emitters containing this segment's origin: found in world.contains() order, pushed newest first because the
             // list is replayed backwards
-            double v_len[PATH_VOL_OVERLAP], v_scale[PATH_VOL_OVERLAP];
-            int32_t v_table[PATH_VOL_OVERLAP], v_kind[PATH_VOL_OVERLAP];
+            double v_len[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_scale[PATH_VOL_OVERLAP] = {0, 0, 0, 0};     // (initialised: the shift below reads every slot)
+            int32_t v_table[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_kind[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
             int n_vol = 0;
             bool contains_needs_stream = false;
             if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
@@ -810,7 +810,11 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     length = sqrt(vx * vx + vy * vy + vz * vz);
                     if (length == 0) return;
                 }
-                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u);
+                // (more than PATH_VOL_OVERLAP volumes: the registers keep the newest ones, the older ones are fetched again below)
+                // bit 3 of the flags: a point lay in more volumes than the registers keep, the re-walk below ran (informational). Kept as an
+                // atomic on purpose: without a memory operation at this point hipcc 7.2 miscompiles the enclosing loop for gfx950 (the
+                // frames of tests/test_gpu_parity.py::test_frames_volume_emitters_stream_parity go wrong, with or without the re-walk).
+                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 8u);
 #pragma unroll
                 for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
                 v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
@@ -818,6 +822,35 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             });
 #pragma unroll
             for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
+            if constexpr (VOLS) {
+                // A point inside more than PATH_VOL_OVERLAP volumes (rare: nested emitters and glasses): the terms beyond the newest
+                // four are produced by walking the same world.contains() enumeration again, once per missing term, oldest last —
+                // the list is replayed backwards, so the push order is newest first.
+                for (int want = n_vol - PATH_VOL_OVERLAP - 1; want >= 0; --want) {
+                    int seen = 0;
+                    bool dummy = false;
+                    world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, dummy, [&](int32_t idx) {
+                        const int32_t vt = q->materials[sc.prims[idx].material].type;
+                        return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || vt == RSX_MAT_DIELECTRIC;
+                    }, [&](int32_t idx) {
+                        const rsx_primitive &vp = sc.prims[idx];
+                        const rsx_material vm = q->materials[vp.material];
+                        double length;
+                        if (vm.type == RSX_MAT_DIELECTRIC) {
+                            const double vx = r.ox - hx, vy = r.oy - hy, vz = r.oz - hz;
+                            length = sqrt(vx * vx + vy * vy + vz * vz);
+                        } else {
+                            double sx, sy, sz, ex, ey, ez;
+                            xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
+                            xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
+                            const double vx = sx - ex, vy = sy - ey, vz = sz - ez;
+                            length = sqrt(vx * vx + vy * vy + vz * vz);
+                            if (length == 0) return;
+                        }
+                        if (seen++ == want) push(length, vm.scale, vm.table, vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL);
+                    });
+                }
+            }
             if constexpr (MODE == 1) {
                 if (contains_needs_stream) {                                  // a CSG volume without a flattened program: redo pass
                     atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
@@ -1094,7 +1127,7 @@ struct AccumParams {
     long long n_tasks;
     int32_t rect[4];
     int32_t ny, bins, spp, power;
-    int32_t n_tables, pad;
+    int32_t n_tables, tables_in_lds;    // tables_in_lds = 0: the spectral tables do not fit the kernel's LDS next to the reciprocals: read from global
     double sensitivity;
     double *mean, *variance;            // per-task outputs [n_tasks, bins] (or null)
     double *fmean, *fvar; int32_t *fn;  // frame [nx, ny, frame_bins] (or null)
@@ -1122,9 +1155,10 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
     const int n_rcp = rcp_table ? ap.spp + 2 : 2;
     double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
+    const bool tab_lds = staged && ap.tables_in_lds;
     if (staged) {
         for (int d = threadIdx.x + 1; d < n_rcp; d += blockDim.x) acc_rcp[d] = refine_rcp((double)d);
-        for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];
+        if (tab_lds) for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];
         __syncthreads();
     }
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1148,7 +1182,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
     auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
-        const double tab = staged ? acc_tab[e] : ap.tables[e];
+        const double tab = tab_lds ? acc_tab[e] : ap.tables[e];
         double x = smp.table < 0 ? 0.0 : smp.a * tab;
         if (VOL) {
             // the reference's recursion unwinding: newest term first. VOL: += (0 + table * scale) * length (uniform.pyx:129-131,
@@ -1161,7 +1195,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                 const int first = blk < ap.n_records ? 0 : 1;
                 for (int j = n - 1; j >= first; --j) {
                     const PathTerm tm = t[j];
-                    const double tv = staged ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
+                    const double tv = tab_lds ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
                     if (tm.kind == TERM_VOL) {
                         const double emission = 0.0 + tv * tm.b;
                         x = x + emission * tm.a;

@@ -1227,9 +1227,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
     if (timed) HIP_TRY(hipEventRecord(re[3], ctx->stream));
-    ap.n_tables = desc->n_tables; ap.pad = 0;
-    const size_t acc_lds = ((desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) + (size_t)std::max(1, desc->n_tables) * B) * 8;
-    if (acc_lds > 60 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "render: %d spectral tables of %d bins do not fit the accumulate kernel's LDS", desc->n_tables, desc->bins);
+    ap.n_tables = desc->n_tables;
+    // LDS of the staged accumulate kernel: the Welford reciprocals and, when they fit next to them, the spectral tables (a 512-bin
+    // slice with twenty materials does not: the kernel then reads the tables from global memory, L1 / L2 resident)
+    const size_t rcp_lds = (desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) * 8, tab_lds = (size_t)std::max(1, desc->n_tables) * B * 8;
+    ap.tables_in_lds = rcp_lds + tab_lds <= 60 * 1024 ? 1 : 0;
+    const size_t acc_lds = rcp_lds + (ap.tables_in_lds ? tab_lds : 8);
     const dim3 acc_grid((unsigned)((total + 255) / 256));
     if (fused) {                                            // the trace kernel merged its own samples; its tickets are re-armed by the next launch
         lane.ticket_armed = false;
@@ -1400,7 +1403,7 @@ extern "C" int rsx_selftest_welford(rsx_ctx *ctx, int64_t n_chains, int32_t spp,
     std::memset(&ap, 0, sizeof(ap));
     ap.samples = ds.as<Sample>(); ap.tables = one.as<double>(); ap.n_tasks = n_chains;
     ap.rect[0] = 0; ap.rect[1] = 0; ap.rect[2] = 1; ap.rect[3] = (int32_t)n_chains;      // one column of n_chains pixels: slot order = task order
-    ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.n_tables = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
+    ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.n_tables = 1; ap.tables_in_lds = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
     // both instantiations the render path uses: the lean one (few samples per pixel) and the staged one (LDS tables, batched loads)
     for (int staged = 0; staged < 2; ++staged) {
         ap.mean = dm.as<double>() + (staged ? N : 0); ap.variance = dv.as<double>() + (staged ? N : 0);
