@@ -666,7 +666,10 @@ struct PathStore {
 #endif
 // VOLS = the scene has materials with a volume contribution (volume emitters, dielectrics): only then is the per-segment
 // world.contains() pass compiled in (its CSG form, a depth-unrolled recursion, costs the CSG instantiation a wave per SIMD).
-template <bool CSG, int MODE = 0, bool VOLS = true>
+// REWALK: the instantiation a pass is traced again with when a path met more overlapping volumes than the registers keep
+// (PATH_VOL_OVERLAP): it produces the older terms by walking world.contains() again. Compiled into the ordinary instantiation the
+// second copy of the enumeration slowed every path pass by 30 % without ever running (and out of line by 20 %: the call ABI).
+template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false>
 __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
@@ -811,10 +814,11 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     if (length == 0) return;
                 }
                 // (more than PATH_VOL_OVERLAP volumes: the registers keep the newest ones, the older ones are fetched again below)
-                // bit 3 of the flags: a point lay in more volumes than the registers keep, the re-walk below ran (informational). Kept as an
-                // atomic on purpose: without a memory operation at this point hipcc 7.2 miscompiles the enclosing loop for gfx950 (the
-                // frames of tests/test_gpu_parity.py::test_frames_volume_emitters_stream_parity go wrong, with or without the re-walk).
-                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 8u);
+                // More volumes at this point than the registers keep: the pass is traced again by the REWALK instantiation (flag bit 2);
+                // REWALK itself notes that it was needed (bit 3, informational). The atomic also stays in REWALK on purpose: without a
+                // memory operation at this point hipcc 7.2 miscompiles the enclosing loop for gfx950 (wrong frames in
+                // tests/test_gpu_parity.py::test_frames_volume_emitters_stream_parity and ::test_lifted_limits_*).
+                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, REWALK ? 8u : 4u);
 #pragma unroll
                 for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
                 v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
@@ -822,10 +826,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             });
 #pragma unroll
             for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
-            if constexpr (VOLS) {
-                // A point inside more than PATH_VOL_OVERLAP volumes (rare: nested emitters and glasses): the terms beyond the newest
-                // four are produced by walking the same world.contains() enumeration again, once per missing term, oldest last —
-                // the list is replayed backwards, so the push order is newest first.
+            if constexpr (VOLS && REWALK) {
+                // the terms beyond the newest four: the same world.contains() enumeration walked again, once per missing term, oldest
+                // last — the list is replayed backwards, so the push order is newest first
                 for (int want = n_vol - PATH_VOL_OVERLAP - 1; want >= 0; --want) {
                     int seen = 0;
                     bool dummy = false;
@@ -1009,6 +1012,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             }
         }
         if (was_active && !active && !abandoned) {                            // path over: its record is complete
+#ifndef RSX_NO_PATHCOST
+            if (q->measure_cost) atomicMax(q->unit_cost + ray_unit, (uint32_t)segments + 1u);   // the unit's longest path: next pass's schedule
+#endif
             smp.pad = pos;
             samples[record] = smp;
             ps.tail[record] = (int32_t)blk;
@@ -1083,7 +1089,9 @@ __device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned lo
 
 // One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
 // and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
-__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp) {
+// flat != 0 (path passes): only the heavy units are pulled forward (list 0, longest first); the rest keep the natural order of their
+// XCD list — sorting ALL units of a path pass by cost scatters neighbouring pixels over the chip and costs more than the tail it removes.
+__global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *order, uint32_t *seg, long long n, int tiles_x, int spp, int flat) {
     __shared__ unsigned int hist[9][ORDER_BUCKETS];
     __shared__ unsigned int offset[9][ORDER_BUCKETS];
     __shared__ unsigned long long total;
@@ -1098,7 +1106,8 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     const unsigned long long mean = total / (unsigned long long)n + 1;
     for (long long i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t c = cost[i];
-        atomicAdd(&hist[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u);
+        const int list = unit_list(i, c, mean, tiles_x, spp);
+        atomicAdd(&hist[list][flat && list ? 0 : cost_bucket(c)], 1u);
     }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -1112,7 +1121,8 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
     __syncthreads();
     for (long long i = threadIdx.x; i < n; i += blockDim.x) {
         const uint32_t c = cost[i];
-        order[atomicAdd(&offset[unit_list(i, c, mean, tiles_x, spp)][cost_bucket(c)], 1u)] = (uint32_t)i;
+        const int list = unit_list(i, c, mean, tiles_x, spp);
+        order[atomicAdd(&offset[list][flat && list ? 0 : cost_bucket(c)], 1u)] = (uint32_t)i;
     }
 }
 

@@ -1087,15 +1087,21 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         order_tiles_x = desc->tasks ? 0 : (int)tiles_x_all;
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
-            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp);
+            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
             HIP_TRY(hipGetLastError());
         }
         rp.unit_order = lane.unit_order;
         rp.seg = lane.n_work;
         // Longest-first ordering pays when a pass is tail-bound (few units per wave); a pass with thousands of units per wave
         // balances by itself, so it keeps the natural (XCD-blocked) order and the kernel skips the cost bookkeeping.
-        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && !two_pass_csg;
+        // Path passes (has_vol) are tail-bound at any size — a few paths trapped by total internal reflection run to the depth limit —
+        // and record the longest path of each unit (atomicMax in k_render_trace_path); spectral slices of one observe() share camera and
+        // units, so slice k + 1 starts the units that held slice k's longest paths first.
+        static const int path_lpt = [] { const char *e = std::getenv("RSX_PATH_LPT"); return e ? std::atoi(e) : 2; }();
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && (has_vol ? path_lpt > 0 : !two_pass_csg);
         rp.measure_cost = want_order ? 1 : 0;
+        if (has_vol && path_lpt == 1) want_order = false;           // (measure, do not re-order: tuning aid)
+        if (want_order && has_vol) HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));   // (after the sort that consumed them)
         lane.order_units = want_order ? 0 : n_units;
         order_n = n_units;
         lane.cost_units = n_units;
@@ -1145,32 +1151,42 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // Paths are deterministic (counter-based random numbers), so a pass whose term arena ran out is simply traced again with
         // a four times larger one — before its records are merged into the frame (one host round trip per path pass, small next
         // to the pass itself). RSX_PATH_ARENA pins the size instead.
+        bool rewalk = false;                                 // second form of the kernels: any number of volumes at a point (slower)
         for (int attempt = 0;; ++attempt) {
             PathStore ps;
             ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
             ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
+            auto launch = [&](const void *kernel, dim3 grid) -> int {
+                HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+                void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&lane.ticket, (void *)&ps};
+                HIP_TRY(hipLaunchKernel(kernel, grid, dim3(WG_THREADS), args, l.lds, lane.stream));
+                return RSX_OK;
+            };
+#define PATH_KERNEL(...) reinterpret_cast<const void *>(k_render_trace_path<__VA_ARGS__>)
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
-                const void *fast = vols ? reinterpret_cast<const void *>(k_render_trace_path<true, 1, true>) : reinterpret_cast<const void *>(k_render_trace_path<true, 1, false>);
-                HIP_TRY(hipFuncSetAttribute(fast, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace_path<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
                 HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
-                if (vols) hipLaunchKernelGGL((k_render_trace_path<true, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-                else hipLaunchKernelGGL((k_render_trace_path<true, 1, false>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+                if ((rc = launch(!vols ? PATH_KERNEL(true, 1, false) : rewalk ? PATH_KERNEL(true, 1, true, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
-                hipLaunchKernelGGL((k_render_trace_path<true, 2>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-            } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace_path<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
-            else hipLaunchKernelGGL(k_render_trace_path<false>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, ps);
+                if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
+            } else if (scene->has_csg) { if ((rc = launch(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
+            else if ((rc = launch(rewalk ? PATH_KERNEL(false, 0, true, true) : PATH_KERNEL(false), l.grid))) return rc;
+#undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
-            if (!has_scatter || std::getenv("RSX_PATH_ARENA")) break;
+            // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
+            if (!(has_scatter && !std::getenv("RSX_PATH_ARENA")) && !(rp.n_vol_emitters > PATH_VOL_OVERLAP && !rewalk)) break;
             unsigned int flags = 0;
             HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
             HIP_TRY(hipStreamSynchronize(lane.stream));
-            if (!(flags & 1u)) break;
-            const size_t bigger = arena_blocks * 4, pool_bytes = (S + bigger) * PATH_BLOCK * sizeof(PathTerm);
-            if (attempt >= 4 || S + bigger >= ((size_t)1 << 31) || pool_bytes > ((size_t)96 << 30)) break;   // reported below
-            arena_blocks = bigger;
-            if ((rc = lane_buffer(lane.terms, lane.terms_bytes, pool_bytes))) return rc;
+            const bool grow = (flags & 1u) && has_scatter && !std::getenv("RSX_PATH_ARENA"), again = (flags & 4u) && !rewalk;
+            if (!grow && !again) break;
+            if (again) rewalk = true;
+            if (grow) {
+                const size_t bigger = arena_blocks * 4, pool_bytes = (S + bigger) * PATH_BLOCK * sizeof(PathTerm);
+                if (attempt >= 5 || S + bigger >= ((size_t)1 << 31) || pool_bytes > ((size_t)96 << 30)) break;   // reported below
+                arena_blocks = bigger;
+                if ((rc = lane_buffer(lane.terms, lane.terms_bytes, pool_bytes))) return rc;
+            }
             HIP_TRY(hipMemsetAsync(lane.overflow, 0, 64, lane.stream));
             if ((rc = reset_ticket(lane))) return rc;
         }
@@ -1200,7 +1216,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
-        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp);
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
     }
