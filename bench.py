@@ -226,7 +226,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--sharding", choices=["auto", "tile", "sample"], default="auto", help="N > 1: tile (strong scaling, default) or sample (weak)")
-    ap.add_argument("--collective", choices=["rsx", "torch"], default="rsx", help="N > 1 data plane: RCCL from librsx (default) or torch.distributed")
+    ap.add_argument("--collective", choices=["rsx", "torch", "host"], default="rsx",
+                    help="N > 1 data plane: RCCL from librsx (default), torch.distributed nccl, or host (frames over gloo: a test aid that lets "
+                         "several ranks share one GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--pmc-keep", default=None, help="directory that receives the PMC summary of this run (e.g. profiles/r02)")
     ap.add_argument("--no-verify", action="store_true", help="tile sharding: skip the one-GPU re-render digest check")
@@ -246,6 +248,7 @@ def main():
     if distributed:
         import torch
         import torch.distributed as dist
+        local_rank = local_rank % max(1, torch.cuda.device_count())     # more ranks than GPUs (--collective host): share
         torch.cuda.set_device(local_rank)
         if collective == "torch":
             with stdout_to_stderr():
@@ -334,6 +337,14 @@ def main():
 
     def exchange_frames():
         """The one exchange step of a multi-GPU render. Returns the frame arrays rank 0 reports on (torch path) or None (in place)."""
+        if collective == "host":                            # frames through host memory and gloo: same shard logic, no RCCL
+            f = pipe.frame
+            t = [torch.from_numpy(a) for a in (f.mean, f.variance, f.samples)]
+            out = D.gather_tile_sharded(*t, rank, dist) if sharding == "tile" else D.merge_sample_sharded(*t, dist)
+            for dst, src in zip(f._host, out):
+                dst[...] = src.numpy()
+            f._host_written()
+            return None
         if comm is not None:
             if sharding == "tile":
                 comm.allgather_tiles(pipe.frame, NX, NY)
@@ -373,7 +384,9 @@ def main():
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        if comm is not None:
+        if collective == "host":
+            pass
+        elif comm is not None:
             from source_amd.optical.observer import StatsArray3D
             tiny = StatsArray3D(world_size * 8, 8, 4)
             tiny._host[2][:] = 1
@@ -554,7 +567,7 @@ def main():
             "config": {"workload": W["name"] + (", %d MI355X" % world_size), "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
                        "rng": "philox4x32-10", "sharding": sharding,
                        "collective": {"none": "none", "rsx": "RCCL from librsx (rsx_allgather_frame / rsx_allreduce_frame)",
-                                      "torch": "torch.distributed nccl"}[collective] + ("; " + comm_note if comm_note else ""),
+                                      "torch": "torch.distributed nccl", "host": "host memory + gloo (test aid)"}[collective] + ("; " + comm_note if comm_note else ""),
                        "collective_ms": round(collective_ms, 3), "frame_digest_equals_single_gpu": digest_ok},
             "roofline": roofline, "cpu_baseline": cpu,
         }
