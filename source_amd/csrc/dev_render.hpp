@@ -1156,8 +1156,10 @@ struct AccumParams {
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
 
-template <bool STAGED, int VOL>         // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
+template <bool STAGED, int VOL, bool TAB_LDS = STAGED>   // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
                                         // VOL = samples carry path terms (k_render_trace_path): 1 = without, 2 = with dielectric attenuation (pow() costs 60 registers)
+                                        // TAB_LDS = false with STAGED: the spectral tables do not fit the LDS next to the reciprocals and are read from global
+                                        // memory (a template parameter: as a run-time flag the choice cost the recurrence 23 %, 5.8 -> 7.1 ms on configs[2])
 __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // LDS: refined reciprocals of 1 .. spp (the Welford divisors are the same for every pixel) and the spectral tables
     extern __shared__ __attribute__((aligned(16))) double acc_lds[];
@@ -1165,7 +1167,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const bool rcp_table = staged && ap.spp <= ACC_RCP_TABLE_MAX;
     const int n_rcp = rcp_table ? ap.spp + 2 : 2;
     double *acc_rcp = acc_lds, *acc_tab = acc_lds + n_rcp;
-    const bool tab_lds = staged && ap.tables_in_lds;
+    constexpr bool tab_lds = STAGED && TAB_LDS;
     if (staged) {
         for (int d = threadIdx.x + 1; d < n_rcp; d += blockDim.x) acc_rcp[d] = refine_rcp((double)d);
         if (tab_lds) for (int e = threadIdx.x; e < ap.n_tables * ap.bins; e += blockDim.x) acc_tab[e] = ap.tables[e];

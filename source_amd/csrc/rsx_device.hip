@@ -1270,14 +1270,16 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (has_vol && has_dielectric) hipLaunchKernelGGL((k_accumulate_xyz<2>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
         else if (has_vol) hipLaunchKernelGGL((k_accumulate_xyz<1>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
         else hipLaunchKernelGGL((k_accumulate_xyz<0>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
-    } else if (has_vol) {
-        if (has_dielectric) {
-            if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 2>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
-            else hipLaunchKernelGGL((k_accumulate<false, 2>), acc_grid, dim3(256), 0, ctx->stream, ap);
-        } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 1>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
-        else hipLaunchKernelGGL((k_accumulate<false, 1>), acc_grid, dim3(256), 0, ctx->stream, ap);
-    } else if (desc->spp >= 4) hipLaunchKernelGGL((k_accumulate<true, 0>), acc_grid, dim3(256), acc_lds, ctx->stream, ap);
-    else hipLaunchKernelGGL((k_accumulate<false, 0>), acc_grid, dim3(256), 0, ctx->stream, ap);
+    } else {
+        const int vol = !has_vol ? 0 : has_dielectric ? 2 : 1;
+        const bool staged = desc->spp >= 4, in_lds = ap.tables_in_lds != 0;
+#define ACC(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V>) \
+                                                                                           : reinterpret_cast<const void *>(k_accumulate<true, V, false>))
+        const void *kernel = vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);
+#undef ACC
+        void *args[] = {(void *)&ap};
+        HIP_TRY(hipLaunchKernel(kernel, acc_grid, dim3(256), args, staged ? acc_lds : 0, ctx->stream));
+    }
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
     HIP_TRY(hipEventRecord(ctx->gate[(size_t)(ctx->render_calls % (long long)ctx->gate.size())], ctx->stream));
