@@ -157,10 +157,12 @@ def collect_pmc(workload, passes, keep_dir=None):
 
 
 def kernel_counters(table, prefix):
-    """Counters of the kernel whose name starts with `prefix` (the instantiation with the most SIMD time when several ran)."""
+    """Counters of the kernel whose name starts with `prefix` (the instantiation that did the most vector work when several ran:
+    a CSG scene launches a fast pass and a — usually idle — redo pass)."""
     best = None
+    weight = lambda c: c.get("SQ_ACTIVE_INST_VALU", c.get("GRBM_GUI_ACTIVE", 0)) * c.get("launches", 1)    # noqa: E731
     for kern, c in table.items():
-        if kern.startswith(prefix) and (best is None or c.get("GRBM_GUI_ACTIVE", 0) * c.get("launches", 1) > best[1].get("GRBM_GUI_ACTIVE", 0) * best[1].get("launches", 1)):
+        if kern.startswith(prefix) and (best is None or weight(c) > weight(best[1])):
             best = (kern, c)
     return best
 
