@@ -256,7 +256,8 @@ def main():
             with stdout_to_stderr():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
-            dist.init_process_group("gloo")                   # control plane only: rendezvous, barriers, the RCCL unique id
+            with stdout_to_stderr():                          # (gloo announces its peers on stdout)
+                dist.init_process_group("gloo")               # control plane only: rendezvous, barriers, the RCCL unique id
         world_size = dist.get_world_size()
     sharding = "none" if world_size == 1 and not distributed else ("tile" if args.sharding == "auto" else args.sharding)
     os.environ["RSX_DEVICE"] = str(local_rank)
