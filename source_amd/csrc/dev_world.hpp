@@ -85,6 +85,9 @@ __device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, 
     if (roots.n > 0) { t = roots.t[0]; faces = (roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4); }
 }
 
+#ifndef RSX_ITEM_PREFETCH
+#define RSX_ITEM_PREFETCH 0            // 1: the first three item ids of a world leaf loaded together — measured 35.2 -> 35.6 ms (the kernel is issue-bound, not latency-bound)
+#endif
 #ifndef RSX_WORLD_COHERENT
 #define RSX_WORLD_COHERENT 0            // 1: scalar-node walk of the world tree while the lanes agree (descend_coherent) — measured neutral on configs[2] (34.9 vs 35.0 ms), slower on configs[3]
 #endif
@@ -118,17 +121,26 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // the enclosing emitter are met 4.4 times per primary ray.
     double wide_t0 = -1.0, wide_t1 = -1.0;
     int32_t wide_faces = 0;
+#if RSX_PHASE_PROF == 2
+    const unsigned long long ph2_wd0 = clock64();
+#endif
     if (sc.wide[0] >= 0) {
         int32_t f0 = 0, f1 = 0;
         analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[0]), sc.wide[0], active, r, rx, ry, rz, wide_t0, f0);
         if (sc.wide[1] >= 0) analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[1]), sc.wide[1], active, r, rx, ry, rz, wide_t1, f1);
         wide_faces = f0 | (f1 << 8);
     }
+#if RSX_PHASE_PROF == 2
+    phase_acc[7] += clock64() - ph2_wd0;
+#endif
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
         int32_t count = 0;
         const int32_t *items = sc.witems;
+#if RSX_PHASE_PROF == 2
+        const unsigned long long ph2_d0 = clock64();
+#endif
         if (active) { UTIL_COUNT(phase_acc, 0) }
         if (active) {
 #if RSX_UTIL_PROF == 2
@@ -141,7 +153,29 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;
             count = nd.count;
+            // a leaf whose items are all wide primitives brings its item list in the node itself (rsx_scene_create): the answers are
+            // in registers, so the visit is two compares per item — in list order, `<=` as in the item loop below (kdtree.pyx:113)
+            const int32_t tag = nd.u.leaf.pad;
+            if (tag < 0) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    if (j < count) {
+                        const bool second = (tag >> j) & 1;
+                        const double t = second ? wide_t1 : wide_t0;
+                        const int32_t faces = second ? wide_faces >> 8 : wide_faces & 255;
+                        if (t >= 0.0 && t <= distance) {
+                            distance = t;
+                            best.prim = second ? sc.wide[1] : sc.wide[0]; best.t = t; best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
+                            best.u = best.v = best.w = 0.0f;
+                        }
+                    }
+                }
+                count = 0;
+            }
         }
+#if RSX_PHASE_PROF == 2
+        phase_acc[4] += clock64() - ph2_d0;
+#endif
         if constexpr (!UNIFORM_ITEMS) {
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
@@ -185,12 +219,21 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
         } else {
+#if RSX_ITEM_PREFETCH
+        // the first item ids of the leaf in one go: a leaf of this level holds one to three items, and a round per item that begins
+        // with a dependent load of its id serialises the visit
+        const int32_t pre0 = 0 < count ? items[0] : 0, pre1 = 1 < count ? items[1] : 0, pre2 = 2 < count ? items[2] : 0;
+#endif
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
 #if RSX_UTIL_PROF == 2
             if (have) { UTIL_COUNT(phase_acc, 2) }
 #endif
+#if RSX_ITEM_PREFETCH
+            const int32_t idx = k == 0 ? pre0 : k == 1 ? pre1 : k == 2 ? pre2 : (have ? items[k] : 0);
+#else
             const int32_t idx = have ? items[k] : 0;
+#endif
             Hit cand;
             cand.prim = -1;
             work += CSG ? 16 : 4;
@@ -221,6 +264,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     if (!__any(gate)) continue;
                 }
                 if (type == RSX_PRIM_MESH) {
+#ifdef RSX_ABLATE_MESH
+                    continue;                                 // (timing ablation: results are wrong)
+#endif
 #if RSX_PHASE_PROF == 2
                     const unsigned long long ph2_m0 = clock64();
 #endif

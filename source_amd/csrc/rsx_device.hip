@@ -575,7 +575,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
     if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
     if (any_fast) UP(upload(sc, fast.data(), fast.size(), &d.csgfast));
-    UP(upload(sc, desc->world_kd.nodes, (size_t)desc->world_kd.n_nodes, &d.wnodes));
+    // (the world nodes are uploaded below, after the wide primitives are known: wide-only leaves are tagged in the device copy)
     UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
     std::memcpy(d.wlower, desc->world_kd.lower, 24);
     std::memcpy(d.wupper, desc->world_kd.upper, 24);
@@ -603,6 +603,25 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 if (d.wide[0] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[0]]) { d.wide[1] = d.wide[0]; d.wide[0] = i; }
                 else if (d.wide[1] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[1]]) d.wide[1] = i;
             }
+        // Device copy of the world nodes. A leaf whose items are ALL wide primitives (at most two: most leaves of a scene with a floor
+        // and an enclosing emitter) carries its whole item list in the node's spare word — bit 31, the count in bits 8..10, the wide slot
+        // of item j in bit j, list order kept — so that visiting it costs no item loads and no per-item rounds (world_trace_wave).
+        std::vector<rsx_kdnode> wnodes(desc->world_kd.nodes, desc->world_kd.nodes + desc->world_kd.n_nodes);
+        if (!std::getenv("RSX_NO_WIDE_LEAVES"))
+            for (rsx_kdnode &nd : wnodes) {
+                if (nd.type >= 0) continue;
+                nd.u.leaf.pad = 0;
+                if (nd.count < 1 || nd.count > 2 || d.wide[0] < 0) continue;
+                uint32_t tag = 0x80000000u | ((uint32_t)nd.count << 8);
+                bool all_wide = true;
+                for (int32_t k = 0; k < nd.count; ++k) {
+                    const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
+                    if (idx == d.wide[0]) continue;
+                    if (idx == d.wide[1]) tag |= 1u << k; else all_wide = false;
+                }
+                if (all_wide) nd.u.leaf.pad = (int32_t)tag;
+            }
+        UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes));
     }
     std::vector<DMesh> meshes((size_t)desc->n_meshes);
     for (int32_t i = 0; i < desc->n_meshes; ++i) {

@@ -38,7 +38,8 @@ if os.environ.get("PHASES") == "2":  # -DRSX_PHASE_PROF=2: coarse s_memtime phas
     print("ray generation      %.3f of the unit" % (c[0] / tot))
     print("world_trace_wave    %.3f" % (c[1] / tot))
     print("  mesh visits       %.3f   (setup %.3f, traversal loop %.3f)" % (c[2] / tot, c[3] / tot, (c[2] - c[3]) / tot))
-    print("  world tree + gates %.3f" % ((c[1] - c[2]) / tot))
+    print("  world tree + gates %.3f   (world descents %.3f, wide-primitive answers %.3f, leaf items and the rest %.3f)" % (
+        (c[1] - c[2]) / tot, c[4] / tot, c[7] / tot, (c[1] - c[2] - c[4] - c[7]) / tot))
     print("cost / shade        %.3f (before the record store)" % ((c[6] - c[0] - c[1]) / tot))
     sys.exit(0)
 if os.environ.get("PHASES"):       # library built with -DRSX_PHASE_PROF=1: s_memtime cycles per phase of mesh_trace_wave
