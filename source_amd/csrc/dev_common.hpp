@@ -338,13 +338,20 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
 
 // Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
 // pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
+__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double tmin, double &tmax, const Stack &st, int32_t &sp);
+
+// PLAIN: the branch steps use the hardware division outright (world tree: no refined reciprocals are kept for it, and branch_step's
+// shortcut would be computed only to be discarded at every step)
+template <bool PLAIN = false>
 __device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
                                               const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
     rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
     while (nd.type >= 0) {
         UTIL_COUNT(util, 4)
         const int axis = nd.type;
-        const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
+        int32_t next;
+        if constexpr (PLAIN) next = world_step(nd.u.split, node + 1, nd.count, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+        else next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
                                          (ad.safe >> axis) & 1, tmin, tmax, st, sp);
         if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
         nx = load_node(nodes, next + 1);

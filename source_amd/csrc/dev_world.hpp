@@ -147,8 +147,10 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
 #elif RSX_WORLD_COHERENT
             const rsx_kdnode nd = descend_coherent(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
-#else
+#elif RSX_WORLD_FAST_DIV
             const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
+#else
+            const rsx_kdnode nd = descend<true>(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
 #endif
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;
