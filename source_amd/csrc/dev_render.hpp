@@ -42,7 +42,8 @@ struct RenderParams {
     const rsx_important_sphere *important;     // ImportanceManager spheres (world.pyx:47-128) or n_important == 0
     int32_t n_important, pad_important;
     double important_path_weight;
-    int32_t n_vol_emitters, pad_path;          // materials with a volume contribution (0: the per-segment world.contains() pass is skipped)
+    int32_t n_vol_emitters, world_lds;         // materials with a volume contribution (0: the per-segment world.contains() pass is skipped);
+                                               // world_lds > 0: byte offset in the workgroup's LDS where the path kernel stages the world tree
     unsigned long long *redo_mask;    // [n_units] CSG scenes: lanes of each unit the fast pass could not finish (ties -> stream merge), or null
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
@@ -670,7 +671,18 @@ struct PathStore {
 // (PATH_VOL_OVERLAP): it produces the older terms by walking world.contains() again. Compiled into the ordinary instantiation the
 // second copy of the enumeration slowed every path pass by 30 % without ever running (and out of line by 20 %: the call ABI).
 template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false>
-__global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+__global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+    DScene sc = sc_arg;
+    if (rp.world_lds > 0) {                                // stage the world tree behind the traversal stacks (see render())
+        int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
+        const int4 *src = reinterpret_cast<const int4 *>(sc_arg.wnodes);
+        for (int i = threadIdx.x; i < sc_arg.n_wnodes; i += blockDim.x) dst[i] = src[i];
+        int32_t *idst = reinterpret_cast<int32_t *>(dst + sc_arg.n_wnodes);
+        for (int i = threadIdx.x; i < sc_arg.n_witems; i += blockDim.x) idst[i] = sc_arg.witems[i];
+        __syncthreads();
+        sc.wnodes = reinterpret_cast<const rsx_kdnode *>(dst);
+        sc.witems = idst;
+    }
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
@@ -696,6 +708,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     uint32_t work = 0;
     r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
     smp.a = 0; smp.weight = 0; smp.table = -1; smp.pad = 0;
+#if RSX_PHASE_PROF == 3
+    unsigned long long pp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
+#endif
     auto push = [&](double a, double b, int32_t table, int32_t kind) {
         if (pos == PATH_BLOCK) {
             const unsigned int nb = atomicAdd(ps.arena_next, 1u);
@@ -771,7 +786,16 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         const bool was_active = active;
         Hit hit;
         work = 0;
+#if RSX_PHASE_PROF == 3
+        const unsigned long long pp0 = clock64();
+        pp_acc[0] += pp0 - pp_mark;                           // refill
+        pp_acc[6] += __popcll(__ballot(active)); pp_acc[7] += 1;
+#endif
         const bool got = world_trace_wave<CSG, MODE == 1>(active, sc, r, st, ms, csg_state, hit, work);
+#if RSX_PHASE_PROF == 3
+        const unsigned long long pp1 = clock64();
+        pp_acc[1] += pp1 - pp0;                               // world_trace_wave
+#endif
         bool abandoned = false;
         if constexpr (MODE == 1) {
             if (active && (work >> 31)) {                                     // this path needs the stream merge: hand it to the redo pass
@@ -789,6 +813,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             finalise<CSG>(sc, r, hit, g);
             double hx, hy, hz;                                                // hit_point.transform(primitive_to_world)
             xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
+#if RSX_PHASE_PROF == 3
+            pp_t2 = clock64();
+#endif
             // volume emitters containing this segment's origin: found in world.contains() order, pushed newest first because the
             // list is replayed backwards
             double v_len[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_scale[PATH_VOL_OVERLAP] = {0, 0, 0, 0};     // (initialised: the shift below reads every slot)
@@ -862,6 +889,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     active = false;
                 }
             }
+#if RSX_PHASE_PROF == 3
+            pp_t3 = clock64();
+#endif
             ++segments;
             if (abandoned) {}
             else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
@@ -1011,6 +1041,14 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 active = false;
             }
         }
+#if RSX_PHASE_PROF == 3
+        {
+            const unsigned long long pp4 = clock64();
+            if (pp_t2) { pp_acc[2] += pp_t2 - pp1; pp_acc[3] += pp_t3 - pp_t2; pp_acc[4] += pp4 - pp_t3; } else pp_acc[4] += pp4 - pp1;
+            pp_t2 = pp_t3 = 0;
+            pp_mark = pp4;
+        }
+#endif
         if (was_active && !active && !abandoned) {                            // path over: its record is complete
 #ifndef RSX_NO_PATHCOST
             if (q->measure_cost) atomicMax(q->unit_cost + ray_unit, (uint32_t)segments + 1u);   // the unit's longest path: next pass's schedule
@@ -1020,6 +1058,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             ps.tail[record] = (int32_t)blk;
         }
     }
+#if RSX_PHASE_PROF == 3
+    if (lane == 0 && q->unit_times) for (int k = 0; k < 8; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
+#endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
     for (int o = 32; o > 0; o >>= 1) spawned += __shfl_xor(spawned, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ps.flags) + 1, spawned);

@@ -582,6 +582,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     d.n_prims = desc->n_primitives;
     d.n_world = desc->n_world;
     d.n_meshes = desc->n_meshes;
+    d.n_wnodes = desc->world_kd.n_nodes; d.n_witems = desc->world_kd.n_items;
     d.wdepth = tree_depth(desc->world_kd) + 1;
     d.mdepth = 1;
     {
@@ -1072,7 +1073,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.sample_offset = desc->sample_offset;
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
     rp.n_important = n_important; rp.pad_important = 0; rp.important_path_weight = desc->important_path_weight;
-    rp.n_vol_emitters = 0; rp.pad_path = 0;
+    rp.n_vol_emitters = 0; rp.world_lds = 0;
     for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
@@ -1146,6 +1147,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
+    rp.world_lds = 0;
+    if (has_vol) {
+        // The path kernel runs two workgroups per CU (256 registers per lane), so 80 KB of LDS per workgroup are there for the taking:
+        // a world tree that fits behind the traversal stacks is staged there. Scattered rays walk it with a dependent load per step
+        // at two waves per SIMD — latency, not issue, is their bound, and LDS answers in a fraction of an L2 round trip.
+        static const bool stage_world = [] { const char *e = std::getenv("RSX_WORLD_LDS_STAGE"); return !e || std::atoi(e) != 0; }();
+        const size_t need = ((size_t)scene->d.n_wnodes * sizeof(rsx_kdnode) + (size_t)scene->d.n_witems * 4 + 15) & ~(size_t)15;
+        if (stage_world && l.lds + need <= 80 * 1024 && need <= 24 * 1024) { rp.world_lds = (int32_t)l.lds; l.lds += need; }
+    }
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
     FuseParams fz;

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Coarse phase profile of the path kernel (GPU box; needs a librsx built with -DRSX_PHASE_PROF=3, pass it as $RSX_LIB):
+tools/path_prof.py [cornell|lambert|lambert_plain|glass|prism] — s_memtime per phase of every segment round, summed over the waves."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from source_amd import api as ns, scenes, _lib  # noqa: E402
+from source_amd.device import get_context  # noqa: E402
+
+cfg = sys.argv[1] if len(sys.argv) > 1 else "cornell"
+if cfg == "cornell":
+    world = scenes.build_cornell(ns)[0]
+    cam, pipe = scenes.cornell_camera(ns, world, (1024, 1024), 16, 15)
+elif cfg == "prism":
+    world = scenes.build_prism(ns)[0]
+    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), 4, 1, 1)
+elif cfg == "glass":
+    world = scenes.build_glass(ns)[0]
+    cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 5, 1, (0.01, 3, 500))
+else:
+    world = scenes.build_lambert(ns, with_volume=cfg == "lambert", csg=cfg == "lambert")[0]
+    cam, pipe = scenes.lambert_camera(ns, world, (1024, 1024), 16, 15, (0.01, 3, 500))
+cam.frame_sampler = ns.RectFrameSampler2D()
+cam.render_engine = ns.HipEngine(rng="philox", seed=20250905)
+ctx = get_context()
+world.build_accelerator()
+cam.observe()                                            # warm-up (arena sizing)
+buf = ctx.alloc(64 * 8)
+ctx.memset(buf, 0, 64 * 8)
+_lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, buf))
+cam.observe()
+ctx.synchronize()
+_lib.check(_lib.lib().rsx_debug_unit_times(ctx.handle, None))
+c = np.zeros(64, dtype=np.uint64)
+ctx.download(c, buf)
+c = c.astype(np.float64)
+tot = c[:5].sum()
+for name, v in zip(("refill / ray generation", "world_trace_wave", "hit geometry", "volume pass (world.contains)", "material + bookkeeping"), c[:5]):
+    print("%-30s %.3f" % (name, v / tot))
+print("segment rounds %.4g, live lanes per round %.1f" % (c[7], c[6] / max(c[7], 1)))
