@@ -8,6 +8,8 @@ import pytest
 
 from source_amd import _lib
 
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
 
 def eq(a, b):
     return np.array_equal(np.asarray(a), np.asarray(b), equal_nan=True)
@@ -234,3 +236,26 @@ def test_philox_counters_advance_between_passes(ns):
     cam.observe()
     assert seen[6] == 114                                                        # same value re-assigned: the count carries on
     assert ns.HipEngine().timing is False
+
+
+def test_bench_roofline_helpers():
+    """bench.py's ceiling arithmetic on a recorded counter set (profiles/: rocprofv3 --pmc summary of a bench run): the binding
+    ceiling is VALU issue, every fraction except the contract's algorithmic-HBM line is below 1, and the dominant instantiation of
+    a multi-kernel workload is the one that did the vector work."""
+    import glob
+    import json
+    import bench
+    path = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c3.json")))[-1]
+    table = json.load(open(path))["kernels"]
+    name, c = bench.kernel_counters(table, "k_render_trace")
+    assert name.startswith("k_render_trace<false, 0, 1")
+    ceil, binding = bench.ceilings(c, 33.0, 14000.0)
+    assert binding == "valu_issue" and 0.6 < ceil["valu_issue"]["frac"] < 1.0
+    assert all(v["frac"] < 1.0 for v in ceil.values()) and ceil["hbm_measured"]["frac"] < 0.1 and 0.7 < ceil["l2"]["hit_rate"] < 1.0
+    assert 0.5 < ceil["valu_issue"]["lane_utilisation"] < 1.0
+    c4 = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_c4.json")))
+    if c4:
+        name, _ = bench.kernel_counters(json.load(open(c4[-1]))["kernels"], "k_render_trace")
+        assert name.startswith("k_render_trace<true, 1")          # the fast CSG pass, not the (idle) redo pass
+    b, per = bench.ray_bytes(dict(nodes=27, items=8, tris=3, prims=5), 1)
+    assert b == 56 + 16 * 27 + 4 * 8 + 48 * 3 + 216 * 5 + 24
