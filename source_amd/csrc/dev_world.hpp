@@ -138,7 +138,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         double distance = 0;
         int32_t count = 0;
         const int32_t *items = sc.witems;
-#if RSX_PHASE_PROF == 2
+#if RSX_PHASE_PROF == 2 || RSX_PHASE_PROF == 3
         const unsigned long long ph2_d0 = clock64();
 #endif
         if (active) { UTIL_COUNT(phase_acc, 0) }
@@ -177,6 +177,8 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         }
 #if RSX_PHASE_PROF == 2
         phase_acc[4] += clock64() - ph2_d0;
+#elif RSX_PHASE_PROF == 3
+        if (phase_acc) { phase_acc[5] += clock64() - ph2_d0; phase_acc[8] += 1; }
 #endif
         if constexpr (!UNIFORM_ITEMS) {
         for (int32_t k = 0; __any(k < count); ++k) {

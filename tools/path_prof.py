@@ -41,3 +41,4 @@ tot = c[:5].sum()
 for name, v in zip(("refill / ray generation", "world_trace_wave", "hit geometry", "volume pass (world.contains)", "material + bookkeeping"), c[:5]):
     print("%-30s %.3f" % (name, v / tot))
 print("segment rounds %.4g, live lanes per round %.1f" % (c[7], c[6] / max(c[7], 1)))
+print("inside world_trace_wave: descents %.3f of it; %.1f leaf-visit rounds per segment round" % (c[5] / max(c[1], 1), c[8] / max(c[7], 1)))
