@@ -24,15 +24,12 @@ decorrelated streams.
 
 Per-pixel statistics use the same Welford recurrence in sample order and the same combine_samples merge as the device kernels.
 """
-import ctypes as C
-
 import numpy as np
 
 from ..core import random as rsrandom
 from ..core.math import Point3D, Vector3D
 from . import _portable as P
 from . import ray as ray_module
-from .ray import Ray
 
 
 class _Pending(BaseException):
@@ -61,18 +58,21 @@ class _Stream:
 
 
 class _Node:
-    __slots__ = ("path", "parent", "ordinal", "depth", "mix", "ray", "norm", "hit", "inside", "result", "children", "stream", "drew")
+    """One ray of a path's call tree. path = (pixel word, sample counter) of the Philox counters; ordinal = position among the
+    parent's daughters (the primary ray keeps its (pixel, sample, row) key there); mix = stream decorrelation word (0 on the chain
+    the device numbers the same way)."""
+    __slots__ = ("path", "parent", "ordinal", "depth", "mix", "ray", "norm", "hit", "inside", "result", "children", "stream")
 
     def __init__(self, path, parent, ordinal, depth, mix, ray):
         self.path, self.parent, self.ordinal, self.depth, self.mix, self.ray = path, parent, ordinal, depth, mix, ray
-        self.norm, self.hit, self.inside, self.result, self.children, self.stream, self.drew = 1.0, None, (), None, None, None, False
+        self.norm, self.hit, self.inside, self.result, self.children, self.stream = 1.0, None, (), None, None, None
 
 
 class WaveScheduler:
     """Traces the paths of one block of pixels of one spectral slice. seed / sample counters as in rsx_render_desc."""
 
-    def __init__(self, world, scene, seed, ny):
-        self.world, self.scene, self.seed, self.ny = world, scene, int(seed), int(ny)
+    def __init__(self, world, scene, seed):
+        self.world, self.scene, self.seed = world, scene, int(seed)
         self.need_hit = []
         self.current, self.ordinal = None, 0
         self.rays = 0
@@ -233,7 +233,7 @@ def render_slice(camera, tasks, slice_id, template, engine, pieces):
         dx, dy, dz = dx * norm, dy * norm, dz * norm
         weight = dz
         wx, wy, wz = m[0] * dx + m[1] * dy + m[2] * dz, m[4] * dx + m[5] * dy + m[6] * dz, m[8] * dx + m[9] * dy + m[10] * dz
-        sched = WaveScheduler(world, scene, key, ny)
+        sched = WaveScheduler(world, scene, key)
         primaries = []
         for r in range(n * spp):
             ray = template.copy(Point3D(*origin), Vector3D(float(wx[r]), float(wy[r]), float(wz[r])))
