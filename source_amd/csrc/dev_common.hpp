@@ -30,8 +30,10 @@ struct DScene {
     const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
     const struct CsgFast *csgfast;   // per primitive: flattened operand tree of a top-level CSG node whose leaves are all analytic (n_leaves = 0: none)
     int32_t n_wnodes, n_witems;   // sizes of the world tree (the path kernel stages a small one in LDS)
-    int32_t wide[2];           // analytic world primitives that sit in several world leaves (floors, walls, enclosing emitters), -1 = none:
-                               // world_trace_wave computes their first root once per ray instead of once per leaf visited
+    int32_t wide[8];           // analytic world primitives that sit in several world leaves (floors, walls, enclosing emitters), most leaves
+                               // first, -1 = none: world_trace_wave computes their first root once per ray instead of once per leaf
+                               // visited — the first two for primary rays, all eight for scattered rays (see there)
+    const rsx_kdnode *wnodes_scatter;   // the world nodes with the wide-only leaves tagged for the eight-slot set (wnodes: for the first two)
 };
 
 struct CsgInfo {

@@ -675,12 +675,12 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     DScene sc = sc_arg;
     if (rp.world_lds > 0) {                                // stage the world tree behind the traversal stacks (see render())
         int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
-        const int4 *src = reinterpret_cast<const int4 *>(sc_arg.wnodes);
+        const int4 *src = reinterpret_cast<const int4 *>(CSG ? sc_arg.wnodes : sc_arg.wnodes_scatter);   // (the copy tagged for this kernel's wide slots)
         for (int i = threadIdx.x; i < sc_arg.n_wnodes; i += blockDim.x) dst[i] = src[i];
         int32_t *idst = reinterpret_cast<int32_t *>(dst + sc_arg.n_wnodes);
         for (int i = threadIdx.x; i < sc_arg.n_witems; i += blockDim.x) idst[i] = sc_arg.witems[i];
         __syncthreads();
-        sc.wnodes = reinterpret_cast<const rsx_kdnode *>(dst);
+        sc.wnodes = sc.wnodes_scatter = reinterpret_cast<const rsx_kdnode *>(dst);     // (contains() walks read type / count / first item only)
         sc.witems = idst;
     }
     Stack st, ms;
@@ -792,9 +792,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         pp_acc[6] += __popcll(__ballot(active)); pp_acc[7] += 1;
 #endif
 #if RSX_PHASE_PROF == 3
-        const bool got = world_trace_wave<CSG, MODE == 1>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, CSG ? 2 : 8>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
 #else
-        const bool got = world_trace_wave<CSG, MODE == 1>(active, sc, r, st, ms, csg_state, hit, work);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, CSG ? 2 : 8>(active, sc, r, st, ms, csg_state, hit, work);
 #endif
 #if RSX_PHASE_PROF == 3
         const unsigned long long pp1 = clock64();

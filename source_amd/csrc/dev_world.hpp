@@ -98,7 +98,31 @@ __device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, 
 // world leaf, so a leaf item is one primitive for all of them and its record comes in over the scalar data path). Scattered rays —
 // the daughters of the path kernel, arbitrary query batches — meet a different primitive in every lane: there each lane tests its
 // own item and only the meshes are grouped (measured with the uniform walk on the path kernel: Cornell box 59 -> 76 ms per pass).
-template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false>
+// Wide primitives (DScene::wide), WIDE_N of them answered before the traversal: two where registers are short (the primary-ray
+// kernel and the query batches at three waves per SIMD, every CSG instantiation — with eight the CSG path kernels spill and the
+// prism slice goes 54 -> 76 ms); eight in the path kernel of scenes without CSG — its per-lane leaf items run at a fraction of the
+// wave's width (a Cornell-box round spent 60 % of its world time there), while eight wave-uniform tests up front run at full width
+// over scalar-loaded records: Cornell box 57.7 -> 51.8 ms per pass.
+struct WideSet8 {
+    double t[8];
+    uint32_t faces[2];         // 8 bits per slot
+};
+template <int N>
+__device__ __forceinline__ void wide_lookup(const WideSet8 &w, int slot, double &t, int32_t &faces) {
+    t = w.t[0]; uint32_t f = w.faces[0];
+#pragma unroll
+    for (int j = 1; j < N; ++j) if (slot == j) { t = w.t[j]; f = j < 4 ? w.faces[0] >> (8 * j) : w.faces[1] >> (8 * (j - 4)); }
+    faces = (int32_t)(f & 255u);
+}
+template <int N>
+__device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     // slot of primitive idx in the first N wide entries, or -1
+    int slot = -1;
+#pragma unroll
+    for (int j = 0; j < N; ++j) if (idx == sc.wide[j]) slot = j;
+    return slot;
+}
+
+template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false, int WIDE_N = 2>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
@@ -119,16 +143,22 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // Primitives that sit in several world leaves (the reference tests a primitive again in every leaf the ray visits,
     // kdtree.pyx:99-116; the answer is the same each time): their first root is computed once, here. configs[2]: the floor box and
     // the enclosing emitter are met 4.4 times per primary ray.
-    double wide_t0 = -1.0, wide_t1 = -1.0;
-    int32_t wide_faces = 0;
+    static_assert(WIDE_N == 2 || WIDE_N == 8, "two tagged copies of the world nodes exist: for two and for eight wide slots");
+    const rsx_kdnode *wnodes = WIDE_N == 2 ? sc.wnodes : sc.wnodes_scatter;
+    WideSet8 wide;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) wide.t[j] = -1.0;
+    wide.faces[0] = wide.faces[1] = 0;
 #if RSX_PHASE_PROF == 2
     const unsigned long long ph2_wd0 = clock64();
 #endif
-    if (sc.wide[0] >= 0) {
-        int32_t f0 = 0, f1 = 0;
-        analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[0]), sc.wide[0], active, r, rx, ry, rz, wide_t0, f0);
-        if (sc.wide[1] >= 0) analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[1]), sc.wide[1], active, r, rx, ry, rz, wide_t1, f1);
-        wide_faces = f0 | (f1 << 8);
+#pragma unroll
+    for (int j = 0; j < WIDE_N; ++j) {
+        if (sc.wide[j] >= 0) {                              // (wave-uniform)
+            int32_t f = 0;
+            analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
+            wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
+        }
     }
 #if RSX_PHASE_PROF == 2
     phase_acc[7] += clock64() - ph2_wd0;
@@ -144,13 +174,13 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         if (active) { UTIL_COUNT(phase_acc, 0) }
         if (active) {
 #if RSX_UTIL_PROF == 2
-            const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
+            const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
 #elif RSX_WORLD_COHERENT
-            const rsx_kdnode nd = descend_coherent(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
+            const rsx_kdnode nd = descend_coherent(wnodes, node, r, ad, tmin, tmax, st, sp);
 #elif RSX_WORLD_FAST_DIV
-            const rsx_kdnode nd = descend(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
+            const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp);
 #else
-            const rsx_kdnode nd = descend<true>(sc.wnodes, node, r, ad, tmin, tmax, st, sp);
+            const rsx_kdnode nd = descend<true>(wnodes, node, r, ad, tmin, tmax, st, sp);
 #endif
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;
@@ -159,15 +189,20 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             // in registers, so the visit is two compares per item — in list order, `<=` as in the item loop below (kdtree.pyx:113)
             const int32_t tag = nd.u.leaf.pad;
             if (tag < 0) {
+                const int n_tagged = (tag >> 28) & 7;          // bit 31: tagged; bits 28..30: items (<= 6); 3 bits per item: its wide slot
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    if (j < count) {
-                        const bool second = (tag >> j) & 1;
-                        const double t = second ? wide_t1 : wide_t0;
-                        const int32_t faces = second ? wide_faces >> 8 : wide_faces & 255;
+                for (int j = 0; j < (WIDE_N == 2 ? 2 : 6); ++j) {
+                    if (j < n_tagged) {
+                        const int slot = (tag >> (3 * j)) & 7;
+                        double t;
+                        int32_t faces;
+                        wide_lookup<WIDE_N>(wide, slot, t, faces);
                         if (t >= 0.0 && t <= distance) {
                             distance = t;
-                            best.prim = second ? sc.wide[1] : sc.wide[0]; best.t = t; best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
+                            int32_t prim = sc.wide[0];
+#pragma unroll
+                            for (int q = 1; q < WIDE_N; ++q) if (slot == q) prim = sc.wide[q];
+                            best.prim = prim; best.t = t; best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
                             best.u = best.v = best.w = 0.0f;
                         }
                     }
@@ -188,15 +223,16 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             Hit cand;
             cand.prim = -1;
             work += CSG ? 16 : 4;
-            const bool wide = idx == sc.wide[0] || idx == sc.wide[1];         // answered before the traversal began
-            if (have && wide) {
-                const bool first = idx == sc.wide[0];
-                const double t = first ? wide_t0 : wide_t1;
-                const int32_t faces = first ? wide_faces & 255 : wide_faces >> 8;
+            const int slot = wide_slot<WIDE_N>(sc, idx);          // >= 0: answered before the traversal began
+            const bool is_wide = slot >= 0;
+            if (have && is_wide) {
+                double t;
+                int32_t faces;
+                wide_lookup<WIDE_N>(wide, slot, t, faces);
                 if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
             }
             double f, b;
-            const bool gate = have && !wide && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            const bool gate = have && !is_wide && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
             const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
             // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
             // descriptor, array bases: scalar loads, SGPRs): a wave that straddles several instances takes one turn per instance.
@@ -251,9 +287,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 const bool mine = have && idx == uidx;
                 todo &= ~__ballot(mine);
                 if (uidx == sc.wide[0] || uidx == sc.wide[1]) {                     // answered before the traversal began
-                    const bool first = uidx == sc.wide[0];
-                    const double t = first ? wide_t0 : wide_t1;
-                    const int32_t faces = first ? wide_faces & 255 : wide_faces >> 8;
+                    double t;
+                    int32_t faces;
+                    wide_lookup<2>(wide, uidx == sc.wide[0] ? 0 : 1, t, faces);
                     if (mine && t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                     continue;
                 }

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 
 #include <time.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdio>
@@ -586,7 +587,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     d.wdepth = tree_depth(desc->world_kd) + 1;
     d.mdepth = 1;
     {
-        // the two analytic world primitives that occur in the most world leaves (at least two): see DScene::wide
+        // the (up to eight) analytic world primitives that occur in the most world leaves (at least two): see DScene::wide
         std::vector<int32_t> leaves((size_t)std::max(1, desc->n_world), 0);
         for (int32_t n = 0; n < desc->world_kd.n_nodes; ++n) {
             const rsx_kdnode &nd = desc->world_kd.nodes[n];
@@ -596,33 +597,39 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 if (idx >= 0 && idx < desc->n_world) leaves[(size_t)idx]++;
             }
         }
-        d.wide[0] = d.wide[1] = -1;
-        if (!std::getenv("RSX_NO_WIDE"))
+        for (int32_t &w : d.wide) w = -1;
+        if (!std::getenv("RSX_NO_WIDE")) {
+            std::vector<int32_t> cand;
             for (int32_t i = 0; i < desc->n_world; ++i) {
                 const int32_t t = desc->primitives[i].type;
-                if ((t != RSX_PRIM_SPHERE && t != RSX_PRIM_BOX && t != RSX_PRIM_CYLINDER) || leaves[(size_t)i] < 2) continue;
-                if (d.wide[0] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[0]]) { d.wide[1] = d.wide[0]; d.wide[0] = i; }
-                else if (d.wide[1] < 0 || leaves[(size_t)i] > leaves[(size_t)d.wide[1]]) d.wide[1] = i;
+                if ((t == RSX_PRIM_SPHERE || t == RSX_PRIM_BOX || t == RSX_PRIM_CYLINDER) && leaves[(size_t)i] >= 2) cand.push_back(i);
             }
-        // Device copy of the world nodes. A leaf whose items are ALL wide primitives (at most two: most leaves of a scene with a floor
-        // and an enclosing emitter) carries its whole item list in the node's spare word — bit 31, the count in bits 8..10, the wide slot
-        // of item j in bit j, list order kept — so that visiting it costs no item loads and no per-item rounds (world_trace_wave).
-        std::vector<rsx_kdnode> wnodes(desc->world_kd.nodes, desc->world_kd.nodes + desc->world_kd.n_nodes);
-        if (!std::getenv("RSX_NO_WIDE_LEAVES"))
+            std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
+            for (size_t k = 0; k < cand.size() && k < 8; ++k) d.wide[k] = cand[k];
+        }
+        // Device copies of the world nodes. A leaf whose items are ALL wide primitives (most leaves of a scene with a floor and an
+        // enclosing emitter; every leaf of a room of boxes) carries its whole item list in the node's spare word — bit 31, the item count
+        // in bits 28..30, the wide slot of item j in bits 3j..3j+2, list order kept — so that visiting it costs no item loads and no
+        // per-item rounds (world_trace_wave). Two copies: tagged for the first two slots (primary rays) and for all eight (scattered rays).
+        for (int n_slots : {2, 8}) {
+            std::vector<rsx_kdnode> wnodes(desc->world_kd.nodes, desc->world_kd.nodes + desc->world_kd.n_nodes);
             for (rsx_kdnode &nd : wnodes) {
                 if (nd.type >= 0) continue;
                 nd.u.leaf.pad = 0;
-                if (nd.count < 1 || nd.count > 2 || d.wide[0] < 0) continue;
-                uint32_t tag = 0x80000000u | ((uint32_t)nd.count << 8);
+                if (std::getenv("RSX_NO_WIDE_LEAVES") || nd.count < 1 || nd.count > (n_slots == 2 ? 2 : 6)) continue;
+                uint32_t tag = 0x80000000u | ((uint32_t)nd.count << 28);
                 bool all_wide = true;
                 for (int32_t k = 0; k < nd.count; ++k) {
                     const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
-                    if (idx == d.wide[0]) continue;
-                    if (idx == d.wide[1]) tag |= 1u << k; else all_wide = false;
+                    int slot = -1;
+                    for (int q = 0; q < n_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) slot = q;
+                    if (slot < 0) all_wide = false; else tag |= (uint32_t)slot << (3 * k);
                 }
                 if (all_wide) nd.u.leaf.pad = (int32_t)tag;
             }
-        UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes));
+            if (n_slots == 2) UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes));
+            else UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes_scatter));
+        }
     }
     std::vector<DMesh> meshes((size_t)desc->n_meshes);
     for (int32_t i = 0; i < desc->n_meshes; ++i) {
