@@ -53,7 +53,9 @@ struct CsgFast {
     int32_t chain_len[CSGF_MAX_LEAVES];
     int32_t chain[CSGF_MAX_LEAVES][CSGF_MAX_CHAIN];   // primitive ids from the top node's operand down to the leaf (inclusive)
     int8_t ops[2 * CSGF_MAX_LEAVES];                  // >= 0: push inside(leaf slot); -1 union, -2 intersect, -3 subtract
+    uint64_t truth[4];                                // the program's value for every combination of "inside leaf k" bits (bit = the mask)
 };
+__device__ __forceinline__ uint32_t csg_truth(const CsgFast &P, uint32_t inside_bits) { return (uint32_t)(P.truth[inside_bits >> 6] >> (inside_bits & 63u)) & 1u; }
 
 struct Ray {
     double ox, oy, oz, dx, dy, dz, maxd;

@@ -220,6 +220,9 @@ __device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
 // in the merge's own order: it prefers operand b at every node (csg.pyx:231-234), i.e. the later leaf in depth-first numbering.
 // Leaf roots live in the (idle) mesh-stack LDS levels: t in the f64 array, (face, axis, exit) packed in the i32 array.
 // Returns 1 = hit (cand filled), 0 = no hit, -1 = use the stream merge.
+#ifndef RSX_ABLATE_CSG
+#define RSX_ABLATE_CSG 0
+#endif
 #ifdef CSGF_COUNT
 __device__ double g_csgf_ex[8];                 // one example of a tie: idx, leaf a, leaf b, t, ray origin
 __device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fast_hit gave up [nan, enter/exit pattern, tie, steps]
@@ -229,13 +232,16 @@ __device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fa
 #endif
 __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const Stack &ms, Hit &cand) {
     const CsgFast &P = sc.csgfast[idx];
+#if RSX_ABLATE_CSG == 2
+    return 0;                                                // (timing ablation: results are wrong)
+#endif
     const int lane = threadIdx.x % WAVE;
     double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
     int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
     Ray l0 = to_local(sc.prims[idx], r);
     l0.maxd = INFINITY;
     uint32_t nroots = 0;                                     // 2 bits per leaf
-    uint32_t exitbits = 0;                                   // bit 2k + j: root j of leaf k is an exit
+    uint32_t lone_exit = 0;                                  // bit k: leaf k has one root, an exit (the ray starts inside it)
     // The chain of a leaf is walked from the top unless it only differs from the previous leaf's in its last entry (siblings):
     // then the parent-space ray, its reciprocals and the verdict of the gates above are kept. The reciprocals 1 / d are shared by
     // every box tested in one space (aabb_rcp: bit-identical to aabb).
@@ -279,31 +285,16 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             if (exiting != (j == roots.n - 1)) { CSGF_WHY(1); return -1; }    // convex solid: (enter, exit) or a lone exit; anything else: stream merge
             lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
             lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((exiting ? 1 : 0) << 16);
-            exitbits |= (exiting ? 1u : 0u) << (2 * k + j);
         }
+        if (roots.n == 1) lone_exit |= 1u << k;
         nroots |= (uint32_t)roots.n << (2 * k);
     }
-    auto inside_solid = [&](uint32_t consumed) {
-        uint32_t stack = 0;
-        int sp = 0;
-        for (int o = 0; o < P.n_ops; ++o) {
-            const int op = P.ops[o];
-            if (op >= 0) {
-                const uint32_t c = (consumed >> (2 * op)) & 3u, n = (nroots >> (2 * op)) & 3u;
-                const uint32_t in = (c < n) && ((exitbits >> (2 * op + (int)c)) & 1u);                  // the next root is an exit
-                stack |= in << sp;
-                ++sp;
-            } else {
-                const uint32_t b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
-                const uint32_t res = op == -1 ? (a | b) : op == -2 ? (a & b) : (a & (b ^ 1u));
-                sp -= 2;
-                stack = (stack & ~(3u << sp)) | (res << sp);
-                ++sp;
-            }
-        }
-        return stack & 1u;
-    };
-    uint32_t consumed = 0;
+    // "inside the solid" is the tree's truth table (CsgFast::truth) looked up with the "inside leaf k" bits: a leaf is inside when
+    // its next root is an exit, i.e. at the start when it has a lone exit root
+#if RSX_ABLATE_CSG == 1
+    return 0;                                                // (timing ablation: results are wrong)
+#endif
+    uint32_t consumed = 0, inside_bits = lone_exit, solid = csg_truth(P, lone_exit);
     for (int step = 0; step <= 2 * P.n_leaves; ++step) {
         int best = -1;
         double best_t = INFINITY;
@@ -316,10 +307,12 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             if (best < 0 || t <= best_t) { best = k; best_t = t; }
         }
         if (best < 0) return 0;
-        const uint32_t before = inside_solid(consumed);
         const uint32_t c = (consumed >> (2 * best)) & 3u;
         consumed += 1u << (2 * best);
-        if (inside_solid(consumed) == before) continue;      // not a surface of the solid: csg_valid() rejects it, next root
+        inside_bits ^= 1u << best;                           // an enter root puts the ray inside the leaf, an exit root outside
+        const uint32_t before = solid;
+        solid = csg_truth(P, inside_bits);
+        if (solid == before) continue;                       // not a surface of the solid: csg_valid() rejects it, next root
         if (!(best_t <= r.maxd)) return 0;                   // csg_identify: accepted only within the ray's reach
         const int32_t m = lds_m[(2 * best + (int)c) * WAVE + lane];
         const uint32_t exiting = (uint32_t)(m >> 16) & 1u, parity = (uint32_t)P.parity[best] & 1u;
@@ -373,20 +366,7 @@ __device__ bool csg_fast_contains(const DScene &sc, int32_t idx, double px, doub
         }
         if (alive && leaf_contains(sc, sc.prims[P.leaf[k]], x, y, z, ms)) inside |= 1u << k;
     }
-    uint32_t stack = 0;
-    int sp = 0;
-    for (int o = 0; o < P.n_ops; ++o) {
-        const int op = P.ops[o];
-        if (op >= 0) { stack |= ((inside >> op) & 1u) << sp; ++sp; }
-        else {
-            const uint32_t b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
-            const uint32_t res = op == -1 ? (a | b) : op == -2 ? (a & b) : (a & (b ^ 1u));
-            sp -= 2;
-            stack = (stack & ~(3u << sp)) | (res << sp);
-            ++sp;
-        }
-    }
-    return (stack & 1u) != 0;
+    return csg_truth(P, inside) != 0;
 }
 
 template <int D>

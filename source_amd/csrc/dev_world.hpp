@@ -122,7 +122,10 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
     return slot;
 }
 
-template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false, int WIDE_N = 2>
+#ifndef RSX_CSG_MAILBOX
+#define RSX_CSG_MAILBOX 4
+#endif
+template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false, int WIDE_N = 2, int CSG_MAILBOX = RSX_CSG_MAILBOX>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
@@ -163,6 +166,12 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
 #if RSX_PHASE_PROF == 2
     phase_acc[7] += clock64() - ph2_wd0;
 #endif
+    constexpr int MB_N = CSG_MAILBOX > 0 ? CSG_MAILBOX : 1;
+    int32_t mb_idx[MB_N], mb_leaf[MB_N], mb_next = 0;
+    uint32_t mb_meta[MB_N];
+    double mb_t[MB_N];
+#pragma unroll
+    for (int j = 0; j < MB_N; ++j) { mb_idx[j] = -1; mb_leaf[j] = 0; mb_meta[j] = 0; mb_t[j] = -1.0; }
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
@@ -231,8 +240,26 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 wide_lookup<WIDE_N>(wide, slot, t, faces);
                 if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
             }
+            // A CSG primitive sits in several leaves (its box is that of the whole solid) and Primitive.hit(ray) does not depend on
+            // the leaf: the answer of the first visit is kept per lane (CSG_MAILBOX entries, round robin) and later leaves reuse it.
+            bool cached = false;
+            if constexpr (CSG && FASTONLY && CSG_MAILBOX > 0) {
+                if (have && !is_wide && is_csg(p.type)) {
+#pragma unroll
+                    for (int j = 0; j < CSG_MAILBOX; ++j) {
+                        if (mb_idx[j] == idx) {
+                            cached = true;
+                            if (mb_t[j] >= 0.0) {
+                                cand.prim = idx; cand.t = mb_t[j]; cand.leaf = mb_leaf[j];
+                                cand.a0 = (int32_t)(int8_t)(mb_meta[j] & 0xff); cand.a1 = (int32_t)(int8_t)((mb_meta[j] >> 8) & 0xff);
+                                cand.flags = mb_meta[j] >> 16; cand.u = cand.v = cand.w = 0.0f; cand.hx = cand.hy = cand.hz = 0.0;
+                            }
+                        }
+                    }
+                }
+            }
             double f, b;
-            const bool gate = have && !is_wide && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            const bool gate = have && !is_wide && !cached && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
             const bool is_mesh = gate && p.type == RSX_PRIM_MESH;
             // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
             // descriptor, array bases: scalar loads, SGPRs): a wave that straddles several instances takes one turn per instance.
@@ -255,6 +282,17 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 bool needs_stream = false;
                 primitive_first_hit<CSG, FASTONLY>(sc, idx, p, r, mesh_stack, csg_state, cand, needs_stream);
                 if (FASTONLY && needs_stream) work |= 0x80000000u;            // top bit of the cost counter: trace this ray again with the stream merge
+            }
+            if constexpr (CSG && FASTONLY && CSG_MAILBOX > 0) {
+                if (have && !is_wide && !cached && is_csg(p.type)) {            // (a failed gate is an answer too)
+                    const bool got = cand.prim >= 0;
+                    const uint32_t meta = ((uint32_t)cand.a0 & 0xffu) | (((uint32_t)cand.a1 & 0xffu) << 8) | (cand.flags << 16);
+#pragma unroll
+                    for (int j = 0; j < CSG_MAILBOX; ++j) {
+                        if (mb_next == j) { mb_idx[j] = idx; mb_t[j] = got ? cand.t : -1.0; mb_leaf[j] = got ? cand.leaf : 0; mb_meta[j] = got ? meta : 0u; }
+                    }
+                    mb_next = mb_next + 1 == CSG_MAILBOX ? 0 : mb_next + 1;
+                }
             }
             if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }

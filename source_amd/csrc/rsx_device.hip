@@ -569,6 +569,24 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 visit(tq.child_b, tq.type == RSX_PRIM_SUBTRACT ? 1 : 0);
                 if (ok) f.ops[f.n_ops++] = tq.type == RSX_PRIM_UNION ? (int8_t)-1 : tq.type == RSX_PRIM_INTERSECT ? (int8_t)-2 : (int8_t)-3;
             }
+            if (ok && f.n_leaves > 0) {                     // the postfix program run once per combination of leaf bits
+                for (uint32_t mask = 0; mask < (1u << f.n_leaves); ++mask) {
+                    uint32_t stack = 0;
+                    int sp = 0;
+                    for (int o = 0; o < f.n_ops; ++o) {
+                        const int op = f.ops[o];
+                        if (op >= 0) { stack |= ((mask >> op) & 1u) << sp; ++sp; }
+                        else {
+                            const uint32_t b = (stack >> (sp - 1)) & 1u, a = (stack >> (sp - 2)) & 1u;
+                            const uint32_t res = op == -1 ? (a | b) : op == -2 ? (a & b) : (a & (b ^ 1u));
+                            sp -= 2;
+                            stack = (stack & ~(3u << sp)) | (res << sp);
+                            ++sp;
+                        }
+                    }
+                    if (stack & 1u) f.truth[mask >> 6] |= 1ULL << (mask & 63u);
+                }
+            }
             if (ok && f.n_leaves > 0) { fast[(size_t)top] = f; any_fast = true; fast_levels = std::max(fast_levels, 2 * f.n_leaves); }
         }
     }
