@@ -33,6 +33,8 @@ struct DScene {
     int32_t wide[8];           // analytic world primitives that sit in several world leaves (floors, walls, enclosing emitters), most leaves
                                // first, -1 = none: world_trace_wave computes their first root once per ray instead of once per leaf
                                // visited — the first two for primary rays, all eight for scattered rays (see there)
+    int32_t wide_csg[4];       // top-level CSG primitives (state-free evaluator form) that sit in several world leaves, -1 = none: the path
+                               // kernel of a CSG scene answers them for the whole wave before the traversal (world_trace_wave's mailbox)
     const rsx_kdnode *wnodes_scatter;   // the world nodes with the wide-only leaves tagged for the eight-slot set (wnodes: for the first two)
 };
 

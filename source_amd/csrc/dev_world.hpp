@@ -172,16 +172,24 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     double mb_t[MB_N];
 #pragma unroll
     for (int j = 0; j < MB_N; ++j) { mb_idx[j] = -1; mb_leaf[j] = 0; mb_meta[j] = 0; mb_t[j] = -1.0; }
+    // CSG primitives that sit in several leaves (DScene::wide_csg) are answered in a round of their own before the traversal, all
+    // lanes at once, through the item loop below (one copy of the evaluator): left to the leaves, every lane meets them in a
+    // different round and the wave runs the evaluator once per round for a few lanes each.
+    bool prefill = false;
+    if constexpr (CSG && FASTONLY && CSG_MAILBOX >= 4 && !UNIFORM_ITEMS) prefill = sc.wide_csg[0] >= 0;
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
         int32_t count = 0;
         const int32_t *items = sc.witems;
+        if (prefill) {
+            if (active) count = (sc.wide_csg[1] < 0) ? 1 : (sc.wide_csg[2] < 0) ? 2 : (sc.wide_csg[3] < 0) ? 3 : 4;
+        }
 #if RSX_PHASE_PROF == 2 || RSX_PHASE_PROF == 3
         const unsigned long long ph2_d0 = clock64();
 #endif
         if (active) { UTIL_COUNT(phase_acc, 0) }
-        if (active) {
+        if (active && !prefill) {
 #if RSX_UTIL_PROF == 2
             const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
 #elif RSX_WORLD_COHERENT
@@ -227,7 +235,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         if constexpr (!UNIFORM_ITEMS) {
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
-            const int32_t idx = have ? items[k] : 0;
+            int32_t idx = 0;
+            if (prefill) idx = k == 0 ? sc.wide_csg[0] : k == 1 ? sc.wide_csg[1] : k == 2 ? sc.wide_csg[2] : sc.wide_csg[3];
+            else if (have) idx = items[k];
             const rsx_primitive &p = sc.prims[idx];
             Hit cand;
             cand.prim = -1;
@@ -294,8 +304,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     mb_next = mb_next + 1 == CSG_MAILBOX ? 0 : mb_next + 1;
                 }
             }
-            if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
+            if (!prefill && cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
+        if (prefill) { prefill = false; continue; }
         } else {
 #if RSX_ITEM_PREFETCH
         // the first item ids of the leaf in one go: a leaf of this level holds one to three items, and a round per item that begins

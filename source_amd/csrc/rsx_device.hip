@@ -625,6 +625,13 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
             for (size_t k = 0; k < cand.size() && k < 8; ++k) d.wide[k] = cand[k];
         }
+        for (int32_t &w : d.wide_csg) w = -1;
+        if (any_fast && !std::getenv("RSX_NO_WIDE_CSG")) {
+            std::vector<int32_t> cand;
+            for (int32_t i = 0; i < desc->n_world; ++i) if (fast[(size_t)i].n_leaves > 0 && leaves[(size_t)i] >= 2) cand.push_back(i);
+            std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
+            for (size_t k = 0; k < cand.size() && k < 4; ++k) d.wide_csg[k] = cand[k];
+        }
         // Device copies of the world nodes. A leaf whose items are ALL wide primitives (most leaves of a scene with a floor and an
         // enclosing emitter; every leaf of a room of boxes) carries its whole item list in the node's spare word — bit 31, the item count
         // in bits 28..30, the wide slot of item j in bits 3j..3j+2, list order kept — so that visiting it costs no item loads and no
