@@ -345,19 +345,21 @@ __device__ __forceinline__ int32_t branch_step(const rsx_kdnode &nd, int32_t nod
 
 // Walk from `node` down to a leaf. Nodes are loaded as (node, node+1) pairs: the lower child is always the next record of the
 // pre-order array, so stepping into it costs no dependent load (its own successor is fetched in the shadow of the step's arithmetic).
-__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double tmin, double &tmax, const Stack &st, int32_t &sp);
+__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double &tmin, double &tmax, const Stack &st, int32_t &sp,
+                                              int32_t cull_bits = 0, double t_cull = 0.0);
 
 // PLAIN: the branch steps use the hardware division outright (world tree: no refined reciprocals are kept for it, and branch_step's
 // shortcut would be computed only to be discarded at every step)
 template <bool PLAIN = false>
 __device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
-                                              const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
+                                              const Stack &st, int32_t &sp, unsigned long long *util = nullptr, double t_cull = 0.0) {
     rsx_kdnode nd = load_node(nodes, node), nx = load_node(nodes, node + 1);
     while (nd.type >= 0) {
         UTIL_COUNT(util, 4)
-        const int axis = nd.type;
+        const int axis = nd.type & 3;                   // (world nodes: bits 2, 3 = the cull bits of world_step)
         int32_t next;
-        if constexpr (PLAIN) next = world_step(nd.u.split, node + 1, nd.count, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp);
+        if constexpr (PLAIN) next = world_step(nd.u.split, node + 1, nd.count, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), tmin, tmax, st, sp,
+                                               nd.type >> 2, t_cull);
         else next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
                                          (ad.safe >> axis) & 1, tmin, tmax, st, sp);
         if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
@@ -383,7 +385,7 @@ __device__ __forceinline__ rsx_kdnode descend_quorum(const rsx_kdnode *nodes, in
         if (__popcll(pending) <= slack) break;
         if (active && !at_leaf) {
             UTIL_COUNT(util, 4)
-            const int axis = nd.type;
+            const int axis = nd.type & 3;
             const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
                                              (ad.safe >> axis) & 1, tmin, tmax, st, sp);
             if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
@@ -400,7 +402,12 @@ __device__ __forceinline__ rsx_kdnode descend_quorum(const rsx_kdnode *nodes, in
 // is a scalar branch instead of twelve per-lane selects, and the child ids are scalars. The arithmetic per lane is the reference's
 // (kdtree3d.pyx:626-700: plane = (split - origin[axis]) / direction[axis], the plain division). The moment the lanes part, the walk
 // continues per lane (descend).
-__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double tmin, double &tmax, const Stack &st, int32_t &sp) {
+// cull_bits (bit 0 / 1: every item below the lower / upper child is a wide primitive, tagged in the device copy of the world nodes)
+// and t_cull (the nearest of the ray's wide answers): a near child whose leaves all end before t_cull cannot accept anything — a
+// leaf accepts t <= min(max_distance, its tmax) <= plane < t_cull <= every candidate — so the walk goes straight to the far child,
+// which begins at the plane exactly as when it is popped after the near side.
+__device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32_t upper, double o, double d, double &tmin, double &tmax, const Stack &st, int32_t &sp,
+                                              int32_t cull_bits, double t_cull) {
     if (__builtin_expect(__any(d == 0), 0)) {
         if (d == 0) return o < split ? lower : upper;
     }
@@ -409,6 +416,7 @@ __device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32
     const int32_t near_id = below ? lower : upper, far_id = below ? upper : lower;
     if (plane > tmax || plane <= 0) return near_id;
     if (plane < tmin) return far_id;
+    if (((below ? cull_bits : cull_bits >> 1) & 1) && plane < t_cull) { tmin = plane; return far_id; }
     stack_push(st, sp, far_id, tmax);
     ++sp;
     tmax = plane;
@@ -429,8 +437,8 @@ __device__ __forceinline__ rsx_kdnode descend_coherent(const rsx_kdnode *nodes, 
         }
         UTIL_COUNT(util, 4)
         const double split = sn->u.split;
-        if (type == 0) node = world_step(split, unode + 1, count, r.ox, r.dx, tmin, tmax, st, sp);
-        else if (type == 1) node = world_step(split, unode + 1, count, r.oy, r.dy, tmin, tmax, st, sp);
+        if ((type & 3) == 0) node = world_step(split, unode + 1, count, r.ox, r.dx, tmin, tmax, st, sp);
+        else if ((type & 3) == 1) node = world_step(split, unode + 1, count, r.oy, r.dy, tmin, tmax, st, sp);
         else node = world_step(split, unode + 1, count, r.oz, r.dz, tmin, tmax, st, sp);
     }
 }

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n,
         int32_t node = 0;
         rsx_kdnode nd = load_node(sc.wnodes, node);
         while (nd.type >= 0) {
-            node = sel3(nd.type, px, py, pz) < nd.u.split ? node + 1 : nd.count;
+            node = sel3(nd.type & 3, px, py, pz) < nd.u.split ? node + 1 : nd.count;
             nd = load_node(sc.wnodes, node);
         }
         for (int32_t k = 0; k < nd.count; ++k) {

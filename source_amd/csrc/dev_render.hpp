@@ -626,7 +626,7 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
     int32_t node = 0;
     rsx_kdnode nd = load_node(sc.wnodes, node);
     while (nd.type >= 0) {
-        node = sel3(nd.type, px, py, pz) < nd.u.split ? node + 1 : nd.count;
+        node = sel3(nd.type & 3, px, py, pz) < nd.u.split ? node + 1 : nd.count;
         nd = load_node(sc.wnodes, node);
     }
     for (int32_t k = 0; k < nd.count; ++k) {

@@ -122,6 +122,9 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
     return slot;
 }
 
+#ifndef RSX_WORLD_CULL
+#define RSX_WORLD_CULL 1
+#endif
 #ifndef RSX_CSG_MAILBOX
 #define RSX_CSG_MAILBOX 4
 #endif
@@ -163,6 +166,13 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
         }
     }
+    // the nearest of those answers: subtrees that hold wide primitives only and end before it are not entered (world_step)
+    double t_cull = INFINITY;
+#pragma unroll
+    for (int j = 0; j < WIDE_N; ++j) if (wide.t[j] >= 0.0 && wide.t[j] < t_cull) t_cull = wide.t[j];
+#if RSX_WORLD_CULL == 0
+    t_cull = -INFINITY;
+#endif
 #if RSX_PHASE_PROF == 2
     phase_acc[7] += clock64() - ph2_wd0;
 #endif
@@ -197,7 +207,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
 #elif RSX_WORLD_FAST_DIV
             const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp);
 #else
-            const rsx_kdnode nd = descend<true>(wnodes, node, r, ad, tmin, tmax, st, sp);
+            const rsx_kdnode nd = descend<true>(wnodes, node, r, ad, tmin, tmax, st, sp, nullptr, t_cull);
 #endif
             distance = r.maxd < tmax ? r.maxd : tmax;
             items += nd.u.leaf.first_item;

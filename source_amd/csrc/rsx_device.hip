@@ -652,6 +652,29 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 }
                 if (all_wide) nd.u.leaf.pad = (int32_t)tag;
             }
+            // inner nodes: bits 2 / 3 of the axis word say that every item below the lower / upper child is one of these wide
+            // primitives (world_step's cull; children come after their parent in the pre-order array, so one backward sweep does it)
+            {
+                std::vector<char> only_wide(wnodes.size(), 0);
+                for (size_t n = wnodes.size(); n-- > 0;) {
+                    rsx_kdnode &nd = wnodes[n];
+                    if (nd.type < 0) {
+                        bool all = true;
+                        for (int32_t k = 0; k < nd.count && all; ++k) {
+                            const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
+                            bool is_wide = false;
+                            for (int q = 0; q < n_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) is_wide = true;
+                            all = is_wide;
+                        }
+                        only_wide[n] = all;
+                    } else {
+                        const size_t lower = n + 1, upper = (size_t)nd.count;
+                        const bool lo = lower < wnodes.size() && only_wide[lower], up = upper < wnodes.size() && only_wide[upper];
+                        only_wide[n] = lo && up;
+                        if (!std::getenv("RSX_NO_WORLD_CULL")) nd.type |= (lo ? 4 : 0) | (up ? 8 : 0);
+                    }
+                }
+            }
             if (n_slots == 2) UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes));
             else UP(upload(sc, wnodes.data(), wnodes.size(), &d.wnodes_scatter));
         }
