@@ -228,6 +228,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--sharding", choices=["auto", "tile", "sample"], default="auto", help="N > 1: tile (strong scaling, default) or sample (weak)")
+    ap.add_argument("--tiles", choices=["balanced", "equal"], default="balanced",
+                    help="tile sharding: column tiles of equal measured cost (default; rank 0 times 32 column blocks before the warmup "
+                         "and broadcasts the cuts) or of equal width")
     ap.add_argument("--collective", choices=["rsx", "torch", "host"], default="rsx",
                     help="N > 1 data plane: RCCL from librsx (default), torch.distributed nccl, or host (frames over gloo: a test aid that lets "
                          "several ranks share one GPU)")
@@ -269,12 +272,44 @@ def main():
     from source_amd.device import get_context
 
     world, cam, pipe = build_workload(args.workload, ns, scenes)
-    my_rect = D.tile_rect(rank, world_size, NX, NY) if sharding == "tile" else (0, 0, NX, NY)
-    cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
     engine = ns.HipEngine(rng="philox", seed=20250905)
     cam.render_engine = engine
     ctx = get_context()
     scene = world.build_accelerator()                      # flatten + KD build (host) + upload: outside the timed region
+
+    # Tile sharding: a step ends with its slowest rank, and the columns of a frame do not cost the same (configs[2]: equal-width
+    # tiles of an 8-way split differ by 1.45x). Rank 0 times N_BLOCKS column blocks — ordinary passes into a frame that is
+    # initialised afresh below — and every rank takes the cuts that equalise the measured cost (distributed.balanced_bounds).
+    tile_bounds = None
+    if sharding == "tile" and world_size > 1 and args.tiles == "balanced":
+        N_BLOCKS = 32
+        bw = max(1, NX // N_BLOCKS)
+        blocks = [(x0, 0, min(NX, x0 + bw), NY) for x0 in range(0, NX, bw)]
+        cost = []
+        engine.sample_offset = 1 << 40                      # (counters of their own: the render's first pass assigns 0 and starts there)
+        for rect in blocks:
+            cam.frame_sampler = ns.RectFrameSampler2D(rect=rect)
+            cam.observe()
+            ctx.synchronize()
+            reps, spent = 1, 0.0
+            while True:
+                t_b = time.perf_counter()
+                for _ in range(reps):
+                    cam.observe()
+                ctx.synchronize()
+                spent = time.perf_counter() - t_b
+                if spent >= 3e-3 or reps >= 64:
+                    break
+                reps *= 4
+            cost.append(spent / reps)
+        if pipe.frame is not None:                          # the timed blocks are not part of the render: drop their frame
+            pipe.frame.release()
+            pipe.frame = None
+        box = [D.balanced_bounds(cost, bw, NX, world_size) if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        tile_bounds = [int(b) for b in box[0]]
+    my_rect = D.tile_rect(rank, world_size, NX, NY, tile_bounds) if sharding == "tile" else (0, 0, NX, NY)
+    cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
 
     def all_agree(ok):
         if dist is None:
@@ -343,19 +378,19 @@ def main():
         if collective == "host":                            # frames through host memory and gloo: same shard logic, no RCCL
             f = pipe.frame
             t = [torch.from_numpy(a) for a in (f.mean, f.variance, f.samples)]
-            out = D.gather_tile_sharded(*t, rank, dist) if sharding == "tile" else D.merge_sample_sharded(*t, dist)
+            out = D.gather_tile_sharded(*t, rank, dist, tile_bounds) if sharding == "tile" else D.merge_sample_sharded(*t, dist)
             for dst, src in zip(f._host, out):
                 dst[...] = src.numpy()
             f._host_written()
             return None
         if comm is not None:
             if sharding == "tile":
-                comm.allgather_tiles(pipe.frame, NX, NY)
+                comm.allgather_tiles(pipe.frame, NX, NY, tile_bounds)
             else:
                 comm.allreduce_samples(pipe.frame)
             return None
         if sharding == "tile":
-            return D.gather_tile_sharded(frames[0], frames[1], frames[2], rank, dist)
+            return D.gather_tile_sharded(frames[0], frames[1], frames[2], rank, dist, tile_bounds)
         return D.merge_sample_sharded(frames[0], frames[1], frames[2], dist, combine_torch)
 
     # first observe() creates the pipeline frame; bind external storage before anything is rendered into it
@@ -391,11 +426,18 @@ def main():
             pass
         elif comm is not None:
             from source_amd.optical.observer import StatsArray3D
-            tiny = StatsArray3D(world_size * 8, 8, 4)
-            tiny._host[2][:] = 1
-            (comm.allgather_tiles(tiny, world_size * 8, 8) if sharding == "tile" else comm.allreduce_samples(tiny))
-            ctx.synchronize()
-            tiny.release()
+            try:
+                tiny = StatsArray3D(world_size * 8, 8, 4)
+                tiny._host[2][:] = 1
+                (comm.allgather_tiles(tiny, world_size * 8, 8) if sharding == "tile" else comm.allreduce_samples(tiny))
+                ctx.synchronize()
+                tiny.release()
+                ok = True
+            except Exception as e:                          # RCCL refused the exchange: the frames go through host memory + gloo instead
+                comm_note, ok = "rsx_comm exchange failed (%s): frames exchanged through host memory" % e, False
+            if not all_agree(ok):
+                comm, collective = None, "host"
+                comm_note = comm_note or "rsx_comm exchange failed on another rank: frames exchanged through host memory"
         else:
             tiny = [torch.zeros(4096, dtype=torch.float64, device="cuda"), torch.zeros(4096, dtype=torch.float64, device="cuda"),
                     torch.ones(4096, dtype=torch.int32, device="cuda")]
@@ -568,7 +610,7 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if sharding == "sample" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": W["name"] + (", %d MI355X" % world_size), "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
-                       "rng": "philox4x32-10", "sharding": sharding,
+                       "rng": "philox4x32-10", "sharding": sharding, "tile_bounds": tile_bounds,
                        "collective": {"none": "none", "rsx": "RCCL from librsx (rsx_allgather_frame / rsx_allreduce_frame)",
                                       "torch": "torch.distributed nccl", "host": "host memory + gloo (test aid)"}[collective] + ("; " + comm_note if comm_note else ""),
                        "collective_ms": round(collective_ms, 3), "frame_digest_equals_single_gpu": digest_ok},

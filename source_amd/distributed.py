@@ -15,11 +15,47 @@ def rank_sample_offset(step, rank, world_size, spp):
     return (step * world_size + rank) * spp
 
 
-def tile_rect(rank, world_size, nx, ny):
-    """Column tile [x0, x1) x [0, ny) of rank (frame is x-major, so a tile is one contiguous block of the frame arrays)."""
+def tile_rect(rank, world_size, nx, ny, bounds=None):
+    """Column tile [x0, x1) x [0, ny) of rank (frame is x-major, so a tile is one contiguous block of the frame arrays).
+    `bounds` = the world_size + 1 column boundaries of a cost-balanced split (balanced_bounds); default: equal widths."""
+    if bounds is not None:
+        if len(bounds) != world_size + 1 or bounds[0] != 0 or bounds[-1] != nx or any(b > a for a, b in zip(bounds[1:], bounds[:-1])):
+            raise ValueError("tile bounds must be %d non-decreasing columns from 0 to %d" % (world_size + 1, nx))
+        return (int(bounds[rank]), 0, int(bounds[rank + 1]), ny)
     x0 = (nx * rank) // world_size
     x1 = (nx * (rank + 1)) // world_size
     return (x0, 0, x1, ny)
+
+
+def balanced_bounds(block_cost, block_width, nx, world_size):
+    """Column boundaries of `world_size` contiguous tiles whose slowest tile is as fast as a split at block boundaries allows.
+    block_cost[i] = measured cost of columns [i * block_width, (i + 1) * block_width). A scene's rays do not cost the same
+    everywhere (configs[2]: the columns through the mesh instances take 1.4x the edge columns), and a step ends with its slowest
+    rank; the reference balances with a task queue (workflow.py:201-251), a static frame split balances by cost instead.
+    Exact minimum of the maximum tile cost (dynamic programme over the block prefix sums); every tile gets at least one block."""
+    cost = [float(c) for c in block_cost]
+    n = len(cost)
+    if n < world_size:
+        raise ValueError("need at least one cost block per rank")
+    prefix = [0.0]
+    for c in cost:
+        prefix.append(prefix[-1] + c)
+    inf = float("inf")
+    # best[k][i] = the smallest possible maximum tile cost when the first i blocks are cut into k non-empty tiles
+    best = [[inf] * (n + 1) for _ in range(world_size + 1)]
+    cut = [[0] * (n + 1) for _ in range(world_size + 1)]
+    best[0][0] = 0.0
+    for k in range(1, world_size + 1):
+        for i in range(k, n + 1):
+            for s in range(k - 1, i):
+                worst = max(best[k - 1][s], prefix[i] - prefix[s])
+                if worst < best[k][i]:
+                    best[k][i], cut[k][i] = worst, s
+    bounds, i = [nx], n
+    for k in range(world_size, 0, -1):
+        i = cut[k][i]
+        bounds.append(min(nx, i * block_width))
+    return bounds[::-1]
 
 
 def combine_arrays(ma, va, na, mb, vb, nb):
@@ -108,14 +144,14 @@ def merge_sample_sharded(mean, variance, samples, dist, combine=None, mode="scat
     return tuple(out)
 
 
-def gather_tile_sharded(mean, variance, samples, rank, dist):
+def gather_tile_sharded(mean, variance, samples, rank, dist, bounds=None):
     """Tile sharding on torch tensors (bench.py --collective torch, and the gloo tests): every rank holds full-size x-major frame
     tensors of which it rendered the column tile tile_rect(rank); returns the assembled (mean, variance, samples). Tiles of unequal
     width (nx not divisible by the world size) are padded to the widest one for the all_gather and cut back afterwards."""
     import torch
     world = dist.get_world_size()
     nx, ny = mean.shape[0], mean.shape[1]
-    rects = [tile_rect(r, world, nx, ny) for r in range(world)]
+    rects = [tile_rect(r, world, nx, ny, bounds) for r in range(world)]
     widest = max(r[2] - r[0] for r in rects)
     x0, _, x1, _ = rects[rank]
     out = []
@@ -166,10 +202,10 @@ class FrameComm:
         _lib.check(_lib.lib().rsx_comm_max_f64(self._h, C.byref(v)))
         return float(v.value)
 
-    def allgather_tiles(self, frame, nx, ny):
+    def allgather_tiles(self, frame, nx, ny, bounds=None):
         """frame: StatsArray3D whose column tile tile_rect(rank) this rank rendered; afterwards the whole frame on every rank."""
         from . import _lib
-        begin = np.array([tile_rect(r, self.world_size, nx, ny)[0] * ny * frame.nz for r in range(self.world_size)] + [nx * ny * frame.nz], dtype=np.int64)
+        begin = np.array([tile_rect(r, self.world_size, nx, ny, bounds)[0] * ny * frame.nz for r in range(self.world_size)] + [nx * ny * frame.nz], dtype=np.int64)
         fm, fv, fn = frame._device(self.context)
         _lib.check(_lib.lib().rsx_allgather_frame(self._h, fm, fv, fn, _lib.ptr(begin)))
         frame._mark_device_written()

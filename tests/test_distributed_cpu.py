@@ -58,6 +58,14 @@ def _worker(rank, world_size, port, out):
     odd[r5[0]:r5[2]] = rank + 1.0
     o5 = D.gather_tile_sharded(torch.from_numpy(odd), torch.from_numpy(odd.copy()), torch.from_numpy(odd.astype(np.int32)), rank, dist)[0].numpy()
     assert (o5[:2] == 1.0).all() and (o5[2:] == 2.0).all()
+    # cost-balanced tiles (bench.py --tiles balanced): unequal widths from measured block costs, same assembly
+    bounds = D.balanced_bounds([5.0, 1.0, 1.0, 1.0, 1.0, 1.0, 1.0], 1, 7, world_size)
+    assert bounds == [0, 2, 7] or bounds == [0, 1, 7]
+    rb = D.tile_rect(rank, world_size, 7, ny, bounds)
+    odd = np.zeros((7, ny, bins))
+    odd[rb[0]:rb[2]] = rank + 1.0
+    ob = D.gather_tile_sharded(torch.from_numpy(odd), torch.from_numpy(odd.copy()), torch.from_numpy(odd.astype(np.int32)), rank, dist, bounds)[0].numpy()
+    assert (ob[:bounds[1]] == 1.0).all() and (ob[bounds[1]:] == 2.0).all()
     np.savez(out % rank, M=M.numpy(), V=V.numpy(), N=N.numpy(), fm=fm, fv=fv, full=full.numpy())
     dist.barrier()
     dist.destroy_process_group()
@@ -93,6 +101,26 @@ def test_gloo_world2_merge(tmp_path, orc, ns):
     desc1 = cam.render_desc(world, None, cam._slice_spectrum()[0], ns.HipEngine(rng="philox", seed=5), keep, rect=(0, 0, 24, 16))
     fm1, _, _ = orc.render_pinhole(world.flatten(), desc1)
     assert np.array_equal(r0["full"], fm1.reshape(16, 24, 5).transpose(1, 0, 2))
+
+
+def test_balanced_tile_bounds():
+    """Contiguous tiles of (near) equal measured cost: every tile non-empty, cuts at block boundaries, never worse than equal widths."""
+    from source_amd import distributed as D
+    rng = np.random.default_rng(3)
+    for n_blocks, ranks, bw, nx in ((32, 8, 64, 2048), (32, 4, 64, 2048), (32, 2, 32, 1024), (8, 8, 3, 24), (33, 5, 3, 97)):
+        cost = 1.0 + rng.random(n_blocks) * (np.arange(n_blocks) % 7 == 0) * 4
+        b = D.balanced_bounds(cost, bw, nx, ranks)
+        assert len(b) == ranks + 1 and b[0] == 0 and b[-1] == nx and all(x1 > x0 for x0, x1 in zip(b[:-1], b[1:]))
+        assert all(x % bw == 0 for x in b[:-1])
+        tile_cost = lambda bounds: max(sum(cost[x0 // bw:-(-x1 // bw)]) for x0, x1 in zip(bounds[:-1], bounds[1:]))
+        equal = [(n_blocks * r // ranks) * bw for r in range(ranks)] + [nx]
+        assert tile_cost(b) <= tile_cost(equal) + 1e-12
+        for r in range(ranks):
+            assert D.tile_rect(r, ranks, nx, 5, b) == (b[r], 0, b[r + 1], 5)
+    with pytest.raises(ValueError):
+        D.balanced_bounds([1.0, 1.0], 4, 8, 3)
+    with pytest.raises(ValueError):
+        D.tile_rect(0, 2, 8, 5, [0, 9, 8])
 
 
 def test_combine_arrays_matches_reference(golden):
