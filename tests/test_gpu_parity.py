@@ -1167,3 +1167,72 @@ def test_lifted_limits_many_tables_and_nested_volumes(orc, ns):
     om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
     assert eq(pipe.frame.mean, om.reshape(32, 48, 4).transpose(1, 0, 2)) and eq(pipe.frame.variance, ov.reshape(32, 48, 4).transpose(1, 0, 2))
     assert cam.stats["rays"] == rays and pipe.frame.mean.min() > 0
+
+
+def test_random_analytic_worlds_wide_slots_and_cull(orc, ns):
+    """The world level of the traversal kernels on worlds made to stress it (tools/stress_world.py, reduced): 3 .. 28 grid-snapped
+    spheres / boxes / cylinders — coincident faces, a quarter of them huge so that they sit in most world leaves (wide primitives),
+    sometimes a mesh (subtrees that cannot be culled) — hit by random, grid-aligned and axis-parallel rays (two wide slots) and
+    path traced with scattering, refracting and emitting materials, half the frames with importance sampling (eight wide slots,
+    cull by the nearest wide answer): ids, distances, geometry and frames equal the oracle bit for bit."""
+    rng = np.random.RandomState(97531)
+    grid = [-1.0, -0.5, -0.25, 0.0, 0.25, 0.5, 1.0]
+    P = ns.Point3D
+
+    def snap(scale=1.0):
+        return scale * (float(rng.choice(grid)) if rng.rand() < 0.6 else float(rng.uniform(-1.0, 1.0)))
+
+    def primitive(world, huge):
+        kind = rng.randint(3)
+        t = ns.translate(snap(1.5), snap(1.5), snap(1.5))
+        if rng.rand() < 0.35:
+            t = t * ns.rotate(float(rng.choice([0, 90, 30, 45])), float(rng.choice([0, 90, 30])), float(rng.choice([0, 90])))
+        s = float(rng.choice([2.0, 3.0, 4.0])) if huge else 1.0
+        if kind == 0:
+            return ns.Sphere(s * float(rng.choice([0.25, 0.5, 0.4])), world, t)
+        if kind == 1:
+            lo = [s * float(rng.choice([-0.5, -0.25])) for _ in range(3)]
+            hi = [s * float(rng.choice([0.25, 0.5])) for _ in range(3)]
+            if huge and rng.rand() < 0.5:
+                ax = rng.randint(3)
+                lo[ax], hi[ax] = -0.05, 0.0
+            return ns.Box(P(*lo), P(*hi), world, t)
+        return ns.Cylinder(s * float(rng.choice([0.25, 0.5])), s * float(rng.choice([0.5, 1.0])), world, t)
+
+    for wi, n_prims in enumerate([3, 8, 9, 12, 20, 28]):
+        world = ns.World()
+        for _ in range(n_prims):
+            primitive(world, huge=rng.rand() < 0.25)
+        if wi % 3 == 2:
+            v, t = scenes.displaced_sphere(4, radius=0.4)
+            ns.Mesh(v, t, parent=world, transform=ns.translate(snap(), snap(), snap()))
+        scene = world.build_accelerator()
+        n = 40000
+        o = rng.uniform(-3, 3, size=(n, 3))
+        d = rng.normal(size=(n, 3))
+        k8 = n // 8
+        o[:k8] = rng.choice(grid + [2.0, -2.0, 3.0], size=(k8, 3))
+        d[k8:2 * k8] = 0.0
+        d[np.arange(k8, 2 * k8), rng.randint(3, size=k8)] = rng.choice([-1.0, 1.0], size=k8)
+        d /= np.linalg.norm(d, axis=1)[:, None]
+        m = np.where(rng.rand(n) < 0.2, rng.uniform(0.1, 4.0, size=n), np.inf)
+        assert_hits_equal(scene.hit_batch(o, d, m, geometry=True), orc.hit_batch(world.flatten(), o, d, m, geometry=True))
+        mats = [ns.Lambert(ns.ConstantSF(0.8)), ns.Dielectric(ns.ConstantSF(1.5), ns.ConstantSF(1.0)), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.5),
+                ns.Lambert(ns.ConstantSF(0.5)), ns.NullMaterial(), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 0.7)]
+        for prim in list(world._primitives):
+            prim.material = mats[rng.randint(len(mats))]
+            if rng.rand() < 0.2:
+                prim.material.importance = float(rng.choice([1.0, 4.0]))
+        ns.Box(P(-6, -6, -6), P(6, 6, 6), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 1.0))
+        pipe = ns.SpectralRadiancePipeline2D()
+        cam = ns.PinholeCamera((64, 64), fov=60, parent=world, pipelines=[pipe], frame_sampler=ns.RectFrameSampler2D(), transform=ns.translate(0.2, 0.1, -4.5))
+        cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = 4, 3, 1, True
+        cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = 0.05, 2, 60
+        cam.ray_importance_sampling = bool(wi % 2)
+        cam.render_engine = ns.HipEngine(rng="philox", seed=wi)
+        cam.observe()
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 64, 64))
+        om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+        assert cam.stats["rays"] == rays
+        assert eq(np.array(pipe.frame.mean), om.reshape(64, 64, 3).transpose(1, 0, 2))
