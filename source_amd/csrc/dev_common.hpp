@@ -252,9 +252,6 @@ __device__ __forceinline__ rsx_kdnode load_node(const rsx_kdnode *nodes, int32_t
 #ifndef RSX_FAST_DIV
 #define RSX_FAST_DIV 1
 #endif
-#ifndef RSX_EXACT_DIV_BRANCHLESS
-#define RSX_EXACT_DIV_BRANCHLESS 0     // straight-line exact_div with one wave-level fallback test: measured neutral (accumulate 7.13 vs 7.17 ms)
-#endif
 
 __device__ __forceinline__ double refine_rcp(double d) {
     const double r = __builtin_amdgcn_rcp(d);
@@ -271,27 +268,12 @@ __device__ __forceinline__ bool div_operand_safe(double x) {          // |x| in 
 
 __device__ __forceinline__ double exact_div(double n, double d, double y, bool d_safe) {
 #if RSX_FAST_DIV
-#if RSX_EXACT_DIV_BRANCHLESS
-    // straight-line form: the shortcut is always computed; a zero numerator keeps n * y (signed zero with the quotient's sign, which the
-    // correction step would lose); operands outside the shortcut's range — one wave-level test — take the plain division
-    const double q0 = n * y;
-    const double r = __builtin_fma(-d, q0, n);
-    double q = __builtin_fma(r, y, q0);
-    const bool zero = n == 0.0;
-    q = zero ? q0 : q;
-    const bool exact = d_safe & (div_operand_safe(n) | zero);
-    if (__builtin_expect(__any(!exact), 0)) {
-        if (!exact) q = n / d;
-    }
-    return q;
-#else
     if (d_safe && div_operand_safe(n)) {
         const double q0 = n * y;
         const double r = __builtin_fma(-d, q0, n);
         return __builtin_fma(r, y, q0);
     }
     if (d_safe && n == 0.0) return n * y;          // signed zero with the quotient's sign (the correction step would lose it)
-#endif
 #endif
     return n / d;
 }
@@ -370,38 +352,7 @@ __device__ __forceinline__ rsx_kdnode descend(const rsx_kdnode *nodes, int32_t &
 }
 
 
-// descend() for a whole wave with a quorum: every lane of the wave calls it together; the walk stops as soon as at most `slack` of
-// the lanes that take part are still above a leaf. Those keep their place (node) and carry on in the next round; the others go to
-// the leaf phase now instead of waiting for the slowest lane of the wave.
-__device__ __forceinline__ rsx_kdnode descend_quorum(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
-                                                     const Stack &st, int32_t &sp, bool active, int slack, bool &at_leaf, unsigned long long *util = nullptr) {
-    rsx_kdnode nd, nx;
-    nd.type = -1; nd.count = 0; nd.u.leaf.first_item = 0; nd.u.leaf.pad = 0;
-    nx = nd;
-    if (active) { nd = load_node(nodes, node); nx = load_node(nodes, node + 1); }
-    at_leaf = nd.type < 0;
-    for (;;) {
-        const unsigned long long pending = __ballot(active && !at_leaf);
-        if (__popcll(pending) <= slack) break;
-        if (active && !at_leaf) {
-            UTIL_COUNT(util, 4)
-            const int axis = nd.type & 3;
-            const int32_t next = branch_step(nd, node, sel3(axis, r.ox, r.oy, r.oz), sel3(axis, r.dx, r.dy, r.dz), sel3(axis, ad.yx, ad.yy, ad.yz),
-                                             (ad.safe >> axis) & 1, tmin, tmax, st, sp);
-            if (next == node + 1) nd = nx; else nd = load_node(nodes, next);
-            nx = load_node(nodes, next + 1);
-            node = next;
-            at_leaf = nd.type < 0;
-        }
-    }
-    return nd;
-}
-
-// The world tree seen by a coherent wave (the samples of one pixel, the rays of a small tile): the lanes sit on the same node nearly
-// always (utilisation 0.997 of the world-level loops on configs[2]), so the node comes in over the scalar data path, the split axis
-// is a scalar branch instead of twelve per-lane selects, and the child ids are scalars. The arithmetic per lane is the reference's
-// (kdtree3d.pyx:626-700: plane = (split - origin[axis]) / direction[axis], the plain division). The moment the lanes part, the walk
-// continues per lane (descend).
+// One branch step of the world tree (kdtree3d.pyx:626-700: plane = (split - origin[axis]) / direction[axis], the plain division).
 // cull_bits (bit 0 / 1: every item below the lower / upper child is a wide primitive, tagged in the device copy of the world nodes)
 // and t_cull (the nearest of the ray's wide answers): a near child whose leaves all end before t_cull cannot accept anything — a
 // leaf accepts t <= min(max_distance, its tmax) <= plane < t_cull <= every candidate — so the walk goes straight to the far child,
@@ -423,22 +374,3 @@ __device__ __forceinline__ int32_t world_step(double split, int32_t lower, int32
     return near_id;
 }
 
-__device__ __forceinline__ rsx_kdnode descend_coherent(const rsx_kdnode *nodes, int32_t &node, const Ray &r, const AxisDiv &ad, double tmin, double &tmax,
-                                                       const Stack &st, int32_t &sp, unsigned long long *util = nullptr) {
-    for (;;) {
-        const int32_t unode = __builtin_amdgcn_readfirstlane(node);
-        if (__builtin_expect(!__all(node == unode), 0)) return descend(nodes, node, r, ad, tmin, tmax, st, sp, util);
-        const RSX_CONST_AS rsx_kdnode *sn = (const RSX_CONST_AS rsx_kdnode *)(unsigned long long)(nodes + unode);
-        const int32_t type = sn->type, count = sn->count;
-        if (type < 0) {
-            rsx_kdnode nd;
-            nd.type = type; nd.count = count; nd.u.leaf.first_item = sn->u.leaf.first_item; nd.u.leaf.pad = 0;
-            return nd;
-        }
-        UTIL_COUNT(util, 4)
-        const double split = sn->u.split;
-        if ((type & 3) == 0) node = world_step(split, unode + 1, count, r.ox, r.dx, tmin, tmax, st, sp);
-        else if ((type & 3) == 1) node = world_step(split, unode + 1, count, r.oy, r.dy, tmin, tmax, st, sp);
-        else node = world_step(split, unode + 1, count, r.oz, r.dz, tmin, tmax, st, sp);
-    }
-}

@@ -220,9 +220,6 @@ __device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
 // in the merge's own order: it prefers operand b at every node (csg.pyx:231-234), i.e. the later leaf in depth-first numbering.
 // Leaf roots live in the (idle) mesh-stack LDS levels: t in the f64 array, (face, axis, exit) packed in the i32 array.
 // Returns 1 = hit (cand filled), 0 = no hit, -1 = use the stream merge.
-#ifndef RSX_ABLATE_CSG
-#define RSX_ABLATE_CSG 0
-#endif
 #ifdef CSGF_COUNT
 __device__ double g_csgf_ex[8];                 // one example of a tie: idx, leaf a, leaf b, t, ray origin
 __device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fast_hit gave up [nan, enter/exit pattern, tie, steps]
@@ -232,9 +229,6 @@ __device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fa
 #endif
 __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const Stack &ms, Hit &cand) {
     const CsgFast &P = sc.csgfast[idx];
-#if RSX_ABLATE_CSG == 2
-    return 0;                                                // (timing ablation: results are wrong)
-#endif
     const int lane = threadIdx.x % WAVE;
     double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
     int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
@@ -291,9 +285,6 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     }
     // "inside the solid" is the tree's truth table (CsgFast::truth) looked up with the "inside leaf k" bits: a leaf is inside when
     // its next root is an exit, i.e. at the start when it has a lone exit root
-#if RSX_ABLATE_CSG == 1
-    return 0;                                                // (timing ablation: results are wrong)
-#endif
     uint32_t consumed = 0, inside_bits = lone_exit, solid = csg_truth(P, lone_exit);
     for (int step = 0; step <= 2 * P.n_leaves; ++step) {
         int best = -1;

@@ -139,9 +139,6 @@ __device__ bool mesh_trace(const DMesh &m, const Ray &r, Stack st, MeshHit &out)
 #define PHASE_DECL
 #define PHASE_ADD(slot)
 #endif
-#ifndef RSX_DESCEND_QUORUM
-#define RSX_DESCEND_QUORUM 0       // k > 0: a round's descent ends when at most (active lanes >> k) lanes are still above a leaf
-#endif
 #ifndef RSX_SKIP_EMPTY
 #define RSX_SKIP_EMPTY 1           // coherent passes: a lane that reaches an empty leaf pops and descends again (this many times) before the wave's leaf phase
 #endif
@@ -202,20 +199,13 @@ __device__ bool mesh_trace_wave(bool want, UMesh m, const Ray &r, const Stack &s
         PHASE_ADD(0)
         rsx_kdnode nd;
         nd.count = 0; nd.u.leaf.first_item = 0;
-        bool at_leaf = true;
 #if RSX_UTIL_PROF == 2
         if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp, nullptr);
-#elif RSX_DESCEND_QUORUM
-        if (active) { UTIL_COUNT(phase_acc, 2) }
-        {
-            const int n_active = __popcll(__ballot(active));
-            nd = descend_quorum(nodes, node, r, ad, tmin, tmax, st, sp, active, n_active >> RSX_DESCEND_QUORUM, at_leaf, phase_acc);
-        }
 #else
         if (active) { UTIL_COUNT(phase_acc, 2) }
         if (active) nd = descend(nodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
 #endif
-        const bool leafy = active && at_leaf;               // (lanes a quorum left above a leaf sit this round's leaf phase out)
+        const bool leafy = active;
         // An empty leaf (70 % of the leaves a ray crosses: the SAH's empty-space cuts) ends nothing: the lane pops and walks on inside
         // the same round — once. Coherent passes: 41.1 -> 40.0 ms on configs[2]; walking on further (4 times, without bound) loses it
         // again (40.8, 41.2 ms: fewer but longer and less balanced rounds), and 1-spp passes do not gain, so they keep the plain round.

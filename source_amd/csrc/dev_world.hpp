@@ -85,15 +85,6 @@ __device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, 
     if (roots.n > 0) { t = roots.t[0]; faces = (roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4); }
 }
 
-#ifndef RSX_ITEM_PREFETCH
-#define RSX_ITEM_PREFETCH 0            // 1: the first three item ids of a world leaf loaded together — measured 35.2 -> 35.6 ms (the kernel is issue-bound, not latency-bound)
-#endif
-#ifndef RSX_WORLD_COHERENT
-#define RSX_WORLD_COHERENT 0            // 1: scalar-node walk of the world tree while the lanes agree (descend_coherent) — measured neutral on configs[2] (34.9 vs 35.0 ms), slower on configs[3]
-#endif
-#ifndef RSX_WORLD_FAST_DIV
-#define RSX_WORLD_FAST_DIV 0
-#endif
 // UNIFORM_ITEMS: the leaf items are walked one wave-uniform primitive at a time (primary rays: the lanes of a wave sit in the same
 // world leaf, so a leaf item is one primitive for all of them and its record comes in over the scalar data path). Scattered rays —
 // the daughters of the path kernel, arbitrary query batches — meet a different primitive in every lane: there each lane tests its
@@ -140,12 +131,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // was measured: 41.1 -> 43.5 ms on configs[2] — the hardware division is ~11 instructions, the shortcut with its operand-range
     // tests is no shorter and costs registers.
     AxisDiv ad;
-#if RSX_WORLD_FAST_DIV
-    ad.yx = rx; ad.yy = ry; ad.yz = rz;
-    ad.safe = (div_operand_safe(r.dx) ? 1 : 0) | (div_operand_safe(r.dy) ? 2 : 0) | (div_operand_safe(r.dz) ? 4 : 0);
-#else
     ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
-#endif
     // Primitives that sit in several world leaves (the reference tests a primitive again in every leaf the ray visits,
     // kdtree.pyx:99-116; the answer is the same each time): their first root is computed once, here. configs[2]: the floor box and
     // the enclosing emitter are met 4.4 times per primary ray.
@@ -202,10 +188,6 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         if (active && !prefill) {
 #if RSX_UTIL_PROF == 2
             const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp, phase_acc);
-#elif RSX_WORLD_COHERENT
-            const rsx_kdnode nd = descend_coherent(wnodes, node, r, ad, tmin, tmax, st, sp);
-#elif RSX_WORLD_FAST_DIV
-            const rsx_kdnode nd = descend(wnodes, node, r, ad, tmin, tmax, st, sp);
 #else
             const rsx_kdnode nd = descend<true>(wnodes, node, r, ad, tmin, tmax, st, sp, nullptr, t_cull);
 #endif
@@ -318,21 +300,12 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         }
         if (prefill) { prefill = false; continue; }
         } else {
-#if RSX_ITEM_PREFETCH
-        // the first item ids of the leaf in one go: a leaf of this level holds one to three items, and a round per item that begins
-        // with a dependent load of its id serialises the visit
-        const int32_t pre0 = 0 < count ? items[0] : 0, pre1 = 1 < count ? items[1] : 0, pre2 = 2 < count ? items[2] : 0;
-#endif
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;
 #if RSX_UTIL_PROF == 2
             if (have) { UTIL_COUNT(phase_acc, 2) }
 #endif
-#if RSX_ITEM_PREFETCH
-            const int32_t idx = k == 0 ? pre0 : k == 1 ? pre1 : k == 2 ? pre2 : (have ? items[k] : 0);
-#else
             const int32_t idx = have ? items[k] : 0;
-#endif
             Hit cand;
             cand.prim = -1;
             work += CSG ? 16 : 4;
