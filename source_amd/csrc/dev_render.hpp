@@ -42,6 +42,7 @@ struct RenderParams {
     const rsx_important_sphere *important;     // ImportanceManager spheres (world.pyx:47-128) or n_important == 0
     int32_t n_important, pad_important;
     double important_path_weight;
+    int32_t prims_lds;                         // > 0: byte offset of the LDS copy of the primitive records (+ CSG programs) in the path kernel
     int32_t n_vol_emitters, world_lds;         // materials with a volume contribution (0: the per-segment world.contains() pass is skipped);
                                                // world_lds > 0: byte offset in the workgroup's LDS where the path kernel stages the world tree
     unsigned long long *redo_mask;    // [n_units] CSG scenes: lanes of each unit the fast pass could not finish (ties -> stream merge), or null
@@ -670,10 +671,13 @@ struct PathStore {
 // REWALK: the instantiation a pass is traced again with when a path met more overlapping volumes than the registers keep
 // (PATH_VOL_OVERLAP): it produces the older terms by walking world.contains() again. Compiled into the ordinary instantiation the
 // second copy of the enumeration slowed every path pass by 30 % without ever running (and out of line by 20 %: the call ABI).
-template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false>
+// STAGED: the primitive records and CSG programs are read from an LDS copy (scenes of a few dozen primitives; see render()). A
+// template parameter, not a run-time choice: a pointer that may be either makes every record access of a big scene a flat load
+// (prism-sized scene unstaged 35 -> 38 ms, Cornell box 42.5 -> 44.5 ms).
+template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false>
 __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     DScene sc = sc_arg;
-    if (rp.world_lds > 0) {                                // stage the world tree behind the traversal stacks (see render())
+    if (STAGED || rp.world_lds > 0) {                      // stage the world tree behind the traversal stacks (see render(); STAGED implies it)
         int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
         const int4 *src = reinterpret_cast<const int4 *>(CSG ? sc_arg.wnodes : sc_arg.wnodes_scatter);   // (the copy tagged for this kernel's wide slots)
         for (int i = threadIdx.x; i < sc_arg.n_wnodes; i += blockDim.x) dst[i] = src[i];
@@ -682,6 +686,21 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         __syncthreads();
         sc.wnodes = sc.wnodes_scatter = reinterpret_cast<const rsx_kdnode *>(dst);     // (contains() walks read type / count / first item only)
         sc.witems = idst;
+        if constexpr (STAGED) {                            // ... and the primitive records and CSG programs the lanes read one by one
+            long long *pdst = reinterpret_cast<long long *>(smem + rp.prims_lds);
+            const long long *psrc = reinterpret_cast<const long long *>(sc_arg.prims);
+            const int n8 = sc_arg.n_prims * (int)(sizeof(rsx_primitive) / 8);
+            for (int i = threadIdx.x; i < n8; i += blockDim.x) pdst[i] = psrc[i];
+            sc.prims = reinterpret_cast<const rsx_primitive *>(pdst);
+            if (CSG && sc_arg.csgfast) {
+                long long *fdst = pdst + n8;
+                const long long *fsrc = reinterpret_cast<const long long *>(sc_arg.csgfast);
+                const int f8 = sc_arg.n_prims * (int)(sizeof(CsgFast) / 8);
+                for (int i = threadIdx.x; i < f8; i += blockDim.x) fdst[i] = fsrc[i];
+                sc.csgfast = reinterpret_cast<const CsgFast *>(fdst);
+            }
+            __syncthreads();
+        }
     }
     Stack st, ms;
     wave_stacks(sc, st, ms);

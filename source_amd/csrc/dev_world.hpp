@@ -148,7 +148,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     for (int j = 0; j < WIDE_N; ++j) {
         if (sc.wide[j] >= 0) {                              // (wave-uniform)
             int32_t f = 0;
-            analytic_first_root(sc, uniform_prim(sc.prims, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
+            analytic_first_root(sc, uniform_prim(sc.prims_uniform, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
             wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
         }
     }
@@ -271,7 +271,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 const int32_t uidx = __builtin_amdgcn_readlane(idx, leader);
                 const bool mine = is_mesh && idx == uidx;
                 todo &= ~__ballot(mine);
-                const UPrim up = uniform_prim(sc.prims, uidx);
+                const UPrim up = uniform_prim(sc.prims_uniform, uidx);
                 Ray l = r;
                 if (mine) l = to_local_uniform(up, r);
                 const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
@@ -325,7 +325,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     if (mine && t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                     continue;
                 }
-                const UPrim up = uniform_prim(sc.prims, uidx);
+                const UPrim up = uniform_prim(sc.prims_uniform, uidx);
                 const int32_t type = up->type;
                 const bool analytic = type != RSX_PRIM_MESH && !(CSG && is_csg(type));
                 bool gate = mine;

@@ -592,6 +592,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     }
 #define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
     UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
+    d.prims_uniform = d.prims;
     if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
     if (any_fast) UP(upload(sc, fast.data(), fast.size(), &d.csgfast));
     // (the world nodes are uploaded below, after the wide primitives are known: wide-only leaves are tagged in the device copy)
@@ -1128,7 +1129,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.sample_offset = desc->sample_offset;
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
     rp.n_important = n_important; rp.pad_important = 0; rp.important_path_weight = desc->important_path_weight;
-    rp.n_vol_emitters = 0; rp.world_lds = 0;
+    rp.n_vol_emitters = 0; rp.world_lds = 0; rp.prims_lds = 0;
     for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
@@ -1202,7 +1203,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
-    rp.world_lds = 0;
+    rp.world_lds = 0; rp.prims_lds = 0;
     if (has_vol) {
         // The path kernel runs two workgroups per CU (256 registers per lane), so 80 KB of LDS per workgroup are there for the taking:
         // a world tree that fits behind the traversal stacks is staged there. Scattered rays walk it with a dependent load per step
@@ -1210,6 +1211,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         static const bool stage_world = [] { const char *e = std::getenv("RSX_WORLD_LDS_STAGE"); return !e || std::atoi(e) != 0; }();
         const size_t need = ((size_t)scene->d.n_wnodes * sizeof(rsx_kdnode) + (size_t)scene->d.n_witems * 4 + 15) & ~(size_t)15;
         if (stage_world && l.lds + need <= 80 * 1024 && need <= 24 * 1024) { rp.world_lds = (int32_t)l.lds; l.lds += need; }
+        // ... and, for a scene of a few dozen primitives, the primitive records (376 bytes each) and the flattened CSG programs that
+        // the lanes read one by one, a different one in every lane
+        static const bool stage_prims = [] { const char *e = std::getenv("RSX_PRIMS_LDS_STAGE"); return !e || std::atoi(e) != 0; }();
+        static_assert(sizeof(rsx_primitive) % 8 == 0 && sizeof(CsgFast) % 8 == 0, "staged with 8-byte copies");
+        const size_t pneed = (size_t)scene->d.n_prims * (sizeof(rsx_primitive) + (scene->d.csgfast ? sizeof(CsgFast) : 0));
+        if (rp.world_lds > 0 && stage_prims && l.lds + pneed <= 80 * 1024 && pneed <= 24 * 1024) { rp.prims_lds = (int32_t)l.lds; l.lds += pneed; }
     }
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
@@ -1262,11 +1269,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
                 HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
-                if ((rc = launch(!vols ? PATH_KERNEL(true, 1, false) : rewalk ? PATH_KERNEL(true, 1, true, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
+                const bool staged = rp.prims_lds > 0;
+                if ((rc = launch(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
+                                 staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
                 if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
             } else if (scene->has_csg) { if ((rc = launch(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
-            else if ((rc = launch(rewalk ? PATH_KERNEL(false, 0, true, true) : PATH_KERNEL(false), l.grid))) return rc;
+            else if ((rc = launch(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false), l.grid))) return rc;
 #undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
