@@ -142,23 +142,53 @@ extern "C" int rsx_comm_barrier(rsx_comm *c) {
 // Tile sharding: rank r owns frame elements [shard_begin[r], shard_begin[r+1]) of the x-major (mean, variance, samples) arrays
 // (column tiles of a frame are contiguous runs). After the call every rank holds the whole frame. In place, no arithmetic: the
 // result is bit-identical to a single-GPU render (Philox counters are per pixel).
+// Every rank holds run [begin[r], begin[r + 1]) of rank r afterwards, in place. xGMI is point to point — every GPU has its own link
+// to every other — so the exchange is one group of direct sends and receives: a rank sends its run to each peer over that peer's
+// link and receives the peers' runs straight into their place, all links busy at once and every byte crossing one link once
+// (a ring-routed ncclBroadcast per run would walk the runs around the ring one after the other). RSX_GATHER=broadcast keeps the
+// grouped in-place broadcasts of round 2's first version.
+static int gather_runs(rsx_comm *c, double *mean, double *variance, int32_t *samples, const int64_t *begin) {
+    rsx_ctx *ctx = c->ctx;
+    rccl::Api &a = rccl::api();
+    static const bool by_broadcast = [] { const char *e = std::getenv("RSX_GATHER"); return e && std::strcmp(e, "broadcast") == 0; }();
+    const int W = c->n_ranks, me = c->rank;
+    RCCL_TRY(a.GroupStart());
+    if (by_broadcast) {
+        for (int r = 0; r < W; ++r) {
+            const size_t off = (size_t)begin[r], len = (size_t)(begin[r + 1] - begin[r]);
+            if (!len) continue;
+            RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+        }
+    } else {
+        const size_t my_off = (size_t)begin[me], my_len = (size_t)(begin[me + 1] - begin[me]);
+        for (int k = 1; k < W; ++k) {
+            const int to = (me + k) % W, from = (me - k + W) % W;         // (every pair meets once per direction; staggered so that no peer is everyone's first)
+            if (my_len) {
+                RCCL_TRY(a.Send(mean + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_TRY(a.Send(variance + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_TRY(a.Send(samples + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
+            }
+            const size_t off = (size_t)begin[from], len = (size_t)(begin[from + 1] - begin[from]);
+            if (len) {
+                RCCL_TRY(a.Recv(mean + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_TRY(a.Recv(variance + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_TRY(a.Recv(samples + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
+            }
+        }
+    }
+    RCCL_TRY(a.GroupEnd());
+    return RSX_OK;
+}
+
 extern "C" int rsx_allgather_frame(rsx_comm *c, double *mean, double *variance, int32_t *samples, const int64_t *shard_begin) {
     if (!c || !mean || !variance || !samples || !shard_begin) return rsx_fail(RSX_EINVAL, "rsx_allgather_frame: null argument");
     for (int r = 0; r < c->n_ranks; ++r) if (shard_begin[r] < 0 || shard_begin[r + 1] < shard_begin[r]) return rsx_fail(RSX_EINVAL, "rsx_allgather_frame: shard offsets must be non-decreasing");
     rsx_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
-    rccl::Api &a = rccl::api();
-    RCCL_TRY(a.GroupStart());
-    for (int r = 0; r < c->n_ranks; ++r) {
-        const size_t off = (size_t)shard_begin[r], len = (size_t)(shard_begin[r + 1] - shard_begin[r]);
-        if (!len) continue;
-        RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-        RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-        RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
-    }
-    RCCL_TRY(a.GroupEnd());
-    return RSX_OK;
+    return gather_runs(c, mean, variance, samples, shard_begin);
 }
 
 // Sample sharding: every rank holds a full n-element frame of its own samples; afterwards every rank holds
@@ -216,14 +246,7 @@ extern "C" int rsx_allreduce_frame(rsx_comm *c, double *mean, double *variance, 
         HIP_TRY(hipMemcpyAsync(variance + off, sv, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(samples + off, sn, mine * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    RCCL_TRY(a.GroupStart());
-    for (int r = 0; r < W; ++r) {
-        const size_t off = seg_off(r), len = seg_len(r);
-        if (!len) continue;
-        RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-        RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-        RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
-    }
-    RCCL_TRY(a.GroupEnd());
-    return RSX_OK;
+    std::vector<int64_t> begin((size_t)W + 1);
+    for (int r = 0; r <= W; ++r) begin[(size_t)r] = (int64_t)seg_off(r);
+    return gather_runs(c, mean, variance, samples, begin.data());
 }
