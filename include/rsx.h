@@ -293,6 +293,16 @@ int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *me
 int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, double *frame_mean,
                              double *frame_variance, int32_t *frame_samples, int32_t frame_bins,
                              int32_t slice_offset, uint64_t *ray_count);
+/* The spectral slices of one observe() (observer.pyx:289-300: one engine.run per slice) touch disjoint bins of the frame, so their
+ * passes need not wait for one another. Between rsx_defer_path_checks(ctx, 1) and rsx_collect_path_checks, rsx_render_pinhole_frame
+ * calls of path-traced scenes (scattering / refracting / volume materials) return without the end-of-pass round trip: the passes
+ * overlap on the device, ray_count comes back as UINT64_MAX (= this call was deferred), and a pass that could not finish (term arena exhausted, more volumes at a point
+ * than the fast kernel keeps) leaves the frame untouched. rsx_collect_path_checks waits for the passes, switches nothing off, and
+ * reports: failed_calls[0 .. *n_failed) = indices (0 = first deferred call since the last collect / switch-on) of the passes the
+ * caller must issue again with deferral off — they then take the ordinary retry path — and *ray_count = rays of all deferred
+ * passes. A path that crossed more surfaces than the build allows makes it return RSX_EUNSUPPORTED as the undeferred call does. */
+int rsx_defer_path_checks(rsx_ctx *ctx, int32_t on);
+int rsx_collect_path_checks(rsx_ctx *ctx, int32_t *failed_calls, int32_t capacity, int32_t *n_failed, uint64_t *ray_count);
 
 /* XYZPixelProcessor (optical/observer/pipeline/rgb.pyx:534-562) for one spectral slice: every sample's spectrum (times its
  * projection weight) is projected on the CIE XYZ curves resampled over the slice (spectrum_to_ciexyz, optical/colour.pyx:158-187:

@@ -137,6 +137,8 @@ SYMBOLS = [
     ("rsx_comm_free", None, [_vp]),
     ("rsx_comm_barrier", C.c_int, [_vp]),
     ("rsx_comm_max_f64", C.c_int, [_vp, C.POINTER(C.c_double)]),
+    ("rsx_defer_path_checks", C.c_int, [_vp, C.c_int32]),
+    ("rsx_collect_path_checks", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("rsx_allgather_frame", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("rsx_allreduce_frame", C.c_int, [_vp, _vp, _vp, _vp, C.c_int64]),
 ]

@@ -1211,6 +1211,8 @@ struct AccumParams {
     const int32_t *tail;                // last block of each sample's list; Sample.pad = slots used in it
     long long n_records;                // block ids below this are the samples' own first blocks, above it arena blocks (slot 0 = link)
     double roulette_norm;               // 1 / (1 - extinction_prob)
+    const unsigned int *abort_flags;    // deferred path passes: PathStore::flags of the trace kernel — a pass whose arena ran out (bit 0), that hit the
+                                        // segment guard (1) or met too many volumes at a point (2) is left out of the frame and rendered again by the caller
 };
 
 // Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
@@ -1241,6 +1243,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const long long total = ap.n_tasks * ap.bins;
     if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
     if (gid >= total) return;
+    if (ap.abort_flags && (*ap.abort_flags & 7u)) return;
     long long p;
     int b;
     if (total < (1LL << 31)) { p = (uint32_t)gid / (uint32_t)ap.bins; b = (int)((uint32_t)gid % (uint32_t)ap.bins); }   // 32-bit divide when it fits

@@ -161,6 +161,13 @@ struct TraceLane {
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
+    // deferred path passes (rsx_defer_path_checks): the lane's own copies of the per-call material / table blobs, and the check that
+    // is still owed for the pass it ran last
+    void *mat_dev = nullptr, *tab_dev = nullptr;
+    size_t mat_dev_bytes = 0, tab_dev_bytes = 0;
+    std::vector<unsigned char> mat_host, tab_host;
+    bool check_pending = false;
+    int32_t pending_call = -1;
 };
 
 struct rsx_ctx {
@@ -187,7 +194,27 @@ struct rsx_ctx {
     size_t pool_bytes[POOL_SLOTS];
     void *staging;             // pinned host mirror of small query workspaces: one copy in, one copy out per call
     size_t staging_bytes;
+    // rsx_defer_path_checks: path passes run on the private lanes and their end-of-pass checks are collected later
+    bool defer_path = false;
+    int32_t deferred_calls = 0;                    // path passes issued since deferral was switched on
+    std::vector<int32_t> deferred_failed;          // ... of which these must be rendered again (term arena ran out, too many volumes at a point)
+    unsigned int deferred_error_flags = 0;
+    unsigned long long deferred_rays = 0;
 };
+
+// the check a deferred path pass still owes: wait for its merge, read its flags and ray count
+static int settle_lane(rsx_ctx *ctx, TraceLane &ln) {
+    if (!ln.check_pending) return RSX_OK;
+    HIP_TRY(hipEventSynchronize(ln.merged));
+    unsigned long long words[2] = {0, 0};
+    HIP_TRY(hipMemcpy(words, ln.overflow, sizeof(words), hipMemcpyDeviceToHost));
+    const unsigned int flags = (unsigned int)(words[0] & 0xffffffffu);
+    if (!(flags & 7u)) ctx->deferred_rays += words[1];    // (a pass that is rendered again reports its rays then)
+    if (flags & 2u) ctx->deferred_error_flags |= 2u;
+    else if (flags & 5u) ctx->deferred_failed.push_back(ln.pending_call);
+    ln.check_pending = false;
+    return RSX_OK;
+}
 
 static int pool_get(rsx_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes > ctx->pool_bytes[slot]) {
@@ -271,7 +298,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow, ln->mat_dev, ln->tab_dev})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -1034,9 +1061,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     }
     // CSG scenes render in two passes (state-free evaluator, then the stream merge for the rays that need it); their passes are not pipelined
     const bool two_pass_csg = scene->has_csg && scene->d.csgfast != nullptr;
-    const bool pipelined = !h_mean && !has_vol && !two_pass_csg && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // Path passes whose end-of-pass checks the caller collects later (rsx_defer_path_checks: the spectral slices of one observe())
+    // run on the private lanes like small primary passes: the tail of a slice — a few paths bouncing inside a prism for hundreds of
+    // segments — then drains while the next slice's bulk fills the chip. Their per-call inputs live in lane-owned buffers.
+    const bool deferred = has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    const bool pipelined = (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    if ((rc = settle_lane(ctx, lane))) return rc;          // (a deferred pass this lane ran before: its buffers are about to be reused)
 
     // materials and the importance manager's spheres share one small buffer: [materials][spheres]
     const int n_important = has_scatter && desc->important ? std::max(0, desc->n_important) : 0;
@@ -1058,11 +1090,31 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return RSX_OK;
     };
+    // the lane's previous pass must have been merged before its buffers (inputs, samples, scheduling state) are reused
+    if (pipelined && lane.in_flight) HIP_TRY(hipStreamWaitEvent(lane.stream, lane.merged, 0));
+    auto lane_upload = [&](void *&dev, size_t &dev_bytes, std::vector<unsigned char> &host, const void *src, size_t bytes) -> int {
+        if (bytes > dev_bytes) {
+            if (dev) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(dev)); dev = nullptr; dev_bytes = 0; }
+            HIP_TRY(hipMalloc(&dev, bytes + 256));
+            dev_bytes = bytes + 256;
+        }
+        host.assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);   // (lives until the lane's next pass)
+        if (bytes) HIP_TRY(hipMemcpyAsync(dev, host.data(), bytes, hipMemcpyHostToDevice, lane.stream));
+        return RSX_OK;
+    };
+    if (deferred) {                                        // every slice brings its own materials and tables: no shared copy, no drain
+        if ((rc = lane_upload(lane.mat_dev, lane.mat_dev_bytes, lane.mat_host, mat_blob.data(), mat_blob.size()))) return rc;
+        d_mat = lane.mat_dev;
+    } else
     if (desc->n_materials && (rc = upload_if_changed(0, d_mat, mat_blob.data(), mat_blob.size()))) return rc;
     // spectral tables; the XYZ form appends the three resampled CIE curves as rows n_tables .. n_tables + 2 ([channel][bin])
     std::vector<double> tab_blob((size_t)(desc->n_tables + (h_xyz ? 3 : 0)) * B);
     if (desc->n_tables) std::memcpy(tab_blob.data(), desc->tables, 8 * B * (size_t)desc->n_tables);
     if (h_xyz) for (size_t b = 0; b < B; ++b) for (int c = 0; c < 3; ++c) tab_blob[((size_t)desc->n_tables + c) * B + b] = h_xyz[3 * b + c];
+    if (deferred) {
+        if ((rc = lane_upload(lane.tab_dev, lane.tab_dev_bytes, lane.tab_host, tab_blob.data(), 8 * tab_blob.size()))) return rc;
+        d_tab = lane.tab_dev;
+    } else
     if (!tab_blob.empty() && (rc = upload_if_changed(1, d_tab, tab_blob.data(), 8 * tab_blob.size()))) return rc;
     if (desc->tasks) {
         if ((rc = pool_get(ctx, POOL_TASKS, T * 8, &d_tasks))) return rc;
@@ -1072,8 +1124,6 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         const size_t out_channels = h_xyz ? 3 : B;
         if ((rc = pool_get(ctx, POOL_MEAN, T * out_channels * 8, &d_mean)) || (rc = pool_get(ctx, POOL_VAR, T * out_channels * 8, &d_var))) return rc;
     }
-    // the lane's previous pass must have been merged before its sample buffer (and scheduling state) is reused
-    if (pipelined && lane.in_flight) HIP_TRY(hipStreamWaitEvent(lane.stream, lane.merged, 0));
     auto lane_buffer = [&](void *&buf, size_t &have, size_t bytes) -> int {
         if (bytes > have) {
             if (buf) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(buf)); buf = nullptr; have = 0; }
@@ -1279,6 +1329,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 #undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
+            if (deferred) break;                             // (the flags are read when the caller collects; k_accumulate leaves a failed pass out of the frame)
             if (!(has_scatter && !std::getenv("RSX_PATH_ARENA")) && !(rp.n_vol_emitters > PATH_VOL_OVERLAP && !rewalk)) break;
             unsigned int flags = 0;
             HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
@@ -1344,6 +1395,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.tail = has_vol ? static_cast<const int32_t *>(lane.tail) : nullptr;
     ap.n_records = (long long)S;
     ap.roulette_norm = 1 / (1 - desc->ray_extinction_prob);      // ray.pyx:388
+    ap.abort_flags = deferred ? lane.overflow : nullptr;
     lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
@@ -1398,6 +1450,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         HIP_TRY(hipMemcpyAsync(h_var, d_var, T * (h_xyz ? 3 : B) * 8, hipMemcpyDeviceToHost, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
     }
+    if (deferred) {                                         // checked by settle_lane: at the lane's next pass or when the caller collects
+        lane.check_pending = true;
+        lane.pending_call = ctx->deferred_calls++;
+        if (ray_count) *ray_count = ~0ULL;                 // "deferred": the count comes with rsx_collect_path_checks
+    } else
     if (has_vol) {                                          // a ray that ran out of term slots or segments must not go unnoticed
         unsigned int flags = 0;
         HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
@@ -1416,6 +1473,30 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 }
 
 }  // namespace
+
+extern "C" int rsx_defer_path_checks(rsx_ctx *ctx, int32_t on) {
+    if (!ctx) return rsx_fail(RSX_EINVAL, "rsx_defer_path_checks: null context");
+    if (on && !ctx->defer_path) { ctx->deferred_calls = 0; ctx->deferred_failed.clear(); ctx->deferred_error_flags = 0; ctx->deferred_rays = 0; }
+    ctx->defer_path = on != 0;
+    return RSX_OK;
+}
+
+extern "C" int rsx_collect_path_checks(rsx_ctx *ctx, int32_t *failed_calls, int32_t capacity, int32_t *n_failed, uint64_t *ray_count) {
+    if (!ctx || !n_failed || capacity < 0 || (capacity > 0 && !failed_calls)) return rsx_fail(RSX_EINVAL, "rsx_collect_path_checks: bad arguments");
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc;
+    for (TraceLane &ln : ctx->lanes) if ((rc = settle_lane(ctx, ln))) return rc;
+    std::sort(ctx->deferred_failed.begin(), ctx->deferred_failed.end());
+    *n_failed = (int32_t)ctx->deferred_failed.size();
+    for (int32_t i = 0; i < *n_failed && i < capacity; ++i) failed_calls[i] = ctx->deferred_failed[(size_t)i];
+    if (ray_count) *ray_count = ctx->deferred_rays;
+    const unsigned int err = ctx->deferred_error_flags;
+    const bool truncated = *n_failed > capacity;
+    ctx->deferred_calls = 0; ctx->deferred_failed.clear(); ctx->deferred_error_flags = 0; ctx->deferred_rays = 0;
+    if (err & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a path crossed more than %d surfaces (limit of this build)", PATH_MAX_SEGMENTS);
+    if (truncated) return rsx_fail(RSX_EINVAL, "rsx_collect_path_checks: %d passes failed, room for %d", *n_failed, capacity);
+    return RSX_OK;
+}
 
 extern "C" int rsx_render_pinhole(rsx_scene *scene, const rsx_render_desc *desc, double *mean, double *variance, uint64_t *ray_count) {
     if (!mean || !variance) return rsx_fail(RSX_EINVAL, "rsx_render_pinhole: null output");

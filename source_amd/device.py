@@ -52,6 +52,17 @@ class DeviceContext:
     def synchronize(self):
         _lib.check(_lib.lib().rsx_synchronize(self._h))
 
+    def defer_path_checks(self, on):
+        """Spectral slices of one observe(): path passes return without their end-of-pass round trip until collect_path_checks()."""
+        _lib.check(_lib.lib().rsx_defer_path_checks(self._h, 1 if on else 0))
+
+    def collect_path_checks(self, capacity=4096):
+        """Waits for the deferred passes; returns (indices of the calls that must be issued again, rays traced by all of them)."""
+        failed = (C.c_int32 * capacity)()
+        n, rays = C.c_int32(0), C.c_uint64(0)
+        _lib.check(_lib.lib().rsx_collect_path_checks(self._h, failed, capacity, C.byref(n), C.byref(rays)))
+        return [int(failed[i]) for i in range(n.value)], int(rays.value)
+
     def last_render_ms(self):
         """(trace_ms, accumulate_ms) of the most recent render call (HIP events on the launch stream)."""
         a, b = C.c_float(0), C.c_float(0)

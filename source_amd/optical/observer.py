@@ -508,11 +508,43 @@ class _ObserverBase(Observer):
         self._slices = slices
         self.stats = {"rays": 0, "kernel_ms": 0.0}
         self._pass_offset = self.pass_sample_offset(self.render_engine)
-        for slice_id, template in enumerate(templates):
-            self.render_engine.run(tasks, self._render_pixel, self._update_state,
-                                   render_args=(slice_id, template), update_args=(slice_id,))
+        # The slices fill disjoint bins of the frames, so on the device their passes need not wait for one another: a HipEngine
+        # render of several slices defers the end-of-pass checks of path-traced scenes (librsx: rsx_defer_path_checks) and the
+        # tail of one slice — a few paths bouncing on for hundreds of segments — drains under the bulk of the next.
+        deferring = self._begin_deferred_slices(len(templates))
+        try:
+            for slice_id, template in enumerate(templates):
+                self.render_engine.run(tasks, self._render_pixel, self._update_state,
+                                       render_args=(slice_id, template), update_args=(slice_id,))
+        finally:
+            if deferring:
+                self._end_deferred_slices()
         self._auto_offset += self._samples_per_pass()
         self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
+
+    def _begin_deferred_slices(self, n_slices):
+        engine = self.render_engine
+        self._deferred = None
+        if n_slices < 2 or not isinstance(engine, HipEngine) or not engine.fused or engine.timing or engine.rng != "philox":
+            return False
+        if any(isinstance(p, RGBPipeline2D) for p in self._pipelines) or self._needs_host_materials(self.root, engine):
+            return False
+        from ..device import get_context
+        self._deferred = []                                 # one re-issue closure per deferred library call, in call order
+        get_context().defer_path_checks(True)
+        return True
+
+    def _end_deferred_slices(self):
+        from ..device import get_context
+        ctx = get_context()
+        calls, self._deferred = self._deferred, None
+        try:
+            failed, rays = ctx.collect_path_checks(max(16, len(calls)))
+        finally:
+            ctx.defer_path_checks(False)
+        self.stats["rays"] = self.stats.get("rays", 0) + rays
+        for k in failed:                                    # (term arena ran out, too many volumes at a point: the ordinary retry path)
+            calls[k]()
 
     def pass_sample_offset(self, engine):
         """First Philox sample counter of the pass about to be rendered: the engine's sample_offset plus the samples this observer's
@@ -811,6 +843,14 @@ class PinholeCamera(Observer2D):
                     fm, fv, fn = pipe.frame._device(scene.context)
                     _lib.check(L.rsx_render_pinhole_frame(scene.handle, C.byref(desc), fm, fv, fn, pipe.frame.nz, sl.offset, C.byref(rays)))
                     pipe.frame._mark_device_written()
+                    if rays.value == 0xFFFFFFFFFFFFFFFF:        # a deferred path pass: counted, and if need be issued again, at the end of observe()
+                        rays.value = 0
+                        def again(desc=desc, keep=keep, power=desc.power, fm=fm, fv=fv, fn=fn, nz=pipe.frame.nz, offset=sl.offset, handle=scene.handle):
+                            desc.power = power
+                            count = C.c_uint64(0)
+                            _lib.check(L.rsx_render_pinhole_frame(handle, C.byref(desc), fm, fv, fn, nz, offset, C.byref(count)))
+                            self.stats["rays"] = self.stats.get("rays", 0) + count.value
+                        self._deferred.append(again)
                     if engine.timing:
                         tr, ac = scene.context.last_render_ms()
                         engine.last_kernel_ms = tr

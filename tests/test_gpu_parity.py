@@ -1236,3 +1236,44 @@ def test_random_analytic_worlds_wide_slots_and_cull(orc, ns):
         om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
         assert cam.stats["rays"] == rays
         assert eq(np.array(pipe.frame.mean), om.reshape(64, 64, 3).transpose(1, 0, 2))
+
+
+def test_deferred_slice_checks_give_the_same_frames(ns, monkeypatch):
+    """A HipEngine render of several spectral slices lets the slices' path passes overlap on the device (rsx_defer_path_checks) and
+    collects their end-of-pass checks at the end of observe(). Frames and ray counts equal the slice-by-slice render bit for bit —
+    (1) on the glass scene with three slices, (2) on a furnace whose paths outgrow the term arena, so that every deferred pass
+    fails its check, leaves the frame untouched and is issued again through the ordinary retry path."""
+    from source_amd.optical import observer as obs
+
+    def render(defer, build):
+        world, cam, pipe = build()
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=3)
+        if not defer:
+            monkeypatch.setattr(obs._ObserverBase, "_begin_deferred_slices", lambda self, n: False)
+        else:
+            monkeypatch.undo()
+        for _ in range(2):
+            cam.observe()
+        return np.array(pipe.frame.mean), np.array(pipe.frame.variance), np.array(pipe.frame.samples), cam.stats["rays"]
+
+    def glass():
+        world = scenes.build_glass(ns)[0]
+        cam, pipe = scenes.glass_camera(ns, world, (96, 64), 4, 6, 3, (0.01, 3, 200))
+        return world, cam, pipe
+
+    def furnace():
+        world = ns.World()
+        P = ns.Point3D
+        ns.Box(P(-1, -1, -1), P(1, 1, 1), world, material=ns.Lambert(ns.ConstantSF(1.0)))
+        ns.Sphere(0.12, world, ns.translate(0.3, -0.2, 0.4), ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 2.0))
+        cam, pipe = scenes.lambert_camera(ns, world, (64, 64), 4, 4, (0.0, 1, 30000))
+        cam.spectral_rays = 2
+        cam.transform = ns.translate(0, 0, -0.9)
+        return world, cam, pipe
+
+    for build in (glass, furnace):
+        a = render(True, build)
+        b = render(False, build)
+        assert a[3] == b[3] and a[3] > 0
+        assert eq(a[0], b[0]) and eq(a[1], b[1]) and eq(a[2], b[2])
