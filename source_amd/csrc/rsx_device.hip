@@ -1066,7 +1066,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // segments — then drains while the next slice's bulk fills the chip. Their per-call inputs live in lane-owned buffers.
     const bool deferred = has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     const bool pipelined = (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
-    TraceLane &lane = pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
+    // (two lanes for path passes: the path kernel fits two workgroups per CU, and each pass brings a grid of that size — the
+    // next slice's workgroups move in as this slice's retire; prism, 32 slices: 3 lanes x 1 workgroup per CU 741 ms, 2 x 2 582 ms)
+    static const int path_lanes = [] { const char *e = std::getenv("RSX_PATH_LANES"); return e ? std::max(1, std::min(RSX_MAX_LANES, std::atoi(e))) : 2; }();
+    TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % std::min(path_lanes, ctx->pipeline_depth)] : pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     if ((rc = settle_lane(ctx, lane))) return rc;          // (a deferred pass this lane ran before: its buffers are about to be reused)
 
@@ -1251,6 +1254,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
     // A pipelined (small, tail-bound) pass takes one workgroup per CU and the neighbouring lane's pass fills the idle CUs.
     int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
+    if (deferred) wg_cap = 2;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
     rp.world_lds = 0; rp.prims_lds = 0;
