@@ -159,6 +159,8 @@ def lib():
                            "(hipcc --offload-arch=gfx950). source_amd has no CPU fallback." % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
+            if os.environ.get("RSX_LIB") and not hasattr(handle, name):
+                continue                   # an A/B build of an earlier revision ($RSX_LIB): entry points added since are simply absent
             fn = getattr(handle, name)     # AttributeError here = ABI drift between rsx.h and the binary
             fn.restype = restype
             fn.argtypes = argtypes
