@@ -679,7 +679,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     DScene sc = sc_arg;
     if (STAGED || rp.world_lds > 0) {                      // stage the world tree behind the traversal stacks (see render(); STAGED implies it)
         int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
-        const int4 *src = reinterpret_cast<const int4 *>(CSG ? sc_arg.wnodes : sc_arg.wnodes_scatter);   // (the copy tagged for this kernel's wide slots)
+        const int4 *src = reinterpret_cast<const int4 *>(CSG && MODE != 1 ? sc_arg.wnodes : sc_arg.wnodes_scatter);   // (the copy annotated for this kernel: world_trace_wave)
         for (int i = threadIdx.x; i < sc_arg.n_wnodes; i += blockDim.x) dst[i] = src[i];
         int32_t *idst = reinterpret_cast<int32_t *>(dst + sc_arg.n_wnodes);
         for (int i = threadIdx.x; i < sc_arg.n_witems; i += blockDim.x) idst[i] = sc_arg.witems[i];

@@ -136,7 +136,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // kdtree.pyx:99-116; the answer is the same each time): their first root is computed once, here. configs[2]: the floor box and
     // the enclosing emitter are met 4.4 times per primary ray.
     static_assert(WIDE_N == 2 || WIDE_N == 8, "two tagged copies of the world nodes exist: for two and for eight wide slots");
-    const rsx_kdnode *wnodes = WIDE_N == 2 ? sc.wnodes : sc.wnodes_scatter;
+    // (CSG kernels with the mailbox: the copy whose cull bits count the CSG primitives answered in the round before the traversal)
+    constexpr bool CSG_ANSWERED = CSG && FASTONLY && CSG_MAILBOX >= 4 && !UNIFORM_ITEMS;
+    const rsx_kdnode *wnodes = (WIDE_N == 8 || CSG_ANSWERED) ? sc.wnodes_scatter : sc.wnodes;
     WideSet8 wide;
 #pragma unroll
     for (int j = 0; j < 8; ++j) wide.t[j] = -1.0;
@@ -298,7 +300,17 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             }
             if (!prefill && cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties
         }
-        if (prefill) { prefill = false; continue; }
+        if (prefill) {
+            prefill = false;
+            if constexpr (CSG_ANSWERED) {                    // the nearest answer now includes the CSG primitives'
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (mb_idx[j] >= 0 && mb_t[j] >= 0.0 && mb_t[j] < t_cull) t_cull = mb_t[j];
+#if RSX_WORLD_CULL == 0
+                t_cull = -INFINITY;
+#endif
+            }
+            continue;
+        }
         } else {
         for (int32_t k = 0; __any(k < count); ++k) {
             const bool have = k < count;

@@ -665,17 +665,21 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         // in bits 28..30, the wide slot of item j in bits 3j..3j+2, list order kept — so that visiting it costs no item loads and no
         // per-item rounds (world_trace_wave). Two copies: tagged for the first two slots (primary rays) and for all eight (scattered rays).
         for (int n_slots : {2, 8}) {
+            // (a CSG scene has no eight-slot kernels: its second copy serves the kernels that answer the wide CSG primitives before
+            // the traversal — two slots for the leaf tags, and cull bits that count those CSG primitives as answered too)
+            const int tag_slots = (n_slots == 8 && sc->has_csg) ? 2 : n_slots;
+            const bool csg_answered = n_slots == 8 && sc->has_csg;
             std::vector<rsx_kdnode> wnodes(desc->world_kd.nodes, desc->world_kd.nodes + desc->world_kd.n_nodes);
             for (rsx_kdnode &nd : wnodes) {
                 if (nd.type >= 0) continue;
                 nd.u.leaf.pad = 0;
-                if (std::getenv("RSX_NO_WIDE_LEAVES") || nd.count < 1 || nd.count > (n_slots == 2 ? 2 : 6)) continue;
+                if (std::getenv("RSX_NO_WIDE_LEAVES") || nd.count < 1 || nd.count > (tag_slots == 2 ? 2 : 6)) continue;
                 uint32_t tag = 0x80000000u | ((uint32_t)nd.count << 28);
                 bool all_wide = true;
                 for (int32_t k = 0; k < nd.count; ++k) {
                     const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
                     int slot = -1;
-                    for (int q = 0; q < n_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) slot = q;
+                    for (int q = 0; q < tag_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) slot = q;
                     if (slot < 0) all_wide = false; else tag |= (uint32_t)slot << (3 * k);
                 }
                 if (all_wide) nd.u.leaf.pad = (int32_t)tag;
@@ -691,7 +695,8 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                         for (int32_t k = 0; k < nd.count && all; ++k) {
                             const int32_t idx = desc->world_kd.items[nd.u.leaf.first_item + k];
                             bool is_wide = false;
-                            for (int q = 0; q < n_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) is_wide = true;
+                            for (int q = 0; q < tag_slots; ++q) if (d.wide[q] >= 0 && idx == d.wide[q]) is_wide = true;
+                            if (csg_answered) for (int32_t w : d.wide_csg) if (w >= 0 && idx == w) is_wide = true;
                             all = is_wide;
                         }
                         only_wide[n] = all;
