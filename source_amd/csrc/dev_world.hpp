@@ -302,7 +302,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
         }
         if (prefill) {
             prefill = false;
-            if constexpr (CSG_ANSWERED) {                    // the nearest answer now includes the CSG primitives'
+            if constexpr (CSG_ANSWERED) {                    // the nearest answer now includes those of the CSG primitives
 #pragma unroll
                 for (int j = 0; j < 4; ++j) if (mb_idx[j] >= 0 && mb_t[j] >= 0.0 && mb_t[j] < t_cull) t_cull = mb_t[j];
 #if RSX_WORLD_CULL == 0
