@@ -229,8 +229,8 @@ def main():
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
     ap.add_argument("--sharding", choices=["auto", "tile", "sample"], default="auto", help="N > 1: tile (strong scaling, default) or sample (weak)")
     ap.add_argument("--tiles", choices=["balanced", "equal"], default="balanced",
-                    help="tile sharding: column tiles of equal measured cost (default; rank 0 times 32 column blocks before the warmup "
-                         "and broadcasts the cuts) or of equal width")
+                    help="tile sharding: column tiles of equal measured time (default; four rounds of every rank timing its own tile "
+                         "and all ranks moving the cuts, before the warmup) or of equal width")
     ap.add_argument("--collective", choices=["rsx", "torch", "host"], default="rsx",
                     help="N > 1 data plane: RCCL from librsx (default), torch.distributed nccl, or host (frames over gloo: a test aid that lets "
                          "several ranks share one GPU)")
@@ -278,17 +278,16 @@ def main():
     scene = world.build_accelerator()                      # flatten + KD build (host) + upload: outside the timed region
 
     # Tile sharding: a step ends with its slowest rank, and the columns of a frame do not cost the same (configs[2]: equal-width
-    # tiles of an 8-way split differ by 1.45x). Rank 0 times N_BLOCKS column blocks — ordinary passes into a frame that is
-    # initialised afresh below — and every rank takes the cuts that equalise the measured cost (distributed.balanced_bounds).
+    # tiles of an 8-way split take 4.1 .. 5.9 ms). Before the warmup every rank times its own tile of the current split — ordinary
+    # passes with Philox counters of their own, into a frame that is dropped afterwards — the times are shared and the cuts move to
+    # the equal-cost quantiles (distributed.rebalance_bounds); a few rounds bring mean / max tile time from 0.90 to 0.97 at N = 8
+    # (tools/tile_balance.py). Every rank computes the same cuts from the same gathered times.
     tile_bounds = None
     if sharding == "tile" and world_size > 1 and args.tiles == "balanced":
-        N_BLOCKS = 32
-        bw = max(1, NX // N_BLOCKS)
-        blocks = [(x0, 0, min(NX, x0 + bw), NY) for x0 in range(0, NX, bw)]
-        cost = []
+        tile_bounds = [(NX * r) // world_size for r in range(world_size)] + [NX]
         engine.sample_offset = 1 << 40                      # (counters of their own: the render's first pass assigns 0 and starts there)
-        for rect in blocks:
-            cam.frame_sampler = ns.RectFrameSampler2D(rect=rect)
+        for _ in range(4):
+            cam.frame_sampler = ns.RectFrameSampler2D(rect=D.tile_rect(rank, world_size, NX, NY, tile_bounds))
             cam.observe()
             ctx.synchronize()
             reps, spent = 1, 0.0
@@ -298,16 +297,15 @@ def main():
                     cam.observe()
                 ctx.synchronize()
                 spent = time.perf_counter() - t_b
-                if spent >= 3e-3 or reps >= 64:
+                if spent >= 10e-3 or reps >= 64:
                     break
                 reps *= 4
-            cost.append(spent / reps)
-        if pipe.frame is not None:                          # the timed blocks are not part of the render: drop their frame
+            times = [None] * world_size
+            dist.all_gather_object(times, spent / reps)
+            tile_bounds = [int(b) for b in D.rebalance_bounds(tile_bounds, times, NX)]
+        if pipe.frame is not None:                          # the timed passes are not part of the render: drop their frame
             pipe.frame.release()
             pipe.frame = None
-        box = [D.balanced_bounds(cost, bw, NX, world_size) if rank == 0 else None]
-        dist.broadcast_object_list(box, src=0)
-        tile_bounds = [int(b) for b in box[0]]
     my_rect = D.tile_rect(rank, world_size, NX, NY, tile_bounds) if sharding == "tile" else (0, 0, NX, NY)
     cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
 

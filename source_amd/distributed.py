@@ -58,6 +58,32 @@ def balanced_bounds(block_cost, block_width, nx, world_size):
     return bounds[::-1]
 
 
+def rebalance_bounds(bounds, times, nx, quantum=8):
+    """One step of balancing column tiles by MEASURED tile times: every rank times its own tile of the current split, the times are
+    shared, and the cuts move to the equal-cost quantiles of the piecewise-constant cost density times[r] / width[r]. Iterated a few
+    times this converges on tiles of equal time — it sees what a sum of small-block costs does not: a tile's time is not additive in
+    its columns (a bigger pass fills the chip better, its tail is amortised). Cuts stay multiples of `quantum` columns (the 8 x 8
+    pixel tiles of the work units) and every tile keeps at least one quantum. Deterministic: every rank computes the same cuts."""
+    n = len(times)
+    if len(bounds) != n + 1:
+        raise ValueError("one time per tile")
+    widths = [bounds[r + 1] - bounds[r] for r in range(n)]
+    density = [max(float(times[r]), 1e-12) / max(widths[r], 1) for r in range(n)]
+    total = sum(density[r] * widths[r] for r in range(n))
+    new, r, acc = [0], 0, 0.0
+    for k in range(1, n):
+        target = total * k / n
+        while r < n - 1 and acc + density[r] * widths[r] < target:
+            acc += density[r] * widths[r]
+            r += 1
+        x = bounds[r] + (target - acc) / density[r]
+        x = int(round(x / quantum)) * quantum
+        x = max(new[-1] + quantum, min(x, nx - (n - k) * quantum))
+        new.append(x)
+    new.append(nx)
+    return new
+
+
 def combine_arrays(ma, va, na, mb, vb, nb):
     """Vectorised numpy restatement of _combine_samples (core/math/statsarray.pyx:780-859): returns combine(a, b)."""
     ma, va, mb, vb = (np.asarray(x, dtype=np.float64) for x in (ma, va, mb, vb))

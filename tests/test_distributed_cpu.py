@@ -123,6 +123,27 @@ def test_balanced_tile_bounds():
         D.tile_rect(0, 2, 8, 5, [0, 9, 8])
 
 
+def test_rebalance_bounds_converges_on_equal_tile_times():
+    """Cuts moved to the equal-cost quantiles of measured tile times: with a fixed (unknown to the function) per-column cost the
+    slowest tile approaches the mean within a few rounds; cuts stay multiples of 8 columns, tiles stay non-empty."""
+    from source_amd import distributed as D
+    nx = 2048
+    col = 1.0 + 0.6 * np.exp(-((np.arange(nx) - 900.0) / 350.0) ** 2) + 0.3 * (np.arange(nx) > 1500)
+    for n in (2, 4, 8):
+        b = [(nx * r) // n for r in range(n)] + [nx]
+        first = None
+        for it in range(5):
+            times = [col[b[r]:b[r + 1]].sum() for r in range(n)]
+            balance = np.mean(times) / np.max(times)
+            first = balance if first is None else first
+            b = D.rebalance_bounds(b, times, nx)
+            assert b[0] == 0 and b[-1] == nx and all(x1 > x0 for x0, x1 in zip(b[:-1], b[1:])) and all(x % 8 == 0 for x in b)
+        assert balance > 0.97 and balance >= first
+    assert D.rebalance_bounds([0, 8, 16], [1.0, 100.0], 16) == [0, 8, 16]        # one quantum per tile is the floor
+    with pytest.raises(ValueError):
+        D.rebalance_bounds([0, 8, 16], [1.0], 16)
+
+
 def test_combine_arrays_matches_reference(golden):
     from source_amd import distributed as D
     g = golden("f09_stats")

@@ -40,3 +40,39 @@ for N, W in ((8, 128), (8, 64), (8, 32), (4, 128), (4, 64), (2, 128)):
         ctx.synchronize()
         ts.append((time.perf_counter() - t0) / 5 * 1e3)
     print(N, W, ["%.2f" % t for t in ts], "max %.2f  mean %.2f  balance %.2f" % (max(ts), sum(ts) / N, sum(ts) / N / max(ts)))
+print("cost-balanced contiguous tiles (bench.py --tiles balanced)")
+bw = 64
+cost = []
+for x0 in range(0, 2048, bw):
+    cam.frame_sampler = ns.RectFrameSampler2D(rect=(x0, 0, x0 + bw, 2048))
+    cam.observe(); ctx.synchronize()
+    t0 = time.perf_counter()
+    for k in range(4): cam.observe()
+    ctx.synchronize()
+    cost.append((time.perf_counter() - t0) / 4)
+for N in (2, 4, 8):
+    b = D.balanced_bounds(cost, bw, 2048, N)
+    ts = []
+    for r in range(N):
+        cam.frame_sampler = ns.RectFrameSampler2D(rect=D.tile_rect(r, N, 2048, 2048, b))
+        for k in range(3): cam.observe()
+        ctx.synchronize()
+        t0 = time.perf_counter()
+        for k in range(5): cam.observe()
+        ctx.synchronize()
+        ts.append((time.perf_counter() - t0) / 5 * 1e3)
+    print(N, b, ["%.2f" % t for t in ts], "max %.2f  mean %.2f  balance %.2f" % (max(ts), sum(ts) / N, sum(ts) / N / max(ts)))
+print("tiles rebalanced by measured tile times (distributed.rebalance_bounds)")
+for N in (4, 8):
+    b = [(2048 * r) // N for r in range(N)] + [2048]
+    for it in range(5):
+        ts = []
+        for r in range(N):
+            cam.frame_sampler = ns.RectFrameSampler2D(rect=D.tile_rect(r, N, 2048, 2048, b))
+            cam.observe(); ctx.synchronize()
+            t0 = time.perf_counter()
+            for k in range(3): cam.observe()
+            ctx.synchronize()
+            ts.append((time.perf_counter() - t0) / 3 * 1e3)
+        print(N, it, b, "max %.2f  mean %.2f  balance %.2f" % (max(ts), sum(ts) / N, sum(ts) / N / max(ts)))
+        b = D.rebalance_bounds(b, ts, 2048)
