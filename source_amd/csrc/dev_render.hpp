@@ -264,8 +264,9 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
     __builtin_amdgcn_wave_barrier();
 }
 
-template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = false>
-__global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
+// PACKET: the unit's rays walk the trees together (dev_packet.hpp) — passes whose units hold a few pixels' samples.
+template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = false, bool PACKET = false>
+__global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, FuseParams fz) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
@@ -338,7 +339,9 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         const unsigned long long ph2_w0 = clock64();
         phase_acc[0] = ph2_w0 - ph2_u0;
 #endif
-        const bool got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
+        bool got;
+        if constexpr (PACKET) { static_assert(!CSG && !FUSED, "the packet walk serves the plain primary-ray kernel"); got = world_trace_packet(valid, sc, r, st, ms, hit, work); }
+        else got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_w1 = clock64();
         phase_acc[1] = ph2_w1 - ph2_w0;

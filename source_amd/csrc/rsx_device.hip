@@ -71,6 +71,13 @@
                                     // three waves with ~30 cold spills, 72 ms. Four waves still spill hot values and lose.
 #endif
 
+#ifndef RSX_PACKET_MIN_WAVES
+#define RSX_PACKET_MIN_WAVES 3      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace
+#endif
+#ifndef RSX_PACKET_MIN_SPP
+#define RSX_PACKET_MIN_SPP 2        // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp)
+#endif
+
 #ifndef RSX_UTIL_PROF
 #define RSX_UTIL_PROF 0            // 1: lane-utilisation counters per loop level into the rsx_debug_unit_times buffer (tuning builds only)
 #endif
@@ -126,6 +133,7 @@ extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
 #include "dev_analytic.hpp"
 #include "dev_csg.hpp"
 #include "dev_world.hpp"
+#include "dev_packet.hpp"
 #include "dev_query_kernels.hpp"
 #include "dev_render.hpp"
 #include "dev_selftest.hpp"
@@ -630,7 +638,9 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     d.n_world = desc->n_world;
     d.n_meshes = desc->n_meshes;
     d.n_wnodes = desc->world_kd.n_nodes; d.n_witems = desc->world_kd.n_items;
-    d.wdepth = tree_depth(desc->world_kd) + 1;
+    // (+ 3: the packet walk may push a node a second time for lanes that take its children in the other order — only where the
+    // rays' common origin lies exactly on a split plane, at most once per axis along a root-to-leaf path; dev_packet.hpp)
+    d.wdepth = tree_depth(desc->world_kd) + 1 + 3;
     d.mdepth = 1;
     {
         // the (up to eight) analytic world primitives that occur in the most world leaves (at least two): see DScene::wide
@@ -758,7 +768,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         std::memcpy(dm.lower, m.kd.lower, 24);
         std::memcpy(dm.upper, m.kd.upper, 24);
         dm.smoothing = m.smoothing; dm.closed = m.closed; dm.n_tris = m.n_triangles;
-        d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1);
+        d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1 + 3);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
     if (any_fast) d.mdepth = std::max(d.mdepth, fast_levels);           // csg_fast_hit keeps the leaf roots in the mesh-stack LDS levels
@@ -1146,6 +1156,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // — opt-in (RSX_FUSE=1): measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. The
     // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
     // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
+    static const int packet_min_spp = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : RSX_PACKET_MIN_SPP; }();   // 0: never
     static const bool fuse_enabled = [] { const char *e = std::getenv("RSX_FUSE"); return e && std::atoi(e) != 0; }();
     const size_t wave_lds = (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
     const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
@@ -1370,6 +1381,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, RSX_STAGE_MIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
             hipLaunchKernelGGL((k_render_trace<false, 0, RSX_STAGE_MIN, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
         }
+    }
+    else if (packet_min_spp > 0 && desc->spp >= packet_min_spp && !ctx->unit_times) {   // few pixels per unit: the wave walks the trees as one packet
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        hipLaunchKernelGGL((k_render_trace<false, 0, 1, false, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     }
     else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
