@@ -14,7 +14,7 @@ struct DMesh {
     const float *vnormals;     // [nn,3] or null
     const int32_t *nidx;       // [nt,3] vertex-normal indices or null
     double lower[3], upper[3];
-    int32_t smoothing, closed, n_tris, pad;
+    int32_t smoothing, closed, n_tris, splits_bounded;     // splits_bounded: every split of `nodes` lies inside [lower, upper]
 };
 
 struct DScene {

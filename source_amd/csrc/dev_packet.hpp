@@ -49,14 +49,16 @@ __device__ __forceinline__ UNode load_node_u(const rsx_kdnode *nodes, int32_t id
 __device__ __forceinline__ float4 load_f4_u(const RSX_CONST_AS PodF4 *p) { return make_float4(p->x, p->y, p->z, p->w); }
 __device__ __forceinline__ double unode_split(const UNode &nd) { return __longlong_as_double((long long)(((unsigned long long)nd.hi << 32) | nd.lo)); }
 
-// Stack of the packet: entry `sp` (wave-uniform) = the node to visit (same value in every lane's slot) + each lane's tmax there.
-// Same LDS / spill layout as the per-lane stacks (Stack), so the launch plan is shared.
+// Stack of the packet: entry `sp` (wave-uniform) = the node to visit + each lane's tmax there. In LDS: tmax[level][lane] (f64) and ONE
+// id per level (every lane writes the same word); deeper levels spill to the wave's global region ([level][lane] for both).
+// 4 world + 14 mesh levels are 9.3 KB per wave: sixteen waves — four per SIMD — fit a CU's 160 KB (packet_lds_bytes, wave_stacks_packet).
+#define PKT_WORLD_LDS_LEVELS 4
+#define PKT_MESH_LDS_LEVELS 14
 __device__ __forceinline__ void pstack_push(const Stack &st, int32_t sp, int32_t id, double t) {
     const int lane = (int)(threadIdx.x % WAVE);
     if (sp < st.lds_levels) {                            // (scalar branch)
-        const int slot = sp * WAVE + lane;
-        *reinterpret_cast<double *>(smem + st.lds_t + slot * 8) = t;
-        *reinterpret_cast<int32_t *>(smem + st.lds_id + slot * 4) = id;
+        *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;
+        *reinterpret_cast<int32_t *>(smem + st.lds_id + sp * 4) = id;
     } else {
         const int g = (sp - st.lds_levels) * WAVE + lane;
         reinterpret_cast<double *>(st.gt)[g] = t;
@@ -67,94 +69,177 @@ __device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t 
     const int lane = (int)(threadIdx.x % WAVE);
     int32_t v;
     if (sp < st.lds_levels) {
-        const int slot = sp * WAVE + lane;
-        t = *reinterpret_cast<const double *>(smem + st.lds_t + slot * 8);
-        v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + slot * 4);
+        t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
+        v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + sp * 4);
     } else {
-        const int g = (sp - st.lds_levels) * WAVE + lane;
-        t = reinterpret_cast<const double *>(st.gt)[g];
-        v = reinterpret_cast<const int32_t *>(st.gid)[g];
+        const int g = (sp - st.lds_levels) * WAVE + lane;          // (non-temporal: keeps the two branches' loads apart — merged, they become flat loads)
+        t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + g);
+        v = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(st.gid) + g);
     }
     id = __builtin_amdgcn_readfirstlane(v);
 }
 
+__host__ __device__ __forceinline__ int packet_world_levels(int wdepth) { return wdepth < PKT_WORLD_LDS_LEVELS ? wdepth : PKT_WORLD_LDS_LEVELS; }
+__host__ __device__ __forceinline__ int packet_mesh_levels(int mdepth) { return mdepth < PKT_MESH_LDS_LEVELS ? mdepth : PKT_MESH_LDS_LEVELS; }
+__host__ __device__ __forceinline__ size_t packet_lds_bytes(int wdepth, int mdepth) {       // per wave
+    const size_t levels = (size_t)(packet_world_levels(wdepth) + packet_mesh_levels(mdepth));
+    return (levels * (WAVE * 8 + 4) + 15) & ~(size_t)15;
+}
+// carve the wave's LDS region and global spill region into the packet's world stack and mesh stack (the spill region is the one plan()
+// sized for the per-lane stacks: the packet keeps at least as many levels in LDS, so it needs no more)
+__device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, Stack &ms) {
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
+    const int pw = packet_world_levels(sc.wdepth), pm = packet_mesh_levels(sc.mdepth);
+    const uint32_t base = (uint32_t)wave * (uint32_t)packet_lds_bytes(sc.wdepth, sc.mdepth);
+    const int spill_levels = (sc.wdepth - pw) + (sc.mdepth - pm);
+    const int plan_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
+    const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
+    char *gbase = sc.spill + gwave * (size_t)(plan_levels > 0 ? plan_levels : 1) * WAVE * 12;
+    char *gt = gbase, *gid = gbase + (size_t)spill_levels * WAVE * 8;
+    ws.stage = nullptr; ms.stage = nullptr;
+    ws.lds_t = base; ws.lds_id = base + (uint32_t)(pw + pm) * WAVE * 8; ws.gt = gt; ws.gid = gid; ws.lds_levels = pw;
+    ms.lds_t = base + (uint32_t)pw * WAVE * 8; ms.lds_id = ws.lds_id + (uint32_t)pw * 4;
+    ms.gt = gt + (size_t)(sc.wdepth - pw) * WAVE * 8; ms.gid = gid + (size_t)(sc.wdepth - pw) * WAVE * 4; ms.lds_levels = pm;
+}
+
 #define PKT_EMPTY (-INFINITY)
 
-// One branch node for the packet. In: the lane's range [tmin, tmax] (tmax == PKT_EMPTY: none). Out: the node to go to and the lane's
-// range there; the other child, when some lane enters it too, is pushed.
-// WORLD: plain division and the cull of world_step (cull bits in nd.type >> 2, t_cull); else the hoisted-reciprocal quotient.
+#ifdef RSX_PKT_PROF
+// tuning builds: wave-level event counts of the packet walk, summed into g_pkt by every wave (printed by rsx_synchronize)
+__device__ unsigned long long g_pkt[16];
+#define PKT_COUNT(slot, n) { pkc[slot] += (uint32_t)(n); }
+#define PKT_ARG , uint32_t *pkc
+#define PKT_PASS , pkc
+#else
+#define PKT_COUNT(slot, n)
+#define PKT_ARG
+#define PKT_PASS
+#endif
+enum { PKC_UNITS = 0, PKC_WSTEPS, PKC_WDIVS, PKC_WLEAVES, PKC_WITEMS, PKC_MVISITS, PKC_MSTEPS, PKC_MLEAVES, PKC_TRIS, PKC_PUSHES, PKC_POPS, PKC_DEFERS, PKC_MSLOW, PKC_N };
+
+__device__ __forceinline__ bool pkt_any(bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ULL; }
+
+// Wave-level facts about the rays' space, fixed for one tree walk.
+typedef unsigned long long lanemask;
+struct PacketSpace {
+    int fast;                  // bit k: on axis k the hoisted-reciprocal quotient needs no per-node range test (see packet_space)
+    lanemask neg[3];           // lanes whose direction component k is negative
+};
+
+// exact_div's shortcut (dev_common.hpp) is valid while numerator and divisor stay clear of the exponent ranges where the hardware
+// division rescales: |d| in [2^-300, 2^300] (AxisDiv::safe) and |num| in [2^-300, 2^300] or num == 0. Here num = split - o with every
+// split inside the tree's bounds, so the numerator's test can be made ONCE per walk instead of at every node: with |o| >= 2^-240 a
+// non-zero difference split - o is at least half an ulp of the smaller operand's binade... and never below 2^-300; with |o| and the
+// bounds below 2^299 it never exceeds 2^300. An axis that fails this (an origin coordinate of exactly 0, say) keeps the per-node test.
+__device__ __forceinline__ PacketSpace packet_space(const Ray &r, const AxisDiv &ad, const double *lo, const double *hi, bool want) {
+    PacketSpace ps;
+    const double o[3] = {r.ox, r.oy, r.oz};
+    int fast = 0;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const double a = __builtin_fabs(o[k]);
+        const bool ok = ((ad.safe >> k) & 1) && a >= 0x1p-240 && a <= 0x1p+299 && __builtin_fabs(lo[k]) <= 0x1p+299 && __builtin_fabs(hi[k]) <= 0x1p+299;
+        if (!pkt_any(want && !ok)) fast |= 1 << k;
+    }
+    ps.fast = fast;
+    ps.neg[0] = __builtin_amdgcn_ballot_w64(r.dx < 0.0); ps.neg[1] = __builtin_amdgcn_ballot_w64(r.dy < 0.0); ps.neg[2] = __builtin_amdgcn_ballot_w64(r.dz < 0.0);
+    return ps;
+}
+
+// One branch node for the packet, on split axis AXIS (the caller dispatches on the node's wave-uniform axis, so the lane's origin,
+// direction and reciprocal components are named, not selected). In: the lane's range [tmin, tmax] (tmax == PKT_EMPTY: none).
+// Out: the node to go to and the lane's range there; the other child, when some lane enters it too, is pushed.
+// WORLD: plain division (skipped when no lane approaches the plane) and the cull of world_step (cull bits in nd.type >> 2, t_cull);
+// else the hoisted-reciprocal quotient (dev_common.hpp: exact_div), range-tested per node only where packet_space could not vouch for it.
+// Lane predicates are kept as 64-bit lane masks (what a vector compare writes anyway): their algebra then runs on the scalar unit, and a
+// mask goes back into a select with inverse_ballot at no cost.
+__device__ __forceinline__ lanemask pkt_mask(bool b) { return __builtin_amdgcn_ballot_w64(b); }
+__device__ __forceinline__ bool pkt_lanes(lanemask m) { return __builtin_amdgcn_inverse_ballot_w64(m); }
+
 template <bool WORLD>
-__device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, const Ray &r, const AxisDiv &ad, double &tmin, double &tmax, const Stack &st,
-                                               int32_t &sp, double t_cull) {
-    const int axis = nd.type & 3;
+__device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t node, double o, double d, double y, bool fast, lanemask m_neg, lanemask m_in,
+                                                    double &tmin, double &tmax, const Stack &st, int32_t &sp, double t_cull PKT_ARG) {
     const double split = unode_split(nd);
     const int32_t lower = node + 1, upper = nd.count;
-    const double o = sel3(axis, r.ox, r.oy, r.oz), d = sel3(axis, r.dx, r.dy, r.dz);
     const double num = split - o;
-    const bool par = d == 0.0;                                             // kdtree3d.pyx:661-667
-    // quotient <= 0 whatever its magnitude: zero numerator, or numerator and direction of opposite sign (kdtree3d.pyx:686 "near only")
-    const bool away = num == 0.0 || ((num < 0.0) != (d < 0.0));
-    bool in = tmax != PKT_EMPTY;
-    double plane = 0.0;
-    if (__any(in && !par && !away)) {
-        if constexpr (WORLD) plane = num / d;
-        else {
-            const double y = sel3(axis, ad.yx, ad.yy, ad.yz);
-            const double q0 = num * y;
-            const double rem = __builtin_fma(-d, q0, num);
-            plane = __builtin_fma(rem, y, q0);
-            const bool exact = ((ad.safe >> axis) & 1) && div_operand_safe(num);
-            if (__builtin_expect(__any(!exact && !away && !par), 0)) {
-                if (!exact) plane = num / d;
-            }
+    double plane;
+    if constexpr (WORLD) {
+        // quotient <= 0 whatever its magnitude — zero numerator, or numerator and direction of opposite sign: "near only" (kdtree3d.pyx:686)
+        const lanemask toward = pkt_mask(num != 0.0) & ~(pkt_mask(num < 0.0) ^ m_neg);
+        plane = 0.0;
+        if (m_in & toward) { plane = num / d; PKT_COUNT(PKC_WDIVS, 1) }
+    } else {
+        const double q0 = num * y;
+        const double rem = __builtin_fma(-d, q0, num);
+        plane = __builtin_fma(rem, y, q0);
+        if (__builtin_expect(!fast, 0)) {
+            const bool exact = div_operand_safe(d) && (div_operand_safe(num) || num == 0.0);
+            if (pkt_any(!exact)) { if (!exact) plane = num / d; }
+            PKT_COUNT(PKC_MSLOW, 1)
         }
     }
-    const bool lower_near = par ? (o < split) : (o < split || (o == split && d < 0.0));      // kdtree3d.pyx:664, 675
-    const bool near_only = par || away || plane > tmax || plane <= 0.0;
-    bool far_only = !near_only && plane < tmin;
-    bool both = in && !near_only && !far_only;
+    // kdtree3d.pyx:661-700 in one form. A ray parallel to the plane (d == 0) has quotient +-inf or NaN: "near only" below, and its near
+    // child is `origin < split ? lower : upper` (:664) — which is what below_split (:675) gives when d < 0 is false.
+    const lanemask m_lower_near = pkt_mask(o < split) | (pkt_mask(o == split) & m_neg);
+    // crosses the plane inside its range: not (:686) "plane > max_range or plane <= 0" (a lane without a range: plane <= -inf fails)
+    const lanemask m_cross = pkt_mask(plane > 0.0) & pkt_mask(plane <= tmax);
+    lanemask m_far = m_cross & pkt_mask(plane < tmin);                     // (:690) far child only
+    lanemask m_both = m_cross & ~m_far;
     if constexpr (WORLD) {
         // world_step's cull: the near subtree holds wide primitives only and ends before the nearest wide answer — straight to the far child
         const int32_t cull_bits = nd.type >> 2;
-        const bool cull = both && (((lower_near ? cull_bits : cull_bits >> 1) & 1) != 0) && plane < t_cull;
-        if (cull) { tmin = plane; far_only = true; both = false; }
-    }
-    unsigned long long b_up = __ballot(both && !lower_near);
-    if (__builtin_expect(b_up != 0ULL, 0)) {
-        if (__ballot(both && lower_near) != 0ULL) {
-            // both-crossing lanes disagree on the near child (the common origin lies exactly on the plane): the upper-first lanes come back
-            // to this node alone, after the others are through with it
-            const bool defer = both && !lower_near;
-            pstack_push(st, sp, node, defer ? tmax : PKT_EMPTY);
-            ++sp;
-            if (defer) { tmax = PKT_EMPTY; in = false; both = false; }
-            b_up = 0ULL;
+        const lanemask m_cullable = m_both & (((cull_bits & 1) ? m_lower_near : 0ULL) | ((cull_bits & 2) ? ~m_lower_near : 0ULL));
+        if (m_cullable) {
+            const lanemask m_cull = m_cullable & pkt_mask(plane < t_cull);
+            tmin = pkt_lanes(m_cull) ? plane : tmin;
+            m_far |= m_cull; m_both &= ~m_cull;
         }
     }
-    const bool single_lower = near_only == lower_near;                     // the one child of a lane that enters one: near_only ? near : far
-    const bool want_lower = in && (both || single_lower), want_upper = in && (both || !single_lower);
+    lanemask b_up = m_both & ~m_lower_near;
+    if (__builtin_expect(b_up != 0ULL && (m_both & m_lower_near) != 0ULL, 0)) {
+        // both-crossing lanes disagree on the near child (the common origin lies exactly on the plane): the upper-first lanes come back
+        // to this node alone, after the others are through with it
+        pstack_push(st, sp, node, pkt_lanes(b_up) ? tmax : PKT_EMPTY);
+        ++sp;
+        tmax = pkt_lanes(b_up) ? PKT_EMPTY : tmax;
+        m_in &= ~b_up; m_both &= ~b_up;
+        b_up = 0ULL;
+        PKT_COUNT(PKC_DEFERS, 1)
+    }
+    const lanemask m_single_lower = m_far ^ m_lower_near;                  // the one child of a lane that enters one: far_only ? far : near
+    const lanemask m_want_lower = m_in & (m_both | m_single_lower), m_want_upper = m_in & (m_both | ~m_single_lower);
     const bool upper_first = b_up != 0ULL;
     const int32_t first = upper_first ? upper : lower, second = upper_first ? lower : upper;
-    const bool want_f = upper_first ? want_upper : want_lower, want_s = upper_first ? want_lower : want_upper;
-    const double t_f = want_f ? (both ? plane : tmax) : PKT_EMPTY;         // (a both-crossing lane's near child is `first` by construction)
-    const double t_s = want_s ? tmax : PKT_EMPTY;
-    if (__any(want_f)) {
-        if (__any(want_s)) { pstack_push(st, sp, second, t_s); ++sp; }
-        tmax = t_f;
+    const lanemask m_want_f = upper_first ? m_want_upper : m_want_lower, m_want_s = upper_first ? m_want_lower : m_want_upper;
+    if (m_want_f) {
+        if (m_want_s) { pstack_push(st, sp, second, pkt_lanes(m_want_s) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
+        const double keep = pkt_lanes(m_both) ? plane : tmax;              // (a both-crossing lane's near child is `first` by construction)
+        tmax = pkt_lanes(m_want_f) ? keep : PKT_EMPTY;
         return first;
     }
-    tmax = t_s;
+    tmax = pkt_lanes(m_want_s) ? tmax : PKT_EMPTY;
     return second;
 }
 
+template <bool WORLD>
+__device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, const Ray &r, const AxisDiv &ad, const PacketSpace &ps, double &tmin, double &tmax,
+                                               const Stack &st, int32_t &sp, double t_cull PKT_ARG) {
+    const int axis = nd.type & 3;                                          // (wave-uniform: a scalar branch)
+    const lanemask m_in = pkt_mask(tmax != PKT_EMPTY);
+    if (axis == 0) return packet_step_axis<WORLD>(nd, node, r.ox, r.dx, ad.yx, (ps.fast & 1) != 0, ps.neg[0], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
+    if (axis == 1) return packet_step_axis<WORLD>(nd, node, r.oy, r.dy, ad.yy, (ps.fast & 2) != 0, ps.neg[1], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
+    return packet_step_axis<WORLD>(nd, node, r.oz, r.dz, ad.yz, (ps.fast & 4) != 0, ps.neg[2], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
+}
+
 // Pops until some lane has a range again. `done` lanes (their ray found its hit) discard theirs. False: the stack is empty.
-__device__ __forceinline__ bool packet_pop(const Stack &st, int32_t &sp, int32_t &node, double &tmax, bool done) {
+__device__ __forceinline__ bool packet_pop(const Stack &st, int32_t &sp, int32_t &node, double &tmax, bool done PKT_ARG) {
     while (sp > 0) {
         --sp;
         double t;
         pstack_pop(st, sp, node, t);
+        PKT_COUNT(PKC_POPS, 1)
         tmax = done ? PKT_EMPTY : t;
-        if (__any(tmax != PKT_EMPTY)) return true;
+        if (pkt_any(tmax != PKT_EMPTY)) return true;
     }
     return false;
 }
@@ -162,29 +247,38 @@ __device__ __forceinline__ bool packet_pop(const Stack &st, int32_t &sp, int32_t
 // MeshData.trace (mesh.pyx:506-563) for the packet: `m` and the ray space are wave-uniform, `want` = the lane's ray passed the
 // BoundPrimitive gate. Leaves of any size are walked the same way: every record comes in once over the scalar data path (the next one
 // while this one is tested) and every lane with a range tests it — in leaf order, strict `<`: the reference's own loop.
-__device__ bool mesh_trace_packet(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work) {
+__device__ __forceinline__ bool mesh_trace_packet(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work PKT_ARG) {
     const rsx_kdnode *nodes = m->nodes;
     const float4 *leaf = m->leaf;
     const AxisDiv ad = axis_div(r);
+    PacketSpace ps;
     double tmin = 0, tmax = 0;
     {
         const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
         const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
                      rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
         if (!(want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax))) tmax = PKT_EMPTY;       // kdtree3d.pyx:589-607
+        ps = packet_space(r, ad, lo, hi, want);
+        if (!m->splits_bounded) ps.fast = 0;
     }
-    if (!__any(tmax != PKT_EMPTY)) return false;
+    if (!pkt_any(tmax != PKT_EMPTY)) return false;
+    PKT_COUNT(PKC_MVISITS, 1)
     const TriRay q = tri_ray(r);
     bool hit = false;
     int32_t node = 0, sp = 0;
     for (;;) {
         UNode nd = load_node_u(nodes, node);
         while (nd.type >= 0) {
-            node = packet_step<false>(nd, node, r, ad, tmin, tmax, st, sp, 0.0);
+            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0 PKT_PASS);
             nd = load_node_u(nodes, node);
             work += 1;
+            PKT_COUNT(PKC_MSTEPS, 1)
         }
+#ifdef PKT_ABLATE_TRIS
+        const int32_t count = 0;                                               // (timing ablation: results are wrong)
+#else
         const int32_t count = nd.count;
+#endif
         if (count > 0) {                                                       // _trace_leaf, mesh.pyx:520-563
             double distance = r.maxd < tmax ? r.maxd : tmax;                   // (no range: -inf, nothing is accepted)
             int32_t closest = -1;
@@ -193,6 +287,8 @@ __device__ bool mesh_trace_packet(bool want, UMesh m, const Ray &r, const Stack 
             float4 a = load_f4_u(rec), b = load_f4_u(rec + 1), c = load_f4_u(rec + 2);
             int32_t tri = __float_as_int(rec[3].x);
             work += (uint32_t)count;
+            PKT_COUNT(PKC_MLEAVES, 1)
+            PKT_COUNT(PKC_TRIS, count)
             for (int32_t k = 0; k < count; ++k) {
                 const int32_t kn = k + 1 < count ? k + 1 : k;
                 const float4 na = load_f4_u(rec + 4 * kn), nb = load_f4_u(rec + 4 * kn + 1), nc = load_f4_u(rec + 4 * kn + 2);
@@ -204,22 +300,25 @@ __device__ bool mesh_trace_packet(bool want, UMesh m, const Ray &r, const Stack 
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; }
         }
         if (tmax != PKT_EMPTY) tmin = tmax;                                    // the next range of this ray begins where this one ended
-        if (!packet_pop(st, sp, node, tmax, hit)) break;
+        if (!packet_pop(st, sp, node, tmax, hit PKT_PASS)) break;
     }
     return hit;
 }
 
 // World.hit for the packet (kdtree.pyx:73-122, boundprimitive.pyx:42-51): world_trace_wave<false, false, 1, true> with the walk above.
 // Leaf items are wave-uniform by construction (the wave is in ONE leaf); wide primitives, leaf tags and the cull as there.
-__device__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work) {
+__device__ __forceinline__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work PKT_ARG) {
     best.prim = -1;
     double tmin = 0, tmax = 0;
     const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
     const bool enters = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
     if (!enters) tmax = PKT_EMPTY;
-    if (!__any(enters)) return false;
+    if (!pkt_any(enters)) return false;
     AxisDiv ad;
     ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
+    PacketSpace ps;
+    ps.fast = 0;
+    ps.neg[0] = __builtin_amdgcn_ballot_w64(r.dx < 0.0); ps.neg[1] = __builtin_amdgcn_ballot_w64(r.dy < 0.0); ps.neg[2] = __builtin_amdgcn_ballot_w64(r.dz < 0.0);
     const rsx_kdnode *wnodes = sc.wnodes;
     WideSet8 wide;
 #pragma unroll
@@ -243,11 +342,13 @@ __device__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, c
     for (;;) {
         UNode nd = load_node_u(wnodes, node);
         while (nd.type >= 0) {
-            node = packet_step<true>(nd, node, r, ad, tmin, tmax, st, sp, t_cull);
+            node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, sp, t_cull PKT_PASS);
             nd = load_node_u(wnodes, node);
             work += 1;
+            PKT_COUNT(PKC_WSTEPS, 1)
         }
         double distance = r.maxd < tmax ? r.maxd : tmax;                       // (no range: -inf, `t <= distance` fails)
+        PKT_COUNT(PKC_WLEAVES, 1)
         const int32_t tag = (int32_t)nd.hi;
         if (tag < 0) {
             // wide-only leaf: its item list rides in the node (rsx_scene_create), the answers are in registers
@@ -272,6 +373,7 @@ __device__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, c
             for (int32_t k = 0; k < count; ++k) {
                 const int32_t idx = items[k];                                  // (scalar load)
                 work += 4;
+                PKT_COUNT(PKC_WITEMS, 1)
                 Hit cand;
                 cand.prim = -1;
                 const bool in = tmax != PKT_EMPTY;
@@ -287,12 +389,16 @@ __device__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, c
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                         double f, b;
                         const bool gate = in && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
-                        if (__any(gate)) {
+#ifdef PKT_ABLATE_MESH
+                        if (false) {                                           // (timing ablation: results are wrong)
+#else
+                        if (pkt_any(gate)) {
+#endif
                             Ray l = r;
                             if (gate) l = to_local_uniform(up, r);
                             const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
                             MeshHit mh;
-                            if (mesh_trace_packet(gate, um, l, mesh_stack, mh, work)) {
+                            if (mesh_trace_packet(gate, um, l, mesh_stack, mh, work PKT_PASS)) {
                                 cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                             }
                         }
@@ -307,7 +413,7 @@ __device__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, c
             }
         }
         if (tmax != PKT_EMPTY) tmin = tmax;
-        if (!packet_pop(st, sp, node, tmax, best.prim >= 0)) break;
+        if (!packet_pop(st, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
     }
     return best.prim >= 0;
 }

@@ -269,7 +269,7 @@ template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = fa
 __global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, FuseParams fz) {
     Stack st, ms;
-    wave_stacks(sc, st, ms);
+    if constexpr (PACKET) wave_stacks_packet(sc, st, ms); else wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
     int fuse_u0 = 0, fuse_u1 = 0, fuse_u2 = 0, fuse_u3 = 0, fuse_n = 0;           // wave-uniform: the units whose records wait in the ring
     Sample *fuse_ring = nullptr;
@@ -340,7 +340,19 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         phase_acc[0] = ph2_w0 - ph2_u0;
 #endif
         bool got;
-        if constexpr (PACKET) { static_assert(!CSG && !FUSED, "the packet walk serves the plain primary-ray kernel"); got = world_trace_packet(valid, sc, r, st, ms, hit, work); }
+        if constexpr (PACKET) { static_assert(!CSG && !FUSED, "the packet walk serves the plain primary-ray kernel"); 
+#ifdef RSX_PKT_PROF
+            uint32_t pkc[PKC_N];
+            for (int c = 0; c < PKC_N; ++c) pkc[c] = 0;
+            pkc[PKC_UNITS] = 1;
+            got = world_trace_packet(valid, sc, r, st, ms, hit, work, pkc);
+            if (lane == 0) for (int c = 0; c < PKC_N; ++c) atomicAdd(&g_pkt[c], (unsigned long long)pkc[c]);
+#elif defined(PKT_ABLATE_TRACE)
+            got = false; hit.prim = -1;                                    // (timing ablation: ray generation and the record store alone)
+#else
+            got = world_trace_packet(valid, sc, r, st, ms, hit, work);
+#endif
+        }
         else got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_w1 = clock64();

@@ -72,7 +72,7 @@
 #endif
 
 #ifndef RSX_PACKET_MIN_WAVES
-#define RSX_PACKET_MIN_WAVES 3      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace
+#define RSX_PACKET_MIN_WAVES 4      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace (128 registers)
 #endif
 #ifndef RSX_PACKET_MIN_SPP
 #define RSX_PACKET_MIN_SPP 2        // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp)
@@ -334,6 +334,13 @@ extern "C" int rsx_synchronize(rsx_ctx *ctx) {
       double ex[8]; (void)hipMemcpyFromSymbol(ex, HIP_SYMBOL(g_csgf_ex), sizeof(ex));
       std::fprintf(stderr, "tie example: prim %g leaves %g %g t %.17g origin %.6f %.6f %.6f dx %.6f\n", ex[0], ex[1], ex[2], ex[3], ex[4], ex[5], ex[6], ex[7]);
       std::fprintf(stderr, "csg_fast_hit: fallback %llu miss %llu hit %llu | why: nan %llu pattern %llu tie %llu\n", c[0], c[1], c[2], w[0], w[1], w[2]); }
+#endif
+#ifdef RSX_PKT_PROF
+    { unsigned long long c[16] = {0}; (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(c, HIP_SYMBOL(g_pkt), sizeof(c));
+      if (c[0]) { const double u = (double)c[0];
+        std::fprintf(stderr, "[packet walk, per unit over %llu units] world: steps %.2f divisions %.2f leaves %.2f items %.2f | mesh: visits %.3f steps %.2f leaves %.2f triangles %.2f slow steps %.2f | pushes %.2f pops %.2f deferrals %.4f\n",
+                     c[0], c[1] / u, c[2] / u, c[3] / u, c[4] / u, c[5] / u, c[6] / u, c[7] / u, c[8] / u, c[12] / u, c[9] / u, c[10] / u, c[11] / u);
+        unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_pkt), z, sizeof(z)); } }
 #endif
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     if (g_hp_on && g_hp_calls) {
@@ -768,6 +775,13 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         std::memcpy(dm.lower, m.kd.lower, 24);
         std::memcpy(dm.upper, m.kd.upper, 24);
         dm.smoothing = m.smoothing; dm.closed = m.closed; dm.n_tris = m.n_triangles;
+        // the packet walk tests the range of a quotient's numerator once per walk from the tree's bounds (packet_space, dev_packet.hpp):
+        // sound while every split lies inside them — true of any tree the builder makes; a tree read from a file is checked, not trusted
+        dm.splits_bounded = 1;
+        for (int32_t k = 0; k < m.kd.n_nodes; ++k) {
+            const rsx_kdnode &nd = m.kd.nodes[k];
+            if (nd.type >= 0 && nd.type <= 2 && !(nd.u.split >= m.kd.lower[nd.type] && nd.u.split <= m.kd.upper[nd.type])) { dm.splits_bounded = 0; break; }
+        }
         d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1 + 3);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
@@ -1383,8 +1397,16 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         }
     }
     else if (packet_min_spp > 0 && desc->spp >= packet_min_spp && !ctx->unit_times) {   // few pixels per unit: the wave walks the trees as one packet
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-        hipLaunchKernelGGL((k_render_trace<false, 0, 1, false, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+        // its stacks are smaller (one range per lane and level, no leaf staging): four waves per SIMD fit the LDS — and the registers
+        const size_t plds = (size_t)WG_WAVES * packet_lds_bytes(scene->d.wdepth, scene->d.mdepth);
+        dim3 pgrid = l.grid;
+        if (!pipelined) {
+            const long long per_cu = std::min<long long>(RSX_MAX_WG_PER_CU, (long long)((160 * 1024) / std::max<size_t>(plds, 1)));
+            const long long needed = ((long long)S + WG_THREADS - 1) / WG_THREADS;
+            pgrid = dim3((unsigned)std::max<long long>(1, std::min<long long>((long long)ctx->n_cus * per_cu, needed)));
+        }
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+        hipLaunchKernelGGL((k_render_trace<false, 0, 1, false, true>), pgrid, dim3(WG_THREADS), plds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     }
     else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
