@@ -36,6 +36,9 @@ struct DScene {
     int32_t wide_csg[4];       // top-level CSG primitives (state-free evaluator form) that sit in several world leaves, -1 = none: the path
                                // kernel of a CSG scene answers them for the whole wave before the traversal (world_trace_wave's mailbox)
     const rsx_primitive *prims_uniform;   // = prims in global memory: what the scalar data path reads (the path kernel may point `prims` at an LDS copy)
+    int32_t wsplits_bounded, pad_w;       // every split of the world tree lies inside [wlower, wupper] (packet_space, dev_packet.hpp)
+    const float4 *rel;                    // camera-relative leaf records of the mesh instances (dev_packet.hpp: RelInfo), or null
+    const struct RelInfo *rel_info;       // per primitive
     const rsx_kdnode *wnodes_scatter;   // the world nodes annotated for the kernels of scattered rays: leaf tags and cull bits for the eight-slot set, or — CSG
                                         // scenes — two slots plus the CSG primitives answered before the traversal (wnodes: for the first two slots)
 };

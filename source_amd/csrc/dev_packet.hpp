@@ -33,6 +33,11 @@
 // skips it; with a common origin and directions inside one pixel that is a wave-uniform outcome.
 // ---------------------------------------------------------------------------------------------------
 
+// The scene as the packet walk reads it: where it lies in the kernel-argument segment, field by field at the point of use (scalar
+// loads that hit the constant cache) — held by value, its pointers and tables sat in scalar registers through the whole unit and the
+// registers the walk needed were spilled around them.
+typedef const RSX_CONST_AS DScene *PScene;
+
 struct UNode {                 // a KD node in scalar registers
     int32_t type, count;       // type: -1 leaf | axis (+ cull bits, world copies);  count: upper child | number of items
     uint32_t lo, hi;           // branch: split (f64 bits);  leaf: first item, tag
@@ -49,33 +54,22 @@ __device__ __forceinline__ UNode load_node_u(const rsx_kdnode *nodes, int32_t id
 __device__ __forceinline__ float4 load_f4_u(const RSX_CONST_AS PodF4 *p) { return make_float4(p->x, p->y, p->z, p->w); }
 __device__ __forceinline__ double unode_split(const UNode &nd) { return __longlong_as_double((long long)(((unsigned long long)nd.hi << 32) | nd.lo)); }
 
-// Stack of the packet: entry `sp` (wave-uniform) = the node to visit + each lane's tmax there. In LDS: tmax[level][lane] (f64) and ONE
-// id per level (every lane writes the same word); deeper levels spill to the wave's global region ([level][lane] for both).
+// Stack of the packet: entry `sp` (wave-uniform) = the node to visit + each lane's tmax there. In LDS: ONE id per level, for every level
+// (every lane writes the same word), and tmax[level][lane] (f64) for the first levels; deeper tmax rows spill to the wave's global region.
 // 4 world + 14 mesh levels are 9.3 KB per wave: sixteen waves — four per SIMD — fit a CU's 160 KB (packet_lds_bytes, wave_stacks_packet).
 #define PKT_WORLD_LDS_LEVELS 4
 #define PKT_MESH_LDS_LEVELS 14
 __device__ __forceinline__ void pstack_push(const Stack &st, int32_t sp, int32_t id, double t) {
     const int lane = (int)(threadIdx.x % WAVE);
-    if (sp < st.lds_levels) {                            // (scalar branch)
-        *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;
-        *reinterpret_cast<int32_t *>(smem + st.lds_id + sp * 4) = id;
-    } else {
-        const int g = (sp - st.lds_levels) * WAVE + lane;
-        reinterpret_cast<double *>(st.gt)[g] = t;
-        reinterpret_cast<int32_t *>(st.gid)[g] = id;
-    }
+    *reinterpret_cast<int32_t *>(smem + st.lds_id + sp * 4) = id;
+    if (sp < st.lds_levels) *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;    // (scalar branch)
+    else reinterpret_cast<double *>(st.gt)[(sp - st.lds_levels) * WAVE + lane] = t;
 }
 __device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
     const int lane = (int)(threadIdx.x % WAVE);
-    int32_t v;
-    if (sp < st.lds_levels) {
-        t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
-        v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + sp * 4);
-    } else {
-        const int g = (sp - st.lds_levels) * WAVE + lane;          // (non-temporal: keeps the two branches' loads apart — merged, they become flat loads)
-        t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + g);
-        v = __builtin_nontemporal_load(reinterpret_cast<const int32_t *>(st.gid) + g);
-    }
+    const int32_t v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + sp * 4);
+    if (sp < st.lds_levels) t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
+    else t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + (sp - st.lds_levels) * WAVE + lane);
     id = __builtin_amdgcn_readfirstlane(v);
 }
 
@@ -83,7 +77,7 @@ __host__ __device__ __forceinline__ int packet_world_levels(int wdepth) { return
 __host__ __device__ __forceinline__ int packet_mesh_levels(int mdepth) { return mdepth < PKT_MESH_LDS_LEVELS ? mdepth : PKT_MESH_LDS_LEVELS; }
 __host__ __device__ __forceinline__ size_t packet_lds_bytes(int wdepth, int mdepth) {       // per wave
     const size_t levels = (size_t)(packet_world_levels(wdepth) + packet_mesh_levels(mdepth));
-    return (levels * (WAVE * 8 + 4) + 15) & ~(size_t)15;
+    return (levels * WAVE * 8 + (size_t)(wdepth + mdepth) * 4 + 15) & ~(size_t)15;
 }
 // carve the wave's LDS region and global spill region into the packet's world stack and mesh stack (the spill region is the one plan()
 // sized for the per-lane stacks: the packet keeps at least as many levels in LDS, so it needs no more)
@@ -95,11 +89,12 @@ __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, 
     const int plan_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
     const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
     char *gbase = sc.spill + gwave * (size_t)(plan_levels > 0 ? plan_levels : 1) * WAVE * 12;
-    char *gt = gbase, *gid = gbase + (size_t)spill_levels * WAVE * 8;
+    char *gt = gbase;
+    (void)spill_levels;
     ws.stage = nullptr; ms.stage = nullptr;
-    ws.lds_t = base; ws.lds_id = base + (uint32_t)(pw + pm) * WAVE * 8; ws.gt = gt; ws.gid = gid; ws.lds_levels = pw;
-    ms.lds_t = base + (uint32_t)pw * WAVE * 8; ms.lds_id = ws.lds_id + (uint32_t)pw * 4;
-    ms.gt = gt + (size_t)(sc.wdepth - pw) * WAVE * 8; ms.gid = gid + (size_t)(sc.wdepth - pw) * WAVE * 4; ms.lds_levels = pm;
+    ws.lds_t = base; ws.lds_id = base + (uint32_t)(pw + pm) * WAVE * 8; ws.gt = gt; ws.gid = nullptr; ws.lds_levels = pw;
+    ms.lds_t = base + (uint32_t)pw * WAVE * 8; ms.lds_id = ws.lds_id + (uint32_t)sc.wdepth * 4;
+    ms.gt = gt + (size_t)(sc.wdepth - pw) * WAVE * 8; ms.gid = nullptr; ms.lds_levels = pm;
 }
 
 #define PKT_EMPTY (-INFINITY)
@@ -129,17 +124,22 @@ struct PacketSpace {
 // exact_div's shortcut (dev_common.hpp) is valid while numerator and divisor stay clear of the exponent ranges where the hardware
 // division rescales: |d| in [2^-300, 2^300] (AxisDiv::safe) and |num| in [2^-300, 2^300] or num == 0. Here num = split - o with every
 // split inside the tree's bounds, so the numerator's test can be made ONCE per walk instead of at every node: with |o| >= 2^-240 a
-// non-zero difference split - o is at least half an ulp of the smaller operand's binade... and never below 2^-300; with |o| and the
-// bounds below 2^299 it never exceeds 2^300. An axis that fails this (an origin coordinate of exactly 0, say) keeps the per-node test.
-__device__ __forceinline__ PacketSpace packet_space(const Ray &r, const AxisDiv &ad, const double *lo, const double *hi, bool want) {
+// non-zero difference split - o is at least an ulp of the smaller operand's binade and never below 2^-300 (with o == 0 it is the split
+// itself: the host notes whether any split is that small); with |o| and the bounds below 2^299 it never exceeds 2^300. An axis that
+// fails this keeps the per-node test.
+__device__ __forceinline__ PacketSpace packet_space(const Ray &r, const AxisDiv &ad, const double *lo, const double *hi, bool want, int splits) {
     PacketSpace ps;
     const double o[3] = {r.ox, r.oy, r.oz};
     int fast = 0;
+    if (splits & 1) {                                    // (bit 0: every split lies inside [lo, hi]; bit 1: no split is closer to 0 than 2^-240)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const double a = __builtin_fabs(o[k]);
-        const bool ok = ((ad.safe >> k) & 1) && a >= 0x1p-240 && a <= 0x1p+299 && __builtin_fabs(lo[k]) <= 0x1p+299 && __builtin_fabs(hi[k]) <= 0x1p+299;
-        if (!pkt_any(want && !ok)) fast |= 1 << k;
+        for (int k = 0; k < 3; ++k) {
+            const double a = __builtin_fabs(o[k]);
+            // an origin coordinate of exactly 0 (a camera on an axis plane) makes the numerator the split itself
+            const bool origin_ok = (a >= 0x1p-240 && a <= 0x1p+299) || (a == 0.0 && (splits & 2));
+            const bool ok = ((ad.safe >> k) & 1) && origin_ok && __builtin_fabs(lo[k]) <= 0x1p+299 && __builtin_fabs(hi[k]) <= 0x1p+299;
+            if (!pkt_any(want && !ok)) fast |= 1 << k;
+        }
     }
     ps.fast = fast;
     ps.neg[0] = __builtin_amdgcn_ballot_w64(r.dx < 0.0); ps.neg[1] = __builtin_amdgcn_ballot_w64(r.dy < 0.0); ps.neg[2] = __builtin_amdgcn_ballot_w64(r.dz < 0.0);
@@ -162,31 +162,47 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
     const double split = unode_split(nd);
     const int32_t lower = node + 1, upper = nd.count;
     const double num = split - o;
-    double plane;
-    if constexpr (WORLD) {
-        // quotient <= 0 whatever its magnitude — zero numerator, or numerator and direction of opposite sign: "near only" (kdtree3d.pyx:686)
-        const lanemask toward = pkt_mask(num != 0.0) & ~(pkt_mask(num < 0.0) ^ m_neg);
-        plane = 0.0;
-        if (m_in & toward) { plane = num / d; PKT_COUNT(PKC_WDIVS, 1) }
-    } else {
-        const double q0 = num * y;
-        const double rem = __builtin_fma(-d, q0, num);
-        plane = __builtin_fma(rem, y, q0);
-        if (__builtin_expect(!fast, 0)) {
-            const bool exact = div_operand_safe(d) && (div_operand_safe(num) || num == 0.0);
-            if (pkt_any(!exact)) { if (!exact) plane = num / d; }
-            PKT_COUNT(PKC_MSLOW, 1)
-        }
+    // the reference's quotient (split - origin) / direction, kdtree3d.pyx:672 (exact_div, dev_common.hpp)
+    const double q0 = num * y;
+    const double rem = __builtin_fma(-d, q0, num);
+    double plane = __builtin_fma(rem, y, q0);
+    if (__builtin_expect(!fast, 0)) {
+        const bool exact = div_operand_safe(d) && (div_operand_safe(num) || num == 0.0);
+        if (pkt_any(!exact)) { if (!exact) plane = num / d; }
+        PKT_COUNT(PKC_MSLOW, 1)
     }
     // kdtree3d.pyx:661-700 in one form. A ray parallel to the plane (d == 0) has quotient +-inf or NaN: "near only" below, and its near
     // child is `origin < split ? lower : upper` (:664) — which is what below_split (:675) gives when d < 0 is false.
-    const lanemask m_lower_near = pkt_mask(o < split) | (pkt_mask(o == split) & m_neg);
+    const lanemask m_lt = pkt_mask(o < split), m_eq = pkt_mask(o == split);
     // crosses the plane inside its range: not (:686) "plane > max_range or plane <= 0" (a lane without a range: plane <= -inf fails)
     const lanemask m_cross = pkt_mask(plane > 0.0) & pkt_mask(plane <= tmax);
     lanemask m_far = m_cross & pkt_mask(plane < tmin);                     // (:690) far child only
+    if (__builtin_expect(m_eq == 0ULL && (m_lt == 0ULL || m_lt == ~0ULL), 1)) {
+        // Every lane has the same near child — rays from one origin that does not lie on the plane: the visit order is a scalar fact.
+        const bool lower_near = m_lt != 0ULL;
+        const int32_t near_id = lower_near ? lower : upper, far_id = lower_near ? upper : lower;
+        if constexpr (WORLD) {
+            // world_step's cull: the near subtree holds wide primitives only and ends before the nearest wide answer — straight to the far child
+            if ((nd.type >> (lower_near ? 2 : 3)) & 1) {
+                const lanemask m_cull = m_cross & ~m_far & pkt_mask(plane < t_cull);
+                tmin = pkt_lanes(m_cull) ? plane : tmin;
+                m_far |= m_cull;
+            }
+        }
+        const lanemask m_want_near = m_in & ~m_far;
+        if (m_want_near) {
+            if (m_cross) { pstack_push(st, sp, far_id, pkt_lanes(m_cross) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
+            const double keep = pkt_lanes(m_cross) ? plane : tmax;         // (near-side lanes that cross go on to the plane, the others keep their range)
+            tmax = pkt_lanes(m_want_near) ? keep : PKT_EMPTY;
+            return near_id;
+        }
+        tmax = pkt_lanes(m_cross) ? tmax : PKT_EMPTY;                      // nobody enters the near child: the crossing lanes all enter the far one only
+        return far_id;
+    }
+    // The general form: lanes may differ in their near child (an origin exactly on the plane, rays with origins of their own).
+    const lanemask m_lower_near = m_lt | (m_eq & m_neg);
     lanemask m_both = m_cross & ~m_far;
     if constexpr (WORLD) {
-        // world_step's cull: the near subtree holds wide primitives only and ends before the nearest wide answer — straight to the far child
         const int32_t cull_bits = nd.type >> 2;
         const lanemask m_cullable = m_both & (((cull_bits & 1) ? m_lower_near : 0ULL) | ((cull_bits & 2) ? ~m_lower_near : 0ULL));
         if (m_cullable) {
@@ -196,9 +212,9 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
         }
     }
     lanemask b_up = m_both & ~m_lower_near;
-    if (__builtin_expect(b_up != 0ULL && (m_both & m_lower_near) != 0ULL, 0)) {
-        // both-crossing lanes disagree on the near child (the common origin lies exactly on the plane): the upper-first lanes come back
-        // to this node alone, after the others are through with it
+    if (b_up != 0ULL && (m_both & m_lower_near) != 0ULL) {
+        // both-crossing lanes disagree on the near child: the upper-first lanes come back to this node alone, after the others are
+        // through with it
         pstack_push(st, sp, node, pkt_lanes(b_up) ? tmax : PKT_EMPTY);
         ++sp;
         tmax = pkt_lanes(b_up) ? PKT_EMPTY : tmax;
@@ -244,10 +260,74 @@ __device__ __forceinline__ bool packet_pop(const Stack &st, int32_t &sp, int32_t
     return false;
 }
 
+// Camera-relative leaf records (k_camera_relative, dev_render.hpp): the rays of a pinhole pass leave ONE point, so stage 1 of the triangle
+// test — vertices minus origin, mesh.pyx:633-643 — gives the same nine numbers for every ray of the pass. They are computed once per
+// (mesh instance, leaf item) before the pass and the walk reads them instead of the vertices: 27 of the ~75 vector instructions of a
+// missed triangle go, the load stays a scalar one. A walk uses them only after it has compared its rays' origin with the one the
+// records were made for (RelInfo::o), bit for bit.
+struct RelInfo {
+    long long offset;          // first record of the instance in DScene::rel (three float4 per leaf item), -1: none
+    double o[3];               // the ray origin in the instance's space they are relative to
+};
+
+struct RelJob { int32_t prim, mesh; long long offset, n_items; };
+
+// Fills the camera-relative records of one mesh instance per blockIdx.y. The origin is formed exactly as the rays' own: camera_ray's
+// expressions for the pinhole in world space (dev_render.hpp), then Point3D.transform into the instance's space (to_local; for an affine
+// matrix its w is exactly 1 and x * (1.0 / 1.0) == x, so it agrees with to_local_uniform's shortcut) — and the walk re-checks it anyway.
+__global__ void k_camera_relative(DScene sc, rsx_camera cam, const RelJob *jobs, float4 *rel, RelInfo *info) {
+    const RelJob job = jobs[blockIdx.y];
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const double *m = cam.to_root;
+    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+    wq = 1.0 / wq;
+    Ray r;
+    r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+    r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+    r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+    r.dx = r.dy = 0.0; r.dz = 1.0; r.maxd = 0.0;
+    const Ray l = to_local(sc.prims[job.prim], r);
+    if (i == 0) { info[job.prim].offset = job.offset; info[job.prim].o[0] = l.ox; info[job.prim].o[1] = l.oy; info[job.prim].o[2] = l.oz; }
+    if (i >= job.n_items) return;
+    const float4 *rec = sc.meshes[job.mesh].leaf + 4 * (size_t)i;
+    const TriVerts t = tri_translate(l.ox, l.oy, l.oz, rec[0], rec[1], rec[2]);
+    float4 *dst = rel + 3 * (size_t)(job.offset + i);
+    // by component: (x1 x2 x3 id)(y1 y2 y3 id)(z1 z2 z3 id) — the axis permutation of a ray space is then a choice of ROWS
+    const float id = rec[3].x;
+    dst[0] = make_float4(t.x1, t.x2, t.x3, id); dst[1] = make_float4(t.y1, t.y2, t.y3, id); dst[2] = make_float4(t.z1, t.z2, t.z3, id);
+}
+
+// One leaf: `count` camera-relative records (three float4 each, by component: x1 x2 x3 id | y1 y2 y3 id | z1 z2 z3 id) against every ray
+// of the wave, in leaf order, strict `<` (mesh.pyx:520-563). SHARED_AXES: the rays also share the axis permutation (ix, iy, iz
+// wave-uniform): stage 2 of the test is then WHICH ROWS are loaded — no instruction at all; otherwise every lane selects its own.
+template <bool SHARED_AXES>
+__device__ __forceinline__ void packet_leaf_scan(const TriRay &q, int ix, int iy, int iz, const float4 *records, int32_t count, double &distance, int32_t &closest,
+                                                 float &bu, float &bv, float &bw) {
+    const RSX_CONST_AS PodF4 *rec = (const RSX_CONST_AS PodF4 *)(unsigned long long)records;
+    const int r0 = SHARED_AXES ? ix : 0, r1 = SHARED_AXES ? iy : 1, r2 = SHARED_AXES ? iz : 2;
+    float4 a = load_f4_u(rec + r0), b = load_f4_u(rec + r1), c = load_f4_u(rec + r2);
+    for (int32_t k = 0; k < count; ++k) {
+        const int32_t kn = k + 1 < count ? k + 1 : k;
+        const float4 na = load_f4_u(rec + 3 * kn + r0), nb = load_f4_u(rec + 3 * kn + r1), nc = load_f4_u(rec + 3 * kn + r2);
+        TriVerts p;
+        if constexpr (SHARED_AXES) { p.x1 = a.x; p.x2 = a.y; p.x3 = a.z; p.y1 = b.x; p.y2 = b.y; p.y3 = b.z; p.z1 = c.x; p.z2 = c.y; p.z3 = c.z; }
+        else {
+            TriVerts t;
+            t.x1 = a.x; t.x2 = a.y; t.x3 = a.z; t.y1 = b.x; t.y2 = b.y; t.y3 = b.z; t.z1 = c.x; t.z2 = c.y; t.z3 = c.z;
+            p = tri_permute(q.ix, q.iy, q.iz, t);
+        }
+        float ht, hu, hv, hw;
+        if (tri_finish(q.sx, q.sy, q.sz, q.maxd, p, ht, hu, hv, hw) && (double)ht < distance) {
+            distance = (double)ht; closest = __float_as_int(a.w); bu = hu; bv = hv; bw = hw;
+        }
+        a = na; b = nb; c = nc;
+    }
+}
+
 // MeshData.trace (mesh.pyx:506-563) for the packet: `m` and the ray space are wave-uniform, `want` = the lane's ray passed the
 // BoundPrimitive gate. Leaves of any size are walked the same way: every record comes in once over the scalar data path (the next one
 // while this one is tested) and every lane with a range tests it — in leaf order, strict `<`: the reference's own loop.
-__device__ __forceinline__ bool mesh_trace_packet(bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work PKT_ARG) {
+__device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work PKT_ARG) {
     const rsx_kdnode *nodes = m->nodes;
     const float4 *leaf = m->leaf;
     const AxisDiv ad = axis_div(r);
@@ -258,12 +338,30 @@ __device__ __forceinline__ bool mesh_trace_packet(bool want, UMesh m, const Ray 
         const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
                      rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
         if (!(want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax))) tmax = PKT_EMPTY;       // kdtree3d.pyx:589-607
-        ps = packet_space(r, ad, lo, hi, want);
-        if (!m->splits_bounded) ps.fast = 0;
+        ps = packet_space(r, ad, lo, hi, want, m->splits_bounded);
     }
     if (!pkt_any(tmax != PKT_EMPTY)) return false;
     PKT_COUNT(PKC_MVISITS, 1)
     const TriRay q = tri_ray(r);
+    // camera-relative records of this instance, if they were made for exactly these rays' origin; and do the rays share their dominant
+    // axis and winding (rays through one pixel nearly always do)?
+    bool relative = false, shared_axes = false;
+    const float4 *rel = nullptr;
+    int ax = 0, ay = 0, az = 0;
+    if (sc->rel_info) {
+        const RSX_CONST_AS RelInfo *ri = (const RSX_CONST_AS RelInfo *)(unsigned long long)(sc->rel_info + prim);
+        const long long off = ri->offset;
+        if (off >= 0) {
+            const double fx = ri->o[0], fy = ri->o[1], fz = ri->o[2];
+            relative = !pkt_any(want && (r.ox != fx || r.oy != fy || r.oz != fz));
+            rel = sc->rel + 3 * (size_t)off;
+            const int first = __ffsll((long long)__builtin_amdgcn_ballot_w64(want)) - 1;
+            const int axes = q.ix | (q.iy << 2) | (q.iz << 4);
+            const int faxes = __builtin_amdgcn_readlane(axes, first);
+            shared_axes = !pkt_any(want && axes != faxes);
+            ax = faxes & 3; ay = (faxes >> 2) & 3; az = (faxes >> 4) & 3;
+        }
+    }
     bool hit = false;
     int32_t node = 0, sp = 0;
     for (;;) {
@@ -283,19 +381,26 @@ __device__ __forceinline__ bool mesh_trace_packet(bool want, UMesh m, const Ray 
             double distance = r.maxd < tmax ? r.maxd : tmax;                   // (no range: -inf, nothing is accepted)
             int32_t closest = -1;
             float bu = 0, bv = 0, bw = 0;
-            const RSX_CONST_AS PodF4 *rec = (const RSX_CONST_AS PodF4 *)(unsigned long long)(leaf + 4 * (size_t)nd.lo);
-            float4 a = load_f4_u(rec), b = load_f4_u(rec + 1), c = load_f4_u(rec + 2);
-            int32_t tri = __float_as_int(rec[3].x);
             work += (uint32_t)count;
             PKT_COUNT(PKC_MLEAVES, 1)
             PKT_COUNT(PKC_TRIS, count)
-            for (int32_t k = 0; k < count; ++k) {
-                const int32_t kn = k + 1 < count ? k + 1 : k;
-                const float4 na = load_f4_u(rec + 4 * kn), nb = load_f4_u(rec + 4 * kn + 1), nc = load_f4_u(rec + 4 * kn + 2);
-                const int32_t ntri = __float_as_int(rec[4 * kn + 3].x);
-                float ht, hu, hv, hw;
-                if (tri_test(q, a, b, c, ht, hu, hv, hw) && (double)ht < distance) { distance = (double)ht; closest = tri; bu = hu; bv = hv; bw = hw; }
-                a = na; b = nb; c = nc; tri = ntri;
+            if (relative) {
+                const float4 *records = rel + 3 * (size_t)nd.lo;
+                if (shared_axes) packet_leaf_scan<true>(q, ax, ay, az, records, count, distance, closest, bu, bv, bw);
+                else packet_leaf_scan<false>(q, 0, 0, 0, records, count, distance, closest, bu, bv, bw);
+            } else {
+                // (no camera-relative records for these rays: the whole test per ray)
+                const RSX_CONST_AS PodF4 *rec = (const RSX_CONST_AS PodF4 *)(unsigned long long)(leaf + 4 * (size_t)nd.lo);
+                float4 a = load_f4_u(rec), b = load_f4_u(rec + 1), c = load_f4_u(rec + 2);
+                int32_t tri = __float_as_int(rec[3].x);
+                for (int32_t k = 0; k < count; ++k) {
+                    const int32_t kn = k + 1 < count ? k + 1 : k;
+                    const float4 na = load_f4_u(rec + 4 * kn), nb = load_f4_u(rec + 4 * kn + 1), nc = load_f4_u(rec + 4 * kn + 2);
+                    const int32_t ntri = __float_as_int(rec[4 * kn + 3].x);
+                    float ht, hu, hv, hw;
+                    if (tri_test(q, a, b, c, ht, hu, hv, hw) && (double)ht < distance) { distance = (double)ht; closest = tri; bu = hu; bv = hv; bw = hw; }
+                    a = na; b = nb; c = nc; tri = ntri;
+                }
             }
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; }
         }
@@ -307,28 +412,29 @@ __device__ __forceinline__ bool mesh_trace_packet(bool want, UMesh m, const Ray 
 
 // World.hit for the packet (kdtree.pyx:73-122, boundprimitive.pyx:42-51): world_trace_wave<false, false, 1, true> with the walk above.
 // Leaf items are wave-uniform by construction (the wave is in ONE leaf); wide primitives, leaf tags and the cull as there.
-__device__ __forceinline__ bool world_trace_packet(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work PKT_ARG) {
+__device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work PKT_ARG) {
     best.prim = -1;
     double tmin = 0, tmax = 0;
-    const double rx = 1.0 / r.dx, ry = 1.0 / r.dy, rz = 1.0 / r.dz;
-    const bool enters = valid && aabb_rcp(sc.wlower, sc.wupper, r, rx, ry, rz, tmin, tmax);
+    // 1.0 / d per axis (BoundingBox3D.intersect, boundingbox.pyx:180-245) and the branch steps' quotients both come from the refined
+    // reciprocals: exact_div(1, d) and exact_div(split - o, d) are the correctly rounded quotients (dev_common.hpp)
+    const AxisDiv ad = axis_div(r);
+    const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
+                 rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
+    const double wlo[3] = {sc->wlower[0], sc->wlower[1], sc->wlower[2]}, whi[3] = {sc->wupper[0], sc->wupper[1], sc->wupper[2]};
+    const bool enters = valid && aabb_rcp(wlo, whi, r, rx, ry, rz, tmin, tmax);
     if (!enters) tmax = PKT_EMPTY;
     if (!pkt_any(enters)) return false;
-    AxisDiv ad;
-    ad.yx = ad.yy = ad.yz = 0.0; ad.safe = 0;
-    PacketSpace ps;
-    ps.fast = 0;
-    ps.neg[0] = __builtin_amdgcn_ballot_w64(r.dx < 0.0); ps.neg[1] = __builtin_amdgcn_ballot_w64(r.dy < 0.0); ps.neg[2] = __builtin_amdgcn_ballot_w64(r.dz < 0.0);
-    const rsx_kdnode *wnodes = sc.wnodes;
+    const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);
+    const rsx_kdnode *wnodes = sc->wnodes;
     WideSet8 wide;
 #pragma unroll
     for (int j = 0; j < 8; ++j) wide.t[j] = -1.0;
     wide.faces[0] = wide.faces[1] = 0;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        if (sc.wide[j] >= 0) {
+        if (sc->wide[j] >= 0) {
             int32_t f = 0;
-            analytic_first_root(sc, uniform_prim(sc.prims_uniform, sc.wide[j]), sc.wide[j], enters, r, rx, ry, rz, wide.t[j], f);
+            analytic_first_root(sc->prims, uniform_prim(sc->prims_uniform, sc->wide[j]), sc->wide[j], enters, r, rx, ry, rz, wide.t[j], f);
             wide.faces[0] |= (uint32_t)f << (8 * j);
         }
     }
@@ -362,14 +468,14 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, const DScene &sc,
                     wide_lookup<2>(wide, slot, t, faces);
                     if (t >= 0.0 && t <= distance) {
                         distance = t;
-                        best.prim = slot == 1 ? sc.wide[1] : sc.wide[0]; best.t = t; best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
+                        best.prim = slot == 1 ? sc->wide[1] : sc->wide[0]; best.t = t; best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
                         best.u = best.v = best.w = 0.0f;
                     }
                 }
             }
         } else {
             const int32_t count = nd.count;
-            const RSX_CONST_AS int32_t *items = (const RSX_CONST_AS int32_t *)(unsigned long long)(sc.witems + nd.lo);
+            const RSX_CONST_AS int32_t *items = (const RSX_CONST_AS int32_t *)(unsigned long long)(sc->witems + nd.lo);
             for (int32_t k = 0; k < count; ++k) {
                 const int32_t idx = items[k];                                  // (scalar load)
                 work += 4;
@@ -377,13 +483,13 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, const DScene &sc,
                 Hit cand;
                 cand.prim = -1;
                 const bool in = tmax != PKT_EMPTY;
-                if (idx == sc.wide[0] || idx == sc.wide[1]) {                  // answered before the traversal began
+                if (idx == sc->wide[0] || idx == sc->wide[1]) {                  // answered before the traversal began
                     double t;
                     int32_t faces;
-                    wide_lookup<2>(wide, idx == sc.wide[0] ? 0 : 1, t, faces);
+                    wide_lookup<2>(wide, idx == sc->wide[0] ? 0 : 1, t, faces);
                     if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                 } else {
-                    const UPrim up = uniform_prim(sc.prims_uniform, idx);
+                    const UPrim up = uniform_prim(sc->prims_uniform, idx);
                     const int32_t type = up->type;
                     if (type == RSX_PRIM_MESH) {
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
@@ -394,18 +500,17 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, const DScene &sc,
 #else
                         if (pkt_any(gate)) {
 #endif
-                            Ray l = r;
-                            if (gate) l = to_local_uniform(up, r);
-                            const UMesh um = (UMesh)(unsigned long long)(sc.meshes + up->mesh);
+                            const Ray l = to_local_uniform(up, r);     // (every lane: the lanes of one space then share one origin)
+                            const UMesh um = (UMesh)(unsigned long long)(sc->meshes + up->mesh);
                             MeshHit mh;
-                            if (mesh_trace_packet(gate, um, l, mesh_stack, mh, work PKT_PASS)) {
+                            if (mesh_trace_packet(sc, idx, gate, um, l, mesh_stack, mh, work PKT_PASS)) {
                                 cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                             }
                         }
                     } else {                                                   // sphere / box / cylinder: Primitive.hit, first root
                         double t;
                         int32_t faces;
-                        analytic_first_root(sc, up, idx, in, r, rx, ry, rz, t, faces);
+                        analytic_first_root(sc->prims, up, idx, in, r, rx, ry, rz, t, faces);
                         if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                     }
                 }

@@ -183,6 +183,9 @@ __device__ __forceinline__ void combine_samples(double mx, double vx, int nx, do
 // it costs: the recurrence (34 instructions per sample and bin) moves into a kernel that is already bound by instruction issue —
 // measured 41.9 ms against 34.9 + 5.8 = 40.8 ms for the two kernels, so the form is opt-in (RSX_FUSE=1, rsx_device.hip).
 #define FUSE_UNITS 4
+#ifndef TICKET_BATCH
+#define TICKET_BATCH 4
+#endif
 struct FuseParams {
     Sample *ring;                       // [n_waves][FUSE_UNITS * WAVE]
     const double *tables;               // [n_tables, bins]
@@ -190,6 +193,7 @@ struct FuseParams {
     double sensitivity;
     int32_t n_tables, bins, power, ny, frame_bins, slice_offset;
     int32_t lds_bytes, tables_in_lds;   // per-wave LDS region size; 1: the spectral tables fit behind the staged records
+    const double *consts;               // [i] = {(double)i, refine_rcp(i)} (k_fill_acc_consts)
 };
 
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
@@ -203,7 +207,7 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
     const int spp = q->spp, bins = fz.bins, ppu = WAVE / spp;             // pixels per unit
     const double *l_a = reinterpret_cast<const double *>(smem + lds_base), *l_w = l_a + FUSE_UNITS * WAVE;
     const int32_t *l_tab = reinterpret_cast<const int32_t *>(l_w + FUSE_UNITS * WAVE);
-    const double *l_rcp = reinterpret_cast<const double *>(l_tab + FUSE_UNITS * WAVE), *l_tables = l_rcp + (spp + 2);
+    const double *l_tables = reinterpret_cast<const double *>(l_tab + FUSE_UNITS * WAVE) + (spp + 2);
     const double scale = fz.power ? fz.sensitivity : 1.0;                 // x * 1.0 is x, bit for bit: one multiply instead of a branch per sample
     const double *tables = TABLES_IN_LDS ? l_tables : fz.tables;
     const int chains = n_units * ppu * bins;
@@ -221,14 +225,24 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
             x = x * l_w[base + i];
             return x * scale;
         };
-        double m = value(0), v = 0, dm = 1.0;
-        for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step()
-            const double x = value(i);
-            const double dn = dm + 1.0, cc = i == 1 ? 1.0 : dm - 1.0;
+        double m = value(0), v = 0;
+        const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
+        for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step(): divisors over the scalar data path,
+            const double x = value(i);                                    // both quotients by exact_div's shortcut, one wave-level range test per step
+            const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
+            const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
             const double pm = m, pv = v;
-            m = pm + exact_div(x - pm, dn, l_rcp[i + 1], true);
-            v = exact_div(pv * cc + (x - pm) * (x - m), dm, l_rcp[i], true);
-            dm = dn;
+            const double n1 = x - pm;
+            const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
+            const double m1 = pm + q1;
+            const double n2 = pv * cc + n1 * (x - m1);
+            const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
+            const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
+            const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
+                m = pm + exact_div(n1, dn, yn, true);
+                v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
+            } else { m = m1; v = q2; }
         }
         const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
         if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
@@ -254,7 +268,6 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
         const Sample smp = ring[u * WAVE + lane];
         l_a[u * WAVE + lane] = smp.a; l_w[u * WAVE + lane] = smp.weight; l_tab[u * WAVE + lane] = smp.table;
     }
-    for (int d = lane + 1; d < spp + 2; d += WAVE) l_rcp[d] = refine_rcp((double)d);
     if (fz.tables_in_lds) for (int e = lane; e < fz.n_tables * fz.bins; e += WAVE) l_tables[e] = fz.tables[e];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -280,6 +293,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
     // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
     const int my_xcd = xcc_id();
     int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
+    long long batch_next = 0, batch_end = 0;   // (wave-uniform) entries of the current ticket not yet rendered
     for (;;) {
         // Render parameters are re-read from the kernel-argument segment at every use site of the unit loop (the pointer is
         // laundered through an empty asm): hoisted out of the loop, the camera matrix and friends sat in ~30 vector registers
@@ -300,14 +314,20 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             redo_lanes = q->redo_mask[unit];
             redo_unit += (long long)gridDim.x * (WG_THREADS / WAVE);
         } else {
-            while (victim < 8) {
+            // A ticket is TICKET_BATCH consecutive entries of a list: the counters are one address per list, an atomic on a contended
+            // address costs the wave a microsecond, and a pass of 4.2 M units through nine counters was bounded by them alone when the
+            // units were cheap (7.8 ms for ray generation + record store without any traversal). Large passes only: a small pass is
+            // tail-bound and hands its units out one by one.
+            if (batch_next < batch_end) tk = batch_next++;
+            else while (victim < 8) {
                 const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
                 const long long begin = q->seg[list], end = q->seg[list + 1];
+                const unsigned long long take = (long long)q->seg[9] > (long long)RSX_LPT_MAX_UNITS ? (unsigned long long)TICKET_BATCH : 1ULL;
                 unsigned long long mine = 0;
-                if (lane == 0) mine = atomicAdd(ticket + 16 * list, 1ULL);
+                if (lane == 0) mine = atomicAdd(ticket + 16 * list, take);
                 const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
                                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
-                if (got < end) { tk = got; break; }
+                if (got < end) { tk = got; batch_next = got + 1; batch_end = got + (long long)take < end ? got + (long long)take : end; break; }
                 ++victim;
             }
             if (tk < 0) break;
@@ -340,17 +360,20 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         phase_acc[0] = ph2_w0 - ph2_u0;
 #endif
         bool got;
-        if constexpr (PACKET) { static_assert(!CSG && !FUSED, "the packet walk serves the plain primary-ray kernel"); 
+        if constexpr (PACKET) { static_assert(!CSG, "the packet walk serves the plain primary-ray kernel");
+            unsigned long long sc_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();       // (`sc` is the first kernel argument)
+            asm volatile("" : "+s"(sc_bits));
+            const PScene scq = (PScene)sc_bits; 
 #ifdef RSX_PKT_PROF
             uint32_t pkc[PKC_N];
             for (int c = 0; c < PKC_N; ++c) pkc[c] = 0;
             pkc[PKC_UNITS] = 1;
-            got = world_trace_packet(valid, sc, r, st, ms, hit, work, pkc);
+            got = world_trace_packet(valid, scq, r, st, ms, hit, work, pkc);
             if (lane == 0) for (int c = 0; c < PKC_N; ++c) atomicAdd(&g_pkt[c], (unsigned long long)pkc[c]);
 #elif defined(PKT_ABLATE_TRACE)
             got = false; hit.prim = -1;                                    // (timing ablation: ray generation and the record store alone)
 #else
-            got = world_trace_packet(valid, sc, r, st, ms, hit, work);
+            got = world_trace_packet(valid, scq, r, st, ms, hit, work);
 #endif
         }
         else got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
@@ -1226,9 +1249,15 @@ struct AccumParams {
     const int32_t *tail;                // last block of each sample's list; Sample.pad = slots used in it
     long long n_records;                // block ids below this are the samples' own first blocks, above it arena blocks (slot 0 = link)
     double roulette_norm;               // 1 / (1 - extinction_prob)
+    const double *consts;               // [i] = {(double)i, refine_rcp(i)} for i = 0 .. ACC_RCP_TABLE_MAX + 2 (k_fill_acc_consts), or null
     const unsigned int *abort_flags;    // deferred path passes: PathStore::flags of the trace kernel — a pass whose arena ran out (bit 0), that hit the
                                         // segment guard (1) or met too many volumes at a point (2) is left out of the frame and rendered again by the caller
 };
+
+__global__ void k_fill_acc_consts(double *consts, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { consts[2 * i] = (double)i; consts[2 * i + 1] = refine_rcp((double)i); }
+}
 
 // Thread order: bin fastest, then iy, then ix (rect mode) — the order of the x-major frame and of the sample records the trace
 // kernel wrote, so both streams are read and written as contiguous runs. Task-list mode keeps task order.
@@ -1319,7 +1348,34 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     const long long rec0 = p * ap.spp;
     double m = value(s[0], rec0), v = 0;
     double dm = 1.0;                                        // (double)i, advanced by exact additions
+    // The step's divisors, their refined reciprocals and the factor prev_n - 1 depend on the sample index alone — wave-uniform: they come
+    // from a table over the scalar data path (ap.consts) and cost the recurrence no vector instruction. The two quotients are formed by
+    // exact_div's shortcut for the whole wave at once, and ONE wave-level test per step checks that every lane's numerators were in its
+    // range (|n| in [2^-300, 2^300], or +0 whose quotient the shortcut also gets right); a step where some lane's was not — a
+    // denormal-sized difference, a -0 — is redone with exact_div proper. Same bits either way (rsx_selftest_welford against the
+    // reference's states), 35 -> 24 vector instructions per sample and bin.
+    const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)ap.consts;
+    const bool fast_steps = rcp_table && ap.consts != nullptr;
+    auto quotient_ok = [](double n) {
+        const double a = __builtin_fabs(n);
+        return (a >= 0x1p-300 && a <= 0x1p+300) || __double_as_longlong(n) == 0LL;
+    };
     auto step = [&](double x, int i) {
+        if (fast_steps) {
+            const double dm_u = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
+            const double c = i == 1 ? 1.0 : consts[2 * i - 2];
+            const double pm = m, pv = v;
+            const double n1 = x - pm;
+            const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
+            const double m1 = pm + q1;
+            const double n2 = pv * c + n1 * (x - m1);
+            const double q2 = __builtin_fma(__builtin_fma(-dm_u, n2 * ym, n2), ym, n2 * ym);
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(quotient_ok(n1) && quotient_ok(n2))) != 0ULL, 0)) {
+                m = pm + exact_div(n1, dn, yn, true);
+                v = exact_div(pv * c + n1 * (x - m), dm_u, ym, true);
+            } else { m = m1; v = q2; }
+            return;
+        }
         const double dn = dm + 1.0, c = i == 1 ? 1.0 : dm - 1.0;
         const double yn = rcp_table ? acc_rcp[i + 1] : refine_rcp(dn), ym = rcp_table ? acc_rcp[i] : refine_rcp(dm);
         const double pm = m, pv = v;
@@ -1327,13 +1383,27 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
         dm = dn;
     };
+    // ... and the NEXT batch is requested before this one is stepped through: the records are a stream that is read once, from HBM,
+    // and a batch's own arithmetic (0.2 us) does not cover that round trip even with eight waves per SIMD.
     int i = 1;
-    for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
-        Sample sm[ACC_BATCH];
+    if (i + ACC_BATCH <= ap.spp) {
+        Sample cur[ACC_BATCH];
 #pragma unroll
-        for (int j = 0; j < ACC_BATCH; ++j) sm[j] = s[i + j];
+        for (int j = 0; j < ACC_BATCH; ++j) cur[j] = s[i + j];
+        for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
+            Sample nxt[ACC_BATCH];
+            const bool more = i + 2 * ACC_BATCH <= ap.spp;                 // (wave-uniform)
+            if (more) {
 #pragma unroll
-        for (int j = 0; j < ACC_BATCH; ++j) step(value(sm[j], rec0 + i + j), i + j);
+                for (int j = 0; j < ACC_BATCH; ++j) nxt[j] = s[i + ACC_BATCH + j];
+            }
+#pragma unroll
+            for (int j = 0; j < ACC_BATCH; ++j) step(value(cur[j], rec0 + i + j), i + j);
+            if (more) {
+#pragma unroll
+                for (int j = 0; j < ACC_BATCH; ++j) cur[j] = nxt[j];
+            }
+        }
     }
     for (; i < ap.spp; ++i) step(value(s[i], rec0 + i), i);
     if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }

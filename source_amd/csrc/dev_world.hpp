@@ -60,7 +60,7 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
 // Primitive.hit of a wave-uniform sphere / box / cylinder (BoundPrimitive gate included): first root t >= 0 and its (face, axis | type)
 // packed as (a0 + 1) | (a1 + 1) << 4, or t = -1 when the ray misses. A box under a translate-only transform divides by the world ray's
 // own direction components: l.d == r.d wherever a component is non-zero (1 * x + 0 * y + 0 * z), so the gates' 1.0 / d are the box's own.
-__device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, int32_t uidx, bool want, const Ray &r, double rx, double ry, double rz,
+__device__ __forceinline__ void analytic_first_root(const rsx_primitive *prims, UPrim up, int32_t uidx, bool want, const Ray &r, double rx, double ry, double rz,
                                                     double &t, int32_t &faces) {
     t = -1.0; faces = 0;
     const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
@@ -81,7 +81,7 @@ __device__ __forceinline__ void analytic_first_root(const DScene &sc, UPrim up, 
         const double prm[6] = {up->params[0], up->params[1], up->params[2], up->params[3], up->params[4], up->params[5]};
         box_roots_uniform(prm, l, identity, rx, ry, rz, roots);
     } else if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(up->params[0], l, roots);
-    else if (type == RSX_PRIM_CYLINDER) cylinder_roots(sc.prims[uidx], l, roots);
+    else if (type == RSX_PRIM_CYLINDER) cylinder_roots(prims[uidx], l, roots);
     if (roots.n > 0) { t = roots.t[0]; faces = (roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4); }
 }
 
@@ -150,7 +150,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     for (int j = 0; j < WIDE_N; ++j) {
         if (sc.wide[j] >= 0) {                              // (wave-uniform)
             int32_t f = 0;
-            analytic_first_root(sc, uniform_prim(sc.prims_uniform, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
+            analytic_first_root(sc.prims, uniform_prim(sc.prims_uniform, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
             wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
         }
     }
@@ -380,7 +380,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 {                                                                   // sphere / box / cylinder: Primitive.hit, first root
                     double t;
                     int32_t faces;
-                    analytic_first_root(sc, up, uidx, gate, r, rx, ry, rz, t, faces);
+                    analytic_first_root(sc.prims, up, uidx, gate, r, rx, ry, rz, t, faces);
                     if (t >= 0.0) { cand.prim = idx; cand.t = t; cand.a0 = (faces & 15) - 1; cand.a1 = (faces >> 4) - 1; cand.u = cand.v = cand.w = 0.0f; }
                 }
             }

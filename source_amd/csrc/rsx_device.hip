@@ -208,6 +208,7 @@ struct rsx_ctx {
     std::vector<int32_t> deferred_failed;          // ... of which these must be rendered again (term arena ran out, too many volumes at a point)
     unsigned int deferred_error_flags = 0;
     unsigned long long deferred_rays = 0;
+    double *acc_consts = nullptr;                  // {(double)i, refine_rcp(i)} for the accumulate kernel's steps (k_fill_acc_consts)
 };
 
 // the check a deferred path pass still owes: wait for its merge, read its flags and ray count
@@ -236,12 +237,19 @@ static int pool_get(rsx_ctx *ctx, int slot, size_t bytes, void **out) {
     return RSX_OK;
 }
 
+struct RelJobHost { int32_t prim, mesh; long long offset, n_items; };
 struct rsx_scene {
     rsx_ctx *ctx;
     DScene d;
     std::vector<void *> allocs;
     int32_t n_world;
     bool has_csg;
+    // camera-relative leaf records of the world's mesh instances (dev_packet.hpp), made on demand for the camera of a packet pass
+    std::vector<RelJobHost> rel_jobs;
+    long long rel_records = 0;
+    void *rel = nullptr, *rel_info = nullptr, *rel_jobs_dev = nullptr;
+    double rel_camera[16];
+    bool rel_valid = false, rel_refused = false;
 };
 
 extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
@@ -295,6 +303,13 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
     }
+    {
+        const int n = ACC_RCP_TABLE_MAX + 3;
+        HIP_TRY(hipMalloc(&ctx->acc_consts, (size_t)n * 16));
+        hipLaunchKernelGGL(k_fill_acc_consts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->acc_consts, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
     guard.c = nullptr;
     *out = ctx;
     return RSX_OK;
@@ -312,6 +327,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
         if (ln->merged) (void)hipEventDestroy(ln->merged);
     }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
+    if (ctx->acc_consts) (void)hipFree(ctx->acc_consts);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev2}) if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ring) (void)hipEventDestroy(e);
@@ -476,6 +492,19 @@ int upload(rsx_scene *sc, const T *host, size_t count, const T **dev) {
     return RSX_OK;
 }
 
+// bit 0: every split of the tree lies inside its bounds; bit 1: no split is closer to zero than 2^-240 without being zero
+// (what packet_space, dev_packet.hpp, needs to know about the numerators split - origin)
+int splits_summary(const rsx_kdtree &kd) {
+    int out = 3;
+    for (int32_t k = 0; k < kd.n_nodes; ++k) {
+        const rsx_kdnode &nd = kd.nodes[k];
+        if (nd.type < 0 || nd.type > 2) continue;
+        if (!(nd.u.split >= kd.lower[nd.type] && nd.u.split <= kd.upper[nd.type])) out &= ~1;
+        if (nd.u.split != 0.0 && std::fabs(nd.u.split) < 0x1p-240) out &= ~2;
+    }
+    return out;
+}
+
 int tree_depth(const rsx_kdtree &kd) {
     // deepest chain of branch nodes = stack levels a traversal can need; iterative over the pre-order layout
     if (kd.n_nodes <= 0) return 0;
@@ -515,6 +544,7 @@ int validate_tree(const rsx_kdtree &kd, int32_t n_ids, const char *what) {
 }  // namespace
 
 extern "C" void rsx_scene_free(rsx_scene *scene) {
+    if (scene) { if (scene->rel) (void)hipFree(scene->rel); if (scene->rel_info) (void)hipFree(scene->rel_info); if (scene->rel_jobs_dev) (void)hipFree(scene->rel_jobs_dev); }
     if (!scene) return;
     (void)hipSetDevice(scene->ctx->device);
     (void)hipStreamSynchronize(scene->ctx->stream);
@@ -777,14 +807,21 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         dm.smoothing = m.smoothing; dm.closed = m.closed; dm.n_tris = m.n_triangles;
         // the packet walk tests the range of a quotient's numerator once per walk from the tree's bounds (packet_space, dev_packet.hpp):
         // sound while every split lies inside them — true of any tree the builder makes; a tree read from a file is checked, not trusted
-        dm.splits_bounded = 1;
-        for (int32_t k = 0; k < m.kd.n_nodes; ++k) {
-            const rsx_kdnode &nd = m.kd.nodes[k];
-            if (nd.type >= 0 && nd.type <= 2 && !(nd.u.split >= m.kd.lower[nd.type] && nd.u.split <= m.kd.upper[nd.type])) { dm.splits_bounded = 0; break; }
-        }
+        dm.splits_bounded = splits_summary(m.kd);
         d.mdepth = std::max(d.mdepth, tree_depth(m.kd) + 1 + 3);
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
+    d.rel = nullptr; d.rel_info = nullptr;
+    d.wsplits_bounded = splits_summary(desc->world_kd); d.pad_w = 0;
+    for (int32_t i = 0; i < desc->n_world; ++i) {
+        const rsx_primitive &p = desc->primitives[i];
+        if (p.type != RSX_PRIM_MESH) continue;
+        RelJobHost job;
+        job.prim = i; job.mesh = p.mesh; job.offset = sc->rel_records; job.n_items = desc->meshes[p.mesh].kd.n_items;
+        if (job.n_items <= 0) continue;
+        sc->rel_jobs.push_back(job);
+        sc->rel_records += job.n_items;
+    }
     if (any_fast) d.mdepth = std::max(d.mdepth, fast_levels);           // csg_fast_hit keeps the leaf roots in the mesh-stack LDS levels
     d.wlds = std::min(d.wdepth, RSX_WORLD_LDS_LEVELS);
     d.mlds = std::min(d.mdepth, std::max(RSX_MESH_LDS_LEVELS, fast_levels));
@@ -1043,6 +1080,43 @@ extern "C" int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *poi
 
 namespace {
 
+// Camera-relative leaf records for a packet pass from `cam` (dev_packet.hpp): (re)made when the camera changed, on `stream`, which the
+// pass itself is queued on next. 48 bytes per (mesh instance, leaf item); scenes that would need more than RSX_REL_MAX_GB (default 64)
+// go without — the walk then takes the vertices and translates per ray.
+int ensure_camera_relative(rsx_scene *scene, const rsx_camera &cam, hipStream_t stream) {
+    static const bool enabled = [] { const char *e = std::getenv("RSX_CAMERA_RELATIVE"); return !e || std::atoi(e) != 0; }();
+    static const double max_gb = [] { const char *e = std::getenv("RSX_REL_MAX_GB"); return e ? std::atof(e) : 64.0; }();
+    if (!enabled || scene->rel_jobs.empty() || scene->rel_refused) { scene->d.rel = nullptr; scene->d.rel_info = nullptr; return RSX_OK; }
+    rsx_ctx *ctx = scene->ctx;
+    if (!scene->rel) {
+        const size_t bytes = (size_t)scene->rel_records * 48;
+        if ((double)bytes > max_gb * 1073741824.0 || scene->rel_jobs.size() > 65535) { scene->rel_refused = true; return RSX_OK; }
+        if (hipMalloc(&scene->rel, bytes) != hipSuccess) { (void)hipGetLastError(); scene->rel = nullptr; scene->rel_refused = true; return RSX_OK; }
+        HIP_TRY(hipMalloc(&scene->rel_info, (size_t)scene->d.n_prims * sizeof(RelInfo)));
+        HIP_TRY(hipMalloc(&scene->rel_jobs_dev, scene->rel_jobs.size() * sizeof(RelJob)));
+        static_assert(sizeof(RelJobHost) == sizeof(RelJob), "same layout");
+        HIP_TRY(hipMemcpy(scene->rel_jobs_dev, scene->rel_jobs.data(), scene->rel_jobs.size() * sizeof(RelJob), hipMemcpyHostToDevice));
+        std::vector<RelInfo> none((size_t)scene->d.n_prims);
+        for (RelInfo &ri : none) { ri.offset = -1; ri.o[0] = ri.o[1] = ri.o[2] = 0.0; }
+        HIP_TRY(hipMemcpy(scene->rel_info, none.data(), none.size() * sizeof(RelInfo), hipMemcpyHostToDevice));
+        scene->rel_valid = false;
+    }
+    scene->d.rel = static_cast<const float4 *>(scene->rel);
+    scene->d.rel_info = static_cast<const RelInfo *>(scene->rel_info);
+    if (scene->rel_valid && std::memcmp(scene->rel_camera, cam.to_root, sizeof(scene->rel_camera)) == 0) return RSX_OK;
+    // passes in flight on other streams may still read the records of the previous camera
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    long long most = 0;
+    for (const RelJobHost &j : scene->rel_jobs) most = std::max(most, j.n_items);
+    hipLaunchKernelGGL(k_camera_relative, dim3((unsigned)((most + 255) / 256), (unsigned)scene->rel_jobs.size()), dim3(256), 0, stream, scene->d, cam,
+                       static_cast<const RelJob *>(scene->rel_jobs_dev), static_cast<float4 *>(scene->rel), static_cast<RelInfo *>(scene->rel_info));
+    HIP_TRY(hipGetLastError());
+    std::memcpy(scene->rel_camera, cam.to_root, sizeof(scene->rel_camera));
+    scene->rel_valid = true;
+    return RSX_OK;
+}
+
 // shared body of rsx_render_pinhole / rsx_render_pinhole_frame
 int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double *h_var, double *fmean, double *fvar, int32_t *fn,
            int32_t frame_bins, int32_t slice_offset, uint64_t *ray_count, const double *h_xyz = nullptr, double delta_wavelength = 0.0) {
@@ -1167,13 +1241,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     };
     // Fused form (dev_render.hpp, "Welford in the trace kernel"): a pass that runs alone on the context stream, merges into a frame,
     // has closed-form materials only and whole pixels per 64-ray unit keeps its sample records in per-wave rings
-    // — opt-in (RSX_FUSE=1): measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. The
+    // — round 2, per-lane walk: measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. That
     // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
     // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
     static const int packet_min_spp = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : RSX_PACKET_MIN_SPP; }();   // 0: never
-    static const bool fuse_enabled = [] { const char *e = std::getenv("RSX_FUSE"); return e && std::atoi(e) != 0; }();
-    const size_t wave_lds = (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
+    static const int fuse_env = [] { const char *e = std::getenv("RSX_FUSE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+    // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
+    const bool use_packet = !has_vol && !scene->has_csg && packet_min_spp > 0 && desc->spp >= packet_min_spp && !ctx->unit_times;
+    const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
     const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
+    // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
+    // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
+    const bool fuse_enabled = fuse_env < 0 ? use_packet : fuse_env != 0;
     const bool fused = fuse_enabled && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
                        !ctx->unit_times && wave_lds >= fuse_fixed;
     if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
@@ -1306,8 +1385,17 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
     FuseParams fz;
     std::memset(&fz, 0, sizeof(fz));
+    // the packet kernel's grid: its stacks are smaller (one range per lane and level, no leaf staging), four waves per SIMD fit the
+    // LDS — and the registers
+    const size_t plds = (size_t)WG_WAVES * packet_lds_bytes(scene->d.wdepth, scene->d.mdepth);
+    dim3 pgrid = l.grid;
+    if (use_packet && !pipelined) {
+        const long long per_cu = std::min<long long>(RSX_MAX_WG_PER_CU, (long long)((160 * 1024) / std::max<size_t>(plds, 1)));
+        const long long needed = ((long long)S + WG_THREADS - 1) / WG_THREADS;
+        pgrid = dim3((unsigned)std::max<long long>(1, std::min<long long>((long long)ctx->n_cus * per_cu, needed)));
+    }
     if (fused) {
-        const size_t n_waves = (size_t)l.grid.x * WG_WAVES;
+        const size_t n_waves = (size_t)(use_packet ? pgrid.x : l.grid.x) * WG_WAVES;
         if ((rc = lane_buffer(lane.ring, lane.ring_bytes, n_waves * FUSE_UNITS * WAVE * sizeof(Sample)))) return rc;
         fz.ring = static_cast<Sample *>(lane.ring);
         fz.tables = static_cast<const double *>(d_tab);
@@ -1316,6 +1404,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         fz.n_tables = desc->n_tables; fz.bins = desc->bins; fz.power = desc->power; fz.ny = desc->camera.ny;
         fz.frame_bins = frame_bins; fz.slice_offset = slice_offset;
         fz.lds_bytes = (int32_t)wave_lds;
+        fz.consts = ctx->acc_consts;
         fz.tables_in_lds = fuse_fixed + (size_t)std::max(1, desc->n_tables) * B * 8 <= wave_lds ? 1 : 0;
     }
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
@@ -1387,6 +1476,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
         hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
+    else if (use_packet) {
+        if ((rc = ensure_camera_relative(scene, desc->camera, lane.stream))) return rc;
+        const void *kernel = fused ? reinterpret_cast<const void *>(k_render_trace<false, 0, 1, true, true>) : reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>);
+        Sample *records = fused ? nullptr : static_cast<Sample *>(lane.samples);
+        HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+        void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&records, (void *)&lane.ticket, (void *)&fz};
+        HIP_TRY(hipLaunchKernel(kernel, pgrid, dim3(WG_THREADS), args, plds, lane.stream));
+    }
     else if (fused) {
         if (desc->spp > RSX_COHERENT_MIN_SPP) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
@@ -1395,18 +1492,6 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, RSX_STAGE_MIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
             hipLaunchKernelGGL((k_render_trace<false, 0, RSX_STAGE_MIN, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
         }
-    }
-    else if (packet_min_spp > 0 && desc->spp >= packet_min_spp && !ctx->unit_times) {   // few pixels per unit: the wave walks the trees as one packet
-        // its stacks are smaller (one range per lane and level, no leaf staging): four waves per SIMD fit the LDS — and the registers
-        const size_t plds = (size_t)WG_WAVES * packet_lds_bytes(scene->d.wdepth, scene->d.mdepth);
-        dim3 pgrid = l.grid;
-        if (!pipelined) {
-            const long long per_cu = std::min<long long>(RSX_MAX_WG_PER_CU, (long long)((160 * 1024) / std::max<size_t>(plds, 1)));
-            const long long needed = ((long long)S + WG_THREADS - 1) / WG_THREADS;
-            pgrid = dim3((unsigned)std::max<long long>(1, std::min<long long>((long long)ctx->n_cus * per_cu, needed)));
-        }
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
-        hipLaunchKernelGGL((k_render_trace<false, 0, 1, false, true>), pgrid, dim3(WG_THREADS), plds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     }
     else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
@@ -1442,6 +1527,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.n_records = (long long)S;
     ap.roulette_norm = 1 / (1 - desc->ray_extinction_prob);      // ray.pyx:388
     ap.abort_flags = deferred ? lane.overflow : nullptr;
+    ap.consts = ctx->acc_consts;
     lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
@@ -1653,6 +1739,7 @@ extern "C" int rsx_selftest_welford(rsx_ctx *ctx, int64_t n_chains, int32_t spp,
     std::memset(&ap, 0, sizeof(ap));
     ap.samples = ds.as<Sample>(); ap.tables = one.as<double>(); ap.n_tasks = n_chains;
     ap.rect[0] = 0; ap.rect[1] = 0; ap.rect[2] = 1; ap.rect[3] = (int32_t)n_chains;      // one column of n_chains pixels: slot order = task order
+    ap.consts = ctx->acc_consts;
     ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.n_tables = 1; ap.tables_in_lds = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
     // both instantiations the render path uses: the lean one (few samples per pixel) and the staged one (LDS tables, batched loads)
     for (int staged = 0; staged < 2; ++staged) {
