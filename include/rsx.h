@@ -356,6 +356,17 @@ int rsx_allgather_frame(rsx_comm *comm, double *frame_mean, double *frame_varian
  * StatsArray3D.combine_samples fold (statsarray.pyx:780-859) of the ranks' frames in rank order — deterministic and identical on
  * every rank. Routed as reduce-scatter + all-gather (xGMI is point to point: 2 (W-1)/W frames per rank instead of W-1). */
 int rsx_allreduce_frame(rsx_comm *comm, double *frame_mean, double *frame_variance, int32_t *frame_samples, int64_t n);
+/* The segment of an n-element frame that rank `rank` owns in rsx_allreduce_frame's reduce-scatter: ceil(n / n_ranks) elements, cut at n
+ * (rank == n_ranks gives the end, length 0). Pure host arithmetic — exported so that it can be checked without a GPU. */
+int rsx_frame_segment(int64_t n, int32_t n_ranks, int32_t rank, int64_t *offset, int64_t *length);
+/* Slice sharding (the slice loop of observer.pyx:299-340 split over the GPUs): rank r rendered the spectral slices that
+ * fill bins [bin_begin[r], bin_begin[r+1]) of every pixel of the [n_pixels, bins] frame arrays. In place; afterwards every rank holds
+ * every bin, bit-identical to a one-GPU render (packed bin planes over direct sends / receives, no arithmetic). bin_begin: host
+ * [n_ranks + 1], bin_begin[0] = 0, bin_begin[n_ranks] = bins. */
+int rsx_allgather_bins(rsx_comm *comm, double *frame_mean, double *frame_variance, int32_t *frame_samples, int64_t n_pixels, int32_t bins,
+                       const int32_t *bin_begin);
+/* How many ranks RCCL says the communicator spans (ncclCommCount). */
+int rsx_comm_size(rsx_comm *comm, int32_t *n_ranks);
 
 #ifdef __cplusplus
 }

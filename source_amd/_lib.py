@@ -141,7 +141,13 @@ SYMBOLS = [
     ("rsx_collect_path_checks", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("rsx_allgather_frame", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     ("rsx_allreduce_frame", C.c_int, [_vp, _vp, _vp, _vp, C.c_int64]),
+    ("rsx_frame_segment", C.c_int, [C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    ("rsx_allgather_bins", C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, C.c_int32, _vp]),
+    ("rsx_comm_size", C.c_int, [_vp, C.POINTER(C.c_int32)]),
 ]
+# Entry points an A/B build of an earlier revision ($RSX_LIB, tools/ab.sh) may lack: callers test `has(name)` before using them.
+# Any other missing symbol is ABI drift between include/rsx.h and the binary and stops the load, whichever library was named.
+OPTIONAL_WITH_RSX_LIB = {"rsx_frame_segment", "rsx_allgather_bins", "rsx_comm_size"}
 
 _lib = None
 
@@ -159,13 +165,20 @@ def lib():
                            "(hipcc --offload-arch=gfx950). source_amd has no CPU fallback." % LIB_PATH)
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
-            if os.environ.get("RSX_LIB") and not hasattr(handle, name):
-                continue                   # an A/B build of an earlier revision ($RSX_LIB): entry points added since are simply absent
-            fn = getattr(handle, name)     # AttributeError here = ABI drift between rsx.h and the binary
+            if not hasattr(handle, name):
+                if os.environ.get("RSX_LIB") and name in OPTIONAL_WITH_RSX_LIB:
+                    continue
+                raise RsxError("%s does not export %s: the binary and include/rsx.h have drifted apart (rebuild librsx)" % (LIB_PATH, name))
+            fn = getattr(handle, name)
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = handle
     return _lib
+
+
+def has(name):
+    """Is an optional entry point (OPTIONAL_WITH_RSX_LIB) present in the loaded library?"""
+    return hasattr(lib(), name)
 
 
 def check(code):

@@ -36,19 +36,27 @@ struct Api {
     int (*Recv)(void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*Broadcast)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*AllReduce)(const void *, void *, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+    int (*CommCount)(const ncclComm_t, int *) = nullptr;
     std::string error;
 };
 
 static Api &api() {
     static Api a;
     if (a.handle || !a.error.empty()) return a;
-    const char *names[] = {std::getenv("RSX_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    const char *chosen = std::getenv("RSX_RCCL_LIB");     // set: that library or none (no silent fallback to another copy)
+    const bool only = chosen && *chosen;
+    const char *names[] = {chosen, "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char *n : names) {
         if (!n || !*n) continue;
+        if (only && n != chosen) break;
         a.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL);
         if (a.handle) break;
     }
-    if (!a.handle) { a.error = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found"); return a; }
+    if (!a.handle) {
+        const char *why = dlerror();                        // (read once: the call clears the message)
+        a.error = std::string("librccl could not be loaded: ") + (why ? why : "not found");
+        return a;
+    }
     auto sym = [&](const char *name) -> void * {
         void *p = dlsym(a.handle, name);
         if (!p && a.error.empty()) a.error = std::string("librccl lacks ") + name;
@@ -64,6 +72,7 @@ static Api &api() {
     a.Recv = reinterpret_cast<decltype(a.Recv)>(sym("ncclRecv"));
     a.Broadcast = reinterpret_cast<decltype(a.Broadcast)>(sym("ncclBroadcast"));
     a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(sym("ncclAllReduce"));
+    a.CommCount = reinterpret_cast<decltype(a.CommCount)>(sym("ncclCommCount"));
     if (!a.error.empty()) { dlclose(a.handle); a.handle = nullptr; }
     return a;
 }
@@ -84,6 +93,29 @@ struct rsx_comm {
         const int r_ = (expr);                                                                                 \
         if (r_ != rccl::ncclSuccess) return rsx_fail(RSX_EHIP, "%s: %s", #expr, rccl::api().GetErrorString ? rccl::api().GetErrorString(r_) : "RCCL error"); \
     } while (0)
+
+// Inside ncclGroupStart .. ncclGroupEnd an early return would leave the communicator inside an open group (every later call on this
+// thread would be queued behind it or hang): the calls of a group record their first failure and the group is always closed.
+struct GroupGuard {
+    rccl::Api &a;
+    int first = rccl::ncclSuccess;
+    const char *what = nullptr;
+    bool open = false;
+    explicit GroupGuard(rccl::Api &api_) : a(api_) {}
+    void start() { const int r = a.GroupStart(); if (r == rccl::ncclSuccess) open = true; else note(r, "ncclGroupStart"); }
+    void note(int r, const char *w) { if (r != rccl::ncclSuccess && first == rccl::ncclSuccess) { first = r; what = w; } }
+    int finish() {
+        if (open) { open = false; note(a.GroupEnd(), "ncclGroupEnd"); }
+        if (first != rccl::ncclSuccess) return rsx_fail(RSX_EHIP, "%s: %s", what, a.GetErrorString ? a.GetErrorString(first) : "RCCL error");
+        return RSX_OK;
+    }
+    ~GroupGuard() { if (open) (void)a.GroupEnd(); }
+};
+#define RCCL_IN_GROUP(g, expr) (g).note((expr), #expr)
+
+// Do all ranks agree that a step succeeded? (max over the ranks of a flag; an allocation that failed on one rank must stop every rank
+// before the exchange, or the others would wait in their sends and receives for ever)
+static int ranks_agree(rsx_comm *c, bool ok_here, bool *ok_everywhere);
 
 extern "C" int rsx_comm_unique_id(void *id128) {
     if (!id128) return rsx_fail(RSX_EINVAL, "rsx_comm_unique_id: null buffer");
@@ -152,34 +184,34 @@ static int gather_runs(rsx_comm *c, double *mean, double *variance, int32_t *sam
     rccl::Api &a = rccl::api();
     static const bool by_broadcast = [] { const char *e = std::getenv("RSX_GATHER"); return e && std::strcmp(e, "broadcast") == 0; }();
     const int W = c->n_ranks, me = c->rank;
-    RCCL_TRY(a.GroupStart());
+    GroupGuard g(a);
+    g.start();
     if (by_broadcast) {
         for (int r = 0; r < W; ++r) {
             const size_t off = (size_t)begin[r], len = (size_t)(begin[r + 1] - begin[r]);
             if (!len) continue;
-            RCCL_TRY(a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+            RCCL_IN_GROUP(g, a.Broadcast(mean + off, mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_IN_GROUP(g, a.Broadcast(variance + off, variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+            RCCL_IN_GROUP(g, a.Broadcast(samples + off, samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
         }
     } else {
         const size_t my_off = (size_t)begin[me], my_len = (size_t)(begin[me + 1] - begin[me]);
         for (int k = 1; k < W; ++k) {
             const int to = (me + k) % W, from = (me - k + W) % W;         // (every pair meets once per direction; staggered so that no peer is everyone's first)
             if (my_len) {
-                RCCL_TRY(a.Send(mean + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
-                RCCL_TRY(a.Send(variance + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
-                RCCL_TRY(a.Send(samples + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(mean + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(variance + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(samples + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
             }
             const size_t off = (size_t)begin[from], len = (size_t)(begin[from + 1] - begin[from]);
             if (len) {
-                RCCL_TRY(a.Recv(mean + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
-                RCCL_TRY(a.Recv(variance + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
-                RCCL_TRY(a.Recv(samples + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(mean + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(variance + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(samples + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
             }
         }
     }
-    RCCL_TRY(a.GroupEnd());
-    return RSX_OK;
+    return g.finish();
 }
 
 extern "C" int rsx_allgather_frame(rsx_comm *c, double *mean, double *variance, int32_t *samples, const int64_t *shard_begin) {
@@ -189,6 +221,33 @@ extern "C" int rsx_allgather_frame(rsx_comm *c, double *mean, double *variance, 
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     return gather_runs(c, mean, variance, samples, shard_begin);
+}
+
+static int ranks_agree(rsx_comm *c, bool ok_here, bool *ok_everywhere) {
+    double bad = ok_here ? 0.0 : 1.0;
+    const int rc = rsx_comm_max_f64(c, &bad);
+    if (rc) return rc;
+    *ok_everywhere = bad == 0.0;
+    return RSX_OK;
+}
+
+extern "C" int rsx_comm_size(rsx_comm *c, int32_t *n_ranks) {
+    if (!c || !n_ranks) return rsx_fail(RSX_EINVAL, "rsx_comm_size: null argument");
+    int n = c->n_ranks;
+    if (rccl::api().CommCount) RCCL_TRY(rccl::api().CommCount(c->comm, &n));     // what RCCL itself says the communicator spans
+    *n_ranks = n;
+    return RSX_OK;
+}
+
+// The 1/W segment of an n-element frame that rank r owns in the reduce-scatter of rsx_allreduce_frame: ceil(n / W) elements each, the
+// last ranks' segments cut at n (possibly empty). Host arithmetic, exported so that it can be tested without a GPU.
+extern "C" int rsx_frame_segment(int64_t n, int32_t n_ranks, int32_t rank, int64_t *offset, int64_t *length) {
+    if (n < 0 || n_ranks < 1 || rank < 0 || rank > n_ranks || !offset || !length) return rsx_fail(RSX_EINVAL, "rsx_frame_segment: bad arguments");
+    const uint64_t N = (uint64_t)n, W = (uint64_t)n_ranks, seg = (N + W - 1) / W;
+    const uint64_t off = std::min(N, seg * (uint64_t)rank), end = std::min(N, seg * ((uint64_t)rank + 1));
+    *offset = (int64_t)off;
+    *length = rank == n_ranks ? 0 : (int64_t)(end - off);                  // (rank == n_ranks: the end of the last segment)
+    return RSX_OK;
 }
 
 // Sample sharding: every rank holds a full n-element frame of its own samples; afterwards every rank holds
@@ -202,36 +261,44 @@ extern "C" int rsx_allreduce_frame(rsx_comm *c, double *mean, double *variance, 
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     const int W = c->n_ranks, me = c->rank;
-    const size_t N = (size_t)n, seg = (N + W - 1) / W;
-    auto seg_off = [&](int r) { return std::min(N, seg * (size_t)r); };
-    auto seg_len = [&](int r) { return std::min(N, seg * (size_t)(r + 1)) - seg_off(r); };
+    auto seg_off = [&](int r) { int64_t o = 0, l = 0; (void)rsx_frame_segment(n, W, r, &o, &l); return (size_t)o; };
+    auto seg_len = [&](int r) { int64_t o = 0, l = 0; (void)rsx_frame_segment(n, W, r, &o, &l); return (size_t)l; };
     const size_t mine = seg_len(me);
     // scratch: W copies of my segment, as [W][mine] doubles (mean), [W][mine] doubles (variance), [W][mine] int32 (samples)
     const size_t need = (size_t)W * mine * 20 + 256;
+    bool have = true;
     if (need > c->scratch_bytes) {
         if (c->scratch) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
-        HIP_TRY(hipMalloc(&c->scratch, need));
-        c->scratch_bytes = need;
+        if (hipMalloc(&c->scratch, need) == hipSuccess) c->scratch_bytes = need;
+        else { (void)hipGetLastError(); c->scratch = nullptr; have = false; }
     }
+    bool all_have = false;
+    const int arc = ranks_agree(c, have, &all_have);
+    if (arc) return arc;
+    if (!all_have) return rsx_fail(RSX_ENOMEM, "rsx_allreduce_frame: %s could not allocate its %zu-byte segment workspace", have ? "another rank" : "this rank", need);
     double *sm = static_cast<double *>(c->scratch), *sv = sm + (size_t)W * mine;
     int32_t *sn = reinterpret_cast<int32_t *>(sv + (size_t)W * mine);
     rccl::Api &a = rccl::api();
-    RCCL_TRY(a.GroupStart());
-    for (int r = 0; r < W; ++r) {
-        if (r == me) continue;
-        const size_t off = seg_off(r), len = seg_len(r);
-        if (len) {
-            RCCL_TRY(a.Send(mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Send(variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Send(samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+    {
+        GroupGuard g(a);
+        g.start();
+        for (int r = 0; r < W; ++r) {
+            if (r == me) continue;
+            const size_t off = seg_off(r), len = seg_len(r);
+            if (len) {
+                RCCL_IN_GROUP(g, a.Send(mean + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(variance + off, len, rccl::ncclFloat64, r, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(samples + off, len, rccl::ncclInt32, r, c->comm, ctx->stream));
+            }
+            if (mine) {
+                RCCL_IN_GROUP(g, a.Recv(sm + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(sv + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(sn + (size_t)r * mine, mine, rccl::ncclInt32, r, c->comm, ctx->stream));
+            }
         }
-        if (mine) {
-            RCCL_TRY(a.Recv(sm + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Recv(sv + (size_t)r * mine, mine, rccl::ncclFloat64, r, c->comm, ctx->stream));
-            RCCL_TRY(a.Recv(sn + (size_t)r * mine, mine, rccl::ncclInt32, r, c->comm, ctx->stream));
-        }
+        const int grc = g.finish();
+        if (grc) return grc;
     }
-    RCCL_TRY(a.GroupEnd());
     if (mine) {
         const size_t off = seg_off(me);
         HIP_TRY(hipMemcpyAsync(sm + (size_t)me * mine, mean + off, mine * 8, hipMemcpyDeviceToDevice, ctx->stream));
@@ -249,4 +316,82 @@ extern "C" int rsx_allreduce_frame(rsx_comm *c, double *mean, double *variance, 
     std::vector<int64_t> begin((size_t)W + 1);
     for (int r = 0; r <= W; ++r) begin[(size_t)r] = (int64_t)seg_off(r);
     return gather_runs(c, mean, variance, samples, begin.data());
+}
+
+// Slice sharding (the reference's slice loop, observer.pyx:299-340): rank r rendered the spectral slices that fill bins
+// [bin_begin[r], bin_begin[r + 1]) of every pixel of the [n_pixels, bins] frame arrays (bin fastest, as StatsArray3D). A rank's share is
+// a strided set of bin planes, so it travels packed: pack own bins -> one group of direct sends / receives of the packed blocks (every
+// byte crosses one xGMI link once) -> unpack the peers' blocks into place. No arithmetic: bit-identical to a one-GPU render.
+template <typename T>
+__global__ void k_pack_bins(const T *frame, T *block, long long n_pixels, int bins, int b0, int nb, int unpack) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pixels * nb) return;
+    const long long p = i / nb;
+    const int j = (int)(i - p * nb);
+    if (unpack) const_cast<T *>(frame)[p * bins + b0 + j] = block[i];
+    else block[i] = frame[p * bins + b0 + j];
+}
+
+extern "C" int rsx_allgather_bins(rsx_comm *c, double *mean, double *variance, int32_t *samples, int64_t n_pixels, int32_t bins, const int32_t *bin_begin) {
+    if (!c || !mean || !variance || !samples || !bin_begin || n_pixels < 0 || bins < 1) return rsx_fail(RSX_EINVAL, "rsx_allgather_bins: bad arguments");
+    const int W = c->n_ranks, me = c->rank;
+    if (bin_begin[0] != 0 || bin_begin[W] != bins) return rsx_fail(RSX_EINVAL, "rsx_allgather_bins: the bin ranges must cover [0, bins)");
+    for (int r = 0; r < W; ++r) if (bin_begin[r + 1] < bin_begin[r]) return rsx_fail(RSX_EINVAL, "rsx_allgather_bins: bin offsets must be non-decreasing");
+    if (W == 1 || n_pixels == 0) return RSX_OK;
+    rsx_ctx *ctx = c->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    const size_t P = (size_t)n_pixels, E = P * (size_t)bins;               // packed blocks of all ranks together: one frame's worth
+    const size_t need = E * 20 + 256;
+    bool have = true;
+    if (need > c->scratch_bytes) {
+        if (c->scratch) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
+        if (hipMalloc(&c->scratch, need) == hipSuccess) c->scratch_bytes = need;
+        else { (void)hipGetLastError(); c->scratch = nullptr; have = false; }
+    }
+    bool all_have = false;
+    const int arc = ranks_agree(c, have, &all_have);
+    if (arc) return arc;
+    if (!all_have) return rsx_fail(RSX_ENOMEM, "rsx_allgather_bins: %s could not allocate its %zu-byte packing workspace", have ? "another rank" : "this rank", need);
+    double *pm = static_cast<double *>(c->scratch), *pv = pm + E;
+    int32_t *pn = reinterpret_cast<int32_t *>(pv + E);
+    auto block_off = [&](int r) { return P * (size_t)bin_begin[r]; };      // blocks in rank order, [n_pixels][nb_r] each
+    auto block_len = [&](int r) { return P * (size_t)(bin_begin[r + 1] - bin_begin[r]); };
+    auto launch = [&](int r, int unpack) -> int {
+        const size_t len = block_len(r);
+        if (!len) return RSX_OK;
+        const dim3 grid((unsigned)((len + 255) / 256));
+        const int b0 = bin_begin[r], nb = bin_begin[r + 1] - bin_begin[r];
+        hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, mean, pm + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
+        hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, variance, pv + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
+        hipLaunchKernelGGL(k_pack_bins<int32_t>, grid, dim3(256), 0, ctx->stream, samples, pn + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
+        HIP_TRY(hipGetLastError());
+        return RSX_OK;
+    };
+    int rc = launch(me, 0);
+    if (rc) return rc;
+    rccl::Api &a = rccl::api();
+    {
+        GroupGuard g(a);
+        g.start();
+        const size_t my_off = block_off(me), my_len = block_len(me);
+        for (int k = 1; k < W; ++k) {
+            const int to = (me + k) % W, from = (me - k + W) % W;
+            if (my_len) {
+                RCCL_IN_GROUP(g, a.Send(pm + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(pv + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Send(pn + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
+            }
+            const size_t off = block_off(from), len = block_len(from);
+            if (len) {
+                RCCL_IN_GROUP(g, a.Recv(pm + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(pv + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                RCCL_IN_GROUP(g, a.Recv(pn + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
+            }
+        }
+        rc = g.finish();
+        if (rc) return rc;
+    }
+    for (int r = 0; r < W; ++r) if (r != me && (rc = launch(r, 1))) return rc;
+    return RSX_OK;
 }

@@ -199,6 +199,38 @@ def gather_tiles(tile, dist):
     return torch.cat(parts, dim=0)
 
 
+def frame_segment(n, world_size, rank):
+    """(offset, length) of the frame segment rank owns in rsx_allreduce_frame's reduce-scatter (librsx's own arithmetic)."""
+    import ctypes as C
+    from . import _lib
+    off, length = C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().rsx_frame_segment(int(n), int(world_size), int(rank), C.byref(off), C.byref(length)))
+    return int(off.value), int(length.value)
+
+
+def slice_bounds(n_slices, world_size):
+    """Slice sharding: rank r renders the spectral slices [bounds[r], bounds[r + 1]) (512 slices -> 64 per GPU)."""
+    return [(n_slices * r) // world_size for r in range(world_size)] + [n_slices]
+
+
+def gather_slice_sharded(mean, variance, samples, rank, dist, bin_bounds):
+    """torch / gloo form of rsx_allgather_bins (test aid and fallback): every rank contributes frame[..., b0:b1] of its bin range."""
+    import torch
+    world = dist.get_world_size()
+    out = []
+    for a in (mean, variance, samples):
+        full = a.clone()
+        for r in range(world):
+            b0, b1 = int(bin_bounds[r]), int(bin_bounds[r + 1])
+            if b1 <= b0:
+                continue
+            part = a[..., b0:b1].contiguous() if r == rank else torch.empty(a.shape[:-1] + (b1 - b0,), dtype=a.dtype, device=a.device)
+            dist.broadcast(part, src=r)
+            full[..., b0:b1] = part
+        out.append(full)
+    return out
+
+
 class FrameComm:
     """rsx_comm wrapper: the framebuffer exchange of a multi-GPU render over RCCL, called straight from librsx (no PyTorch in the
     data path). ``exchange(payload)`` is any callable that returns rank 0's payload on every rank (a torch.distributed
@@ -242,6 +274,24 @@ class FrameComm:
         fm, fv, fn = frame._device(self.context)
         _lib.check(_lib.lib().rsx_allreduce_frame(self._h, fm, fv, fn, frame.length))
         frame._mark_device_written()
+
+    def allgather_slices(self, frame, nx, ny, bin_bounds):
+        """frame: StatsArray3D of which this rank rendered the spectral slices filling bins [bin_bounds[rank], bin_bounds[rank + 1]);
+        afterwards every bin on every rank (slice sharding)."""
+        from . import _lib
+        begin = np.asarray(bin_bounds, dtype=np.int32)
+        assert len(begin) == self.world_size + 1
+        fm, fv, fn = frame._device(self.context)
+        _lib.check(_lib.lib().rsx_allgather_bins(self._h, fm, fv, fn, nx * ny, frame.nz, _lib.ptr(begin)))
+        frame._mark_device_written()
+
+    def size(self):
+        """Ranks RCCL says the communicator spans."""
+        import ctypes as C
+        from . import _lib
+        n = C.c_int32(0)
+        _lib.check(_lib.lib().rsx_comm_size(self._h, C.byref(n)))
+        return int(n.value)
 
     def close(self):
         from . import _lib

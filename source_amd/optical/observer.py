@@ -58,12 +58,19 @@ class HipEngine(RenderEngine):
     Philox sample counters: pass p of an observer draws the counters ``sample_offset + p * pixel_samples ...`` — consecutive
     observe() calls of one observer never reuse a (pixel, sample) counter, like the reference's engines, which draw fresh random
     numbers every pass. Assigning ``engine.sample_offset`` between passes restarts the count from the assigned value (that is how
-    the multi-GPU shards place their samples, source_amd/distributed.py).
+    the multi-GPU shards place their samples, source_amd/distributed.py); a sample-sharded process that does NOT reassign it every
+    pass must set ``sample_stride`` to the number of processes (otherwise pass p + 1 of rank r would reuse the counters of pass p of
+    rank r + 1 and correlated samples would be merged as if independent).
     """
 
-    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False):
+    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False, sample_stride=1, slice_range=None):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
+        # multi-process renders (source_amd/distributed.py). sample_stride = N with sample_offset = rank * pixel_samples: pass p of this
+        # process draws the counters (p * N + rank) * pixel_samples ..., so N sample-sharded processes never share a (pixel, sample)
+        # counter however many passes they run; slice_range = (first, last): render those spectral slices only (slice sharding).
+        self.sample_stride = int(sample_stride)
+        self.slice_range = None if slice_range is None else (int(slice_range[0]), int(slice_range[1]))
         self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
         self.host_materials = bool(host_materials)    # True: evaluate every material on the host (source_amd/optical/hybrid.py) even when
                                                       # all of them have device lowerings — scenes with a user-written material always do
@@ -513,14 +520,27 @@ class _ObserverBase(Observer):
         # tail of one slice — a few paths bouncing on for hundreds of segments — drains under the bulk of the next.
         deferring = self._begin_deferred_slices(len(templates))
         try:
+            # (slice sharding, SURVEY.md 8e: an engine with a slice_range renders those spectral slices only — another GPU the rest)
+            first, last = getattr(self.render_engine, "slice_range", None) or (0, len(templates))
             for slice_id, template in enumerate(templates):
+                if not first <= slice_id < last:
+                    continue
                 self.render_engine.run(tasks, self._render_pixel, self._update_state,
                                        render_args=(slice_id, template), update_args=(slice_id,))
         finally:
             if deferring:
                 self._end_deferred_slices()
-        self._auto_offset += self._samples_per_pass()
+        # (sample_stride: a process that renders 1 / N of a sample-sharded job leaves the counters between its passes to the others)
+        self._auto_offset += self._samples_per_pass() * max(1, int(getattr(self.render_engine, "sample_stride", 1)))
         self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
+
+    def _needs_host_materials(self, world, engine):
+        """True when the slice must go through the host-callback path: a material without a device lowering (a user-written
+        Material subclass), or an engine that asks for it."""
+        if getattr(engine, "host_materials", False):
+            return True
+        from .material import has_device_lowering
+        return not all(has_device_lowering(p.material) for p in world._primitives)
 
     def _begin_deferred_slices(self, n_slices):
         engine = self.render_engine
@@ -793,14 +813,6 @@ class PinholeCamera(Observer2D):
             t = np.array(tasks, dtype=np.int64).reshape(-1, 2)
             xs, ys = t[:, 0], t[:, 1]
         pipe.update_block(xs, ys, mean, var)
-
-    def _needs_host_materials(self, world, engine):
-        """True when the slice must go through the host-callback path: a material without a device lowering (a user-written
-        Material subclass), or an engine that asks for it."""
-        if getattr(engine, "host_materials", False):
-            return True
-        from .material import has_device_lowering
-        return not all(has_device_lowering(p.material) for p in world._primitives)
 
     HOST_RAYS_PER_PIECE = 1 << 16     # primary rays per scheduler run of the host-callback path (bounds the Python objects alive at once)
 

@@ -229,19 +229,42 @@ class Spectrum(SpectralFunction):
         s.samples[:] = self.samples
         return s
 
-    def evaluate(self, wavelength):                         # spectrum.pyx: piecewise constant over the bins, nearest outside
-        i = int((wavelength - self.min_wavelength) / self.delta_wavelength)
-        return float(self.samples[min(max(i, 0), self.bins - 1)])
+    def _wavelength_check(self, min_wavelength, max_wavelength):     # spectrum.pyx:105-111
+        if min_wavelength <= 0.0 or max_wavelength <= 0.0:
+            raise ValueError("Wavelength cannot be less than or equal to zero.")
+        if min_wavelength >= max_wavelength:
+            raise ValueError("Minimum wavelength cannot be greater or equal to the maximum wavelength.")
 
+    def _attribute_check(self):                             # spectrum.pyx:113-120
+        if self.samples is None:
+            raise ValueError("Cannot generate sample as the sample array is None.")
+        if self.samples.shape[0] != self.bins:
+            raise ValueError("Sample array length is inconsistent with the number of bins.")
+
+    # spectrum.pyx:202-300: the samples are point values at the bin CENTRES, integrated as the piecewise-linear curve through them,
+    # extended by its end values (utility.pyx integrate) — and nothing is cached: `samples` is mutated in place by the *_scalar /
+    # *_array operations, so a cached resampling would go stale. (The reference's Spectrum defines no evaluate().)
     def integrate(self, min_wavelength, max_wavelength):
-        lo, hi = max(min_wavelength, self.min_wavelength), min(max_wavelength, self.max_wavelength)
-        total = 0.0
-        for i in range(self.bins):
-            a = self.min_wavelength + i * self.delta_wavelength
-            overlap = min(hi, a + self.delta_wavelength) - max(lo, a)
-            if overlap > 0:
-                total += self.samples[i] * overlap
-        return total
+        self._wavelength_check(min_wavelength, max_wavelength)
+        self._attribute_check()
+        return float(_integrate([float(v) for v in self.wavelengths], [float(v) for v in self.samples], float(min_wavelength), float(max_wavelength)))
+
+    def average(self, min_wavelength, max_wavelength):
+        return self.integrate(min_wavelength, max_wavelength) / (max_wavelength - min_wavelength)
+
+    def sample(self, min_wavelength, max_wavelength, bins):
+        self._wavelength_check(min_wavelength, max_wavelength)
+        self._attribute_check()
+        x, y = [float(v) for v in self.wavelengths], [float(v) for v in self.samples]
+        samples = np.zeros(bins, dtype=np.float64)
+        delta = (max_wavelength - min_wavelength) / bins
+        lower = min_wavelength
+        reciprocal = 1.0 / delta
+        for i in range(bins):
+            upper = min_wavelength + (i + 1) * delta
+            samples[i] = reciprocal * _integrate(x, y, float(lower), float(upper))
+            lower = upper
+        return samples
 
     def total(self):
         return float(self.samples.sum() * self.delta_wavelength)

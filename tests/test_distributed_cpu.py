@@ -66,6 +66,13 @@ def _worker(rank, world_size, port, out):
     odd[rb[0]:rb[2]] = rank + 1.0
     ob = D.gather_tile_sharded(torch.from_numpy(odd), torch.from_numpy(odd.copy()), torch.from_numpy(odd.astype(np.int32)), rank, dist, bounds)[0].numpy()
     assert (ob[:bounds[1]] == 1.0).all() and (ob[bounds[1]:] == 2.0).all()
+    # --- slice sharding (bench.py --sharding slice, host route): each rank owns a range of bins of every pixel -------------------------
+    bb = [0, 2, bins]
+    own = np.zeros((nx, ny, bins))
+    own[..., bb[rank]:bb[rank + 1]] = rank + 1.0
+    sm_, sv_, sn_ = D.gather_slice_sharded(torch.from_numpy(own), torch.from_numpy(own.copy()), torch.from_numpy(own.astype(np.int32)), rank, dist, bb)
+    assert (sm_.numpy()[..., :2] == 1.0).all() and (sm_.numpy()[..., 2:] == 2.0).all() and torch.equal(sm_, sv_) and (sn_.numpy()[..., 2:] == 2).all()
+    assert D.slice_bounds(512, 8) == [64 * r for r in range(9)] and D.slice_bounds(5, 2) == [0, 2, 5]
     np.savez(out % rank, M=M.numpy(), V=V.numpy(), N=N.numpy(), fm=fm, fv=fv, full=full.numpy())
     dist.barrier()
     dist.destroy_process_group()

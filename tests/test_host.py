@@ -259,3 +259,79 @@ def test_bench_roofline_helpers():
         assert name.startswith("k_render_trace<true, 1")          # the fast CSG pass, not the (idle) redo pass
     b, per = bench.ray_bytes(dict(nodes=27, items=8, tris=3, prims=5), 1)
     assert b == 56 + 16 * 27 + 4 * 8 + 48 * 3 + 216 * 5 + 24
+
+
+def test_frame_segments_of_the_reduce_scatter():
+    """rsx_frame_segment: the segment arithmetic of rsx_allreduce_frame (rsx_comm.hpp) — the segments of W ranks tile [0, n) in rank
+    order without gaps or overlap whatever n % W is, including frames shorter than the number of ranks."""
+    from source_amd import distributed as D
+    for n in (0, 1, 7, 8, 9, 10, 63, 64, 65, 1000003, 2048 * 2048 * 15):
+        for w in (1, 2, 3, 4, 7, 8):
+            segs = [D.frame_segment(n, w, r) for r in range(w)]
+            at = 0
+            for off, length in segs:
+                assert off == at and length >= 0
+                at += length
+            assert at == n and D.frame_segment(n, w, w) == (n, 0)
+            width = -(-n // w)
+            assert all(length in (width, max(0, n - off)) for off, length in segs)       # ceil(n / W) each, the tail cut at n
+            assert max(l for _, l in segs) - min(l for _, l in segs if l or n == 0) <= width
+    assert D.frame_segment(10, 4, 3) == (9, 1) and D.frame_segment(7, 8, 7) == (7, 0)
+
+
+def test_missing_rccl_is_an_error_code_not_a_crash(tmp_path):
+    """librccl that cannot be loaded: rsx_comm_unique_id / rsx_comm_create must RETURN RSX_EUNSUPPORTED with the loader's message
+    (bench.py falls back to another exchange on it) — round 2's form read dlerror() twice and dereferenced the second, null, answer."""
+    import subprocess
+    import sys
+    code = """
+import ctypes as C, sys
+sys.path.insert(0, %r)
+from source_amd import _lib
+L = _lib.lib()
+buf = (C.c_char * 128)()
+rc = L.rsx_comm_unique_id(buf)
+msg = L.rsx_last_error().decode()
+h = C.c_void_p()
+rc2 = L.rsx_comm_create(None, 2, 0, buf, C.byref(h))
+print(rc, rc2, msg)
+""" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RSX_RCCL_LIB=str(tmp_path / "no_such_librccl.so"))      # ($RSX_RCCL_LIB names THE library: no fallback to another copy)
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-1500:]
+    rc, rc2, msg = r.stdout.strip().split(" ", 2)
+    assert int(rc) == -5 and int(rc2) in (-5, -1), (rc, rc2, msg)      # RSX_EUNSUPPORTED (the null ctx of the second call may be refused first)
+    assert "librccl could not be loaded" in msg and "no_such_librccl.so" in msg
+
+
+def test_spectrum_resampling_follows_the_reference(ns):
+    """Spectrum.integrate / average / sample (spectrum.pyx:202-300): the samples are values at the bin centres, integrated as the
+    piecewise-linear curve through them and extended by its end values; nothing is cached across in-place mutation."""
+    s = ns.Spectrum(1.0, 4.0, 3)
+    s.samples[:] = [1.0, 2.0, 3.0]
+    assert s.integrate(1.0, 2.0) == 1.125                   # 0.5 * 1 (flat to the first centre) + 0.5 * (1 + 1.5) * 0.5
+    assert s.average(1.0, 2.0) == 1.125
+    assert np.allclose(s.sample(1.0, 4.0, 3), [1.125, 2.0, 2.875])
+    first = s.sample(1.5, 3.5, 2).copy()
+    s.mul_scalar(2.0)
+    assert np.allclose(s.sample(1.5, 3.5, 2), 2.0 * first)  # (a cached resampling would have gone stale here)
+    assert s.integrate(0.25, 0.75) == 1.0                   # below the first centre: its value, nearest-neighbour
+    with pytest.raises(ValueError):
+        s.integrate(2.0, 2.0)
+    from source_amd.optical.spectral import SpectralFunction
+    assert ns.Spectrum.evaluate is SpectralFunction.evaluate   # (the reference's Spectrum defines no evaluate() of its own)
+
+
+def test_stale_library_is_refused_at_load_time(tmp_path):
+    """A binary that lacks a declared entry point must stop the load with the symbol's name ($RSX_LIB or not) — only the explicit list
+    of newer, optional entry points may be absent from an A/B build."""
+    import subprocess
+    import sys
+    src = tmp_path / "stub.c"
+    src.write_text("int rsx_version(void) { return 0; }\n")
+    so = tmp_path / "librsx_stub.so"
+    subprocess.check_call(["gcc", "-shared", "-fPIC", str(src), "-o", str(so)])
+    code = "import sys; sys.path.insert(0, %r)\nfrom source_amd import _lib\ntry:\n    _lib.lib()\n    print('loaded')\nexcept _lib.RsxError as e:\n    print('refused', e)\n" % \
+        os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_LIB=str(so)), capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.startswith("refused") and "does not export" in r.stdout, r.stdout + r.stderr[-800:]
