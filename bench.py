@@ -13,7 +13,10 @@ One "step" = one observe() pass over the frame = 268 435 456 primary rays at N =
 two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford over the 64 samples, merged into the
 device-resident spectral frame. Scene, camera tables and the frame are resident in HBM when the timed region starts.
 --workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass); --workload c4 = configs[3] (demos/csg.py
-tree, 1024x1024, 16 spp/pass); --workload flat = one 1M-triangle mesh without instancing (geometry far larger than L2).
+tree, 1024x1024, 16 spp/pass); --workload flat = one 1M-triangle mesh without instancing (geometry far larger than L2);
+--workload c1 = configs[0]'s scene path traced on the device (Cornell box: Lambert walls, glass, importance sampling; 1024x1024,
+16 spp/pass); --workload c5 = configs[4] (demos/prism.py scene, 1024x1024, 512 spectral bins rendered as 512 one-bin slices, 1 spp
+per slice and pass: 537 M paths per step, a 10.7 GB frame — run it with a small --steps).
 
 N > 1 (one process per GPU; control plane = torch.distributed/gloo for rendezvous and barriers, data plane = RCCL called
 from librsx, include/rsx.h rsx_allgather_frame / rsx_allreduce_frame):
@@ -22,7 +25,11 @@ from librsx, include/rsx.h rsx_allgather_frame / rsx_allreduce_frame):
       Total work is fixed ("scaling": "strong"); the gathered frame is bit-identical to a one-GPU render — rank 0 re-renders the
       whole frame alone after the timed region and compares SHA-256 digests (config.frame_digest_equals_single_gpu).
   --sharding sample: every rank renders the whole frame with its own Philox sample counters (weak scaling), then ONE
-      combine_samples all-reduce (reduce-scatter + all-gather over point-to-point xGMI links), inside the timed region.
+      combine_samples all-reduce (reduce-scatter + all-gather over point-to-point xGMI links), inside the timed region. Rank 0
+      then renders the N * spp samples of every pass alone and checks the merged frame against that render (mean to 1e-12 relative,
+      variance to the 16 eps (mean^2 + var) of the combine law's own cancellation): config.sample_merge_equals_single_gpu.
+  --sharding slice (configs[4]): rank r renders the spectral slices [r S / N, (r + 1) S / N) of every pass (strong
+      scaling); ONE gather of the ranks' bin planes (rsx_allgather_bins, no arithmetic), digest-checked like the tiles.
 """
 import argparse
 import csv
@@ -61,11 +68,19 @@ WORKLOADS = {
     "c4": dict(nx=1024, ny=1024, spp=16, counter_rows=8,
                name="configs[3]: demos/csg.py Boolean tree (sphere/box/cylinder Union/Intersect/Subtract, 5 CSG objects), PinholeCamera "
                     "1024x1024, 16 spp/pass, 15 spectral bins, primary rays only"),
+    "c1": dict(nx=1024, ny=1024, spp=16, counter_rows=8, paths=True,
+               name="configs[0]'s scene on the device: Cornell box after demos/cornell_box.py (Lambert walls, ceiling light, glass block and "
+                    "sphere, multiple importance sampling, Russian roulette), PinholeCamera 1024x1024, 16 spp/pass, 15 spectral bins, path traced"),
+    "c5": dict(nx=1024, ny=1024, spp=1, counter_rows=8, paths=True, bins=512, slices=512,
+               name="configs[4]: demos/prism.py scene (SF11 prism, N-BK7 stand: Sellmeier dispersion per spectral slice), PinholeCamera "
+                    "1024x1024, 512 spectral bins as 512 one-bin slices, 1 spp per slice and pass (256 passes = the config's 256 spp), path traced"),
+    "c5s": dict(nx=128, ny=128, spp=2, counter_rows=8, paths=True, bins=16, slices=16,
+                name="configs[4] in small (test aid): demos/prism.py scene, 128x128, 16 one-bin spectral slices, 2 spp per slice and pass"),
 }
 PMC_GROUPS = [
     ["FETCH_SIZE"],                                                               # 3 of the 4 TCC slots
     ["WRITE_SIZE", "TCC_HIT_sum", "TCC_MISS_sum"],                                # 2 + 1 + 1 TCC slots
-    ["SQ_WAVES", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
+    ["SQ_INSTS_SALU", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU",
      "SQ_THREAD_CYCLES_VALU", "GRBM_GUI_ACTIVE"],                                 # 8 SQ slots + 1 GRBM
 ]
 
@@ -81,6 +96,12 @@ def build_workload(key, ns, scenes):
     elif key == "flat":
         world = scenes.build_flat(ns, n=512)[0]
         cam, pipe = scenes.c2_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    elif key == "c1":
+        world = scenes.build_cornell(ns)[0]
+        cam, pipe = scenes.cornell_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
+    elif key in ("c5", "c5s"):
+        world = scenes.build_prism(ns)[0]
+        cam, pipe = scenes.prism_camera(ns, world, (w["nx"], w["ny"]), w["spp"], w["bins"], w["slices"])
     else:
         world = scenes.build_csg_demo(ns)[0]
         cam, pipe = scenes.csg_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
@@ -168,32 +189,42 @@ def kernel_counters(table, prefix):
 
 
 def ceilings(c, kernel_ms, algorithmic_gbs):
-    """Locates one kernel against its ceilings from the counters of the profiled run. Returns (dict, name of the binding ceiling)."""
+    """Locates one kernel against its ceilings from the counters of the profiled run. Every entry has the same shape —
+    {achieved, peak, unit, frac, ...} — so that whichever binds can be lifted to the top of `roofline` as it is.
+    Returns (dict, name of the binding ceiling)."""
     out = {}
     secs = kernel_ms * 1e-3
     if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
         # rocprofv3 FETCH_SIZE / WRITE_SIZE are KiB; on gfx950 FETCH_SIZE tallies 128-B reads at 64 B: doubled (guide, §HBM)
         hbm_bytes = c["FETCH_SIZE"] * 1024 * 2 + c["WRITE_SIZE"] * 1024
-        out["hbm_measured"] = {"bytes_per_launch": int(hbm_bytes), "achieved_gbs": round(hbm_bytes / secs / 1e9, 1), "peak_gbs": PEAK_HBM_GBS,
-                               "frac": round(hbm_bytes / secs / 1e9 / PEAK_HBM_GBS, 4)}
+        out["hbm_measured"] = {"achieved": round(hbm_bytes / secs / 1e9, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                               "frac": round(hbm_bytes / secs / 1e9 / PEAK_HBM_GBS, 4), "bytes_per_launch": int(hbm_bytes),
+                               "note": "2 x FETCH_SIZE + WRITE_SIZE of the kernel (rocprofv3 --pmc, separate passes)"}
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         req = c["TCC_HIT_sum"] + c["TCC_MISS_sum"]
-        out["l2"] = {"hit_rate": round(c["TCC_HIT_sum"] / max(1.0, req), 4), "requests_per_launch": int(req),
-                     "achieved_gbs": round(req * 128 / secs / 1e9, 1), "peak_gbs": PEAK_L2_GBS, "frac": round(req * 128 / secs / 1e9 / PEAK_L2_GBS, 4),
+        out["l2"] = {"achieved": round(req * 128 / secs / 1e9, 1), "peak": PEAK_L2_GBS, "unit": "GB/s", "frac": round(req * 128 / secs / 1e9 / PEAK_L2_GBS, 4),
+                     "hit_rate": round(c["TCC_HIT_sum"] / max(1.0, req), 4), "requests_per_launch": int(req),
                      "note": "requests x 128-B lines (upper estimate)"}
-    # the algorithmic bytes (node / triangle / primitive records every ray reads) are served by the per-CU vector caches
-    out["l1_vector_cache"] = {"achieved_gbs": round(algorithmic_gbs, 1), "peak_gbs": PEAK_L1_GBS, "frac": round(algorithmic_gbs / PEAK_L1_GBS, 4),
-                              "note": "algorithmic bytes / (64 B/clk/CU x 256 CUs x 2.4 GHz)"}
+    if algorithmic_gbs is not None:
+        # the algorithmic bytes (node / triangle / primitive records every ray reads) are served by the per-CU caches
+        out["l1_vector_cache"] = {"achieved": round(algorithmic_gbs, 1), "peak": PEAK_L1_GBS, "unit": "GB/s", "frac": round(algorithmic_gbs / PEAK_L1_GBS, 4),
+                                  "note": "algorithmic bytes / (64 B/clk/CU x 256 CUs x 2.4 GHz)"}
     if "SQ_ACTIVE_INST_VALU" in c and "GRBM_GUI_ACTIVE" in c:
         # GRBM_GUI_ACTIVE sums the 8 XCDs' busy cycles; SQ_* cycle counters tick every 4 cycles (guide: quad-cycles)
         simd_cycles = c["GRBM_GUI_ACTIVE"] / 8.0 * N_CUS * SIMDS_PER_CU
         busy = c["SQ_ACTIVE_INST_VALU"] * 4
-        out["valu_issue"] = {"valu_busy_cycles": int(busy), "simd_cycles": int(simd_cycles), "frac": round(busy / simd_cycles, 4),
+        out["valu_issue"] = {"achieved": int(busy), "peak": int(simd_cycles), "unit": "SIMD-cycles per launch (vector ALU busy / available)",
+                             "frac": round(busy / simd_cycles, 4),
                              "wave_instructions": int(c.get("SQ_INSTS_VALU", 0)),
                              "issue_model_frac": round(c.get("SQ_INSTS_VALU", 0) * VALU_CYCLES_PER_WAVE_INSTR / simd_cycles, 4),
                              "lane_utilisation": round(c.get("SQ_THREAD_CYCLES_VALU", 0) / max(1.0, 64.0 * c["SQ_ACTIVE_INST_VALU"]), 4),
                              "wave_wait_frac": round(c.get("SQ_WAIT_ANY", 0) / max(1.0, c.get("SQ_WAVE_CYCLES", 0)), 4),
                              "effective_clock_ghz": round(c["GRBM_GUI_ACTIVE"] / 8.0 / secs / 1e9, 3)}
+        if "SQ_INSTS_SALU" in c:
+            # the scalar unit of a CU serves its four SIMDs in turn: one scalar instruction per SIMD per 4 cycles, the vector rate
+            sbusy = c["SQ_INSTS_SALU"] * 4
+            out["salu_issue"] = {"achieved": int(sbusy), "peak": int(simd_cycles), "unit": "SIMD-cycles per launch (scalar instructions x 4 / available)",
+                                 "frac": round(sbusy / simd_cycles, 4), "wave_instructions": int(c["SQ_INSTS_SALU"])}
     binding = max(out, key=lambda k: out[k]["frac"]) if out else None
     return out, binding
 
@@ -227,7 +258,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
-    ap.add_argument("--sharding", choices=["auto", "tile", "sample"], default="auto", help="N > 1: tile (strong scaling, default) or sample (weak)")
+    ap.add_argument("--sharding", choices=["auto", "tile", "sample", "slice"], default="auto",
+                    help="N > 1: tile (strong scaling, default), sample (weak) or slice (strong; spectral slices of configs[4])")
     ap.add_argument("--tiles", choices=["balanced", "equal"], default="balanced",
                     help="tile sharding: column tiles of equal measured time (default; four rounds of every rank timing its own tile "
                          "and all ranks moving the cuts, before the warmup) or of equal width")
@@ -236,13 +268,14 @@ def main():
                          "several ranks share one GPU)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child runs (roofline.traffic = null)")
     ap.add_argument("--pmc-keep", default=None, help="directory that receives the PMC summary of this run (e.g. profiles/r02)")
-    ap.add_argument("--no-verify", action="store_true", help="tile sharding: skip the one-GPU re-render digest check")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the one-GPU re-render that the exchanged frame is checked against")
     ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.child:
         return child_main(args)
     W = WORKLOADS[args.workload]
     NX, NY, SPP = W["nx"], W["ny"], W["spp"]
+    BINS, SLICES = W.get("bins", 15), W.get("slices", 1)      # (shadows the module default: configs[4] has 512 bins in 512 slices)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,7 +295,9 @@ def main():
             with stdout_to_stderr():                          # (gloo announces its peers on stdout)
                 dist.init_process_group("gloo")               # control plane only: rendezvous, barriers, the RCCL unique id
         world_size = dist.get_world_size()
-    sharding = "none" if world_size == 1 and not distributed else ("tile" if args.sharding == "auto" else args.sharding)
+    sharding = "none" if world_size == 1 and not distributed else (("slice" if SLICES >= 8 else "tile") if args.sharding == "auto" else args.sharding)
+    if sharding == "slice" and SLICES < world_size:
+        raise SystemExit("--sharding slice needs at least one spectral slice per rank (workload %s has %d)" % (args.workload, SLICES))
     os.environ["RSX_DEVICE"] = str(local_rank)
 
     import __graft_entry__ as ge
@@ -308,6 +343,16 @@ def main():
             pipe.frame = None
     my_rect = D.tile_rect(rank, world_size, NX, NY, tile_bounds) if sharding == "tile" else (0, 0, NX, NY)
     cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
+    # slice sharding: rank r renders the spectral slices [slice_bounds[r], slice_bounds[r + 1]) of every pass; they fill the bins
+    # [bin_bounds[r], bin_bounds[r + 1]) of every pixel
+    slice_bounds = bin_bounds = None
+    my_slices = SLICES
+    if sharding == "slice":
+        slice_bounds = D.slice_bounds(SLICES, world_size)
+        sl_all = cam._slice_spectrum()
+        bin_bounds = [sl_all[k].offset if k < SLICES else BINS for k in slice_bounds]
+        engine.slice_range = (slice_bounds[rank], slice_bounds[rank + 1])
+        my_slices = slice_bounds[rank + 1] - slice_bounds[rank]
 
     def all_agree(ok):
         if dist is None:
@@ -376,7 +421,8 @@ def main():
         if collective == "host":                            # frames through host memory and gloo: same shard logic, no RCCL
             f = pipe.frame
             t = [torch.from_numpy(a) for a in (f.mean, f.variance, f.samples)]
-            out = D.gather_tile_sharded(*t, rank, dist, tile_bounds) if sharding == "tile" else D.merge_sample_sharded(*t, dist)
+            out = (D.gather_tile_sharded(*t, rank, dist, tile_bounds) if sharding == "tile" else
+                   D.gather_slice_sharded(*t, rank, dist, bin_bounds) if sharding == "slice" else D.merge_sample_sharded(*t, dist))
             for dst, src in zip(f._host, out):
                 dst[...] = src.numpy()
             f._host_written()
@@ -384,11 +430,15 @@ def main():
         if comm is not None:
             if sharding == "tile":
                 comm.allgather_tiles(pipe.frame, NX, NY, tile_bounds)
+            elif sharding == "slice":
+                comm.allgather_slices(pipe.frame, NX, NY, bin_bounds)
             else:
                 comm.allreduce_samples(pipe.frame)
             return None
         if sharding == "tile":
             return D.gather_tile_sharded(frames[0], frames[1], frames[2], rank, dist, tile_bounds)
+        if sharding == "slice":
+            return D.gather_slice_sharded(frames[0], frames[1], frames[2], rank, dist, bin_bounds)
         return D.merge_sample_sharded(frames[0], frames[1], frames[2], dist, combine_torch)
 
     # first observe() creates the pipeline frame; bind external storage before anything is rendered into it
@@ -427,7 +477,12 @@ def main():
             try:
                 tiny = StatsArray3D(world_size * 8, 8, 4)
                 tiny._host[2][:] = 1
-                (comm.allgather_tiles(tiny, world_size * 8, 8) if sharding == "tile" else comm.allreduce_samples(tiny))
+                if sharding == "tile":
+                    comm.allgather_tiles(tiny, world_size * 8, 8)
+                elif sharding == "slice":
+                    comm.allgather_slices(tiny, world_size * 8, 8, [(4 * r) // world_size for r in range(world_size)] + [4])
+                else:
+                    comm.allreduce_samples(tiny)
                 ctx.synchronize()
                 tiny.release()
                 ok = True
@@ -466,110 +521,133 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed, collective_ms = float(tmax[0].item()), float(tmax[1].item())
 
-    rays_per_step_rank = (my_rect[2] - my_rect[0]) * (my_rect[3] - my_rect[1]) * SPP
-    rays_per_step_job = NX * NY * SPP * (world_size if sharding == "sample" else 1)
+    rays_per_step_rank = (my_rect[2] - my_rect[0]) * (my_rect[3] - my_rect[1]) * SPP * my_slices
+    rays_per_step_job = NX * NY * SPP * SLICES * (world_size if sharding == "sample" else 1)
     value = rays_per_step_job * args.steps / elapsed
 
-    # per-launch kernel durations of the timed steps (HIP events recorded by librsx on its launch stream)
-    n_hist = min(args.steps, 512)
+    # per-launch kernel durations of the timed steps (HIP events recorded by librsx on its launch stream): one library call per
+    # spectral slice; a fused pass (Welford inside the trace kernel) has no second kernel
+    n_hist = max(1, min(args.steps * my_slices, 512))
     trace_ms, accum_ms = ctx.render_history(n_hist)
     trace_avg, accum_avg = float(np.mean(trace_ms)), float(np.mean(accum_ms))
+    fused = accum_avg < 0.05                               # (two back-to-back event records: microseconds)
 
     out = None
     if rank == 0:
         # sanity of the rendered frame
         passes = prewarm + args.warmup + args.steps
         if merged is not None:
-            mean, samples = merged[0].cpu().numpy(), merged[2].cpu().numpy()
+            mean, variance, samples = (m_.cpu().numpy() for m_ in merged)
         else:
-            mean, samples = pipe.frame.mean, pipe.frame.samples
+            mean, variance, samples = pipe.frame.mean, pipe.frame.variance, pipe.frame.samples
         expect = passes * SPP * (world_size if sharding == "sample" else 1)
         assert int(samples.min()) == int(samples.max()) == expect, "frame sample count mismatch (%d..%d, expected %d)" % (samples.min(), samples.max(), expect)
         assert np.isfinite(mean).all() and mean.max() > 0
-        digest_ok = None
-        if sharding == "tile" and world_size > 1 and not args.no_verify:
-            # the gathered frame must equal a one-GPU render of the same passes bit for bit: render it alone, compare digests
-            if merged is not None:
-                h = hashlib.sha256()
-                for t in merged:
-                    h.update(np.ascontiguousarray(t.cpu().numpy()).tobytes())
-                got = h.hexdigest()[:32]
-            else:
-                got = frame_digest(pipe.frame)
+        digest_ok = merge_ok = None
+        if world_size > 1 and sharding in ("tile", "slice", "sample") and not args.no_verify:
+            # The exchanged frame against a one-GPU render of the same job, rendered here, alone, after the timed region.
+            # tile / slice sharding move data only: the frames must be equal bit for bit (SHA-256 of mean, variance, samples).
+            # sample sharding folds N frames with the combine_samples law: rank 0 renders every pass's N * spp samples in one go (the
+            # same Philox counters: pass p of rank r drew (p N + r) spp ...) and the merged frame must agree to rounding.
+            h = hashlib.sha256()
+            for a in (mean, variance, samples):
+                h.update(np.ascontiguousarray(a).tobytes())
+            got = h.hexdigest()[:32]
             world1, cam1, pipe1 = build_workload(args.workload, ns, scenes)
             cam1.frame_sampler = ns.RectFrameSampler2D()
             eng1 = ns.HipEngine(rng="philox", seed=20250905)
             cam1.render_engine = eng1
-            for p in range(passes):
-                eng1.sample_offset = p * SPP
+            if sharding == "sample":
+                cam1.pixel_samples = SPP * world_size
+            for p_ in range(passes):
+                eng1.sample_offset = p_ * SPP * (world_size if sharding == "sample" else 1)
                 cam1.observe()
-            digest_ok = frame_digest(pipe1.frame) == got
+            if sharding == "sample":
+                m1, v1, n1 = pipe1.frame.mean, pipe1.frame.variance, pipe1.frame.samples
+                eps = np.finfo(np.float64).eps
+                err_m = float(np.max(np.abs(mean - m1) / np.maximum(np.abs(m1), 1e-300)))
+                bound_v = 16 * eps * (m1 * m1 + v1) + 1e-300
+                err_v = float(np.max(np.abs(variance - v1) / bound_v))
+                merge_ok = bool(np.array_equal(samples, n1) and err_m <= 1e-12 and err_v <= 1.0)
+                assert merge_ok, "sample-sharded merge differs from the one-GPU render (mean rel %.3g, variance %.3g of its bound)" % (err_m, err_v)
+            else:
+                digest_ok = frame_digest(pipe1.frame) == got
+                assert digest_ok, "%s-sharded frame differs from the one-GPU render" % sharding
             pipe1.frame.release()
-            assert digest_ok, "tile-sharded frame differs from the one-GPU render"
 
         from oracle import oracle as orc
         flat = scene.flat
-        # mean per-ray traversal counters on every k-th row of the same camera (pixel-centre rays), instrumented oracle
-        rows = np.arange(0, NY, W["counter_rows"])
-        tasks = np.array([(ix, iy) for iy in rows for ix in range(NX)], dtype=np.int32)
-        from source_amd import _lib
-        d2 = _lib.RenderDesc()
-        d2.camera = cam.device_camera()
-        u = np.full(2 * len(tasks), 0.5)
-        d2.tasks, d2.n_tasks, d2.spp, d2.uniforms = _lib.ptr(tasks), len(tasks), 1, _lib.ptr(u)
-        rays = orc.pinhole_rays(d2)
         nthreads = orc.max_threads()
-        cnt = orc.hit_batch(flat, rays[:, 0:3], rays[:, 3:6], None, threads=nthreads, counters=True)["counters"]
-        b_ray, per_ray = ray_bytes(cnt, len(tasks))
-        achieved = b_ray * rays_per_step_rank / (trace_avg * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                    "frac": round(achieved / PEAK_HBM_GBS, 5), "traffic": None, "kernel": "k_render_trace",
-                    "kernel_ms": round(trace_avg, 4), "accumulate_kernel_ms": round(accum_avg, 4),
-                    "bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()},
-                    "line": "achieved/peak/frac = the contract's HBM line: SURVEY 8d algorithmic bytes per ray x rays per launch / kernel time against the "
-                            "8 TB/s HBM peak. The bytes are node / triangle / primitive records that the caches serve, so it can exceed 1; "
-                            "`ceilings` prices the kernel against what it is actually bound by (counters of this run), `bound` names the highest."}
+        kernel_prefix = "k_render_trace_path" if W.get("paths") else "k_render_trace"
+        # ---- the contract's HBM line: algorithmic bytes per primary ray x rays per launch / kernel time against the HBM
+        # peak. The counters are mean per-ray traversal counts of the instrumented oracle on every k-th row of the same camera
+        # (pixel-centre rays). A fused pass writes no sample record: its rays carry the frame term 40 B x bins / spp instead of 24 B.
+        hbm_contract = None
+        if not W.get("paths"):
+            rows = np.arange(0, NY, W["counter_rows"])
+            tasks = np.array([(ix, iy) for iy in rows for ix in range(NX)], dtype=np.int32)
+            from source_amd import _lib
+            d2 = _lib.RenderDesc()
+            d2.camera = cam.device_camera()
+            u = np.full(2 * len(tasks), 0.5)
+            d2.tasks, d2.n_tasks, d2.spp, d2.uniforms = _lib.ptr(tasks), len(tasks), 1, _lib.ptr(u)
+            rays = orc.pinhole_rays(d2)
+            cnt = orc.hit_batch(flat, rays[:, 0:3], rays[:, 3:6], None, threads=nthreads, counters=True)["counters"]
+            b_ray, per_ray = ray_bytes(cnt, len(tasks))
+            if fused:
+                b_ray += 40.0 * BINS / SPP - 24.0
+            achieved = b_ray * rays_per_step_rank / (trace_avg * 1e-3) / 1e9
+            hbm_contract = {"bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "achieved": round(achieved, 2),
+                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
+                            "note": "SURVEY 8d algorithmic bytes per ray x rays per launch / kernel time against the 8 TB/s HBM peak. The bytes are node / "
+                                    "triangle / primitive records that the caches serve (measured HBM traffic: hbm_measured), so this fraction can exceed 1; "
+                                    "it is not the ceiling that binds the kernel"}
+        # ---- roofline: top level = ONE ceiling, the one that binds the dominant kernel, from the counters of this run
+        roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
+                    "kernel": kernel_prefix, "kernel_ms": round(trace_avg * my_slices, 4), "launches_per_step": my_slices,
+                    "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices, 4),
+                    "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract}
         if not args.no_pmc and world_size == 1:
-            table, note = collect_pmc(args.workload, 3, args.pmc_keep)
+            table, note = collect_pmc(args.workload, 3 if SLICES == 1 else 1, args.pmc_keep)
             if table is None:
                 roofline["pmc_error"] = note
             else:
                 if note:
                     roofline["pmc_error"] = note
-                tr = kernel_counters(table, "k_render_trace")
+                tr = kernel_counters(table, kernel_prefix)
                 if tr is not None:
                     c = tr[1]
-                    ceil, binding = ceilings(c, trace_avg, achieved)
+                    ceil, binding = ceilings(c, trace_avg, hbm_contract["achieved"] if hbm_contract else None)
                     roofline["kernel"] = tr[0]
-                    roofline["ceilings"] = ceil
+                    roofline.update(ceil)                      # hbm_measured, l2, l1_vector_cache, valu_issue: each {achieved, peak, unit, frac, ...}
                     if "hbm_measured" in ceil:
                         roofline["traffic"] = ceil["hbm_measured"]["bytes_per_launch"]
-                        roofline["hbm_measured_gbs"] = ceil["hbm_measured"]["achieved_gbs"]
-                        roofline["hbm_measured_frac"] = ceil["hbm_measured"]["frac"]
-                    if "l2" in ceil:
-                        roofline["l2_hit_rate"] = ceil["l2"]["hit_rate"]
                     if binding:
-                        roofline["bound"] = binding
-                        roofline["bound_frac"] = ceil[binding]["frac"]
+                        b = ceil[binding]
+                        roofline.update({"bound": binding, "achieved": b["achieved"], "peak": b["peak"], "unit": b["unit"], "frac": b["frac"]})
                 ac = kernel_counters(table, "k_accumulate")
-                if ac is not None and accum_avg > 1e-3:
+                if ac is not None and not fused:
                     bytes_acc = (24.0 * SPP + 40.0 * BINS) * NX * NY
                     ceil_a, bind_a = ceilings(ac[1], accum_avg, bytes_acc / (accum_avg * 1e-3) / 1e9)
-                    roofline["accumulate"] = {"kernel": ac[0], "algorithmic_gbs": round(bytes_acc / (accum_avg * 1e-3) / 1e9, 1), "ceilings": ceil_a, "bound": bind_a}
+                    roofline["accumulate"] = dict(ceil_a, kernel=ac[0], bound=bind_a)
+        if roofline["bound"] is None and hbm_contract is not None:
+            # no counters in this run (--no-pmc, N > 1): only the contract's line can be given
+            roofline.update({"bound": "hbm", "achieved": hbm_contract["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_contract["frac"],
+                             "note": "counters were not collected in this run: this is the contract's algorithmic-bytes line (see hbm_contract.note), not a measured ceiling"})
 
         cpu = None
         if not args.no_cpu_baseline and world_size == 1:       # the CPU baseline is timed at N = 1 only (the other ranks would idle at the barrier)
             # bounded sample of the same workload on the host cores, same Philox samples: calibrate on a 16-row band, then size
             # the sample for ~args.cpu_seconds of CPU work — whole passes when one fits, otherwise a centred band of rows
             keep = []
-            sl = cam._slice_spectrum()[0]
+            sl = cam._slice_spectrum()[SLICES // 2]
             engine.sample_offset = 0
             band = (0, NY // 2 - 8, NX, NY // 2 + 8)
             desc = cam.render_desc(world, None, sl, engine, keep, rect=band)
             orc.render_pinhole(flat, desc, threads=nthreads)        # thread-pool warm-up
             tcal = time.perf_counter()
             m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
-            rate = nr / (time.perf_counter() - tcal)
+            rate = NX * 16 * SPP / (time.perf_counter() - tcal)
             target = rate * args.cpu_seconds
             saved = cam.pixel_samples
             if target >= NX * NY * SPP:
@@ -577,19 +655,36 @@ def main():
                 cam.pixel_samples = SPP * n_pass
                 rect = (0, 0, NX, NY)
                 what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, SPP)
+                centred = False
             else:
                 nrows = int(max(16, min(NY, target // (NX * SPP))))
                 rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
                 what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, SPP)
+                centred = True
+            if SLICES > 1:
+                what += ", one of the %d spectral slices" % SLICES
             desc = cam.render_desc(world, None, sl, engine, keep, rect=rect)
+            n_primary = (rect[2] - rect[0]) * (rect[3] - rect[1]) * cam.pixel_samples
             cam.pixel_samples = saved
             tcpu = time.perf_counter()
             m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
             tcpu = time.perf_counter() - tcpu
             assert np.isfinite(m).all()
-            cpu = {"value": round(nr / tcpu, 1), "unit": "primary rays/s", "cores": nthreads, "kind": "port",
-                   "sample": "%s of the same workload (%d rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
-                             "with OpenMP on %d host threads, %.1f s" % (what, nr, nthreads, tcpu)}
+            cpu = {"value": round(n_primary / tcpu, 1), "unit": "primary rays/s", "cores": nthreads, "kind": "port",
+                   "sample": "%s of the same workload (%d primary rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
+                             "with OpenMP on %d host threads, %.1f s" % (what, n_primary, nthreads, tcpu)}
+            if centred:
+                cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
+            # ... and on ONE host thread, a sample sized for a few seconds
+            one_rows = int(max(2, min(rect[3] - rect[1], (rate / max(1, nthreads)) * min(4.0, args.cpu_seconds / 3) * 2 // (NX * SPP))))
+            rect1 = (0, NY // 2 - one_rows // 2, NX, NY // 2 - one_rows // 2 + one_rows)
+            desc1 = cam.render_desc(world, None, sl, engine, keep, rect=rect1)
+            t1 = time.perf_counter()
+            orc.render_pinhole(flat, desc1, threads=1)
+            t1 = time.perf_counter() - t1
+            n1 = NX * one_rows * SPP
+            cpu["one_thread"] = {"value": round(n1 / t1, 1), "unit": "primary rays/s", "cores": 1,
+                                 "sample": "centred band of %d rows x %d px x %d spp (%d primary rays), %.1f s" % (one_rows, NX, SPP, n1, t1)}
             # the compiled Cython reference itself, measured where it can run (development container; tests/golden/time_reference.py)
             ref_path = os.path.join(ROOT, "tests", "golden", "reference_timing.json")
             if os.path.exists(ref_path):
@@ -603,15 +698,22 @@ def main():
                                         "port_over_reference_one_core": r["oracle_1_over_reference_serial"],
                                         "note": "cpu_baseline.value is the C port; a Raysect user's CPU rate is lower by port_over_reference"}
 
+        rccl_ranks = None
+        if comm is not None:
+            try:
+                rccl_ranks = comm.size()
+            except Exception:
+                rccl_ranks = None
         out = {
             "metric": "primary rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if sharding == "sample" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": W["name"] + (", %d MI355X" % world_size), "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
-                       "rng": "philox4x32-10", "sharding": sharding, "tile_bounds": tile_bounds,
+                       "rng": "philox4x32-10", "sharding": sharding, "tile_bounds": tile_bounds, "slice_bounds": slice_bounds, "rccl_ranks": rccl_ranks,
                        "collective": {"none": "none", "rsx": "RCCL from librsx (rsx_allgather_frame / rsx_allreduce_frame)",
                                       "torch": "torch.distributed nccl", "host": "host memory + gloo (test aid)"}[collective] + ("; " + comm_note if comm_note else ""),
-                       "collective_ms": round(collective_ms, 3), "frame_digest_equals_single_gpu": digest_ok},
+                       "collective_ms": round(collective_ms, 3), "frame_digest_equals_single_gpu": digest_ok,
+                       "sample_merge_equals_single_gpu": merge_ok},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(out))

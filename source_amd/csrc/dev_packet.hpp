@@ -99,6 +99,11 @@ __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, 
 
 #define PKT_EMPTY (-INFINITY)
 
+// a value that is the same in every lane, declared so to the compiler (it then lives in scalar registers)
+__device__ __forceinline__ unsigned long long pkt_uniform64(unsigned long long v) {
+    return ((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
 #ifdef RSX_PKT_PROF
 // tuning builds: wave-level event counts of the packet walk, summed into g_pkt by every wave (printed by rsx_synchronize)
 __device__ unsigned long long g_pkt[16];
@@ -327,6 +332,9 @@ __device__ __forceinline__ void packet_leaf_scan(const TriRay &q, int ix, int iy
 // MeshData.trace (mesh.pyx:506-563) for the packet: `m` and the ray space are wave-uniform, `want` = the lane's ray passed the
 // BoundPrimitive gate. Leaves of any size are walked the same way: every record comes in once over the scalar data path (the next one
 // while this one is tested) and every lane with a range tests it — in leaf order, strict `<`: the reference's own loop.
+// (Measured and not adopted — the mesh walk as a real call, `noinline`, so that the world walk's state would sit in callee-saved
+// registers across a visit instead of being spilled piecemeal: configs[2] 27.4 -> 33.3 ms. The call's own traffic — arguments through
+// vector registers and memory, uniform values re-established with readfirstlane, the callee's saves — cost more than the spills.)
 __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work PKT_ARG) {
     const rsx_kdnode *nodes = m->nodes;
     const float4 *leaf = m->leaf;
@@ -417,11 +425,18 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     double tmin = 0, tmax = 0;
     // 1.0 / d per axis (BoundingBox3D.intersect, boundingbox.pyx:180-245) and the branch steps' quotients both come from the refined
     // reciprocals: exact_div(1, d) and exact_div(split - o, d) are the correctly rounded quotients (dev_common.hpp)
-    const AxisDiv ad = axis_div(r);
-    const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
-                 rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
+    AxisDiv ad = axis_div(r);
+    // (1.0 / d is two instructions away from the refined reciprocal: it is formed again wherever a box is tested — RCP3 — instead of
+    // living in six registers through the mesh walks; the asm keeps the compiler from merging the copies back into one long-lived value)
+    const bool all_safe = !pkt_any(ad.safe != 7);
+#define RCP3 \
+    asm volatile("" : "+v"(ad.yx), "+v"(ad.yy), "+v"(ad.yz)); \
+    const double rx = all_safe ? __builtin_fma(__builtin_fma(-r.dx, ad.yx, 1.0), ad.yx, ad.yx) : 1.0 / r.dx, \
+                 ry = all_safe ? __builtin_fma(__builtin_fma(-r.dy, ad.yy, 1.0), ad.yy, ad.yy) : 1.0 / r.dy, \
+                 rz = all_safe ? __builtin_fma(__builtin_fma(-r.dz, ad.yz, 1.0), ad.yz, ad.yz) : 1.0 / r.dz;
+    bool enters;
     const double wlo[3] = {sc->wlower[0], sc->wlower[1], sc->wlower[2]}, whi[3] = {sc->wupper[0], sc->wupper[1], sc->wupper[2]};
-    const bool enters = valid && aabb_rcp(wlo, whi, r, rx, ry, rz, tmin, tmax);
+    { RCP3 enters = valid && aabb_rcp(wlo, whi, r, rx, ry, rz, tmin, tmax); }
     if (!enters) tmax = PKT_EMPTY;
     if (!pkt_any(enters)) return false;
     const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);
@@ -434,6 +449,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     for (int j = 0; j < 2; ++j) {
         if (sc->wide[j] >= 0) {
             int32_t f = 0;
+            RCP3
             analytic_first_root(sc->prims, uniform_prim(sc->prims_uniform, sc->wide[j]), sc->wide[j], enters, r, rx, ry, rz, wide.t[j], f);
             wide.faces[0] |= (uint32_t)f << (8 * j);
         }
@@ -491,6 +507,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                 } else {
                     const UPrim up = uniform_prim(sc->prims_uniform, idx);
                     const int32_t type = up->type;
+                    RCP3
                     if (type == RSX_PRIM_MESH) {
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                         double f, b;
@@ -500,7 +517,8 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
 #else
                         if (pkt_any(gate)) {
 #endif
-                            const Ray l = to_local_uniform(up, r);     // (every lane: the lanes of one space then share one origin)
+                            Ray l = to_local_uniform(up, r);           // (every lane: the lanes of one space then share one origin ...
+                            l.ox = readlane_f64(l.ox, 0); l.oy = readlane_f64(l.oy, 0); l.oz = readlane_f64(l.oz, 0);   // ... which then lives in scalar registers)
                             const UMesh um = (UMesh)(unsigned long long)(sc->meshes + up->mesh);
                             MeshHit mh;
                             if (mesh_trace_packet(sc, idx, gate, um, l, mesh_stack, mh, work PKT_PASS)) {
@@ -521,4 +539,5 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
         if (!packet_pop(st, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
     }
     return best.prim >= 0;
+#undef RCP3
 }

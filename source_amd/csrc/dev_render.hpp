@@ -277,6 +277,24 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
     __builtin_amdgcn_wave_barrier();
 }
 
+// The flush as a real call (packet kernel): once per FUSE_UNITS units, everything it needs is wave-uniform and re-read from the
+// kernel-argument segment inside (the render parameters and the FuseParams lie there, second and fifth argument of k_render_trace) —
+// inlined into the unit loop its chains' registers competed with the walk's and cost the kernel sixteen more spilled registers.
+__device__ __attribute__((noinline)) void fused_flush_call(unsigned long long rp_bits_, const Sample *ring_, int u0_, int u1_, int u2_, int u3_, int n_units_, uint32_t lds_base_) {
+    const Sample *ring = (const Sample *)pkt_uniform64((unsigned long long)ring_);
+    const int u0 = __builtin_amdgcn_readfirstlane(u0_), u1 = __builtin_amdgcn_readfirstlane(u1_), u2 = __builtin_amdgcn_readfirstlane(u2_),
+              u3 = __builtin_amdgcn_readfirstlane(u3_), n_units = __builtin_amdgcn_readfirstlane(n_units_);
+    const uint32_t lds_base = (uint32_t)__builtin_amdgcn_readfirstlane((int)lds_base_);
+    const unsigned long long rp_bits = pkt_uniform64(rp_bits_);           // where the render parameters lie in the kernel-argument segment
+    const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
+    const RSX_CONST_AS FuseParams *fq = (const RSX_CONST_AS FuseParams *)(rp_bits + ((sizeof(RenderParams) + 7) & ~(size_t)7) + 16);   // (+ samples, ticket)
+    FuseParams fz;
+    fz.ring = fq->ring; fz.tables = fq->tables; fz.fmean = fq->fmean; fz.fvar = fq->fvar; fz.fn = fq->fn; fz.sensitivity = fq->sensitivity;
+    fz.n_tables = fq->n_tables; fz.bins = fq->bins; fz.power = fq->power; fz.ny = fq->ny; fz.frame_bins = fq->frame_bins; fz.slice_offset = fq->slice_offset;
+    fz.lds_bytes = fq->lds_bytes; fz.tables_in_lds = fq->tables_in_lds; fz.consts = fq->consts;
+    fused_flush(q, fz, ring, u0, u1, u2, u3, n_units, lds_base);
+}
+
 // PACKET: the unit's rays walk the trees together (dev_packet.hpp) — passes whose units hold a few pixels' samples.
 template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = false, bool PACKET = false>
 __global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
@@ -355,6 +373,12 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
         Hit hit;
         uint32_t work = 0;
+        if constexpr (PACKET) {
+            // the projection weight goes to its record NOW (its two registers are then free through the walk); a and table follow the walk
+            if constexpr (FUSED) fuse_ring[fuse_n * WAVE + lane].weight = weight;
+            else if (px.valid) samples[px.slot * q->spp + px.s].weight = weight;
+            r.ox = readlane_f64(r.ox, 0); r.oy = readlane_f64(r.oy, 0); r.oz = readlane_f64(r.oz, 0);     // (the pinhole: one origin, kept in scalar registers)
+        }
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_w0 = clock64();
         phase_acc[0] = ph2_w0 - ph2_u0;
@@ -413,7 +437,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         if constexpr (MODE == 2) { if (!((q2->redo_mask[unit] >> lane) & 1ULL)) continue; }
         if (!FUSED && !px2.valid) continue;
         Sample smp;
-        smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
+        smp.a = 0.0; smp.weight = PACKET ? 0.0 : weight; smp.table = -1; smp.pad = 0;
         if (got) {                                                                 // optical/ray.pyx:391-393
             const rsx_primitive &p = sc.prims[hit.prim];
             const rsx_material mat = q2->materials[p.material];
@@ -430,16 +454,26 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
                 }
             }
         }
+        if constexpr (FUSED && PACKET) {
+            Sample *rec = fuse_ring + fuse_n * WAVE + lane;                // (weight: stored before the walk)
+            rec->a = smp.a; rec->table = smp.table; rec->pad = 0;
+        }
         if constexpr (FUSED) {
-            fuse_ring[fuse_n * WAVE + lane] = smp;                         // (lanes of pixels outside the frame write a record nobody reads)
+            if constexpr (!PACKET) fuse_ring[fuse_n * WAVE + lane] = smp;  // (lanes of pixels outside the frame write a record nobody reads)
             if (fuse_n == 0) fuse_u0 = unit; else if (fuse_n == 1) fuse_u1 = unit; else if (fuse_n == 2) fuse_u2 = unit; else fuse_u3 = unit;
-            if (++fuse_n == FUSE_UNITS) { fused_flush(q2, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t); fuse_n = 0; }
-        } else samples[px2.slot * q2->spp + px2.s] = smp;
+            if (++fuse_n == FUSE_UNITS) {
+                if constexpr (PACKET) fused_flush_call(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t);
+                else fused_flush(q2, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t);
+                fuse_n = 0;
+            }
+        } else if constexpr (PACKET) { Sample *rec = samples + px2.slot * q2->spp + px2.s; rec->a = smp.a; rec->table = smp.table; rec->pad = 0; }
+        else samples[px2.slot * q2->spp + px2.s] = smp;
     }
     if constexpr (FUSED) {
         if (fuse_n) {
             const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
-            fused_flush((const RSX_CONST_AS RenderParams *)rp_bits, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
+            if constexpr (PACKET) fused_flush_call(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
+            else fused_flush((const RSX_CONST_AS RenderParams *)rp_bits, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
         }
     }
 }

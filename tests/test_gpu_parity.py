@@ -5,6 +5,7 @@ from the compiled reference. Bar: bit-exact for primitive / triangle ids, distan
 geometry and — in RSX_RNG_STREAM mode — the rendered frames (mean, variance, samples).
 """
 import hashlib
+import os
 
 import numpy as np
 import pytest
@@ -16,6 +17,7 @@ from source_amd._flatten import FlatScene
 from source_amd.optical.observer import FrameSampler2D
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 class RectSampler(FrameSampler2D):
@@ -1277,3 +1279,28 @@ def test_deferred_slice_checks_give_the_same_frames(ns, monkeypatch):
         b = render(False, build)
         assert a[3] == b[3] and a[3] > 0
         assert eq(a[0], b[0]) and eq(a[1], b[1]) and eq(a[2], b[2])
+
+
+@pytest.mark.parametrize("workload,sharding", [("c2", "tile"), ("c2", "sample"), ("c5s", "slice")])
+def test_bench_distributed_paths_start_on_rccl(workload, sharding):
+    """bench.py under torch.distributed.run with ONE rank, for each sharding: dlopen(librccl), ncclCommInitRank, the untimed first
+    exchange and the timed one (rsx_allgather_frame / rsx_allreduce_frame / rsx_allgather_bins) all run from librsx on this box —
+    what the driver's 2 / 4 / 8-GPU runs start from. (More than one rank needs more than one GPU: the CPU gloo tests cover the shard
+    logic, bench.py checks the exchanged frame against a one-GPU render in the run itself.)"""
+    import json
+    import subprocess
+    import sys
+    port = 29600 + (os.getpid() + hash(sharding)) % 300
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline", "--workload", workload,
+           "--sharding", sharding]
+    r = subprocess.run(cmd, cwd=ROOT, capture_output=True, text=True, timeout=900, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    d = json.loads(line)
+    cfg = d["config"]
+    assert cfg["sharding"] == sharding and cfg["collective"].startswith("RCCL from librsx"), cfg["collective"]
+    assert cfg["rccl_ranks"] == 1 and d["n_gpus"] == 1 and d["value"] > 0
+    assert d["scaling"] == ("weak" if sharding == "sample" else "strong")
+    if sharding == "slice":
+        assert cfg["slice_bounds"] == [0, 16]
