@@ -26,7 +26,7 @@ extern "C" {
 #define RSX_ENODEV       -2   /* no usable gfx950 device / HIP failure at init */
 #define RSX_EHIP         -3   /* HIP runtime error (text in rsx_last_error) */
 #define RSX_ENOMEM       -4
-#define RSX_EUNSUPPORTED -5   /* scene uses something outside the device path (e.g. CSG nesting too deep) */
+#define RSX_EUNSUPPORTED -5   /* something outside the device path (CSG nesting beyond 64 levels, librccl missing, ...) */
 
 /* ---- primitive and material enumerations ------------------------------------------------------ */
 enum {

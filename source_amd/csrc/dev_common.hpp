@@ -36,6 +36,8 @@ struct DScene {
     int32_t wide_csg[4];       // top-level CSG primitives (state-free evaluator form) that sit in several world leaves, -1 = none: the path
                                // kernel of a CSG scene answers them for the whole wave before the traversal (world_trace_wave's mailbox)
     const rsx_primitive *prims_uniform;   // = prims in global memory: what the scalar data path reads (the path kernel may point `prims` at an LDS copy)
+    struct NodeSt *csg_arena;             // node states of the CSG stream merge for trees too big for the kernels' private arrays, or null:
+    int32_t csg_arena_slots, csg_arena_lanes;   // [csg_arena_lanes][csg_arena_slots] (dev_csg.hpp: csg_slots)
     int32_t wsplits_bounded, pad_w;       // every split of the world tree lies inside [wlower, wupper] (packet_space, dev_packet.hpp)
     const float4 *rel;                    // camera-relative leaf records of the mesh instances (dev_packet.hpp: RelInfo), or null
     const struct RelInfo *rel_info;       // per primitive

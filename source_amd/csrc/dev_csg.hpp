@@ -7,17 +7,14 @@
 //       :326-348 Union, :421-446 Intersect, :523-568 Subtract (+_modify_intersection)
 //
 // The reference merges two lazily evaluated, ordered root streams per CSG node and keeps the stream heads cached on the
-// node object. Here the same state machine runs per lane with the per-node state in private (scratch) memory, and the
-// recursion over nested CSG nodes is unrolled by a depth template (CSG_MAX_DEPTH nested levels below the top node; deeper
-// trees are rejected by rsx_scene_create). Only the kernels instantiated with CSG=true contain this code.
+// node object. Here the same state machine runs per lane with the per-node state in a slot array — private memory for trees of up
+// to CSG_MAX_SLOTS nodes, a per-lane region of DScene::csg_arena for bigger ones — and the recursion over nested CSG nodes is a loop
+// over an explicit frame stack (csg_run). Only the kernels instantiated with CSG=true contain this code.
 // ---------------------------------------------------------------------------------------------------
 #ifndef RSX_CSGFAST_MIN_WAVES
 #define RSX_CSGFAST_MIN_WAVES 2             // waves per SIMD of the kernels that carry only the state-free CSG evaluator
 #endif
 #define CSG_MAX_SLOTS 16
-#ifndef CSG_MAX_DEPTH
-#define CSG_MAX_DEPTH 4
-#endif
 #define F_VALID 1u
 #define F_EXIT 2u
 #define F_FLIP 4u
@@ -47,6 +44,12 @@ struct CsgEval {
     NodeSt *st;
     Stack mesh_stack;
 };
+
+// where this lane keeps its node states: the kernel's private array, or — scenes with an operand tree of more than CSG_MAX_SLOTS nodes —
+// the lane's region of the scene's arena (rsx_scene_create sizes it for the grids such scenes are launched with)
+__device__ __forceinline__ NodeSt *csg_arena_slots(const DScene &sc) {
+    return sc.csg_arena + ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * (size_t)sc.csg_arena_slots;
+}
 
 __device__ __forceinline__ bool is_csg(int type) { return type == RSX_PRIM_UNION || type == RSX_PRIM_INTERSECT || type == RSX_PRIM_SUBTRACT; }
 
@@ -126,84 +129,119 @@ __device__ __forceinline__ int csg_closest(const Rec &a, const Rec &b) {
     return 0;
 }
 
-template <int D> __device__ void node_next(CsgEval &e, int32_t idx, Rec &out);
+// The merge as one loop over an explicit stack (csg_run). The reference recurses: hit() / next_intersection() of a CSG node call those
+// of its operands (csg.pyx:132-234, through BoundPrimitive, boundprimitive.pyx:42-60), to any depth. Here a frame is (node, where to
+// resume) in a per-lane array; everything else a frame of the recursion would hold lives in the node's state slot — the two stream
+// heads are advanced IN PLACE (the reference advances local copies and stores them only when it returns a root; the copies it drops
+// belong to a stream that has just ended, and an ended stream is never asked again: _closest_intersection cannot select a head that
+// is None), and a CSG node keeps the ray in its own space in the slot's mesh-leaf fields, which it does not use otherwise.
+// Depth is bounded by the frame array alone (CSG_STACK_MAX nested levels), the number of nodes by the state slots the launch provides.
+#ifndef CSG_STACK_MAX
+#define CSG_STACK_MAX 64
+#endif
+enum { CSGP_FIRST = 0, CSGP_GOT_FA, CSGP_GOT_FB, CSGP_NEXT, CSGP_GOT_NA, CSGP_GOT_NB, CSGP_IDENT };
 
-template <int D>
-__device__ void csg_identify(CsgEval &e, int32_t idx, NodeSt &st, Rec &a, Rec &b, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    out.flags = 0;
-    int closest = csg_closest(a, b);
-    while (closest >= 0) {
-        const Rec &c = closest ? a : b;
-        if (csg_valid(p.type, a, b, closest != 0)) {
-            if (c.t <= st.maxd) {
-                st.a = a; st.b = b; st.last_is_a = closest; st.invalid = 0;
-                out = c;
-                if (p.type == RSX_PRIM_SUBTRACT && !closest) out.flags ^= (F_EXIT | F_FLIP);   // _modify_intersection
-            }
-            return;
+__device__ __noinline__ void csg_run(CsgEval &e, int32_t top, bool first, const Ray &pr, Rec &out) {
+    int32_t frames[CSG_STACK_MAX];              // (node << 3) | phase to resume at
+    int sp = 0;
+    int32_t cur = top;
+    int phase = first ? CSGP_FIRST : CSGP_NEXT;
+    Ray ray_in = pr;                            // CSGP_FIRST: the ray in the PARENT's space (hit() argument)
+    Rec ret;
+    ret.flags = 0;
+    bool finished = false;                      // (one loop, one exit test, no `continue` inside: see node_contains)
+    while (!finished) {
+        const rsx_primitive &p = e.sc->prims[cur];
+        NodeSt &st = e.st[e.sc->csg[cur].slot];
+        int32_t child = -1;
+        bool want_first = false;
+        int resume = 0;
+        bool done = false;                      // this node's call has its result in `ret`
+        if (phase == CSGP_FIRST) {                                                                 // CSGPrimitive.hit, csg.pyx:132-155
+            st.invalid = 1;
+            st.maxd = ray_in.maxd;
+            const Ray l = to_local(p, ray_in);
+            st.nox = l.ox; st.noy = l.oy; st.noz = l.oz; st.ndx = l.dx; st.ndy = l.dy; st.ndz = l.dz;   // (its max_distance is INFINITY)
+            child = p.child_a; want_first = true; resume = CSGP_GOT_FA;
+        } else if (phase == CSGP_GOT_FA) {
+            st.a = ret;
+            if (p.type != RSX_PRIM_UNION && !(ret.flags & F_VALID)) { ret.flags = 0; done = true; }    // terminate_early
+            else { child = p.child_b; want_first = true; resume = CSGP_GOT_FB; }
+        } else if (phase == CSGP_NEXT) {                                                           // next_intersection, csg.pyx:160-179
+            if (st.invalid) { ret.flags = 0; done = true; }
+            else if (st.last_is_a) { child = p.child_a; resume = CSGP_GOT_NA; }
+            else { child = p.child_b; resume = CSGP_GOT_NB; }
+        } else {
+            if (phase == CSGP_GOT_FB || phase == CSGP_GOT_NB) st.b = ret;
+            else if (phase == CSGP_GOT_NA) st.a = ret;
+            // _identify_intersection, csg.pyx:181-222 — one turn of its loop per visit of this block
+            const int closest = csg_closest(st.a, st.b);
+            if (closest < 0) { ret.flags = 0; done = true; }
+            else if (csg_valid(p.type, st.a, st.b, closest != 0)) {
+                const Rec &c = closest ? st.a : st.b;
+                if (c.t <= st.maxd) {
+                    st.last_is_a = closest; st.invalid = 0;
+                    ret = c;
+                    if (p.type == RSX_PRIM_SUBTRACT && !closest) ret.flags ^= (F_EXIT | F_FLIP);       // _modify_intersection
+                } else ret.flags = 0;
+                done = true;
+            } else if (closest) { child = p.child_a; resume = CSGP_GOT_NA; }
+            else { child = p.child_b; resume = CSGP_GOT_NB; }
         }
-        if (closest) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
-        closest = csg_closest(a, b);
+        if (!done) {
+            // BoundPrimitive.hit / next_intersection over the operand (boundprimitive.pyx:42-60): a leaf answers at once, a CSG operand
+            // becomes the current node and this one waits in a frame
+            const rsx_primitive &cp = e.sc->prims[child];
+            NodeSt &cst = e.st[e.sc->csg[child].slot];
+            bool answered = true;
+            ret.flags = 0;
+            if (want_first) {
+                Ray l;
+                l.ox = st.nox; l.oy = st.noy; l.oz = st.noz; l.dx = st.ndx; l.dy = st.ndy; l.dz = st.ndz; l.maxd = INFINITY;
+                double f, b;
+                if (!aabb(cp.box_lower, cp.box_upper, l, f, b)) cst.tested = 0;
+                else {
+                    cst.tested = 1;
+                    if (is_csg(cp.type)) { answered = false; ray_in = l; }
+                    else if (cp.type != RSX_PRIM_NULL) leaf_first(e, child, cst, l, ret);
+                }
+            } else if (cst.tested) {
+                if (is_csg(cp.type)) answered = false;
+                else if (cp.type != RSX_PRIM_NULL) leaf_next(e, child, cst, ret);
+            }
+            if (answered) phase = resume;
+            else {
+                frames[sp] = (cur << 3) | resume;               // (rsx_scene_create refuses trees nested deeper than the array)
+                sp += 1;
+                cur = child;
+                phase = want_first ? CSGP_FIRST : CSGP_NEXT;
+            }
+        } else if (sp == 0) {
+            finished = true;
+        } else {
+            sp -= 1;
+            const int32_t fr = frames[sp];
+            cur = fr >> 3;
+            phase = fr & 7;
+        }
     }
+    out = ret;
 }
 
-template <int D> __device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out);
-
-template <int D>
-__device__ void csg_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {                     // CSGPrimitive.hit
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    st.invalid = 1;
-    st.maxd = pr.maxd;
-    Ray l = to_local(p, pr);
-    l.maxd = INFINITY;
-    Rec a, b;
-    node_first<D>(e, p.child_a, l, a);
-    if (p.type != RSX_PRIM_UNION && !(a.flags & F_VALID)) return;                                  // terminate_early
-    node_first<D>(e, p.child_b, l, b);
-    csg_identify<D>(e, idx, st, a, b, out);
+// (the two homes of the node states are two calls rather than one call through a selected pointer: the callee then sees a private or a
+// global address, not a generic one)
+__device__ __forceinline__ void csg_call(CsgEval &e, int32_t idx, bool first, const Ray &pr, Rec &out) {
+    if (e.sc->csg_arena) {
+        CsgEval big;
+        big.sc = e.sc; big.st = csg_arena_slots(*e.sc); big.mesh_stack = e.mesh_stack;
+        csg_run(big, idx, first, pr, out);
+    } else csg_run(e, idx, first, pr, out);
 }
-
-template <int D>
-__device__ void csg_next(CsgEval &e, int32_t idx, Rec &out) {                                      // CSGPrimitive.next_intersection
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    if (st.invalid) return;
-    Rec a = st.a, b = st.b;
-    if (st.last_is_a) node_next<D>(e, p.child_a, a); else node_next<D>(e, p.child_b, b);
-    csg_identify<D>(e, idx, st, a, b, out);
-}
-
-// BoundPrimitive.hit / next_intersection over an operand (boundprimitive.pyx:42-60)
-template <int D>
-__device__ void node_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    double f, b;
-    out.flags = 0;
-    if (!aabb(p.box_lower, p.box_upper, pr, f, b)) { st.tested = 0; return; }
-    st.tested = 1;
-    if (is_csg(p.type)) {
-        if constexpr (D > 0) csg_first<D - 1>(e, idx, pr, out);
-    } else if (p.type != RSX_PRIM_NULL) {
-        leaf_first(e, idx, st, pr, out);
-    }
-}
-
-template <int D>
-__device__ void node_next(CsgEval &e, int32_t idx, Rec &out) {
-    const rsx_primitive &p = e.sc->prims[idx];
-    NodeSt &st = e.st[e.sc->csg[idx].slot];
-    out.flags = 0;
-    if (!st.tested) return;
-    if (is_csg(p.type)) {
-        if constexpr (D > 0) csg_next<D - 1>(e, idx, out);
-    } else if (p.type != RSX_PRIM_NULL) {
-        leaf_next(e, idx, st, out);
-    }
+__device__ __forceinline__ void csg_first(CsgEval &e, int32_t idx, const Ray &pr, Rec &out) { csg_call(e, idx, true, pr, out); }      // CSGPrimitive.hit
+__device__ __forceinline__ void csg_next(CsgEval &e, int32_t idx, Rec &out) {                                                          // next_intersection
+    Ray none;
+    none.ox = none.oy = none.oz = none.dx = none.dy = none.dz = 0.0; none.maxd = 0.0;
+    csg_call(e, idx, false, none, out);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -360,28 +398,59 @@ __device__ bool csg_fast_contains(const DScene &sc, int32_t idx, double px, doub
     return csg_truth(P, inside) != 0;
 }
 
-template <int D>
-__device__ bool node_contains(const DScene &sc, int32_t idx, double px, double py, double pz, Stack mesh_stack) {
-    const rsx_primitive &p = sc.prims[idx];
-    if (!aabb_contains(p.box_lower, p.box_upper, px, py, pz)) return false;
-    if (!is_csg(p.type)) return leaf_contains(sc, p, px, py, pz, mesh_stack);
-    if constexpr (D > 0) {
-        double qx, qy, qz;
-        xform_point(p.to_local, px, py, pz, qx, qy, qz);
-        const bool a = node_contains<D - 1>(sc, p.child_a, qx, qy, qz, mesh_stack);
-        if (p.type == RSX_PRIM_UNION) return a || node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
-        if (p.type == RSX_PRIM_INTERSECT) return a && node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
-        return a && !node_contains<D - 1>(sc, p.child_b, qx, qy, qz, mesh_stack);
+// contains() of any operand tree: the recursion of csg.pyx:350-353 / :448-451 / :570-573 over BoundPrimitive.contains as a loop over
+// an explicit stack of (node, what is known of it); a CSG node's point in its own space is kept per level.
+// (One loop with one exit test and no `continue` / `return` inside: written with early continues and a return in the middle, hipcc 7.2
+// compiled a loop that is right for a single lane — traced with printf — and wrong when the lanes of a wave leave it at different
+// turns; tests/test_gpu_parity.py::test_csg_trees_of_any_depth_and_size_vs_oracle pins this form.)
+__device__ __noinline__ bool node_contains(const DScene &sc, int32_t top, double px, double py, double pz, Stack mesh_stack) {
+    int32_t frames[CSG_STACK_MAX];              // (node << 1) | 1 when operand a is known and operand b is being evaluated
+    double pts[3 * (CSG_STACK_MAX + 1)];        // level k: the point in the space the node at level k is tested in
+    int sp = 0;
+    int32_t cur = top;
+    pts[0] = px; pts[1] = py; pts[2] = pz;
+    bool result = false;
+    bool have = false;                          // `result` answers the node whose frame was popped last (or `top`)
+    bool finished = false;
+    while (!finished) {
+        if (!have) {
+            const rsx_primitive &p = sc.prims[cur];
+            const double x = pts[3 * sp], y = pts[3 * sp + 1], z = pts[3 * sp + 2];
+            if (!aabb_contains(p.box_lower, p.box_upper, x, y, z)) { result = false; have = true; }
+            else if (!is_csg(p.type)) { result = leaf_contains(sc, p, x, y, z, mesh_stack); have = true; }
+            else if (sp >= CSG_STACK_MAX) { result = false; have = true; }
+            else {
+                double qx, qy, qz;
+                xform_point(p.to_local, x, y, z, qx, qy, qz);
+                pts[3 * sp + 3] = qx; pts[3 * sp + 4] = qy; pts[3 * sp + 5] = qz;
+                frames[sp] = cur << 1;
+                sp += 1;
+                cur = p.child_a;
+            }
+        } else if (sp == 0) {
+            finished = true;
+        } else {
+            const int32_t fr = frames[sp - 1];
+            const rsx_primitive &p = sc.prims[fr >> 1];
+            if (!(fr & 1)) {                    // operand a is known: a || b, a && b, a && !b
+                const bool need_b = p.type == RSX_PRIM_UNION ? !result : result;
+                if (need_b) { frames[sp - 1] = fr | 1; cur = p.child_b; have = false; }
+                else sp -= 1;                   // (a is the node's answer: true for a Union, false for the others)
+            } else {
+                if (p.type == RSX_PRIM_SUBTRACT) result = !result;
+                sp -= 1;
+            }
+        }
     }
-    return false;
+    return result;
 }
 
 // Rebuild the Intersection a CSG node returns for a root: leaf geometry in the leaf's space, lifted operand by operand into
 // the top node's space (csg.pyx:198-208), Subtract's swap/negate applied by parity (it commutes with the affine lifts).
 __device__ void csg_geom(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
-    int32_t chain[CSG_MAX_DEPTH + 3];
+    int32_t chain[CSG_STACK_MAX + 2];
     int n = 0;
-    for (int32_t i = h.leaf; i != h.prim && n < CSG_MAX_DEPTH + 2; i = sc.csg[i].parent) chain[n++] = i;
+    for (int32_t i = h.leaf; i != h.prim && n < CSG_STACK_MAX + 1; i = sc.csg[i].parent) chain[n++] = i;
     Ray l = to_local(sc.prims[h.prim], r);
     for (int k = n - 1; k >= 0; --k) l = to_local(sc.prims[chain[k]], l);
     const rsx_primitive &leaf = sc.prims[h.leaf];

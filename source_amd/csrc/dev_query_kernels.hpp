@@ -129,7 +129,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
                 e.sc = &sc; e.st = csg_state;
                 e.mesh_stack = ms;
                 Rec rec;
-                csg_first<CSG_MAX_DEPTH>(e, pidx, r, rec);
+                csg_first(e, pidx, r, rec);
                 while ((rec.flags & F_VALID) && c < max_roots) {
                     t[i * max_roots + c] = rec.t;
                     exiting[i * max_roots + c] = (rec.flags & F_EXIT) ? 1 : 0;
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_roots(DScene sc, int32_t pidx, l
                         emit(c, g, on_mesh ? rec.a0 : -1, on_mesh ? rec.u : 0.0f, on_mesh ? rec.v : 0.0f, on_mesh ? rec.w : 0.0f);
                     }
                     ++c;
-                    csg_next<CSG_MAX_DEPTH>(e, pidx, rec);
+                    csg_next(e, pidx, rec);
                 }
             }
         } else if (p.type == RSX_PRIM_MESH) {
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_contains(DScene sc, long long n,
             bool in;
             if constexpr (CSG) {                                                                // BoundPrimitive.contains: box gate first
                 if (is_csg(p.type) && sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);   // flattened analytic tree
-                else in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
+                else in = node_contains(sc, idx, px, py, pz, ms);
             }
             else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
             inside[i * sc.n_world + idx] = in ? 1 : 0;

@@ -407,6 +407,10 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
 #endif
         // the unit's pixel bookkeeping is recomputed rather than carried through the traversal (`unit` is laundered so that the
         // compiler cannot merge this with the computation above)
+        // (readfirstlane first: both are wave-uniform by construction, but the "+s" constraint fails in the backend — "illegal VGPR to SGPR
+        // copy" — whenever the optimiser has decided to carry one of them in a vector register across the walk)
+        unit = __builtin_amdgcn_readfirstlane(unit);
+        rp_bits = pkt_uniform64(rp_bits);
         asm volatile("" : "+s"(unit));
         asm volatile("" : "+s"(rp_bits));
         const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
@@ -712,7 +716,7 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
                 if (sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);
                 else { in = false; needs_stream = true; }
             } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
-        } else if constexpr (CSG) in = node_contains<CSG_MAX_DEPTH + 1>(sc, idx, px, py, pz, ms);
+        } else if constexpr (CSG) in = node_contains(sc, idx, px, py, pz, ms);
         else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
         if (in) f(idx);
     }

@@ -36,7 +36,7 @@ __device__ __forceinline__ void primitive_first_hit(const DScene &sc, int32_t id
             CsgEval e;
             e.sc = &sc; e.st = csg_state; e.mesh_stack = mesh_stack;
             Rec rec;
-            csg_first<CSG_MAX_DEPTH>(e, idx, r, rec);
+            csg_first(e, idx, r, rec);
             if (rec.flags & F_VALID) {
                 cand.prim = idx; cand.t = rec.t; cand.a0 = rec.a0; cand.a1 = rec.a1; cand.u = rec.u; cand.v = rec.v; cand.w = rec.w;
                 cand.leaf = rec.leaf; cand.flags = rec.flags; cand.hx = rec.hx; cand.hy = rec.hy; cand.hz = rec.hz;

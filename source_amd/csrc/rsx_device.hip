@@ -89,6 +89,9 @@
 #define UTIL_COUNT(acc, slot)
 #endif
 
+#ifndef RSX_CSG_ARENA_WG_PER_CU
+#define RSX_CSG_ARENA_WG_PER_CU 2   // grid limit (workgroups per CU) of scenes whose CSG node states live in the scene's arena
+#endif
 #ifndef RSX_CSG_MIN_WAVES
 #define RSX_CSG_MIN_WAVES 1         // launch-bounds waves per SIMD of the CSG instantiations of the traversal kernels
 #endif
@@ -576,6 +579,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     std::memset(&d, 0, sizeof(d));
     // CSG bookkeeping: per operand tree assign per-lane state slots, parent links and nesting depth
     std::vector<CsgInfo> info((size_t)desc->n_primitives, CsgInfo{-1, 0, 0, -1});
+    int32_t max_slots = 0;                                  // nodes of the biggest operand tree
     for (int32_t top = 0; top < desc->n_primitives; ++top) {
         const int tt = desc->primitives[top].type;
         const bool csg_node = tt == RSX_PRIM_UNION || tt == RSX_PRIM_INTERSECT || tt == RSX_PRIM_SUBTRACT;
@@ -591,7 +595,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             const rsx_primitive &q = desc->primitives[i];
             const bool inner = q.type == RSX_PRIM_UNION || q.type == RSX_PRIM_INTERSECT || q.type == RSX_PRIM_SUBTRACT;
             if (!inner) continue;
-            if (depth > CSG_MAX_DEPTH) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG nesting deeper than %d levels", top, CSG_MAX_DEPTH + 1); }
+            if (depth >= CSG_STACK_MAX) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG nesting deeper than %d levels", top, CSG_STACK_MAX); }
             for (int side = 0; side < 2; ++side) {
                 const int32_t c = side ? q.child_b : q.child_a;
                 if (info[(size_t)c].top >= 0) { delete sc; return rsx_fail(RSX_EINVAL, "primitive %d is an operand of two CSG nodes", c); }
@@ -599,7 +603,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 todo.push_back({c, depth + 1});
             }
         }
-        if (slots > CSG_MAX_SLOTS) { delete sc; return rsx_fail(RSX_EUNSUPPORTED, "primitive %d: CSG tree with %d nodes (limit %d)", top, slots, CSG_MAX_SLOTS); }
+        max_slots = std::max(max_slots, slots);
     }
     // flattened operand trees for the state-free first-hit evaluator (csg_fast_hit): analytic leaves only
     std::vector<CsgFast> fast;
@@ -666,6 +670,22 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
     d.prims_uniform = d.prims;
     if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
+    d.csg_arena = nullptr; d.csg_arena_slots = 0; d.csg_arena_lanes = 0;
+    if (max_slots > CSG_MAX_SLOTS) {
+        // an operand tree with more nodes than the kernels' private state arrays hold: the stream merge keeps its node states in a
+        // per-lane region of this arena instead (dev_csg.hpp: csg_slots), and plan() launches such a scene with at most
+        // RSX_CSG_ARENA_WG_PER_CU workgroups per CU so that the arena covers every lane of the grid
+        const size_t lanes = (size_t)ctx->n_cus * RSX_CSG_ARENA_WG_PER_CU * WG_THREADS;
+        const size_t bytes = lanes * (size_t)max_slots * sizeof(NodeSt);
+        void *arena = nullptr;
+        if (hipMalloc(&arena, bytes) != hipSuccess) {
+            (void)hipGetLastError();
+            rsx_scene_free(sc);
+            return rsx_fail(RSX_ENOMEM, "CSG tree with %d nodes: %zu bytes of stream-merge state could not be allocated", max_slots, bytes);
+        }
+        sc->allocs.push_back(arena);
+        d.csg_arena = static_cast<NodeSt *>(arena); d.csg_arena_slots = max_slots; d.csg_arena_lanes = (int32_t)lanes;
+    }
     if (any_fast) UP(upload(sc, fast.data(), fast.size(), &d.csgfast));
     // (the world nodes are uploaded below, after the wide primitives are known: wide-only leaves are tagged in the device copy)
     UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
@@ -842,6 +862,7 @@ struct Launch {
 
 // persistent grid: enough workgroups to fill every CU at the occupancy the LDS stacks allow
 int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg_per_cu_cap = RSX_MAX_WG_PER_CU) {
+    if (sc->d.csg_arena) wg_per_cu_cap = std::min(wg_per_cu_cap, RSX_CSG_ARENA_WG_PER_CU);      // the arena holds the states of that many lanes
     const int lds_levels = sc->d.wlds + sc->d.mlds;
     l.lds = (size_t)WG_WAVES * ((size_t)lds_levels * WAVE * 12 + STAGE_BYTES);
     if (l.lds > 160 * 1024) return rsx_fail(RSX_EUNSUPPORTED, "traversal stack does not fit LDS (%d levels)", lds_levels);

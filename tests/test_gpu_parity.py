@@ -1304,3 +1304,86 @@ def test_bench_distributed_paths_start_on_rccl(workload, sharding):
     assert d["scaling"] == ("weak" if sharding == "sample" else "strong")
     if sharding == "slice":
         assert cfg["slice_bounds"] == [0, 16]
+
+
+def test_csg_trees_of_any_depth_and_size_vs_oracle(orc, ns):
+    """CSG operand trees beyond the former limits (5 nested levels, 16 nodes; csg.pyx:132-234 recurses without a bound): a 12-level
+    Union chain, a 14-level mixed chain, and random trees of 33 - 70 nodes — first hits with full geometry, next_intersection
+    sequences, contains(), and a path-traced frame, all against the oracle's recursion, bit for bit. (The stream merge runs as one
+    loop over an explicit frame stack; trees of more than 16 nodes keep their node states in the scene's arena.)"""
+    rng = np.random.RandomState(77)
+    P = ns.Point3D
+
+    def leaf(k):
+        t = ns.translate(0.18 * np.cos(0.9 * k), 0.18 * np.sin(1.3 * k), 0.07 * ((k % 5) - 2)) * ns.rotate(17.0 * k, 11.0 * k, 5.0 * k)
+        kind = k % 3
+        if kind == 0:
+            return ns.Sphere(0.25 + 0.02 * (k % 4), transform=t)
+        if kind == 1:
+            return ns.Box(P(-0.2, -0.25, -0.15), P(0.25, 0.2, 0.3), transform=t)
+        return ns.Cylinder(0.2, 0.5, transform=t)
+
+    def chain(n, ops):
+        node = leaf(0)
+        for k in range(1, n + 1):
+            node = ops[k % len(ops)](node, leaf(k), transform=ns.translate(0.01 * k, -0.005 * k, 0.0) * ns.rotate(3.0 * k, 0, 2.0 * k))
+        return node
+
+    def random_tree(depth):
+        if depth == 0 or (depth < 5 and rng.rand() < 0.2):
+            return leaf(int(rng.randint(1000)))
+        op = [ns.Union, ns.Union, ns.Intersect, ns.Subtract][rng.randint(4)]
+        return op(random_tree(depth - 1), random_tree(depth - 1), transform=ns.translate(*(0.05 * rng.randn(3))))
+
+    def nodes(p):
+        return 1 + nodes(p.primitive_a) + nodes(p.primitive_b) if hasattr(p, "primitive_a") else 1
+
+    world = ns.World()
+    trees = [chain(12, [ns.Union]), chain(14, [ns.Union, ns.Subtract, ns.Union, ns.Intersect, ns.Union])]
+    while len(trees) < 5:
+        t = random_tree(6)
+        if 33 <= nodes(t) <= 70:
+            trees.append(t)
+    assert nodes(trees[0]) == 25 and max(nodes(t) for t in trees) >= 33
+    for k, t in enumerate(trees):
+        t.parent = world
+        t.transform = ns.translate(1.6 * (k - 2), 0.3 * (k % 2), 0.0) * (t.transform or ns.translate(0, 0, 0))
+        t.material = ns.AbsorbingSurface()
+    flat = world.flatten()
+    sc = world.build_accelerator()
+    n = 60000
+    o = rng.uniform(-4.5, 4.5, (n, 3)) * [1.0, 0.5, 1.0]
+    tgt = np.stack([1.6 * (rng.randint(5, size=n) - 2) + 0.3 * rng.randn(n), 0.3 * rng.randn(n), 0.3 * rng.randn(n)], axis=1)
+    d = tgt - o
+    d /= np.linalg.norm(d, axis=1)[:, None]
+    m = np.where(rng.rand(n) < 0.2, rng.uniform(0.5, 6.0, n), np.inf)
+    dev = sc.hit_batch(o, d, m, geometry=True)
+    ref = orc.hit_batch(flat, o, d, m, geometry=True, threads=orc.max_threads())
+    assert (ref["prim"] >= 0).sum() > n // 4
+    assert_hits_equal(dev, ref, geometry=True)
+    for index in range(len(trees)):
+        counts, t, ex = sc.roots_batch(index, o[:6000], d[:6000], None, max_roots=96)
+        rc, rt, rex = orc.roots_batch(flat, index, o[:6000], d[:6000], None, max_roots=96)
+        assert eq(counts, rc) and counts.max() >= 2, index
+        mask = np.arange(96)[None, :] < counts[:, None]
+        assert eq(t[mask], rt[mask]) and eq(ex[mask], rex[mask]), index
+    pts = np.concatenate([tgt[:20000] + 0.2 * rng.randn(20000, 3), rng.uniform(-4, 4, (5000, 3))])
+    cd, cr = sc.contains_batch(pts), orc.contains_batch(flat, pts)
+    assert eq(cd, cr) and cr.sum() > 2000
+    # path traced: the same solids as glass, diffuse and emitting bodies inside an emitting shell
+    mats = [ns.Lambert(ns.ConstantSF(0.8)), ns.Dielectric(ns.ConstantSF(1.5), ns.ConstantSF(1.0)), ns.UniformVolumeEmitter(ns.ConstantSF(1.0), 0.5),
+            ns.Lambert(ns.ConstantSF(0.5)), ns.Dielectric(ns.ConstantSF(1.3), ns.ConstantSF(1.0), transmission_only=True)]
+    for k, prim in enumerate(list(world._primitives)):
+        prim.material = mats[k % len(mats)]
+    ns.Box(P(-6, -6, -6), P(6, 6, 6), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 1.0))
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera((80, 48), fov=70, parent=world, pipelines=[pipe], frame_sampler=ns.RectFrameSampler2D(), transform=ns.translate(0.1, 0.2, -4.5))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = 3, 3, 1, True
+    cam.ray_extinction_prob, cam.ray_extinction_min_depth, cam.ray_max_depth = 0.05, 2, 40
+    cam.render_engine = ns.HipEngine(rng="philox", seed=4)
+    cam.observe()
+    keep = []
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 80, 48))
+    om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    assert eq(np.array(pipe.frame.mean), om.reshape(48, 80, 3).transpose(1, 0, 2)) and eq(np.array(pipe.frame.variance), ov.reshape(48, 80, 3).transpose(1, 0, 2))
+    assert cam.stats["rays"] == rays

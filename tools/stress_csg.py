@@ -2,7 +2,9 @@
 """One-off stress run on the GPU box for the state-free CSG evaluator: random operand trees of spheres, boxes and cylinders — many
 with deliberately coplanar faces and shared centres, so that exact ties between operand roots are common — hit by random, axis-parallel
 and grid-aligned rays; rsx_hit_batch (fast pass + stream-merge redo pass) against the oracle's stream merge: primitive id, distance,
-exiting flag and the full intersection geometry must be identical.   python tools/stress_csg.py [worlds] [rays_per_world]"""
+exiting flag and the full intersection geometry must be identical.   python tools/stress_csg.py [worlds] [rays_per_world] [depth]
+depth (default 3: trees of at most 8 leaves, the state-free evaluator's domain) up to 12 and beyond: deeper, bigger trees go through the
+stream merge alone (one loop over an explicit frame stack, node states in the scene's arena beyond 16 nodes)."""
 import os
 import sys
 
@@ -14,6 +16,8 @@ from source_amd import api as ns  # noqa: E402
 
 n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 n_rays = int(sys.argv[2]) if len(sys.argv) > 2 else 200000
+DEPTH = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+MAX_LEAVES = 8 if DEPTH <= 3 else 80
 rng = np.random.RandomState(12345)
 GRID = [-0.5, -0.25, 0.0, 0.25, 0.5]                         # coordinates snap to a grid: coincident faces and centres
 
@@ -37,7 +41,7 @@ def leaf():
 
 
 def tree(depth):
-    if depth == 0 or rng.rand() < 0.3:
+    if depth == 0 or rng.rand() < (0.3 if DEPTH <= 3 else 0.12):
         return leaf()
     op = [ns.Union, ns.Intersect, ns.Subtract][rng.randint(3)]
     t = ns.translate(snap(), snap(), snap()) if rng.rand() < 0.5 else None
@@ -53,8 +57,8 @@ for wi in range(n_worlds):
     world = ns.World()
     made = 0
     while made < 4:
-        obj = tree(3)
-        if not hasattr(obj, "primitive_a") or count_leaves(obj) > 8:
+        obj = tree(DEPTH)
+        if not hasattr(obj, "primitive_a") or count_leaves(obj) > MAX_LEAVES:
             continue
         obj.parent = world
         obj.transform = ns.translate(float(rng.choice([-1.5, 0, 1.5])), float(rng.choice([-1.5, 0, 1.5])), 0.0) * (obj.transform or ns.translate(0, 0, 0))
