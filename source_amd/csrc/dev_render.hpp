@@ -706,19 +706,22 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
         node = sel3(nd.type & 3, px, py, pz) < nd.u.split ? node + 1 : nd.count;
         nd = load_node(sc.wnodes, node);
     }
+    // (no `continue` and no early return in the bodies handed in: hipcc 7.2 miscompiles divergent loops that lanes leave in the middle —
+    // tests/toolchain/divergent_loop_exit.hip reproduces it — and round 2 held this one together with an atomic it did not need)
     for (int32_t k = 0; k < nd.count; ++k) {
         const int32_t idx = sc.witems[nd.u.leaf.first_item + k];
         const rsx_primitive &p = sc.prims[idx];
-        if (!want(idx)) continue;
-        bool in;
-        if constexpr (CSG && FASTONLY) {
-            if (is_csg(p.type)) {
-                if (sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);
-                else { in = false; needs_stream = true; }
-            } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
-        } else if constexpr (CSG) in = node_contains(sc, idx, px, py, pz, ms);
-        else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
-        if (in) f(idx);
+        if (want(idx)) {
+            bool in;
+            if constexpr (CSG && FASTONLY) {
+                if (is_csg(p.type)) {
+                    if (sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);
+                    else { in = false; needs_stream = true; }
+                } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+            } else if constexpr (CSG) in = node_contains(sc, idx, px, py, pz, ms);
+            else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+            if (in) f(idx);
+        }
     }
 }
 
@@ -928,6 +931,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 const rsx_primitive &vp = sc.prims[idx];
                 const rsx_material vm = q->materials[vp.material];
                 double length;
+                bool skip = false;
                 if (vm.type == RSX_MAT_DIELECTRIC) {                          // dielectric.pyx:300-328: world-space length
                     const double vx = r.ox - hx, vy = r.oy - hy, vz = r.oz - hz;  // start_point.vector_to(end_point)
                     length = sqrt(vx * vx + vy * vy + vz * vz);
@@ -937,18 +941,17 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
                     const double vx = sx - ex, vy = sy - ey, vz = sz - ez;    // end.vector_to(start)
                     length = sqrt(vx * vx + vy * vy + vz * vz);
-                    if (length == 0) return;
+                    skip = length == 0;                                       // homogeneous.pyx:92-94: nothing to add (no early return: see world_contains_each)
                 }
-                // (more than PATH_VOL_OVERLAP volumes: the registers keep the newest ones, the older ones are fetched again below)
-                // More volumes at this point than the registers keep: the pass is traced again by the REWALK instantiation (flag bit 2);
-                // REWALK itself notes that it was needed (bit 3, informational). The atomic also stays in REWALK on purpose: without a
-                // memory operation at this point hipcc 7.2 miscompiles the enclosing loop for gfx950 (wrong frames in
-                // tests/test_gpu_parity.py::test_frames_volume_emitters_stream_parity and ::test_lifted_limits_*).
-                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, REWALK ? 8u : 4u);
+                if (!skip) {
+                    // More volumes at this point than the registers keep (the newest PATH_VOL_OVERLAP): the pass is traced again by the REWALK
+                    // instantiation (flag bit 2), which fetches the older ones again below.
+                    if constexpr (!REWALK) { if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u); }
 #pragma unroll
-                for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
-                v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
-                ++n_vol;
+                    for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
+                    v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
+                    ++n_vol;
+                }
             });
 #pragma unroll
             for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
@@ -974,9 +977,10 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                             xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
                             const double vx = sx - ex, vy = sy - ey, vz = sz - ez;
                             length = sqrt(vx * vx + vy * vy + vz * vz);
-                            if (length == 0) return;
                         }
-                        if (seen++ == want) push(length, vm.scale, vm.table, vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL);
+                        if (vm.type == RSX_MAT_DIELECTRIC || length != 0) {
+                            if (seen++ == want) push(length, vm.scale, vm.table, vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL);
+                        }
                     });
                 }
             }

@@ -1387,3 +1387,19 @@ def test_csg_trees_of_any_depth_and_size_vs_oracle(orc, ns):
     om, ov, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
     assert eq(np.array(pipe.frame.mean), om.reshape(48, 80, 3).transpose(1, 0, 2)) and eq(np.array(pipe.frame.variance), ov.reshape(48, 80, 3).transpose(1, 0, 2))
     assert cam.stats["rays"] == rays
+
+
+def test_toolchain_divergent_loop_exit_workaround(tmp_path):
+    """hipcc 7.2 miscompiles per-lane loops that the lanes of a wave leave at different turns through a `return` / `continue` in the
+    middle of the body (tests/toolchain/divergent_loop_exit.hip holds both forms of one loop and says so in its output). librsx writes
+    such loops — CSG contains(), the stream merge, the volume enumeration of the path kernel — with ONE exit test; this test builds
+    the reproducer with the box's own hipcc and fails if that form stops being right, i.e. if the next toolchain moves the fault."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    exe = str(tmp_path / "divergent_loop_exit")
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-unused-value", "-Wno-unused-result",
+                           os.path.join(ROOT, "tests", "toolchain", "divergent_loop_exit.hip"), "-o", exe])
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout.strip())
+    assert r.returncode == 0 and "single_exit wrong: 0 of" in r.stdout, r.stdout + r.stderr
