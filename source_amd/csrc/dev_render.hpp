@@ -1231,6 +1231,51 @@ __device__ __forceinline__ int unit_list(long long unit, uint32_t c, unsigned lo
     return 1 + unit_xcd(unit, tiles_x, spp);
 }
 
+// The work lists of a pass whose unit costs are not known (a lane's first pass over these units, every pass of more than
+// RSX_LPT_MAX_UNITS units): no heavy list, every unit in the list of its XCD, in about natural order. Three small launches over all CUs —
+// count per block, scan, scatter — instead of the one-workgroup sort below, which walked 4.2 M units of a configs[2] pass three times
+// on one CU (9 ms, a third of the pass it prepared).
+#define ORDER_BLOCK_UNITS 16384
+__global__ __launch_bounds__(1024) void k_order_natural_count(uint32_t *block_counts, long long n, int tiles_x, int spp) {
+    __shared__ unsigned int h[8];
+    if (threadIdx.x < 8) h[threadIdx.x] = 0;
+    __syncthreads();
+    const long long begin = (long long)blockIdx.x * ORDER_BLOCK_UNITS, end = begin + ORDER_BLOCK_UNITS < n ? begin + ORDER_BLOCK_UNITS : n;
+    unsigned int mine[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) {
+        const int x = unit_xcd(i, tiles_x, spp);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) mine[k] += x == k;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) if (mine[k]) atomicAdd(&h[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x < 8) block_counts[(size_t)blockIdx.x * 8 + threadIdx.x] = h[threadIdx.x];
+}
+__global__ __launch_bounds__(1024) void k_order_natural_scan(uint32_t *block_counts, uint32_t *seg, int n_blocks) {
+    // thread x < 8 walks list x's per-block counts and turns them into offsets inside the list; then the lists are laid end to end
+    __shared__ unsigned int totals[8];
+    if (threadIdx.x < 8) {
+        unsigned int run = 0;
+        for (int b = 0; b < n_blocks; ++b) { const unsigned int c = block_counts[(size_t)b * 8 + threadIdx.x]; block_counts[(size_t)b * 8 + threadIdx.x] = run; run += c; }
+        totals[threadIdx.x] = run;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned int run = 0;
+        seg[0] = 0;                                          // (list 0, the heavy units: empty)
+        for (int x = 0; x < 8; ++x) { seg[1 + x] = run; run += totals[x]; }
+        seg[9] = run;
+    }
+}
+__global__ __launch_bounds__(1024) void k_order_natural_scatter(const uint32_t *block_counts, const uint32_t *seg, uint32_t *order, long long n, int tiles_x, int spp) {
+    __shared__ unsigned int at[8];
+    if (threadIdx.x < 8) at[threadIdx.x] = seg[1 + threadIdx.x] + block_counts[(size_t)blockIdx.x * 8 + threadIdx.x];
+    __syncthreads();
+    const long long begin = (long long)blockIdx.x * ORDER_BLOCK_UNITS, end = begin + ORDER_BLOCK_UNITS < n ? begin + ORDER_BLOCK_UNITS : n;
+    for (long long i = begin + threadIdx.x; i < end; i += blockDim.x) order[atomicAdd(&at[unit_xcd(i, tiles_x, spp)], 1u)] = (uint32_t)i;
+}
+
 // One workgroup: counting sort of the units by (list, descending cost bucket). Splitting a heavy unit over several waves was tried
 // and dropped: a silhouette tile is bound by its single slowest ray, so parts only multiplied the waves.
 // flat != 0 (path passes): only the heavy units are pulled forward (list 0, longest first); the rest keep the natural order of their

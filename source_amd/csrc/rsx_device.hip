@@ -167,6 +167,8 @@ struct TraceLane {
     size_t redo_bytes = 0;
     void *samples = nullptr, *uniforms = nullptr, *terms = nullptr, *tail = nullptr;   // terms / tail: PathTerm blocks of the path kernel
     size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0, tail_bytes = 0;
+    void *order_counts = nullptr;      // k_order_natural_*: per-block list counts / offsets
+    size_t order_counts_bytes = 0;
     void *ring = nullptr;              // fused passes: FUSE_UNITS x 64 sample records per wave of the grid
     size_t ring_bytes = 0;
     unsigned int *overflow = nullptr;
@@ -324,7 +326,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow, ln->mat_dev, ln->tab_dev})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -1348,7 +1350,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             lane.sorts_done = 0;
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
-            hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, n_units, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
+            {   // no costs yet: natural order per XCD list, laid out by all CUs (k_order_natural_*)
+                const int n_blocks = (int)((n_units + ORDER_BLOCK_UNITS - 1) / ORDER_BLOCK_UNITS);
+                if ((rc = lane_buffer(lane.order_counts, lane.order_counts_bytes, (size_t)n_blocks * 8 * 4 + 64))) return rc;
+                uint32_t *bc = static_cast<uint32_t *>(lane.order_counts);
+                hipLaunchKernelGGL(k_order_natural_count, dim3((unsigned)n_blocks), dim3(1024), 0, lane.stream, bc, n_units, order_tiles_x, (int)desc->spp);
+                hipLaunchKernelGGL(k_order_natural_scan, dim3(1), dim3(64), 0, lane.stream, bc, lane.n_work, n_blocks);
+                hipLaunchKernelGGL(k_order_natural_scatter, dim3((unsigned)n_blocks), dim3(1024), 0, lane.stream, bc, lane.n_work, lane.unit_order, n_units, order_tiles_x, (int)desc->spp);
+            }
             HIP_TRY(hipGetLastError());
         }
         rp.unit_order = lane.unit_order;

@@ -690,8 +690,13 @@ class PinholeCamera(Observer2D):
     MAX_RAYS_PER_CALL = 1 << 29       # rays per librsx render call (12.9 GB of sample records); larger slices are cut, see _render_slice_device
 
     def __init__(self, pixels, fov=None, sensitivity=None, frame_sampler=None, pipelines=None, parent=None, transform=None, name=None):
-        pipelines = pipelines or [SpectralRadiancePipeline2D()]     # reference default is the (out-of-scope) RGB pipeline
-        frame_sampler = frame_sampler or FullFrameSampler2D()
+        if not pipelines and not frame_sampler:                 # pinhole.pyx:76-83: an adaptively sampled RGB pipeline by default
+            rgb = RGBPipeline2D()
+            pipelines = [rgb]
+            frame_sampler = RGBAdaptiveSampler2D(rgb)
+        else:
+            pipelines = pipelines or [RGBPipeline2D()]
+            frame_sampler = frame_sampler or FullFrameSampler2D()
         self._fov = 45
         super().__init__(pixels, frame_sampler, pipelines, parent=parent, transform=transform, name=name)
         self.fov = fov or 45

@@ -102,6 +102,13 @@ def test_observer_defaults_and_slicing(ns):
     cam = ns.PinholeCamera((64, 32), parent=world)
     assert (cam.spectral_bins, cam.spectral_rays, cam.min_wavelength, cam.max_wavelength) == (15, 1, 375.0, 740.0)
     assert cam.pixel_samples == 100 and cam.ray_max_depth == 500
+    # pinhole.pyx:76-83: neither pipelines nor sampler given -> an RGB pipeline sampled adaptively on it; one given -> the other's plain default
+    assert isinstance(cam.pipelines[0], ns.RGBPipeline2D) and isinstance(cam.frame_sampler, ns.RGBAdaptiveSampler2D)
+    assert cam.frame_sampler.pipeline is cam.pipelines[0]
+    spectral = ns.PinholeCamera((8, 8), parent=world, pipelines=[ns.SpectralRadiancePipeline2D()])
+    assert isinstance(spectral.frame_sampler, ns.FullFrameSampler2D)
+    sampled = ns.PinholeCamera((8, 8), parent=world, frame_sampler=ns.FullFrameSampler2D())
+    assert isinstance(sampled.pipelines[0], ns.RGBPipeline2D)
     cam.spectral_bins, cam.spectral_rays = 7, 3
     assert [(s.offset, s.bins) for s in cam._slice_spectrum()] == [(0, 2), (2, 3), (5, 2)]
     with pytest.raises(ValueError):
