@@ -1479,7 +1479,10 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         for (int j = 0; j < ACC_BATCH; ++j) cur[j] = s[i + j];
         for (; i + ACC_BATCH <= ap.spp; i += ACC_BATCH) {
             Sample nxt[ACC_BATCH];
-            const bool more = i + 2 * ACC_BATCH <= ap.spp;                 // (wave-uniform)
+            // (samples without path terms only: the replay of a term list needs the registers itself — Cornell box 9.2 -> 13.1 ms with it.
+            // Also measured there and not adopted: the four lists of a batch replayed together, one term of each per turn — 11.6 ms: the
+            // replay waits on HBM for the term blocks, 6.4 GB per launch, not on its own dependent multiplications)
+            const bool more = VOL == 0 && i + 2 * ACC_BATCH <= ap.spp;     // (wave-uniform)
             if (more) {
 #pragma unroll
                 for (int j = 0; j < ACC_BATCH; ++j) nxt[j] = s[i + ACC_BATCH + j];
@@ -1489,6 +1492,9 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
             if (more) {
 #pragma unroll
                 for (int j = 0; j < ACC_BATCH; ++j) cur[j] = nxt[j];
+            } else if (VOL != 0 && i + 2 * ACC_BATCH <= ap.spp) {
+#pragma unroll
+                for (int j = 0; j < ACC_BATCH; ++j) cur[j] = s[i + ACC_BATCH + j];
             }
         }
     }

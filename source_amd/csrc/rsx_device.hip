@@ -75,7 +75,11 @@
 #define RSX_PACKET_MIN_WAVES 4      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace (128 registers)
 #endif
 #ifndef RSX_PACKET_MIN_SPP
-#define RSX_PACKET_MIN_SPP 2        // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp)
+#define RSX_PACKET_MIN_SPP 16       // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp): a 64-ray
+                                    // unit then holds at most four pixels. Measured on the configs[2] scene at 1024 x 1024 (trace kernel,
+                                    // per-lane walk -> packet walk): 64 spp 8.2 -> 5.6 ms per 2^24 rays, 32 spp 7.2 -> 6.5, 16 spp 9.9 -> 8.8,
+                                    // 8 spp 6.0 -> 5.9, 4 spp 3.2 -> 3.6, 2 spp 1.8 -> 2.4, 1 spp (8 x 8 pixel tiles) 0.85 -> 1.20: the union of
+                                    // the nodes 16 or more different pixels visit outgrows what the shared walk saves. $RSX_PACKET_MIN_SPP.
 #endif
 
 #ifndef RSX_UTIL_PROF

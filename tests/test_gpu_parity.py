@@ -1403,3 +1403,40 @@ def test_toolchain_divergent_loop_exit_workaround(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout.strip())
     assert r.returncode == 0 and "single_exit wrong: 0 of" in r.stdout, r.stdout + r.stderr
+
+
+def test_packet_walk_equals_per_lane_walk_at_any_sample_count():
+    """The packet walk (dev_packet.hpp: the 64 rays of a unit traverse the trees together) serves passes of 16 samples per pixel
+    and more by default; forced on for passes of 2, 3, 5 and 12 samples per pixel — units of up to 32 different pixels, odd splits of
+    pixels over units, frames that are not a multiple of the 8 x 8 unit tiles — it must give the frames of the per-lane walk bit for
+    bit (which other tests tie to the oracle), fused Welford or not."""
+    import subprocess
+    import sys
+    code = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from source_amd import api as ns, scenes
+world = scenes.build_c3(ns, n=24)[0]
+out = []
+for (nx, ny, spp) in ((72, 44, 2), (50, 61, 3), (64, 40, 5), (33, 47, 12), (40, 24, 16), (24, 24, 64)):
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam, _ = scenes.c3_camera(ns, world, (nx, ny), spp=spp, bins=5)
+    cam.pipelines = [pipe]
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=3)
+    cam.observe(); cam.observe()
+    h = hashlib.sha256()
+    for a in (pipe.frame.mean, pipe.frame.variance, pipe.frame.samples):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert (pipe.frame.samples == 2 * spp).all() and pipe.frame.mean.max() > 0
+    out.append(h.hexdigest())
+print(" ".join(out))
+""" % ROOT
+    digests = {}
+    for name, env in (("per-lane", dict(RSX_PACKET_MIN_SPP="0")), ("packet", dict(RSX_PACKET_MIN_SPP="2", RSX_FUSE="0")),
+                      ("packet fused", dict(RSX_PACKET_MIN_SPP="2", RSX_FUSE="1", RSX_PIPELINE="1")), ("default", {})):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, name + ": " + r.stderr[-2000:]
+        digests[name] = r.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests

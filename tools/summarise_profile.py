@@ -25,9 +25,10 @@ if os.path.exists(bench) and os.path.getsize(bench):
     line = [l for l in open(bench) if l.startswith('{"metric"')][-1]
     open(os.path.join(dst, "%s_bench_%s.json" % (tag, wl)), "w").write(line)
     d = json.loads(line)
-    print("ms/step %.3f, value %.4g %s; bound %s (%.3f); kernel %.3f ms + accumulate %.3f ms" % (
-        d["ms_per_step"], d["value"], d["unit"], d["roofline"].get("bound"), d["roofline"].get("bound_frac", float("nan")),
-        d["roofline"]["kernel_ms"], d["roofline"]["accumulate_kernel_ms"]))
+    r = d["roofline"]
+    print("ms/step %.3f, value %.4g %s; bound %s (%s); kernel %.3f ms, Welford: %s%s" % (
+        d["ms_per_step"], d["value"], d["unit"], r.get("bound"), r.get("frac"), r["kernel_ms"], r.get("welford"),
+        "" if r.get("accumulate_kernel_ms") is None else " %.3f ms" % r["accumulate_kernel_ms"]))
 pmc = os.path.join(src, "pmc_%s.json" % wl)
 if os.path.exists(pmc):
     shutil.copy(pmc, os.path.join(dst, "%s_pmc_%s.json" % (tag, wl)))
