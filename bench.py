@@ -62,6 +62,9 @@ WORKLOADS = {
     "c2": dict(nx=1024, ny=1024, spp=1, counter_rows=8,
                name="configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera 1024x1024, 1 spp/pass, "
                     "15 spectral bins, primary rays only"),
+    "c2k": dict(nx=1024, ny=1024, spp=1, counter_rows=8, passes_per_call=16,
+                name="configs[1] with 16 passes per library call: 69 432-triangle displaced-sphere mesh, PinholeCamera 1024x1024, a step = one "
+                     "observe() of HipEngine(passes_per_call=16) = 16 passes of 1 spp (the frame of 16 observe() calls, bit for bit), 15 spectral bins"),
     "flat": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
                  name="HBM stress (SURVEY.md 8d M1M-flat): ONE 1 047 552-triangle displaced-sphere mesh (no instancing), PinholeCamera "
                       "2048x2048, 64 spp/pass, 15 spectral bins, primary rays only"),
@@ -90,7 +93,7 @@ def build_workload(key, ns, scenes):
     if key == "c3":
         world = scenes.build_c3(ns, n=132)[0]
         cam, pipe = scenes.c3_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
-    elif key == "c2":
+    elif key in ("c2", "c2k"):
         world = scenes.build_c2(ns, n=132)[0]
         cam, pipe = scenes.c2_camera(ns, world, (w["nx"], w["ny"]), spp=w["spp"], bins=BINS)
     elif key == "flat":
@@ -274,7 +277,9 @@ def main():
     if args.child:
         return child_main(args)
     W = WORKLOADS[args.workload]
-    NX, NY, SPP = W["nx"], W["ny"], W["spp"]
+    NX, NY, CAM_SPP = W["nx"], W["ny"], W["spp"]
+    PPC = W.get("passes_per_call", 1)                        # passes per observe() (HipEngine.passes_per_call)
+    SPP = CAM_SPP * PPC                                      # samples per pixel per STEP: a step is one observe()
     BINS, SLICES = W.get("bins", 15), W.get("slices", 1)      # (shadows the module default: configs[4] has 512 bins in 512 slices)
 
     rank = int(os.environ.get("RANK", "0"))
@@ -307,8 +312,10 @@ def main():
     from source_amd.device import get_context
 
     world, cam, pipe = build_workload(args.workload, ns, scenes)
-    engine = ns.HipEngine(rng="philox", seed=20250905)
+    engine = ns.HipEngine(rng="philox", seed=20250905, passes_per_call=PPC)
     cam.render_engine = engine
+    if PPC > 1 and sharding == "sample":
+        raise SystemExit("workload %s renders several passes per call: shard it by tiles" % args.workload)
     ctx = get_context()
     scene = world.build_accelerator()                      # flatten + KD build (host) + upload: outside the timed region
 
@@ -555,10 +562,10 @@ def main():
             got = h.hexdigest()[:32]
             world1, cam1, pipe1 = build_workload(args.workload, ns, scenes)
             cam1.frame_sampler = ns.RectFrameSampler2D()
-            eng1 = ns.HipEngine(rng="philox", seed=20250905)
+            eng1 = ns.HipEngine(rng="philox", seed=20250905, passes_per_call=PPC)
             cam1.render_engine = eng1
             if sharding == "sample":
-                cam1.pixel_samples = SPP * world_size
+                cam1.pixel_samples = CAM_SPP * world_size
             for p_ in range(passes):
                 eng1.sample_offset = p_ * SPP * (world_size if sharding == "sample" else 1)
                 cam1.observe()
@@ -650,19 +657,19 @@ def main():
             orc.render_pinhole(flat, desc, threads=nthreads)        # thread-pool warm-up
             tcal = time.perf_counter()
             m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
-            rate = NX * 16 * SPP / (time.perf_counter() - tcal)
+            rate = NX * 16 * CAM_SPP / (time.perf_counter() - tcal)
             target = rate * args.cpu_seconds
             saved = cam.pixel_samples
-            if target >= NX * NY * SPP:
-                n_pass = int(min(2048, max(1, round(target / (NX * NY * SPP)))))
-                cam.pixel_samples = SPP * n_pass
+            if target >= NX * NY * CAM_SPP:
+                n_pass = int(min(2048, max(1, round(target / (NX * NY * CAM_SPP)))))
+                cam.pixel_samples = CAM_SPP * n_pass
                 rect = (0, 0, NX, NY)
-                what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, SPP)
+                what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, CAM_SPP)
                 centred = False
             else:
-                nrows = int(max(16, min(NY, target // (NX * SPP))))
+                nrows = int(max(16, min(NY, target // (NX * CAM_SPP))))
                 rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
-                what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, SPP)
+                what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, CAM_SPP)
                 centred = True
             if SLICES > 1:
                 what += ", one of the %d spectral slices" % SLICES
@@ -679,15 +686,15 @@ def main():
             if centred:
                 cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
             # ... and on ONE host thread, a sample sized for a few seconds
-            one_rows = int(max(2, min(rect[3] - rect[1], (rate / max(1, nthreads)) * min(4.0, args.cpu_seconds / 3) * 2 // (NX * SPP))))
+            one_rows = int(max(2, min(rect[3] - rect[1], (rate / max(1, nthreads)) * min(4.0, args.cpu_seconds / 3) * 2 // (NX * CAM_SPP))))
             rect1 = (0, NY // 2 - one_rows // 2, NX, NY // 2 - one_rows // 2 + one_rows)
             desc1 = cam.render_desc(world, None, sl, engine, keep, rect=rect1)
             t1 = time.perf_counter()
             orc.render_pinhole(flat, desc1, threads=1)
             t1 = time.perf_counter() - t1
-            n1 = NX * one_rows * SPP
+            n1 = NX * one_rows * CAM_SPP
             cpu["one_thread"] = {"value": round(n1 / t1, 1), "unit": "primary rays/s", "cores": 1,
-                                 "sample": "centred band of %d rows x %d px x %d spp (%d primary rays), %.1f s" % (one_rows, NX, SPP, n1, t1)}
+                                 "sample": "centred band of %d rows x %d px x %d spp (%d primary rays), %.1f s" % (one_rows, NX, CAM_SPP, n1, t1)}
             # the compiled Cython reference itself, measured where it can run (development container; tests/golden/time_reference.py)
             ref_path = os.path.join(ROOT, "tests", "golden", "reference_timing.json")
             if os.path.exists(ref_path):

@@ -76,7 +76,7 @@ class RenderDesc(C.Structure):
                 ("n_tables", C.c_int32), ("bins", C.c_int32), ("spp", C.c_int32), ("power", C.c_int32),
                 ("rng_mode", C.c_int32), ("seed", C.c_uint64), ("sample_offset", C.c_uint64),
                 ("ray_max_depth", C.c_int32), ("ray_extinction_min_depth", C.c_int32), ("ray_extinction_prob", C.c_double),
-                ("important", C.POINTER(ImportantSphere)), ("n_important", C.c_int32), ("pad_important", C.c_int32),
+                ("important", C.POINTER(ImportantSphere)), ("n_important", C.c_int32), ("passes", C.c_int32),
                 ("important_path_weight", C.c_double)]
 
 

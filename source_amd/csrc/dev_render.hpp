@@ -40,7 +40,7 @@ struct RenderParams {
     int32_t ray_max_depth, ray_min_depth;      // Ray.max_depth / extinction_min_depth / extinction_prob: path kernel only
     double ray_extinction_prob;
     const rsx_important_sphere *important;     // ImportanceManager spheres (world.pyx:47-128) or n_important == 0
-    int32_t n_important, pad_important;
+    int32_t n_important, passes;
     double important_path_weight;
     int32_t prims_lds;                         // > 0: byte offset of the LDS copy of the primitive records (+ CSG programs) in the path kernel
     int32_t n_vol_emitters, world_lds;         // materials with a volume contribution (0: the per-segment world.contains() pass is skipped);
@@ -1337,6 +1337,7 @@ struct AccumParams {
     long long n_records;                // block ids below this are the samples' own first blocks, above it arena blocks (slot 0 = link)
     double roulette_norm;               // 1 / (1 - extinction_prob)
     const double *consts;               // [i] = {(double)i, refine_rcp(i)} for i = 0 .. ACC_RCP_TABLE_MAX + 2 (k_fill_acc_consts), or null
+    int32_t passes, pad_passes;         // consecutive passes of spp samples per pixel in the records (rsx_render_desc.passes; 1 = the usual case)
     const unsigned int *abort_flags;    // deferred path passes: PathStore::flags of the trace kernel — a pass whose arena ran out (bit 0), that hit the
                                         // segment guard (1) or met too many volumes at a point (2) is left out of the frame and rendered again by the caller
 };
@@ -1388,7 +1389,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
         k = (long long)ly * w + lx;
     }
-    const Sample *s = ap.samples + p * ap.spp;
+    const Sample *s = ap.samples + p * ap.spp * ap.passes;   // (passes > 1: the records of a pixel's passes follow one another)
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
     auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
@@ -1432,8 +1433,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
     // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
     // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
-    const long long rec0 = p * ap.spp;
-    double m = value(s[0], rec0), v = 0;
+    long long rec0 = p * ap.spp * ap.passes;
+    double m = 0, v = 0;
     double dm = 1.0;                                        // (double)i, advanced by exact additions
     // The step's divisors, their refined reciprocals and the factor prev_n - 1 depend on the sample index alone — wave-uniform: they come
     // from a table over the scalar data path (ap.consts) and cost the recurrence no vector instruction. The two quotients are formed by
@@ -1470,6 +1471,17 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
         dm = dn;
     };
+    // rsx_render_desc.passes = K > 1: K consecutive passes of spp samples each in this one launch — per pass the recurrence from its first
+    // sample and the frame merge, in pass order: the frame of K calls. The frame cell stays in registers between the merges.
+    size_t f = 0;
+    double fm = 0, fv = 0;
+    int fcount = 0;
+    if (ap.fmean) {
+        f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+        fm = ap.fmean[f]; fv = ap.fvar[f]; fcount = ap.fn[f];
+    }
+    for (int pass = 0; pass < ap.passes; ++pass, s += ap.spp, rec0 += ap.spp) {
+    m = value(s[0], rec0); v = 0; dm = 1.0;
     // ... and the NEXT batch is requested before this one is stepped through: the records are a stream that is read once, from HBM,
     // and a batch's own arithmetic (0.2 us) does not cover that round trip even with eight waves per SIMD.
     int i = 1;
@@ -1499,15 +1511,16 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         }
     }
     for (; i < ap.spp; ++i) step(value(s[i], rec0 + i), i);
-    if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
     if (ap.fmean) {
-        const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
         if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
         double mt, vt;
         int nt;
-        combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
-        ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
+        combine_samples(fm, fv, fcount, m, v, ap.spp, mt, vt, nt);
+        fm = mt; fv = vt; fcount = nt;
     }
+    }
+    if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }    // (per-task outputs: passes == 1)
+    if (ap.fmean) { ap.fmean[f] = fm; ap.fvar[f] = fv; ap.fn[f] = fcount; }
 }
 
 // XYZPixelProcessor (rgb.pyx:534-562): one thread per (task, channel). Every sample's spectrum, times its projection weight, is

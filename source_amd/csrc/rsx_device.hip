@@ -1158,6 +1158,26 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (desc->materials[i].type != RSX_MAT_ABSORBER && desc->materials[i].type != RSX_MAT_NULL &&
             (desc->materials[i].table < 0 || desc->materials[i].table >= desc->n_tables))
             return rsx_fail(RSX_EINVAL, "render: material %d references table %d of %d", i, desc->materials[i].table, desc->n_tables);
+    // passes = K > 1: K consecutive passes in one launch. The trace side sees ONE pass of K * spp samples per pixel — the Philox counter of
+    // sample s of pass p is sample_offset + p * spp + s either way, and a pixel's records follow one another pass by pass; the accumulate
+    // kernel runs the recurrence and the frame merge once per pass. Small passes (1024^2 x 1 spp is 16 k waves, a fraction of a millisecond)
+    // are bound by launch tails and by incoherent waves; K of them in one launch are neither.
+    const int32_t passes = desc->passes > 1 ? desc->passes : 1;
+    rsx_render_desc widened;
+    if (passes > 1) {
+        if (!fmean || h_mean || h_xyz) return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 accumulates into a device frame (rsx_render_pinhole_frame)");
+        if (desc->rng_mode != RSX_RNG_PHILOX) return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 needs RSX_RNG_PHILOX (a serial stream is consumed pass by pass)");
+        if ((long long)desc->spp * passes > (1 << 20)) return rsx_fail(RSX_EINVAL, "render: spp * passes out of range");
+        for (int32_t i = 0; i < desc->n_materials; ++i) {
+            const int32_t mt = desc->materials[i].type;
+            if (mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC)
+                return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 is for scenes without path terms (a path pass that runs out of term blocks is rendered again by itself)");
+        }
+        widened = *desc;
+        widened.spp = desc->spp * passes;
+        widened.passes = 1;
+        desc = &widened;
+    }
     if (ray_count) *ray_count = (uint64_t)desc->n_tasks * (uint64_t)desc->spp;
     if (desc->n_tasks == 0) return RSX_OK;
     rsx_ctx *ctx = scene->ctx;
@@ -1274,13 +1294,16 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     static const int packet_min_spp = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : RSX_PACKET_MIN_SPP; }();   // 0: never
     static const int fuse_env = [] { const char *e = std::getenv("RSX_FUSE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
     // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
-    const bool use_packet = !has_vol && !scene->has_csg && packet_min_spp > 0 && desc->spp >= packet_min_spp && !ctx->unit_times;
+    // (a task list — FullFrameSampler2D shuffles its pixels, an adaptive sampler picks them — puts unrelated pixels side by side: there a
+    // unit must be ONE pixel's samples for its rays to share their way through the trees)
+    const bool use_packet = !has_vol && !scene->has_csg && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
+                            !ctx->unit_times;
     const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
     const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
     // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
     // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
     const bool fuse_enabled = fuse_env < 0 ? use_packet : fuse_env != 0;
-    const bool fused = fuse_enabled && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
+    const bool fused = fuse_enabled && passes == 1 && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
                        !ctx->unit_times && wave_lds >= fuse_fixed;
     if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
     if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
@@ -1317,7 +1340,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.seed = desc->seed;
     rp.sample_offset = desc->sample_offset;
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
-    rp.n_important = n_important; rp.pad_important = 0; rp.important_path_weight = desc->important_path_weight;
+    rp.n_important = n_important; rp.passes = 1; rp.important_path_weight = desc->important_path_weight;
     rp.n_vol_emitters = 0; rp.world_lds = 0; rp.prims_lds = 0;
     for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
@@ -1549,7 +1572,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.tasks = rp.tasks;
     ap.n_tasks = desc->n_tasks;
     std::memcpy(ap.rect, desc->rect, sizeof(ap.rect));
-    ap.ny = desc->camera.ny; ap.bins = desc->bins; ap.spp = desc->spp; ap.power = desc->power;
+    ap.ny = desc->camera.ny; ap.bins = desc->bins; ap.spp = desc->spp / passes; ap.power = desc->power;
+    ap.passes = passes; ap.pad_passes = 0;
     ap.sensitivity = desc->camera.sensitivity;
     ap.mean = h_mean ? static_cast<double *>(d_mean) : nullptr;
     ap.variance = h_mean ? static_cast<double *>(d_var) : nullptr;
@@ -1569,7 +1593,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.n_tables = desc->n_tables;
     // LDS of the staged accumulate kernel: the Welford reciprocals and, when they fit next to them, the spectral tables (a 512-bin
     // slice with twenty materials does not: the kernel then reads the tables from global memory, L1 / L2 resident)
-    const size_t rcp_lds = (desc->spp <= ACC_RCP_TABLE_MAX ? (size_t)desc->spp + 2 : 2) * 8, tab_lds = (size_t)std::max(1, desc->n_tables) * B * 8;
+    const size_t rcp_lds = (ap.spp <= ACC_RCP_TABLE_MAX ? (size_t)ap.spp + 2 : 2) * 8, tab_lds = (size_t)std::max(1, desc->n_tables) * B * 8;
     ap.tables_in_lds = rcp_lds + tab_lds <= 60 * 1024 ? 1 : 0;
     const size_t acc_lds = rcp_lds + (ap.tables_in_lds ? tab_lds : 8);
     const dim3 acc_grid((unsigned)((total + 255) / 256));
@@ -1595,7 +1619,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         else hipLaunchKernelGGL((k_accumulate_xyz<0>), xyz_grid, dim3(256), 0, ctx->stream, ap, desc->n_tables, delta_wavelength);
     } else {
         const int vol = !has_vol ? 0 : has_dielectric ? 2 : 1;
-        const bool staged = desc->spp >= 4, in_lds = ap.tables_in_lds != 0;
+        const bool staged = ap.spp >= 4, in_lds = ap.tables_in_lds != 0;
 #define ACC(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V>) \
                                                                                            : reinterpret_cast<const void *>(k_accumulate<true, V, false>))
         const void *kernel = vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);
@@ -1774,7 +1798,7 @@ extern "C" int rsx_selftest_welford(rsx_ctx *ctx, int64_t n_chains, int32_t spp,
     ap.samples = ds.as<Sample>(); ap.tables = one.as<double>(); ap.n_tasks = n_chains;
     ap.rect[0] = 0; ap.rect[1] = 0; ap.rect[2] = 1; ap.rect[3] = (int32_t)n_chains;      // one column of n_chains pixels: slot order = task order
     ap.consts = ctx->acc_consts;
-    ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.n_tables = 1; ap.tables_in_lds = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
+    ap.ny = (int32_t)n_chains; ap.bins = 1; ap.spp = spp; ap.passes = 1; ap.n_tables = 1; ap.tables_in_lds = 1; ap.sensitivity = 1.0; ap.roulette_norm = 1.0;
     // both instantiations the render path uses: the lean one (few samples per pixel) and the staged one (LDS tables, batched loads)
     for (int staged = 0; staged < 2; ++staged) {
         ap.mean = dm.as<double>() + (staged ? N : 0); ap.variance = dv.as<double>() + (staged ? N : 0);

@@ -61,9 +61,16 @@ class HipEngine(RenderEngine):
     the multi-GPU shards place their samples, source_amd/distributed.py); a sample-sharded process that does NOT reassign it every
     pass must set ``sample_stride`` to the number of processes (otherwise pass p + 1 of rank r would reuse the counters of pass p of
     rank r + 1 and correlated samples would be merged as if independent).
+
+    ``passes_per_call=K``: one observe() renders K consecutive passes of ``pixel_samples`` samples each as ONE library call per spectral
+    slice (rsx_render_desc.passes) and leaves the frames that K observe() calls would — bit for bit, the K merges included. For
+    accumulating spectral pipelines on the fused Philox path, scenes without scattering or volume materials; anything else raises.
+    A one-sample pass of a megapixel frame is a fraction of a millisecond of device work: K of them in one launch cost neither K launch
+    tails nor waves whose 64 rays cross 64 pixels.
     """
 
-    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False, sample_stride=1, slice_range=None):
+    def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False, sample_stride=1, slice_range=None,
+                 passes_per_call=1):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
         # multi-process renders (source_amd/distributed.py). sample_stride = N with sample_offset = rank * pixel_samples: pass p of this
@@ -77,6 +84,9 @@ class HipEngine(RenderEngine):
         self.timing = bool(timing)          # True: read back HIP-event kernel times after each library call (one stream sync per call:
                                             # a tuning aid, it defeats the pipelined render lanes)
         self.sample_offset = int(sample_offset)
+        self.passes_per_call = int(passes_per_call)
+        if self.passes_per_call < 1:
+            raise ValueError("passes_per_call must be at least 1")
         self.last_kernel_ms = None
 
     def worker_count(self):
@@ -531,7 +541,8 @@ class _ObserverBase(Observer):
             if deferring:
                 self._end_deferred_slices()
         # (sample_stride: a process that renders 1 / N of a sample-sharded job leaves the counters between its passes to the others)
-        self._auto_offset += self._samples_per_pass() * max(1, int(getattr(self.render_engine, "sample_stride", 1)))
+        self._auto_offset += (self._samples_per_pass() * max(1, int(getattr(self.render_engine, "sample_stride", 1)))
+                              * max(1, int(getattr(self.render_engine, "passes_per_call", 1))))
         self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
 
     def _needs_host_materials(self, world, engine):
@@ -830,7 +841,7 @@ class PinholeCamera(Observer2D):
         from .material import NullSurface, Lambert, Dielectric
         if any(isinstance(p.material, (NullSurface, Lambert, Dielectric)) for p in world._primitives):
             limit = min(limit, 1 << 24)                     # the volume path also keeps 768 B of emission terms per ray
-        per_call = max(1, limit // self._pixel_samples)
+        per_call = max(1, limit // (self._pixel_samples * max(1, int(getattr(self.render_engine, "passes_per_call", 1)))))
         if isinstance(tasks, RectTasks):
             x0, y0, x1, y1 = tasks.rect
             band = max(1, per_call // max(1, y1 - y0))
@@ -840,6 +851,8 @@ class PinholeCamera(Observer2D):
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
         world = self.root
         if self._needs_host_materials(world, engine):
+            if int(getattr(engine, "passes_per_call", 1)) > 1:
+                raise ValueError("passes_per_call > 1 needs device lowerings for every material (host-evaluated materials render pass by pass)")
             from . import hybrid
             hybrid.render_slice(self, tasks, slice_id, template, engine, self._pieces(tasks, world, self.HOST_RAYS_PER_PIECE))
             return
@@ -849,8 +862,15 @@ class PinholeCamera(Observer2D):
         L = _lib.lib()
         rays = C.c_uint64(0)
         offset = getattr(self, "_pass_offset", None)
+        passes = max(1, int(getattr(engine, "passes_per_call", 1)))
+        if passes > 1:
+            if not engine.fused or engine.rng != "philox":
+                raise ValueError("passes_per_call > 1 needs the fused Philox path (HipEngine(rng='philox', fused=True))")
+            if any(isinstance(pipe, RGBPipeline2D) or not getattr(pipe, "accumulate", False) for pipe in self._pipelines):
+                raise ValueError("passes_per_call > 1 is for accumulating spectral pipelines (accumulate=True): the passes of one call are merged into the frame")
         for piece in self._pieces(tasks, world):
             desc = self.render_desc(world, piece.get("tasks"), sl, engine, keep, rect=piece.get("rect"), sample_offset=offset)
+            desc.passes = passes
             if engine.fused:
                 for pipe in self._pipelines:
                     if isinstance(pipe, RGBPipeline2D):

@@ -1435,8 +1435,70 @@ print(" ".join(out))
 """ % ROOT
     digests = {}
     for name, env in (("per-lane", dict(RSX_PACKET_MIN_SPP="0")), ("packet", dict(RSX_PACKET_MIN_SPP="2", RSX_FUSE="0")),
-                      ("packet fused", dict(RSX_PACKET_MIN_SPP="2", RSX_FUSE="1", RSX_PIPELINE="1")), ("default", {})):
+                      ("packet fused", dict(RSX_PACKET_MIN_SPP="2", RSX_FUSE="1", RSX_PIPELINE="1")),
+                      ("packet on vertex records", dict(RSX_PACKET_MIN_SPP="2", RSX_CAMERA_RELATIVE="0")), ("default", {})):
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, name + ": " + r.stderr[-2000:]
         digests[name] = r.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_passes_per_call_equals_separate_passes(ns):
+    """rsx_render_desc.passes / HipEngine(passes_per_call=K): K passes submitted as one library call leave the frames that K observe()
+    calls leave (observer.pyx:265-309 called K times: K Welford chains per pixel and bin, K merges) — mean, variance and sample counts
+    bit for bit: mesh scenes, a CSG scene, a task-list pass with a mask, several spectral slices, power and radiance pipelines."""
+    def frames(make, K, calls, together):
+        world, cam, pipes = make()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=11, passes_per_call=K if together else 1)
+        for _ in range(calls * (1 if together else K)):
+            cam.observe()
+        return [np.concatenate([p.frame.mean.ravel(), p.frame.variance.ravel(), p.frame.samples.ravel().astype(np.float64)]) for p in pipes]
+
+    def c2(spp, pixels=(72, 50), slices=1):
+        def make():
+            world = scenes.build_c2(ns, n=24)[0]
+            pipes = [ns.SpectralRadiancePipeline2D(), ns.SpectralPowerPipeline2D()]
+            cam, _ = scenes.c2_camera(ns, world, pixels, spp=spp, bins=6)
+            cam.spectral_rays = slices
+            cam.pipelines = pipes
+            cam.frame_sampler = ns.RectFrameSampler2D()
+            return world, cam, pipes
+        return make
+
+    def c3_masked():
+        world = scenes.build_c3(ns, n=24)[0]
+        pipes = [ns.SpectralRadiancePipeline2D()]
+        cam, _ = scenes.c3_camera(ns, world, (40, 36), spp=3, bins=5)
+        cam.pipelines = pipes
+        mask = np.zeros((40, 36), dtype=bool)
+        mask[3:31, 5:29] = True
+        mask[10, 10] = False
+        cam.frame_sampler = ns.FullFrameSampler2D(mask)
+        return world, cam, pipes
+
+    def csg():
+        world = scenes.build_csg_demo(ns)[0]
+        pipes = [ns.SpectralRadiancePipeline2D()]
+        cam, _ = scenes.csg_camera(ns, world, (48, 40), spp=2, bins=4)
+        cam.pipelines = pipes
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        return world, cam, pipes
+
+    for name, make, K, calls in (("c2 1 spp x 16", c2(1), 16, 2), ("c2 1 spp x 3", c2(1), 3, 1), ("c2 4 spp x 5, 3 slices", c2(4, slices=3), 5, 2),
+                                 ("c2 20 spp x 4", c2(20, (33, 21)), 4, 1), ("c3 masked 3 spp x 7", c3_masked, 7, 2), ("csg 2 spp x 8", csg, 8, 1)):
+        one, many = frames(make, K, calls, True), frames(make, K, calls, False)
+        for a, b in zip(one, many):
+            assert a.max() > 0 and np.array_equal(a.view(np.uint64), b.view(np.uint64)), name
+
+    # what the option does not cover fails loudly
+    world, cam, pipes = c2(1)()
+    cam.pipelines = [ns.SpectralRadiancePipeline2D(accumulate=False)]
+    cam.render_engine = ns.HipEngine(passes_per_call=4)
+    with pytest.raises(ValueError):
+        cam.observe()
+    world = scenes.build_lambert(ns)[0]
+    cam, _ = scenes.lambert_camera(ns, world)
+    cam.pipelines = [ns.SpectralRadiancePipeline2D()]
+    cam.render_engine = ns.HipEngine(passes_per_call=4)
+    with pytest.raises(Exception, match="passes"):
+        cam.observe()
