@@ -62,9 +62,9 @@ WORKLOADS = {
     "c2": dict(nx=1024, ny=1024, spp=1, counter_rows=8,
                name="configs[1]: 69 432-triangle displaced-sphere mesh (Stanford-bunny stand-in), PinholeCamera 1024x1024, 1 spp/pass, "
                     "15 spectral bins, primary rays only"),
-    "c2k": dict(nx=1024, ny=1024, spp=1, counter_rows=8, passes_per_call=16,
-                name="configs[1] with 16 passes per library call: 69 432-triangle displaced-sphere mesh, PinholeCamera 1024x1024, a step = one "
-                     "observe() of HipEngine(passes_per_call=16) = 16 passes of 1 spp (the frame of 16 observe() calls, bit for bit), 15 spectral bins"),
+    "c2k": dict(nx=1024, ny=1024, spp=1, counter_rows=8, passes_per_call=64,
+                name="configs[1] with 64 passes per library call: 69 432-triangle displaced-sphere mesh, PinholeCamera 1024x1024, a step = one "
+                     "observe() of HipEngine(passes_per_call=64) = 64 passes of 1 spp (the frame of 64 observe() calls, bit for bit), 15 spectral bins"),
     "flat": dict(nx=2048, ny=2048, spp=64, counter_rows=32,
                  name="HBM stress (SURVEY.md 8d M1M-flat): ONE 1 047 552-triangle displaced-sphere mesh (no instancing), PinholeCamera "
                       "2048x2048, 64 spp/pass, 15 spectral bins, primary rays only"),
@@ -127,14 +127,14 @@ def child_main(args):
     from source_amd.device import get_context
     world, cam, pipe = build_workload(args.workload, ns, scenes)
     cam.frame_sampler = ns.RectFrameSampler2D()
-    cam.render_engine = ns.HipEngine(rng="philox", seed=20250905)
+    cam.render_engine = ns.HipEngine(rng="philox", seed=20250905, passes_per_call=args.passes_per_call or WORKLOADS[args.workload].get("passes_per_call", 1))
     world.build_accelerator()
     for _ in range(max(1, args.steps)):
         cam.observe()
     get_context().synchronize()
 
 
-def collect_pmc(workload, passes, keep_dir=None):
+def collect_pmc(workload, passes, keep_dir=None, passes_per_call=0):
     """Runs `rocprofv3 --pmc <group> -- python bench.py --child` once per counter group (the HBM counters in their own passes, never
     together with a trace option: /opt/skills/guides/MI355X_MICROARCH.md) and returns {kernel: {counter: mean per launch}}, or
     (None, reason)."""
@@ -149,7 +149,7 @@ def collect_pmc(workload, passes, keep_dir=None):
     for gi, group in enumerate(PMC_GROUPS):
         out = os.path.join(out_root, "g%d" % gi)
         cmd = [rocprof, "--pmc", *group, "-d", out, "-o", "k", "--output-format", "csv", "--", sys.executable, os.path.join(ROOT, "bench.py"),
-               "--child", "--workload", workload, "--steps", str(passes)]
+               "--child", "--workload", workload, "--steps", str(passes), "--passes-per-call", str(passes_per_call)]
         try:
             r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=240)
         except subprocess.TimeoutExpired:
@@ -261,6 +261,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU work the cpu_baseline sample is sized for")
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="c3")
+    ap.add_argument("--passes-per-call", type=int, default=0, help="passes per observe() (HipEngine.passes_per_call); default: the workload's (c2k: 64, others 1)")
     ap.add_argument("--sharding", choices=["auto", "tile", "sample", "slice"], default="auto",
                     help="N > 1: tile (strong scaling, default), sample (weak) or slice (strong; spectral slices of configs[4])")
     ap.add_argument("--tiles", choices=["balanced", "equal"], default="balanced",
@@ -278,7 +279,7 @@ def main():
         return child_main(args)
     W = WORKLOADS[args.workload]
     NX, NY, CAM_SPP = W["nx"], W["ny"], W["spp"]
-    PPC = W.get("passes_per_call", 1)                        # passes per observe() (HipEngine.passes_per_call)
+    PPC = args.passes_per_call or W.get("passes_per_call", 1)   # passes per observe() (HipEngine.passes_per_call)
     SPP = CAM_SPP * PPC                                      # samples per pixel per STEP: a step is one observe()
     BINS, SLICES = W.get("bins", 15), W.get("slices", 1)      # (shadows the module default: configs[4] has 512 bins in 512 slices)
 
@@ -618,7 +619,7 @@ def main():
             roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on two streams and overlap, so "
                                           "the sum exceeds ms_per_step" % my_slices)
         if not args.no_pmc and world_size == 1:
-            table, note = collect_pmc(args.workload, 3 if SLICES == 1 else 1, args.pmc_keep)
+            table, note = collect_pmc(args.workload, 3 if SLICES == 1 else 1, args.pmc_keep, PPC)
             if table is None:
                 roofline["pmc_error"] = note
             else:
@@ -718,7 +719,7 @@ def main():
             "metric": "primary rays/sec", "value": round(value, 1), "unit": "rays/s", "n_gpus": world_size,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
             "higher_is_better": True, "scaling": "weak" if sharding == "sample" else "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": W["name"] + (", %d MI355X" % world_size), "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
+            "config": {"workload": W["name"] + (", %d MI355X" % world_size), "passes_per_call": PPC, "rays_per_step": rays_per_step_job, "rays_per_step_per_gpu": rays_per_step_rank,
                        "rng": "philox4x32-10", "sharding": sharding, "tile_bounds": tile_bounds, "slice_bounds": slice_bounds, "rccl_ranks": rccl_ranks,
                        "collective": {"none": "none", "rsx": "RCCL from librsx (rsx_allgather_frame / rsx_allreduce_frame)",
                                       "torch": "torch.distributed nccl", "host": "host memory + gloo (test aid)"}[collective] + ("; " + comm_note if comm_note else ""),

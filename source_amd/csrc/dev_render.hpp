@@ -134,6 +134,7 @@ __device__ __forceinline__ void camera_ray(const RSX_CONST_AS RenderParams *q, i
 struct IntRcp {
     double d, y;
     __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
+    __device__ __forceinline__ IntRcp(double d_, double y_) : d(d_), y(y_) {}
     __device__ __forceinline__ double div(double numer) const { return exact_div(numer, d, y, d > 0.0); }
 };
 
@@ -147,16 +148,18 @@ __device__ __forceinline__ void add_sample(double x, double &m, double &v, int &
     v = by_nm1.div(pv * (pn - 1) + (x - pm) * (x - m));
 }
 
-__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
+// `rcp(n)` = IntRcp(n): computed (v_rcp_f64 and two refinement steps per divisor), or read from a table when the counts are wave-uniform
+template <class Rcp>
+__device__ __forceinline__ void combine_samples_with(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt, Rcp rcp) {
     if (nx < ny) { const int ti = nx; nx = ny; ny = ti; double td = mx; mx = my; my = td; td = vx; vx = vy; vy = td; }
     if (nx > 1 && ny > 1) {
         nt = nx + ny;
-        const IntRcp by_nt(nt);
+        const IntRcp by_nt = rcp(nt);
         mt = by_nt.div(nx * mx + ny * my);
-        vx = IntRcp(nx).div((nx - 1) * vx);
-        vy = IntRcp(ny).div((ny - 1) * vy);
+        vx = rcp(nx).div((nx - 1) * vx);
+        vy = rcp(ny).div((ny - 1) * vy);
         vt = by_nt.div(nx * (mx * mx + vx) + ny * (my * my + vy)) - mt * mt;
-        vt = IntRcp(nt - 1).div(nt * vt);
+        vt = rcp(nt - 1).div(nt * vt);
         return;
     }
     if (nx == 0 && ny == 0) { nt = 0; mt = 0; vt = 0; }
@@ -165,8 +168,25 @@ __device__ __forceinline__ void combine_samples(double mx, double vx, int nx, do
         else { nt = 2; mt = 0.5 * (mx + my); const double temp = mx - mt; vt = 2 * temp * temp; }
     } else if (nx > 1) {
         nt = nx; mt = mx; vt = vx;
-        if (ny == 1) add_sample(my, mt, vt, nt, IntRcp(nx + 1), IntRcp(nx));
+        if (ny == 1) add_sample(my, mt, vt, nt, rcp(nx + 1), rcp(nx));
     } else { nt = 0; mt = 0; vt = 0; }
+}
+
+__device__ __forceinline__ void combine_samples(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt) {
+    combine_samples_with(mx, vx, nx, my, vy, ny, mt, vt, nt, [](int n) { return IntRcp(n); });
+}
+
+// The same merge for a wave whose lanes all hold the same two counts — every pixel of an ordinary render has seen the same passes —
+// and counts within the table `consts` ([i] = {(double)i, refine_rcp(i)}, k_fill_acc_consts): the divisors and their reciprocals come
+// over the scalar data path and the case analysis is scalar control flow. Same operations on the same values; anything else (an
+// adaptive sampler's uneven counts, long renders) takes combine_samples. `limit` = entries in the table.
+__device__ __forceinline__ void combine_samples_uniform(double mx, double vx, int nx, double my, double vy, int ny, double &mt, double &vt, int &nt,
+                                                        const RSX_CONST_AS double *consts, int limit) {
+    const int nxu = __builtin_amdgcn_readfirstlane(nx), nyu = __builtin_amdgcn_readfirstlane(ny);
+    const bool same = __builtin_amdgcn_ballot_w64(nx != nxu || ny != nyu) == 0ULL;
+    if (consts != nullptr && same && nxu >= 0 && nyu >= 0 && (long long)nxu + nyu + 1 < limit)
+        combine_samples_with(mx, vx, nxu, my, vy, nyu, mt, vt, nt, [consts](int n) { return IntRcp(consts[2 * n], consts[2 * n + 1]); });
+    else combine_samples(mx, vx, nx, my, vy, ny, mt, vt, nt);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -183,6 +203,7 @@ __device__ __forceinline__ void combine_samples(double mx, double vx, int nx, do
 // it costs: the recurrence (34 instructions per sample and bin) moves into a kernel that is already bound by instruction issue —
 // measured 41.9 ms against 34.9 + 5.8 = 40.8 ms for the two kernels, so the form is opt-in (RSX_FUSE=1, rsx_device.hip).
 #define FUSE_UNITS 4
+#define ACC_CONSTS_ENTRIES (65536 + 3)   // entries of the scalar-path table {(double)i, refine_rcp(i)}: Welford steps up to ACC_RCP_TABLE_MAX, frame merges up to 65536 samples
 #ifndef TICKET_BATCH
 #define TICKET_BATCH 4
 #endif
@@ -194,6 +215,7 @@ struct FuseParams {
     int32_t n_tables, bins, power, ny, frame_bins, slice_offset;
     int32_t lds_bytes, tables_in_lds;   // per-wave LDS region size; 1: the spectral tables fit behind the staged records
     const double *consts;               // [i] = {(double)i, refine_rcp(i)} (k_fill_acc_consts)
+    int32_t passes, pass_spp;           // rsx_render_desc.passes: a pixel's spp = passes * pass_spp samples are `passes` chains, merged one after the other
 };
 
 // MODE 0: everything in one kernel. CSG scenes run two passes instead: MODE 1 has only the state-free CSG evaluator (csg_fast_hit), so
@@ -201,7 +223,7 @@ struct FuseParams {
 // redo_mask and traced again by MODE 2, which carries the reference's stream merge (one wave per SIMD, usually nothing to do).
 // STAGE_MIN: see mesh_trace_wave (1 for passes with more than one sample per pixel).
 // The chains of the units a wave has gathered in its ring: Welford over each pixel's spp samples per bin, merged into the frame.
-template <bool TABLES_IN_LDS>
+template <bool TABLES_IN_LDS, bool MULTI>      // MULTI: the pixel's samples are several passes (rsx_render_desc.passes), merged one after the other
 __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q, const FuseParams &fz, int u0, int u1, int u2, int u3, int n_units, uint32_t lds_base) {
     const int lane = threadIdx.x % WAVE;
     const int spp = q->spp, bins = fz.bins, ppu = WAVE / spp;             // pixels per unit
@@ -225,34 +247,69 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
             x = x * l_w[base + i];
             return x * scale;
         };
-        double m = value(0), v = 0;
-        const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
-        for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step(): divisors over the scalar data path,
-            const double x = value(i);                                    // both quotients by exact_div's shortcut, one wave-level range test per step
-            const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
-            const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
-            const double pm = m, pv = v;
-            const double n1 = x - pm;
-            const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
-            const double m1 = pm + q1;
-            const double n2 = pv * cc + n1 * (x - m1);
-            const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
-            const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
-            const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
-                m = pm + exact_div(n1, dn, yn, true);
-                v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
-            } else { m = m1; v = q2; }
+        if constexpr (!MULTI) {
+            double m = value(0), v = 0;
+            const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
+            for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step(): divisors over the scalar data path,
+                const double x = value(i);                                    // both quotients by exact_div's shortcut, one wave-level range test per step
+                const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
+                const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
+                const double pm = m, pv = v;
+                const double n1 = x - pm;
+                const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
+                const double m1 = pm + q1;
+                const double n2 = pv * cc + n1 * (x - m1);
+                const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
+                const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
+                const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
+                    m = pm + exact_div(n1, dn, yn, true);
+                    v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
+                } else { m = m1; v = q2; }
+            }
+            const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
+            if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
+            double mt, vt;
+            int nt;
+            combine_samples(fz.fmean[f], fz.fvar[f], fz.fn[f], m, v, spp, mt, vt, nt);
+            fz.fmean[f] = mt; fz.fvar[f] = vt; fz.fn[f] = nt;
+        } else {
+            const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
+            const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
+            double fm = fz.fmean[f], fv = fz.fvar[f];
+            int fcount = fz.fn[f];
+            const int pass_spp = fz.pass_spp;
+            for (int first = 0; first < spp; first += pass_spp) {             // (one pass, or the rsx_render_desc.passes of this call in their order)
+                double m = value(first), v = 0;
+                for (int i = 1; i < pass_spp; ++i) {                          // _add_sample, as k_accumulate's step(): divisors over the scalar data path,
+                    const double x = value(first + i);                        // both quotients by exact_div's shortcut, one wave-level range test per step
+                    const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
+                    const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
+                    const double pm = m, pv = v;
+                    const double n1 = x - pm;
+                    const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
+                    const double m1 = pm + q1;
+                    const double n2 = pv * cc + n1 * (x - m1);
+                    const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
+                    const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
+                    const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
+                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
+                        m = pm + exact_div(n1, dn, yn, true);
+                        v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
+                    } else { m = m1; v = q2; }
+                }
+                if (v < 0) v = 0;                                             // statsarray.pyx:649-650
+                double mt, vt;
+                int nt;
+                combine_samples_uniform(fm, fv, fcount, m, v, pass_spp, mt, vt, nt, consts, ACC_CONSTS_ENTRIES);
+                fm = mt; fv = vt; fcount = nt;
+            }
+            fz.fmean[f] = fm; fz.fvar[f] = fv; fz.fn[f] = fcount;
         }
-        const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
-        if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
-        double mt, vt;
-        int nt;
-        combine_samples(fz.fmean[f], fz.fvar[f], fz.fn[f], m, v, spp, mt, vt, nt);
-        fz.fmean[f] = mt; fz.fvar[f] = vt; fz.fn[f] = nt;
     }
 }
 
+template <bool MULTI = false>
 __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, const FuseParams &fz, const Sample *ring, int u0, int u1, int u2, int u3, int n_units,
                                             uint32_t lds_base) {
     const int lane = threadIdx.x % WAVE;
@@ -272,14 +329,17 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (fz.tables_in_lds) fused_chains<true>(q, fz, u0, u1, u2, u3, n_units, lds_base);
-    else fused_chains<false>(q, fz, u0, u1, u2, u3, n_units, lds_base);
+    if (fz.tables_in_lds) fused_chains<true, MULTI>(q, fz, u0, u1, u2, u3, n_units, lds_base);
+    else fused_chains<false, MULTI>(q, fz, u0, u1, u2, u3, n_units, lds_base);
     __builtin_amdgcn_wave_barrier();
 }
 
 // The flush as a real call (packet kernel): once per FUSE_UNITS units, everything it needs is wave-uniform and re-read from the
 // kernel-argument segment inside (the render parameters and the FuseParams lie there, second and fifth argument of k_render_trace) —
 // inlined into the unit loop its chains' registers competed with the walk's and cost the kernel sixteen more spilled registers.
+// (MULTI — several passes per call — is a kernel of its own: as a run-time branch in here the larger callee cost the one-pass kernel
+// 22 more spilled registers around the call and configs[2] 27.2 -> 28.4 ms)
+template <bool MULTI>
 __device__ __attribute__((noinline)) void fused_flush_call(unsigned long long rp_bits_, const Sample *ring_, int u0_, int u1_, int u2_, int u3_, int n_units_, uint32_t lds_base_) {
     const Sample *ring = (const Sample *)pkt_uniform64((unsigned long long)ring_);
     const int u0 = __builtin_amdgcn_readfirstlane(u0_), u1 = __builtin_amdgcn_readfirstlane(u1_), u2 = __builtin_amdgcn_readfirstlane(u2_),
@@ -291,12 +351,12 @@ __device__ __attribute__((noinline)) void fused_flush_call(unsigned long long rp
     FuseParams fz;
     fz.ring = fq->ring; fz.tables = fq->tables; fz.fmean = fq->fmean; fz.fvar = fq->fvar; fz.fn = fq->fn; fz.sensitivity = fq->sensitivity;
     fz.n_tables = fq->n_tables; fz.bins = fq->bins; fz.power = fq->power; fz.ny = fq->ny; fz.frame_bins = fq->frame_bins; fz.slice_offset = fq->slice_offset;
-    fz.lds_bytes = fq->lds_bytes; fz.tables_in_lds = fq->tables_in_lds; fz.consts = fq->consts;
-    fused_flush(q, fz, ring, u0, u1, u2, u3, n_units, lds_base);
+    fz.lds_bytes = fq->lds_bytes; fz.tables_in_lds = fq->tables_in_lds; fz.consts = fq->consts; fz.passes = fq->passes; fz.pass_spp = fq->pass_spp;
+    fused_flush<MULTI>(q, fz, ring, u0, u1, u2, u3, n_units, lds_base);
 }
 
 // PACKET: the unit's rays walk the trees together (dev_packet.hpp) — passes whose units hold a few pixels' samples.
-template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, bool FUSED = false, bool PACKET = false>
+template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, int FUSED = 0, bool PACKET = false>     // FUSED: 0 no, 1 yes, 2 yes with several passes per call (packet kernel)
 __global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, FuseParams fz) {
     Stack st, ms;
@@ -304,7 +364,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
     const int lane = threadIdx.x % WAVE;
     int fuse_u0 = 0, fuse_u1 = 0, fuse_u2 = 0, fuse_u3 = 0, fuse_n = 0;           // wave-uniform: the units whose records wait in the ring
     Sample *fuse_ring = nullptr;
-    if constexpr (FUSED) fuse_ring = fz.ring + ((size_t)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE))) * (FUSE_UNITS * WAVE);
+    if constexpr (FUSED != 0) fuse_ring = fz.ring + ((size_t)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE))) * (FUSE_UNITS * WAVE);
     NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
     long long redo_unit = (long long)blockIdx.x * (WG_THREADS / WAVE) + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));   // MODE 2: units are strided over the waves
     // Work is handed out from eight longest-first lists, one per XCD (k_order_units): a wave drains the list of the XCD it runs on
@@ -375,7 +435,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         uint32_t work = 0;
         if constexpr (PACKET) {
             // the projection weight goes to its record NOW (its two registers are then free through the walk); a and table follow the walk
-            if constexpr (FUSED) fuse_ring[fuse_n * WAVE + lane].weight = weight;
+            if constexpr (FUSED != 0) fuse_ring[fuse_n * WAVE + lane].weight = weight;
             else if (px.valid) samples[px.slot * q->spp + px.s].weight = weight;
             r.ox = readlane_f64(r.ox, 0); r.oy = readlane_f64(r.oy, 0); r.oz = readlane_f64(r.oz, 0);     // (the pinhole: one origin, kept in scalar registers)
         }
@@ -439,7 +499,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             if (redo) continue;
         }
         if constexpr (MODE == 2) { if (!((q2->redo_mask[unit] >> lane) & 1ULL)) continue; }
-        if (!FUSED && !px2.valid) continue;
+        if (FUSED == 0 && !px2.valid) continue;
         Sample smp;
         smp.a = 0.0; smp.weight = PACKET ? 0.0 : weight; smp.table = -1; smp.pad = 0;
         if (got) {                                                                 // optical/ray.pyx:391-393
@@ -458,25 +518,25 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
                 }
             }
         }
-        if constexpr (FUSED && PACKET) {
+        if constexpr (FUSED != 0 && PACKET) {
             Sample *rec = fuse_ring + fuse_n * WAVE + lane;                // (weight: stored before the walk)
             rec->a = smp.a; rec->table = smp.table; rec->pad = 0;
         }
-        if constexpr (FUSED) {
+        if constexpr (FUSED != 0) {
             if constexpr (!PACKET) fuse_ring[fuse_n * WAVE + lane] = smp;  // (lanes of pixels outside the frame write a record nobody reads)
             if (fuse_n == 0) fuse_u0 = unit; else if (fuse_n == 1) fuse_u1 = unit; else if (fuse_n == 2) fuse_u2 = unit; else fuse_u3 = unit;
             if (++fuse_n == FUSE_UNITS) {
-                if constexpr (PACKET) fused_flush_call(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t);
+                if constexpr (PACKET) fused_flush_call<FUSED == 2>(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t);
                 else fused_flush(q2, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, FUSE_UNITS, st.lds_t);
                 fuse_n = 0;
             }
         } else if constexpr (PACKET) { Sample *rec = samples + px2.slot * q2->spp + px2.s; rec->a = smp.a; rec->table = smp.table; rec->pad = 0; }
         else samples[px2.slot * q2->spp + px2.s] = smp;
     }
-    if constexpr (FUSED) {
+    if constexpr (FUSED != 0) {
         if (fuse_n) {
             const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
-            if constexpr (PACKET) fused_flush_call(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
+            if constexpr (PACKET) fused_flush_call<FUSED == 2>(rp_bits, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
             else fused_flush((const RSX_CONST_AS RenderParams *)rp_bits, fz, fuse_ring, fuse_u0, fuse_u1, fuse_u2, fuse_u3, fuse_n, st.lds_t);
         }
     }
@@ -1480,8 +1540,14 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
         fm = ap.fmean[f]; fv = ap.fvar[f]; fcount = ap.fn[f];
     }
+    Sample head = s[0];
     for (int pass = 0; pass < ap.passes; ++pass, s += ap.spp, rec0 += ap.spp) {
-    m = value(s[0], rec0); v = 0; dm = 1.0;
+    // (the first record of the NEXT pass is requested before this pass's merge: K one-sample passes are K dependent merges per thread, and
+    // a load in front of each was what they waited for — 0.99 -> 0.88 ms for 16 passes of configs[1]; fetching the table entry ahead as
+    // well measured 1.10 ms)
+    const Sample first = head;
+    if (pass + 1 < ap.passes) head = s[ap.spp];
+    m = value(first, rec0); v = 0; dm = 1.0;
     // ... and the NEXT batch is requested before this one is stepped through: the records are a stream that is read once, from HBM,
     // and a batch's own arithmetic (0.2 us) does not cover that round trip even with eight waves per SIMD.
     int i = 1;
@@ -1515,7 +1581,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
         double mt, vt;
         int nt;
-        combine_samples(fm, fv, fcount, m, v, ap.spp, mt, vt, nt);
+        combine_samples_uniform(fm, fv, fcount, m, v, ap.spp, mt, vt, nt, consts, ACC_CONSTS_ENTRIES);
         fm = mt; fv = vt; fcount = nt;
     }
     }

@@ -313,7 +313,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
     }
     {
-        const int n = ACC_RCP_TABLE_MAX + 3;
+        const int n = ACC_CONSTS_ENTRIES;
         HIP_TRY(hipMalloc(&ctx->acc_consts, (size_t)n * 16));
         hipLaunchKernelGGL(k_fill_acc_consts, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, ctx->acc_consts, n);
         HIP_TRY(hipGetLastError());
@@ -1303,7 +1303,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
     // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
     const bool fuse_enabled = fuse_env < 0 ? use_packet : fuse_env != 0;
-    const bool fused = fuse_enabled && passes == 1 && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
+    const bool fused = fuse_enabled && (passes == 1 || use_packet) && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
                        !ctx->unit_times && wave_lds >= fuse_fixed;
     if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
     if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
@@ -1462,6 +1462,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         fz.frame_bins = frame_bins; fz.slice_offset = slice_offset;
         fz.lds_bytes = (int32_t)wave_lds;
         fz.consts = ctx->acc_consts;
+        fz.passes = passes; fz.pass_spp = desc->spp / passes;
         fz.tables_in_lds = fuse_fixed + (size_t)std::max(1, desc->n_tables) * B * 8 <= wave_lds ? 1 : 0;
     }
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
@@ -1535,7 +1536,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     else if (use_packet) {
         if ((rc = ensure_camera_relative(scene, desc->camera, lane.stream))) return rc;
-        const void *kernel = fused ? reinterpret_cast<const void *>(k_render_trace<false, 0, 1, true, true>) : reinterpret_cast<const void *>(k_render_trace<false, 0, 1, false, true>);
+        const void *kernel = fused ? (passes > 1 ? reinterpret_cast<const void *>(k_render_trace<false, 0, 1, 2, true>) : reinterpret_cast<const void *>(k_render_trace<false, 0, 1, 1, true>))
+                                   : reinterpret_cast<const void *>(k_render_trace<false, 0, 1, 0, true>);
         Sample *records = fused ? nullptr : static_cast<Sample *>(lane.samples);
         HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
         void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&records, (void *)&lane.ticket, (void *)&fz};
@@ -1543,11 +1545,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     }
     else if (fused) {
         if (desc->spp > RSX_COHERENT_MIN_SPP) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-            hipLaunchKernelGGL((k_render_trace<false, 0, 1, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, 1, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            hipLaunchKernelGGL((k_render_trace<false, 0, 1, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
         } else {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, RSX_STAGE_MIN, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-            hipLaunchKernelGGL((k_render_trace<false, 0, RSX_STAGE_MIN, true>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<false, 0, RSX_STAGE_MIN, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+            hipLaunchKernelGGL((k_render_trace<false, 0, RSX_STAGE_MIN, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(nullptr), lane.ticket, fz);
         }
     }
     else if (desc->spp > RSX_COHERENT_MIN_SPP) {            // coherent waves (several samples of a pixel side by side): always stage big leaves

@@ -1447,8 +1447,16 @@ def test_passes_per_call_equals_separate_passes(ns):
     """rsx_render_desc.passes / HipEngine(passes_per_call=K): K passes submitted as one library call leave the frames that K observe()
     calls leave (observer.pyx:265-309 called K times: K Welford chains per pixel and bin, K merges) — mean, variance and sample counts
     bit for bit: mesh scenes, a CSG scene, a task-list pass with a mask, several spectral slices, power and radiance pipelines."""
-    def frames(make, K, calls, together):
+    def frames(make, K, calls, together, uneven=False):
         world, cam, pipes = make()
+        if uneven:                                          # pixels with different histories in one wave: the merge's per-lane form
+            sampler = cam.frame_sampler
+            mask = np.zeros(cam.pixels, dtype=bool)
+            mask[5:-3:2, 1:-2] = True
+            cam.frame_sampler = ns.FullFrameSampler2D(mask)
+            cam.render_engine = ns.HipEngine(rng="philox", seed=5)
+            cam.observe()
+            cam.frame_sampler = sampler
         cam.render_engine = ns.HipEngine(rng="philox", seed=11, passes_per_call=K if together else 1)
         for _ in range(calls * (1 if together else K)):
             cam.observe()
@@ -1486,7 +1494,8 @@ def test_passes_per_call_equals_separate_passes(ns):
 
     for name, make, K, calls in (("c2 1 spp x 16", c2(1), 16, 2), ("c2 1 spp x 3", c2(1), 3, 1), ("c2 4 spp x 5, 3 slices", c2(4, slices=3), 5, 2),
                                  ("c2 20 spp x 4", c2(20, (33, 21)), 4, 1), ("c3 masked 3 spp x 7", c3_masked, 7, 2), ("csg 2 spp x 8", csg, 8, 1)):
-        one, many = frames(make, K, calls, True), frames(make, K, calls, False)
+        uneven = name == "c2 1 spp x 3"
+        one, many = frames(make, K, calls, True, uneven), frames(make, K, calls, False, uneven)
         for a, b in zip(one, many):
             assert a.max() > 0 and np.array_equal(a.view(np.uint64), b.view(np.uint64)), name
 
