@@ -1414,7 +1414,7 @@ __global__ void k_fill_acc_consts(double *consts, int n) {
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
 
-template <bool STAGED, int VOL, bool TAB_LDS = STAGED>   // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
+template <bool STAGED, int VOL, bool TAB_LDS = STAGED, bool MULTI = false>   // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
                                         // VOL = samples carry path terms (k_render_trace_path): 1 = without, 2 = with dielectric attenuation (pow() costs 60 registers)
                                         // TAB_LDS = false with STAGED: the spectral tables do not fit the LDS next to the reciprocals and are read from global
                                         // memory (a template parameter: as a run-time flag the choice cost the recurrence 23 %, 5.8 -> 7.1 ms on configs[2])
@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         ix = ap.rect[0] + lx; iy = ap.rect[1] + ly;
         k = (long long)ly * w + lx;
     }
-    const Sample *s = ap.samples + p * ap.spp * ap.passes;   // (passes > 1: the records of a pixel's passes follow one another)
+    const Sample *s = ap.samples + p * ap.spp * (MULTI ? ap.passes : 1);   // (passes > 1: the records of a pixel's passes follow one another)
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
     auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
@@ -1493,7 +1493,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // _add_sample (statsarray.pyx:743-776) unrolled over the pass: the first sample sets (m, 0); sample i >= 1 divides by the new
     // count i + 1 and by i, and scales the previous variance by prev_n - 1 with prev_n := 2 when only one sample was held.
     // Records are fetched ACC_BATCH at a time so that their loads are in flight together (one dependent load per sample was the bound).
-    long long rec0 = p * ap.spp * ap.passes;
+    long long rec0 = p * ap.spp * (MULTI ? ap.passes : 1);
     double m = 0, v = 0;
     double dm = 1.0;                                        // (double)i, advanced by exact additions
     // The step's divisors, their refined reciprocals and the factor prev_n - 1 depend on the sample index alone — wave-uniform: they come
@@ -1531,22 +1531,24 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
         dm = dn;
     };
-    // rsx_render_desc.passes = K > 1: K consecutive passes of spp samples each in this one launch — per pass the recurrence from its first
-    // sample and the frame merge, in pass order: the frame of K calls. The frame cell stays in registers between the merges.
+    // rsx_render_desc.passes = K > 1 (MULTI): K consecutive passes of spp samples each in this one launch — per pass the recurrence from its
+    // first sample and the frame merge, in pass order: the frame of K calls. The frame cell stays in registers between the merges. A kernel
+    // of its own: as a run-time trip count the pass loop cost the one-pass kernels 10 - 20 % (Cornell box replay 9.2 -> 11.3 ms).
+    const int n_pass = MULTI ? ap.passes : 1;
     size_t f = 0;
     double fm = 0, fv = 0;
     int fcount = 0;
-    if (ap.fmean) {
+    if (MULTI && ap.fmean) {
         f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
         fm = ap.fmean[f]; fv = ap.fvar[f]; fcount = ap.fn[f];
     }
     Sample head = s[0];
-    for (int pass = 0; pass < ap.passes; ++pass, s += ap.spp, rec0 += ap.spp) {
+    for (int pass = 0; pass < n_pass; ++pass, s += ap.spp, rec0 += ap.spp) {
     // (the first record of the NEXT pass is requested before this pass's merge: K one-sample passes are K dependent merges per thread, and
     // a load in front of each was what they waited for — 0.99 -> 0.88 ms for 16 passes of configs[1]; fetching the table entry ahead as
     // well measured 1.10 ms)
     const Sample first = head;
-    if (pass + 1 < ap.passes) head = s[ap.spp];
+    if (pass + 1 < n_pass) head = s[ap.spp];
     m = value(first, rec0); v = 0; dm = 1.0;
     // ... and the NEXT batch is requested before this one is stepped through: the records are a stream that is read once, from HBM,
     // and a batch's own arithmetic (0.2 us) does not cover that round trip even with eight waves per SIMD.
@@ -1577,7 +1579,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         }
     }
     for (; i < ap.spp; ++i) step(value(s[i], rec0 + i), i);
-    if (ap.fmean) {
+    if (MULTI && ap.fmean) {
         if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
         double mt, vt;
         int nt;
@@ -1586,7 +1588,16 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     }
     }
     if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }    // (per-task outputs: passes == 1)
-    if (ap.fmean) { ap.fmean[f] = fm; ap.fvar[f] = fv; ap.fn[f] = fcount; }
+    if (MULTI) {
+        if (ap.fmean) { ap.fmean[f] = fm; ap.fvar[f] = fv; ap.fn[f] = fcount; }
+    } else if (ap.fmean) {
+        f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+        if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
+        double mt, vt;
+        int nt;
+        combine_samples(ap.fmean[f], ap.fvar[f], ap.fn[f], m, v, ap.spp, mt, vt, nt);
+        ap.fmean[f] = mt; ap.fvar[f] = vt; ap.fn[f] = nt;
+    }
 }
 
 // XYZPixelProcessor (rgb.pyx:534-562): one thread per (task, channel). Every sample's spectrum, times its projection weight, is

@@ -1624,7 +1624,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         const bool staged = ap.spp >= 4, in_lds = ap.tables_in_lds != 0;
 #define ACC(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V>) \
                                                                                            : reinterpret_cast<const void *>(k_accumulate<true, V, false>))
-        const void *kernel = vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);
+#define ACC_MULTI (!staged ? reinterpret_cast<const void *>(k_accumulate<false, 0, false, true>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, 0, true, true>) \
+                                                                                                  : reinterpret_cast<const void *>(k_accumulate<true, 0, false, true>))
+        const void *kernel = passes > 1 ? ACC_MULTI : vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);     // (passes > 1: scenes without path terms)
+#undef ACC_MULTI
 #undef ACC
         void *args[] = {(void *)&ap};
         HIP_TRY(hipLaunchKernel(kernel, acc_grid, dim3(256), args, staged ? acc_lds : 0, ctx->stream));

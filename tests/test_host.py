@@ -347,3 +347,20 @@ def test_stale_library_is_refused_at_load_time(tmp_path):
         os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_LIB=str(so)), capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.startswith("refused") and "does not export" in r.stdout, r.stdout + r.stderr[-800:]
+
+
+def test_passes_per_call_bookkeeping(ns):
+    """HipEngine(passes_per_call=K): K passes per observe() — the Philox counters an observe() hands out and the rays one library
+    call may carry both scale with K (the frames themselves: tests/test_gpu_parity.py::test_passes_per_call_equals_separate_passes)."""
+    from source_amd import scenes
+    with pytest.raises(ValueError):
+        ns.HipEngine(passes_per_call=0)
+    world = scenes.build_c2(ns, n=8)[0]
+    cam, pipe = scenes.c2_camera(ns, world, (64, 32), spp=3, bins=4)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.MAX_RAYS_PER_CALL = 64 * 32 * 3 * 2
+    cam.render_engine = ns.HipEngine(passes_per_call=1)
+    assert len(cam._pieces(cam._generate_tasks(), world)) == 1
+    cam.render_engine = ns.HipEngine(passes_per_call=4)
+    pieces = cam._pieces(cam._generate_tasks(), world)
+    assert len(pieces) == 2 and pieces[0]["rect"] == (0, 0, 32, 32)    # (4 passes x 3 spp per pixel: half the frame per call)
