@@ -1229,6 +1229,24 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     std::vector<unsigned char> mat_blob(mat_bytes + imp_bytes, 0);
     if (desc->n_materials) std::memcpy(mat_blob.data(), desc->materials, sizeof(rsx_material) * (size_t)desc->n_materials);
     if (n_important) std::memcpy(mat_blob.data() + mat_bytes, desc->important, imp_bytes);
+    // A dielectric whose transmission is exactly 1 in every bin of this slice leaves every spectrum unchanged in evaluate_volume
+    // (dielectric.pyx:300-328: samples *= pow(1, length) = 1, and x * 1 = x): the library marks it in ITS copy of the materials
+    // (light_dir[2] = 1) and the path kernel does not list it among the volumes of a segment — no world.contains() pass at all when
+    // nothing else in the scene has a volume contribution (a Cornell box with clear glass), no attenuation terms to replay.
+    int32_t n_vol_contributors = 0;
+    {
+        rsx_material *bm = reinterpret_cast<rsx_material *>(mat_blob.data());
+        for (int32_t i = 0; i < desc->n_materials; ++i) {
+            if (bm[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER) ++n_vol_contributors;
+            else if (bm[i].type == RSX_MAT_DIELECTRIC) {
+                bool unit = desc->tables != nullptr;
+                const double *row = desc->tables + (size_t)bm[i].table * B;
+                for (size_t b = 0; unit && b < B; ++b) unit = row[b] == 1.0;
+                bm[i].light_dir[2] = unit ? 1.0 : 0.0;
+                if (!unit) ++n_vol_contributors;
+            }
+        }
+    }
     if ((rc = pool_get(ctx, POOL_MATERIALS, mat_blob.size(), &d_mat)) ||
         (rc = pool_get(ctx, POOL_TABLES, 8 * B * (size_t)(std::max(1, desc->n_tables) + 3), &d_tab))) return rc;
     // small per-call inputs are uploaded only when they differ from what the device already holds (steady-state
@@ -1342,7 +1360,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
     rp.n_important = n_important; rp.passes = 1; rp.important_path_weight = desc->important_path_weight;
     rp.n_vol_emitters = 0; rp.world_lds = 0; rp.prims_lds = 0;
-    for (int32_t i = 0; i < desc->n_materials; ++i) rp.n_vol_emitters += desc->materials[i].type == RSX_MAT_UNIFORM_VOLUME_EMITTER || desc->materials[i].type == RSX_MAT_DIELECTRIC;
+    rp.n_vol_emitters = n_vol_contributors;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
     // longest-first unit schedule from the costs this lane's previous pass over the same units measured

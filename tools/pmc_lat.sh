@@ -10,11 +10,11 @@ for grp in "SQ_INST_LEVEL_VMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES"
   RSX_PIPELINE=1 timeout 200 rocprofv3 --pmc $grp -d "$OUT/$tag" -o k --output-format csv -- python $R/bench.py --child --workload $WL --steps 3 > "$OUT/$tag.log" 2>&1
 done
 python3 - "$OUT" <<'PY'
-import csv, glob, collections, sys
+import csv, glob, collections, sys, os
 agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_render_trace' in r['Kernel_Name']:
+        if os.environ.get('KERNEL', 'k_render_trace') in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 a = {k: sum(v) / len(v) for k, v in agg.items()}
 for k, v in sorted(a.items()):

@@ -14,11 +14,11 @@ for v in $VARS; do
   done
   echo "== $WL $v"
   python3 - "$OUT" <<'PY'
-import csv, glob, collections, sys
+import csv, glob, collections, sys, os
 agg = collections.defaultdict(list)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'k_render_trace' in r['Kernel_Name']:
+        if os.environ.get('KERNEL', 'k_render_trace') in r['Kernel_Name']:
             agg[r['Counter_Name']].append(float(r['Counter_Value']))
 for k, v in sorted(agg.items()):
     print("%-28s n=%2d avg=%.5g" % (k, len(v), sum(v) / len(v)))
