@@ -1524,6 +1524,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
                 if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
             } else if (scene->has_csg) { if ((rc = launch(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
+            else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
+                if ((rc = launch(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false), l.grid))) return rc;
+            }
             else if ((rc = launch(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false), l.grid))) return rc;
 #undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
