@@ -1415,6 +1415,10 @@ __global__ void k_fill_acc_consts(double *consts, int n) {
 #ifndef ACC_BATCH
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
+#ifndef ACC_PATH_CHUNK
+#define ACC_PATH_CHUNK 8            // path passes: samples whose term lists a lane walks back to back before the wave meets for their Welford steps
+                                    // (Cornell box: 4 -> 5.4 ms, 8 -> 5.2 ms, 16 -> 8.8 ms: the values wait in LDS, 2 KB per sample and workgroup)
+#endif
 
 template <bool STAGED, int VOL, bool TAB_LDS = STAGED, bool MULTI = false>   // STAGED = many samples per pixel: LDS tables, batched record loads; else the lean one-shot form.
                                         // VOL = samples carry path terms (k_render_trace_path): 1 = without, 2 = with dielectric attenuation (pow() costs 60 registers)
@@ -1452,40 +1456,42 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         k = (long long)ly * w + lx;
     }
     const Sample *s = ap.samples + p * ap.spp * (MULTI ? ap.passes : 1);   // (passes > 1: the records of a pixel's passes follow one another)
+    // One term of a path's list applied to the running value x (newest term first: the reference's recursion unwinding).
+    // VOL: += (0 + table * scale) * length (uniform.pyx:129-131, homogeneous.pyx:99-100). LAMBERT: [daughter's roulette normalisation,
+    // ray.pyx:399] * reflectivity * pdf * (1 / pdf) (lambert.pyx:101-103, material.pyx:356-358).
+    // One straight line for every kind — the lanes of a wave replay the lists of four or five pixels, whose terms differ in kind at
+    // every step: as branches each step ran every kind's code in turn (and `||` of two kind tests became branches again: the tests
+    // below are arithmetic). A factor a kind does not have is 1.0 — x * 1.0 = x exactly, any x: NORM terms are stored with a = b = 1 —
+    // and the emission sum is chosen by a select. 9.2 -> 8.3 ms on the Cornell box.
+    auto apply_term = [&](double x, const PathTerm &tm) {
+        const double tv = tab_lds ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
+        static_assert(TERM_LAMBERT == 1 && TERM_LAMBERT_NORM == 2 && TERM_NORM == 4 && TERM_ATTEN == 5, "kind tests below");
+        const bool has_norm = ((0x14u >> (unsigned)tm.kind) & 1u) != 0u;
+        const double emission = 0.0 + tv * tm.b;
+        const double with_emission = x + emission * tm.a;
+        double y = x * (has_norm ? ap.roulette_norm : 1.0);
+        y = y * (tm.kind == TERM_NORM ? 1.0 : tv);
+        y = y * tm.a;
+        y = y * tm.b;
+        y = tm.kind == TERM_VOL ? with_emission : y;
+        if constexpr (VOL == 2) {                                  // dielectric.pyx:325-326; pow(1, length) = 1 exactly
+            if (tm.kind == TERM_ATTEN) y = tv != 1.0 ? x * portable_pow(tv, tm.a) : x;
+        }                                                          // (VOL == 1: no dielectric absorbs, and none left a term — render())
+        return y;
+    };
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
     auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
         const double tab = tab_lds ? acc_tab[e] : ap.tables[e];
         double x = smp.table < 0 ? 0.0 : smp.a * tab;
         if (VOL) {
-            // the reference's recursion unwinding: newest term first. VOL: += (0 + table * scale) * length (uniform.pyx:129-131,
-            // homogeneous.pyx:99-100). LAMBERT: [daughter's roulette normalisation, ray.pyx:399] * reflectivity * pdf * (1 / pdf)
-            // (lambert.pyx:101-103, material.pyx:356-358).
             long long blk = ap.tail[record];
             int n = smp.pad;
             for (;;) {
                 const PathTerm *t = ap.pool + blk * PATH_BLOCK;
                 const int first = blk < ap.n_records ? 0 : 1;
                 for (int j = n - 1; j >= first; --j) {
-                    const PathTerm tm = t[j];       // (fetching term j - 1 before term j is used: 8.3 -> 8.7 ms)
-                    const double tv = tab_lds ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
-                    // One straight line for every kind — the lanes of a wave replay the lists of four or five pixels, whose terms differ
-                    // in kind at every step: as branches each step ran every kind's code in turn (and `||` of two kind tests became
-                    // branches again: the tests below are arithmetic). A factor a kind does not have is 1.0 — x * 1.0 = x exactly, any
-                    // x: NORM terms are stored with a = b = 1 — and the emission sum is chosen by a select. 9.2 -> 8.3 ms on the Cornell box.
-                    static_assert(TERM_LAMBERT == 1 && TERM_LAMBERT_NORM == 2 && TERM_NORM == 4 && TERM_ATTEN == 5, "kind tests below");
-                    const bool has_norm = ((0x14u >> (unsigned)tm.kind) & 1u) != 0u;
-                    const double emission = 0.0 + tv * tm.b;
-                    const double with_emission = x + emission * tm.a;
-                    double y = x * (has_norm ? ap.roulette_norm : 1.0);
-                    y = y * (tm.kind == TERM_NORM ? 1.0 : tv);
-                    y = y * tm.a;
-                    y = y * tm.b;
-                    y = tm.kind == TERM_VOL ? with_emission : y;
-                    if constexpr (VOL == 2) {                                  // dielectric.pyx:325-326; pow(1, length) = 1 exactly
-                        if (tm.kind == TERM_ATTEN) y = tv != 1.0 ? x * portable_pow(tv, tm.a) : x;
-                    }                                                          // (VOL == 1: no dielectric absorbs, and none left a term — render())
-                    x = y;
+                    x = apply_term(x, t[j]);       // (fetching term j - 1 before term j is used: 8.3 -> 8.7 ms)
                 }
                 if (first == 0) break;
                 blk = t[0].table;
@@ -1537,6 +1543,61 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
         dm = dn;
     };
+    if constexpr (VOL != 0 && STAGED && !MULTI) {
+        // Path passes. The lanes of a wave are the bins of four or five pixels, and the lists of those pixels' samples differ in length
+        // (path lengths are geometric): walked sample by sample, every lane waited for the longest list of every sample and 0.4 of the
+        // lane-slots did work. Here every lane walks ITS lists one after the other — a step is one term of whatever sample the lane
+        // has reached — over ACC_PATH_CHUNK samples at a time, leaving each sample's value in LDS; the Welford steps of the chunk then
+        // run for all lanes together (their divisors depend on the sample index alone and come over the scalar data path).
+        // Same operations in the same order per (pixel, bin); the loop has one exit (see the toolchain note in dev_csg.hpp).
+        double *acc_xs = acc_tab + (tab_lds ? ap.n_tables * ap.bins : 1);      // [ACC_PATH_CHUNK][blockDim.x]
+        const long long rec_base = p * ap.spp;
+        for (int chunk0 = 0; chunk0 < ap.spp; chunk0 += ACC_PATH_CHUNK) {
+            const int cn = ap.spp - chunk0 < ACC_PATH_CHUNK ? ap.spp - chunk0 : ACC_PATH_CHUNK;     // (wave-uniform)
+            int si = 0;
+            Sample cur = s[chunk0], nxt = cur;
+            long long blk = ap.tail[rec_base + chunk0], nblk = blk;
+            if (cn > 1) { nxt = s[chunk0 + 1]; nblk = ap.tail[rec_base + chunk0 + 1]; }
+            int j = cur.pad - 1, first = blk < ap.n_records ? 0 : 1;
+            double x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
+            bool live = true;
+            while (live) {
+                if (j >= first) {
+                    x = apply_term(x, ap.pool[blk * PATH_BLOCK + j]);          // (term j - 1 requested before term j is applied: 5.2 -> 5.5 ms)
+                    --j;
+                } else if (first == 1) {                                       // an arena block: slot 0 links to the block before it
+                    blk = ap.pool[blk * PATH_BLOCK].table;
+                    j = PATH_BLOCK - 1;
+                    first = blk < ap.n_records ? 0 : 1;
+                } else {                                                       // this sample's list is done
+                    x = x * cur.weight;
+                    if (ap.power) x = x * ap.sensitivity;
+                    acc_xs[si * blockDim.x + threadIdx.x] = x;
+                    ++si;
+                    if (si < cn) {
+                        cur = nxt; blk = nblk;
+                        j = cur.pad - 1; first = blk < ap.n_records ? 0 : 1;
+                        x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
+                        if (si + 1 < cn) { nxt = s[chunk0 + si + 1]; nblk = ap.tail[rec_base + chunk0 + si + 1]; }
+                    } else live = false;
+                }
+            }
+            for (int i = 0; i < cn; ++i) {
+                const double xi = acc_xs[i * blockDim.x + threadIdx.x];
+                if (chunk0 + i == 0) { m = xi; v = 0; } else step(xi, chunk0 + i);
+            }
+        }
+        if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
+        if (ap.fmean) {
+            const size_t ff = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+            if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
+            double mt, vt;
+            int nt;
+            combine_samples(ap.fmean[ff], ap.fvar[ff], ap.fn[ff], m, v, ap.spp, mt, vt, nt);
+            ap.fmean[ff] = mt; ap.fvar[ff] = vt; ap.fn[ff] = nt;
+        }
+        return;
+    }
     // rsx_render_desc.passes = K > 1 (MULTI): K consecutive passes of spp samples each in this one launch — per pass the recurrence from its
     // first sample and the frame merge, in pass order: the frame of K calls. The frame cell stays in registers between the merges. A kernel
     // of its own: as a run-time trip count the pass loop cost the one-pass kernels 10 - 20 % (Cornell box replay 9.2 -> 11.3 ms).

@@ -1617,8 +1617,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // LDS of the staged accumulate kernel: the Welford reciprocals and, when they fit next to them, the spectral tables (a 512-bin
     // slice with twenty materials does not: the kernel then reads the tables from global memory, L1 / L2 resident)
     const size_t rcp_lds = (ap.spp <= ACC_RCP_TABLE_MAX ? (size_t)ap.spp + 2 : 2) * 8, tab_lds = (size_t)std::max(1, desc->n_tables) * B * 8;
-    ap.tables_in_lds = rcp_lds + tab_lds <= 60 * 1024 ? 1 : 0;
-    const size_t acc_lds = rcp_lds + (ap.tables_in_lds ? tab_lds : 8);
+    // (path passes also keep ACC_PATH_CHUNK sample values per thread there: k_accumulate's flattened list walk)
+    const size_t xs_lds = has_vol && !h_xyz && ap.spp >= 4 ? (size_t)ACC_PATH_CHUNK * 256 * 8 : 0;
+    ap.tables_in_lds = rcp_lds + tab_lds + xs_lds <= 60 * 1024 ? 1 : 0;
+    const size_t acc_lds = rcp_lds + (ap.tables_in_lds ? tab_lds : 8) + xs_lds;
     const dim3 acc_grid((unsigned)((total + 255) / 256));
     if (fused) {                                            // the trace kernel merged its own samples; its tickets are re-armed by the next launch
         lane.ticket_armed = false;
