@@ -163,6 +163,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RsxError("librsx.so not found at %s — run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(hipcc --offload-arch=gfx950). source_amd has no CPU fallback." % LIB_PATH)
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")    # (the render lanes are streams that must run side by side: see rsx_init)
         handle = C.CDLL(LIB_PATH)
         for name, restype, argtypes in SYMBOLS:
             if not hasattr(handle, name):

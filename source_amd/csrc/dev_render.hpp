@@ -792,7 +792,24 @@ struct PathStore {
     unsigned int arena_blocks;
     unsigned int *arena_next;  // bump allocator over the arena
     unsigned int *flags;       // bit 0: arena exhausted, bit 1: segment guard, bit 2: more than PATH_VOL_OVERLAP emitters at a point
+    struct PathState *queue;   // paths handed on by waves that ran out of new rays (see k_render_trace_path), or null
+    unsigned int *queue_count; // [0] paths in the queue, [1] paths taken out of it again
+    unsigned int queue_cap;
+    int32_t drain;             // 1: this launch takes its paths from the queue instead of the camera
 };
+
+// A path between two segments — everything a lane carries from one round of k_render_trace_path to the next.
+struct PathState {
+    Ray r;
+    Sample smp;
+    long long record, blk;
+    uint64_t rng_pixel, rng_sample;
+    unsigned long long path_spawned;
+    int32_t pos, depth, segments, ray_unit, ray_slot, pad;
+};
+#ifndef PATH_DONATE_MAX
+#define PATH_DONATE_MAX 32          // a wave out of new rays with this many live paths or fewer hands them on and retires
+#endif
 
 // Lanes are refilled: a lane whose path has ended takes the next ray of the wave's current 64-ray unit (a new unit when that one is
 // used up), so a wave keeps all its lanes on live paths instead of waiting for the longest of 64 (path lengths are geometric: the
@@ -896,6 +913,27 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     for (;;) {
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(!active);
+        if (__builtin_expect(ps.drain != 0, 0)) {
+            // second launch of a pass: the paths the first launch's retiring waves handed on, packed 64 to a wave again
+            while (idle && !exhausted) {
+                const int n_idle = __popcll(idle);
+                unsigned int start = 0;
+                if (lane == 0) start = atomicAdd(ps.queue_count + 1, (unsigned int)n_idle);
+                start = (unsigned int)__builtin_amdgcn_readfirstlane((int)start);
+                const unsigned int filled = __builtin_amdgcn_readfirstlane((int)ps.queue_count[0]);      // (final: the first launch has ended)
+                const int take = start >= filled ? 0 : (filled - start < (unsigned int)n_idle ? (int)(filled - start) : n_idle);
+                const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
+                if (!active && rank < take) {
+                    const PathState stt = ps.queue[start + (unsigned int)rank];
+                    r = stt.r; smp = stt.smp; record = stt.record; blk = stt.blk; rng_pixel = stt.rng_pixel; rng_sample = stt.rng_sample;
+                    pos = stt.pos; depth = stt.depth; segments = stt.segments; ray_unit = stt.ray_unit;
+                    if constexpr (MODE == 1) { path_spawned = stt.path_spawned; ray_slot = stt.ray_slot; }       // (what a path leaves to the redo pass)
+                    active = true;
+                }
+                if (take < n_idle) exhausted = true;
+                idle = __ballot(!active);
+            }
+        }
         while (idle && !exhausted) {
             if (cursor >= WAVE) {
                 long long tk = -1;
@@ -938,6 +976,31 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             }
             cursor += take;
             idle = __ballot(!active);
+        }
+        // Out of new rays with only a few paths left: a trapped path (total internal reflection inside glass, hundreds of segments) would
+        // keep this wave — and with it the workgroup's place on its CU — for milliseconds at one live lane in 64. The wave hands its
+        // paths on and retires; a second, small launch (ps.drain) walks the handed-on paths of all waves, packed 64 to a wave, while the
+        // places this launch gave back take the next pass's workgroups. Which wave walks a path never shows in the result (random
+        // numbers, sample record and term list are keyed by pixel and sample).
+        if (__builtin_expect(exhausted && ps.queue != nullptr && !ps.drain, 0)) {
+            const unsigned long long live = __ballot(active);
+            const int n_live = __popcll(live);
+            if (n_live > 0 && n_live <= PATH_DONATE_MAX) {
+                unsigned int base = 0;
+                if (lane == 0) base = atomicAdd(ps.queue_count, (unsigned int)n_live);
+                base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+                if (base + (unsigned int)n_live <= ps.queue_cap) {
+                    if (active) {
+                        PathState stt;
+                        stt.r = r; stt.smp = smp; stt.record = record; stt.blk = blk; stt.rng_pixel = rng_pixel; stt.rng_sample = rng_sample;
+                        stt.path_spawned = 0; stt.ray_slot = 0;
+                        if constexpr (MODE == 1) { stt.path_spawned = path_spawned; stt.ray_slot = ray_slot; }
+                        stt.pos = pos; stt.depth = depth; stt.segments = segments; stt.ray_unit = ray_unit; stt.pad = 0;
+                        ps.queue[base + (unsigned int)__popcll(live & ((1ULL << lane) - 1ULL))] = stt;
+                        active = false;
+                    }
+                } else if (lane == 0) atomicSub(ps.queue_count, (unsigned int)n_live);      // (cannot happen: the queue holds every wave's share)
+            }
         }
         if (!__any(active)) break;
         // ---- one segment of every live path ----

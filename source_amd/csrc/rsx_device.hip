@@ -56,7 +56,7 @@
 #define RSX_MAX_WG_PER_CU 8
 #endif
 #define STAGE_BYTES (WAVE * 52)     // per-wave leaf staging area: 64 x (48-byte triangle record + 4-byte id)
-#define RSX_MAX_LANES 4
+#define RSX_MAX_LANES 8
 #ifndef RSX_RENDER_WG_PER_CU
 #define RSX_RENDER_WG_PER_CU 1
 #endif
@@ -175,6 +175,8 @@ struct TraceLane {
     size_t order_counts_bytes = 0;
     void *ring = nullptr;              // fused passes: FUSE_UNITS x 64 sample records per wave of the grid
     size_t ring_bytes = 0;
+    void *path_queue = nullptr;        // path passes: PathState records handed from the first launch's retiring waves to the drain launch
+    size_t path_queue_bytes = 0;
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
@@ -195,6 +197,7 @@ struct rsx_ctx {
     TraceLane main, lanes[RSX_MAX_LANES];
     int render_wg_override;    // env RSX_RENDER_WG: workgroups per CU of a pipelined pass (tuning aid; 0 = heuristic)
     int pipeline_depth;        // 1 = renders run on the ctx stream only; n = rotate over n private lanes
+    int path_lanes;            // lanes the deferred path passes rotate over (>= pipeline_depth lanes exist then)
     long long max_in_flight;   // render passes the host may run ahead of the device
     bool timing;               // record per-call timing events (rsx_render_history); off removes four timed events per pass
     std::vector<hipEvent_t> gate;   // untimed completion event per recent pass (host run-ahead throttle)
@@ -263,6 +266,10 @@ struct rsx_scene {
 
 extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     if (!out) return rsx_fail(RSX_EINVAL, "rsx_init: null out");
+    // The render lanes are HIP streams that must run side by side; the runtime maps a process's streams onto four hardware queues unless
+    // told otherwise, and two lanes on one queue run one after the other (prism, 512 slices: 3.6 s with four queues, 2.0 s with
+    // twelve). Read when the runtime initialises: a process that has used HIP before this call keeps what it had.
+    setenv("GPU_MAX_HW_QUEUES", "12", 0);
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return rsx_fail(RSX_ENODEV, "no HIP device visible");
     if (device_ordinal < 0 || device_ordinal >= count) return rsx_fail(RSX_ENODEV, "device ordinal %d out of range (0..%d)", device_ordinal, count - 1);
@@ -289,6 +296,12 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         if (ctx->pipeline_depth > RSX_MAX_LANES) ctx->pipeline_depth = RSX_MAX_LANES;
         env = std::getenv("RSX_RENDER_WG");
         ctx->render_wg_override = env ? std::atoi(env) : 0;
+        // path passes whose checks are deferred (the spectral slices of one observe()): each is a bulk of a few milliseconds and a
+        // drain launch of ten and more (a few paths trapped in glass), so many of them are kept in flight — one lane, one stream each
+        env = std::getenv("RSX_PATH_LANES");
+        ctx->path_lanes = env ? std::atoi(env) : 8;
+        if (ctx->path_lanes < 1) ctx->path_lanes = 1;
+        if (ctx->path_lanes > RSX_MAX_LANES) ctx->path_lanes = RSX_MAX_LANES;
         const char *env2 = std::getenv("RSX_MAX_IN_FLIGHT");
         ctx->max_in_flight = env2 ? std::atoll(env2) : 16;
         if (ctx->max_in_flight < 1) ctx->max_in_flight = 1;
@@ -304,8 +317,10 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
     HIP_TRY(hipEventCreate(&ctx->ev2));
     ctx->main.stream = ctx->stream;
     int lane_no = -1;
-    for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
-        if (ln != &ctx->main && ++lane_no >= ctx->pipeline_depth) continue;      // only the lanes the pipeline depth uses get a stream (= an HSA queue)
+    std::vector<TraceLane *> all_lanes{&ctx->main};
+    for (TraceLane &l8 : ctx->lanes) all_lanes.push_back(&l8);
+    for (TraceLane *ln : all_lanes) {
+        if (ln != &ctx->main && ++lane_no >= std::max(ctx->pipeline_depth, ctx->path_lanes)) continue;      // only the lanes in use get a stream (= an HSA queue)
         if (ln != &ctx->main && ctx->pipeline_depth < 2) continue;
         if (ln != &ctx->main) HIP_TRY(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
         HIP_TRY(hipMalloc(&ln->ticket, 9 * 16 * sizeof(unsigned long long)));   // one ticket per XCD list, a cache line apart
@@ -328,9 +343,11 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    for (TraceLane *ln : {&ctx->main, &ctx->lanes[0], &ctx->lanes[1], &ctx->lanes[2], &ctx->lanes[3]}) {
+    std::vector<TraceLane *> all_lanes{&ctx->main};
+    for (TraceLane &l8 : ctx->lanes) all_lanes.push_back(&l8);
+    for (TraceLane *ln : all_lanes) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -1218,8 +1235,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const bool pipelined = (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     // (two lanes for path passes: the path kernel fits two workgroups per CU, and each pass brings a grid of that size — the
     // next slice's workgroups move in as this slice's retire; prism, 32 slices: 3 lanes x 1 workgroup per CU 741 ms, 2 x 2 582 ms)
-    static const int path_lanes = [] { const char *e = std::getenv("RSX_PATH_LANES"); return e ? std::max(1, std::min(RSX_MAX_LANES, std::atoi(e))) : 2; }();
-    TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % std::min(path_lanes, ctx->pipeline_depth)] : pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
+    // (round 3: up to eight lanes — with the trapped paths handed to a small drain launch a pass gives its workgroup places back after
+    // its bulk, and what limits the slices per second is how many passes are in flight; each lane keeps its own sample records and
+    // term blocks, 0.4 KB per path: the lanes in use stay below 48 GB)
+    const size_t lane_bytes = S * (sizeof(Sample) + (size_t)PATH_BLOCK * sizeof(PathTerm) * 5 / 4 + 4) + 1;
+    const int path_lanes = (int)std::max<size_t>(2, std::min<size_t>((size_t)ctx->path_lanes, ((size_t)48 << 30) / lane_bytes));
+    TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % path_lanes] : pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     if ((rc = settle_lane(ctx, lane))) return rc;          // (a deferred pass this lane ran before: its buffers are about to be reused)
 
@@ -1508,26 +1529,49 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             PathStore ps;
             ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
             ps.arena_blocks = (unsigned int)arena_blocks; ps.flags = lane.overflow; ps.arena_next = lane.overflow + 1;
+            // waves that run out of new rays with a few long paths left hand them to a second, small launch (dev_render.hpp, PathState)
+            static const int path_donate = [] { const char *e = std::getenv("RSX_PATH_DONATE"); return e ? std::atoi(e) : 1; }();
+            ps.queue = nullptr; ps.queue_count = lane.overflow + 4; ps.queue_cap = 0; ps.drain = 0;
+            // (passes that overlap others — the slices of one observe(): a pass that runs alone frees its places for nobody, and its last
+            // paths would only move to a smaller grid; RSX_PATH_DONATE=2 hands on in every path pass, 0 in none)
+            if (has_scatter && (path_donate > 1 || (path_donate == 1 && deferred))) {
+                const size_t cap = (size_t)l.grid.x * WG_WAVES * PATH_DONATE_MAX;
+                if ((rc = lane_buffer(lane.path_queue, lane.path_queue_bytes, cap * sizeof(PathState)))) return rc;
+                ps.queue = static_cast<PathState *>(lane.path_queue); ps.queue_cap = (unsigned int)cap;
+            }
+            const dim3 drain_grid(std::min<unsigned>(l.grid.x, 128u));
             auto launch = [&](const void *kernel, dim3 grid) -> int {
                 HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
                 void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&lane.ticket, (void *)&ps};
                 HIP_TRY(hipLaunchKernel(kernel, grid, dim3(WG_THREADS), args, l.lds, lane.stream));
                 return RSX_OK;
             };
+            // a launch and, behind it, the drain launch of the same kernel for the paths it handed on
+            auto launch_drained = [&](const void *kernel, dim3 grid) -> int {
+                int rc2 = launch(kernel, grid);
+                if (rc2 || !ps.queue) return rc2;
+                ps.drain = 1;
+                rc2 = launch(kernel, drain_grid);
+                ps.drain = 0;
+                return rc2;
+            };
 #define PATH_KERNEL(...) reinterpret_cast<const void *>(k_render_trace_path<__VA_ARGS__>)
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
                 HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
                 const bool staged = rp.prims_lds > 0;
-                if ((rc = launch(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
-                                 staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
+                if ((rc = launch_drained(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
+                                         staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
+                PathState *const queue = ps.queue;
+                ps.queue = nullptr;                                            // (the redo pass — usually a handful of paths — keeps them)
                 if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
-            } else if (scene->has_csg) { if ((rc = launch(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
+                ps.queue = queue;
+            } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
-                if ((rc = launch(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false), l.grid))) return rc;
+                if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false), l.grid))) return rc;
             }
-            else if ((rc = launch(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false), l.grid))) return rc;
+            else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false), l.grid))) return rc;
 #undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps

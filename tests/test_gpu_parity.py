@@ -1511,3 +1511,40 @@ def test_passes_per_call_equals_separate_passes(ns):
     cam.render_engine = ns.HipEngine(passes_per_call=4)
     with pytest.raises(Exception, match="passes"):
         cam.observe()
+
+
+def test_handed_on_paths_give_the_same_frames():
+    """Path passes: waves that run out of new rays hand their last paths to a second, small launch (k_render_trace_path, PathState) —
+    by default only in passes that overlap others (the spectral slices of one observe()). Forced on for every path pass
+    (RSX_PATH_DONATE=2), forced off (0) and by default the frames and ray counts must be the same bit for bit: glass with
+    trapped paths over three slices, a diffuse room with CSG and volumes (the two-pass CSG form), the Cornell box."""
+    import subprocess
+    import sys
+    code = """
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, %r)
+from source_amd import api as ns, scenes
+out = []
+for build, camera, kw in ((scenes.build_glass, scenes.glass_camera, dict(pixels=(96, 80), spp=4)),
+                          (scenes.build_lambert, scenes.lambert_camera, dict(pixels=(64, 48), spp=4)),
+                          (scenes.build_cornell, scenes.cornell_camera, dict(pixels=(96, 96), spp=4)),
+                          (scenes.build_prism, scenes.prism_camera, dict(pixels=(96, 64), spp=2, bins=8, spectral_rays=8))):
+    world = build(ns)[0]
+    cam, pipe = camera(ns, world, **kw)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=5)
+    cam.observe(); cam.observe()
+    h = hashlib.sha256()
+    for a in (pipe.frame.mean, pipe.frame.variance, pipe.frame.samples):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert pipe.frame.mean.max() > 0
+    out.append(h.hexdigest() + ":%%d" %% cam.stats["rays"])
+print(" ".join(out))
+""" % ROOT
+    digests = {}
+    for mode in ("0", "1", "2"):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_PATH_DONATE=mode), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, mode + ": " + r.stderr[-2000:]
+        digests[mode] = r.stdout.strip().splitlines()[-1]
+    assert len(set(digests.values())) == 1, digests

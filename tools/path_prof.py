@@ -16,7 +16,7 @@ if cfg == "cornell":
     cam, pipe = scenes.cornell_camera(ns, world, (1024, 1024), 16, 15)
 elif cfg == "prism":
     world = scenes.build_prism(ns)[0]
-    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), 4, 1, 1)
+    cam, pipe = scenes.prism_camera(ns, world, (1024, 1024), int(sys.argv[2]) if len(sys.argv) > 2 else 4, 1, 1)
 elif cfg == "glass":
     world = scenes.build_glass(ns)[0]
     cam, pipe = scenes.glass_camera(ns, world, (1024, 1024), 16, 5, 1, (0.01, 3, 500))
