@@ -616,7 +616,7 @@ def main():
                     "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices, 4),
                     "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract}
         if my_slices > 1:
-            roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on two streams and overlap, so "
+            roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on up to eight streams and overlap, so "
                                           "the sum exceeds ms_per_step" % my_slices)
         if not args.no_pmc and world_size == 1:
             table, note = collect_pmc(args.workload, 3 if SLICES == 1 else 1, args.pmc_keep, PPC)
