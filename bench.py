@@ -45,6 +45,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# librsx's render lanes are HIP streams that must run side by side (rsx_init); torch may initialise HIP before librsx is loaded
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "12")
 
 import numpy as np  # noqa: E402
 
