@@ -1459,7 +1459,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
     // A pipelined (small, tail-bound) pass takes one workgroup per CU and the neighbouring lane's pass fills the idle CUs.
     int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
-    if (deferred) wg_cap = 2;
+    if (deferred) wg_cap = RSX_PATH_MIN_WAVES;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
     rp.world_lds = 0; rp.prims_lds = 0;
@@ -1469,13 +1469,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // at two waves per SIMD — latency, not issue, is their bound, and LDS answers in a fraction of an L2 round trip.
         static const bool stage_world = [] { const char *e = std::getenv("RSX_WORLD_LDS_STAGE"); return !e || std::atoi(e) != 0; }();
         const size_t need = ((size_t)scene->d.n_wnodes * sizeof(rsx_kdnode) + (size_t)scene->d.n_witems * 4 + 15) & ~(size_t)15;
-        if (stage_world && l.lds + need <= 80 * 1024 && need <= 24 * 1024) { rp.world_lds = (int32_t)l.lds; l.lds += need; }
+        if (stage_world && l.lds + need <= (160 / RSX_PATH_MIN_WAVES) * 1024 && need <= 24 * 1024) { rp.world_lds = (int32_t)l.lds; l.lds += need; }
         // ... and, for a scene of a few dozen primitives, the primitive records (376 bytes each) and the flattened CSG programs that
         // the lanes read one by one, a different one in every lane
         static const bool stage_prims = [] { const char *e = std::getenv("RSX_PRIMS_LDS_STAGE"); return !e || std::atoi(e) != 0; }();
         static_assert(sizeof(rsx_primitive) % 8 == 0 && sizeof(CsgFast) % 8 == 0, "staged with 8-byte copies");
         const size_t pneed = (size_t)scene->d.n_prims * (sizeof(rsx_primitive) + (scene->d.csgfast ? sizeof(CsgFast) : 0));
-        if (rp.world_lds > 0 && stage_prims && l.lds + pneed <= 80 * 1024 && pneed <= 24 * 1024) { rp.prims_lds = (int32_t)l.lds; l.lds += pneed; }
+        if (rp.world_lds > 0 && stage_prims && l.lds + pneed <= (160 / RSX_PATH_MIN_WAVES) * 1024 && pneed <= 24 * 1024) { rp.prims_lds = (int32_t)l.lds; l.lds += pneed; }
     }
     HIP_TRY(hipFuncSetAttribute(scene->has_csg ? reinterpret_cast<const void *>(k_render_trace<true>) : reinterpret_cast<const void *>(k_render_trace<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
     if (!lane.ticket_armed && (rc = reset_ticket(lane))) return rc;
