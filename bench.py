@@ -689,7 +689,12 @@ def main():
             if centred:
                 cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
             # ... and on ONE host thread, a sample sized for a few seconds
-            one_rows = int(max(2, min(rect[3] - rect[1], (rate / max(1, nthreads)) * min(4.0, args.cpu_seconds / 3) * 2 // (NX * CAM_SPP))))
+            # (calibrated on its own two-row band: one thread alone runs far faster than one of 256 that share the caches and the memory)
+            cal1 = cam.render_desc(world, None, sl, engine, keep, rect=(0, NY // 2 - 1, NX, NY // 2 + 1))
+            t1 = time.perf_counter()
+            orc.render_pinhole(flat, cal1, threads=1)
+            rate1 = 2 * NX * CAM_SPP / max(time.perf_counter() - t1, 1e-6)
+            one_rows = int(max(2, min(NY, rate1 * min(4.0, args.cpu_seconds / 3) // (NX * CAM_SPP))))
             rect1 = (0, NY // 2 - one_rows // 2, NX, NY // 2 - one_rows // 2 + one_rows)
             desc1 = cam.render_desc(world, None, sl, engine, keep, rect=rect1)
             t1 = time.perf_counter()
