@@ -1190,6 +1190,27 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             if (mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC)
                 return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 is for scenes without path terms (a path pass that runs out of term blocks is rendered again by itself)");
         }
+        // K x spp that does not divide the 64 rays of a unit (or exceeds them) would cut pixels across units and keep the recurrence out of the
+        // packet kernel: such a call is served as several — the largest power-of-two groups that fit, then the rest (24 passes of 1 spp
+        // = 16 + 8) — passes are merged in their order either way
+        if (desc->spp < WAVE && WAVE % desc->spp == 0 && (WAVE % (desc->spp * passes) != 0 || desc->spp * passes > WAVE)) {
+            uint64_t rays = 0;
+            int32_t done = 0;
+            while (done < passes) {
+                int32_t k = 1;
+                while (2 * k <= passes - done && desc->spp * 2 * k <= WAVE) k *= 2;
+                rsx_render_desc part = *desc;
+                part.passes = k;
+                part.sample_offset = desc->sample_offset + (uint64_t)done * (uint64_t)desc->spp;
+                uint64_t count = 0;
+                const int rc_part = render(scene, &part, h_mean, h_var, fmean, fvar, fn, frame_bins, slice_offset, &count, h_xyz, delta_wavelength);
+                if (rc_part) return rc_part;
+                rays += count;
+                done += k;
+            }
+            if (ray_count) *ray_count = rays;
+            return RSX_OK;
+        }
         widened = *desc;
         widened.spp = desc->spp * passes;
         widened.passes = 1;

@@ -1493,7 +1493,7 @@ def test_passes_per_call_equals_separate_passes(ns):
         return world, cam, pipes
 
     for name, make, K, calls in (("c2 1 spp x 16", c2(1), 16, 2), ("c2 1 spp x 3", c2(1), 3, 1), ("c2 4 spp x 5, 3 slices", c2(4, slices=3), 5, 2),
-                                 ("c2 20 spp x 4", c2(20, (33, 21)), 4, 1), ("c3 masked 3 spp x 7", c3_masked, 7, 2), ("csg 2 spp x 8", csg, 8, 1)):
+                                 ("c2 20 spp x 4", c2(20, (33, 21)), 4, 1), ("c2 1 spp x 100 (served as 64 + 32 + 4)", c2(1, (40, 24)), 100, 1), ("c3 masked 3 spp x 7", c3_masked, 7, 2), ("csg 2 spp x 8", csg, 8, 1)):
         uneven = name == "c2 1 spp x 3"
         one, many = frames(make, K, calls, True, uneven), frames(make, K, calls, False, uneven)
         for a, b in zip(one, many):
