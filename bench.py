@@ -12,7 +12,8 @@ PinholeCamera 2048x2048, 64 samples/pixel/pass, 15 spectral bins, primary rays o
 One "step" = one observe() pass over the frame = 268 435 456 primary rays at N = 1: ray generation (Philox jitter) ->
 two-level KD traversal + watertight triangle tests -> shading -> per-pixel/bin Welford over the 64 samples, merged into the
 device-resident spectral frame. Scene, camera tables and the frame are resident in HBM when the timed region starts.
---workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass); --workload c4 = configs[3] (demos/csg.py
+--workload c2 = configs[1] (single 69 432-triangle mesh, 1024x1024, 1 spp/pass), --workload c2k the same with 64 passes per library call
+(HipEngine(passes_per_call=64): a step = one observe() = 64 passes = 67 M rays; --passes-per-call K overrides); --workload c4 = configs[3] (demos/csg.py
 tree, 1024x1024, 16 spp/pass); --workload flat = one 1M-triangle mesh without instancing (geometry far larger than L2);
 --workload c1 = configs[0]'s scene path traced on the device (Cornell box: Lambert walls, glass, importance sampling; 1024x1024,
 16 spp/pass); --workload c5 = configs[4] (demos/prism.py scene, 1024x1024, 512 spectral bins rendered as 512 one-bin slices, 1 spp
