@@ -219,12 +219,12 @@ __device__ void analytic_geom(const rsx_primitive &p, const Ray &l, double t, in
 }
 
 // the `exiting` flag analytic_geom would compute, without the points it does not need (same normal, same dot product)
-__device__ __forceinline__ bool analytic_exiting(const rsx_primitive &p, const Ray &l, double t, int a0, int a1) {
+__device__ __forceinline__ bool analytic_exiting(int32_t type, const Ray &l, double t, int a0, int a1) {
     double nx = 0, ny = 0, nz = 0;
-    if (p.type == RSX_PRIM_SPHERE) {
+    if (type == RSX_PRIM_SPHERE) {
         nx = l.ox + t * l.dx; ny = l.oy + t * l.dy; nz = l.oz + t * l.dz;
         normalise3(nx, ny, nz);
-    } else if (p.type == RSX_PRIM_BOX) {
+    } else if (type == RSX_PRIM_BOX) {
         const double s = a0 == LOWER_FACE ? -1.0 : 1.0;
         if (a1 == 0) nx = s; else if (a1 == 1) ny = s; else if (a1 == 2) nz = s;
     } else if (a1 == T_CYLINDER) {
@@ -233,6 +233,7 @@ __device__ __forceinline__ bool analytic_exiting(const rsx_primitive &p, const R
     } else nz = a0 == LOWER_FACE ? -1.0 : 1.0;
     return (l.dx * nx + l.dy * ny + l.dz * nz) >= 0.0;
 }
+__device__ __forceinline__ bool analytic_exiting(const rsx_primitive &p, const Ray &l, double t, int a0, int a1) { return analytic_exiting(p.type, l, t, a0, a1); }
 
 // MeshData.calc_intersection / _intersection_normal. `t` is the LOCAL distance from l's origin.
 __device__ void mesh_geom(const DMesh &m, const Ray &l, double t, int32_t tri, float u, float v, float w, Geom &g) {

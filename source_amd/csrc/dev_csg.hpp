@@ -356,6 +356,135 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
     return -1;
 }
 
+// csg_fast_hit for a wave whose lanes all ask about the SAME top-level primitive (primary rays: the leaf items of a coherent wave are
+// one primitive at a time, world_trace_wave) — every lane calls it, `want` marks the lanes that ask. The flattened tree, every node's
+// and leaf's box, matrix and parameters come in over the scalar data path (no 376-byte record per lane and operand), the walk over
+// leaves and chains is scalar control flow, and a lane that is done is switched off by a predicate: the function has no exit in the
+// middle of a loop (see the toolchain note at node_contains). Same operations on the same values per lane as csg_fast_hit.
+// Returns per lane 1 = hit (cand filled), 0 = no hit, -1 = use the stream merge; lanes without `want` get 0.
+__device__ __forceinline__ uint32_t csg_truth_uniform(const RSX_CONST_AS CsgFast *P, uint32_t inside_bits) {
+    const uint64_t w0 = P->truth[0], w1 = P->truth[1], w2 = P->truth[2], w3 = P->truth[3];
+    const uint32_t word = inside_bits >> 6;
+    const uint64_t w = word == 0 ? w0 : word == 1 ? w1 : word == 2 ? w2 : w3;
+    return (uint32_t)(w >> (inside_bits & 63u)) & 1u;
+}
+
+__device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, const Ray &r, const Stack &ms, Hit &cand) {
+    const RSX_CONST_AS CsgFast *P = (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast + uidx);
+    const int lane = threadIdx.x % WAVE;
+    double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
+    int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
+    const int n_leaves = P->n_leaves, top_a_leaves = P->top_a_leaves, top_type = P->top_type;
+    Ray l0 = to_local_uniform(uniform_prim(sc.prims_uniform, uidx), r);
+    l0.maxd = INFINITY;
+    int result = 0;
+    bool on = want;                                          // this lane is still being answered
+    uint32_t nroots = 0, lone_exit = 0;
+    const double l0rx = 1.0 / l0.dx, l0ry = 1.0 / l0.dy, l0rz = 1.0 / l0.dz;
+    Ray cur = l0;
+    double crx = l0rx, cry = l0ry, crz = l0rz;
+    bool prefix_alive = true;
+    for (int k = 0; k < n_leaves; ++k) {
+        // CSGPrimitive.hit's early exit (csg.pyx:148-150): operand a of an Intersect / Subtract has no root -> no hit
+        if (k == top_a_leaves && top_type != RSX_PRIM_UNION) { if (on && nroots == 0) { result = 0; on = false; } }
+        const int len = P->chain_len[k];
+        bool sibling = k > 0 && P->chain_len[k > 0 ? k - 1 : 0] == len;
+        for (int j = 0; sibling && j + 1 < len; ++j) sibling = P->chain[k][j] == P->chain[k > 0 ? k - 1 : 0][j];
+        if (!sibling) {
+            cur = l0; crx = l0rx; cry = l0ry; crz = l0rz;
+            prefix_alive = true;
+            for (int j = 0; j + 1 < len; ++j) {              // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
+                const UPrim node = uniform_prim(sc.prims_uniform, P->chain[k][j]);
+                const double lo[3] = {node->box_lower[0], node->box_lower[1], node->box_lower[2]}, hi[3] = {node->box_upper[0], node->box_upper[1], node->box_upper[2]};
+                double f, b;
+                const bool through = aabb_rcp(lo, hi, cur, crx, cry, crz, f, b);
+                // (a lane whose gate failed keeps its ray where it stopped; it is not looked at again before the next reset)
+                const Ray down = to_local_uniform(node, cur);
+                const bool go = prefix_alive && through;
+                cur.ox = go ? down.ox : cur.ox; cur.oy = go ? down.oy : cur.oy; cur.oz = go ? down.oz : cur.oz;
+                cur.dx = go ? down.dx : cur.dx; cur.dy = go ? down.dy : cur.dy; cur.dz = go ? down.dz : cur.dz;
+                crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz;
+                prefix_alive = go;
+            }
+        }
+        const int32_t leaf_id = P->leaf[k];
+        const UPrim leaf = uniform_prim(sc.prims_uniform, leaf_id);
+        bool meets = on && prefix_alive;
+        {
+            const double lo[3] = {leaf->box_lower[0], leaf->box_lower[1], leaf->box_lower[2]}, hi[3] = {leaf->box_upper[0], leaf->box_upper[1], leaf->box_upper[2]};
+            double f, b;
+            meets = aabb_rcp(lo, hi, cur, crx, cry, crz, f, b) && meets;
+        }
+        if (__builtin_amdgcn_ballot_w64(meets) != 0ULL) {
+            const Ray ll = to_local_uniform(leaf, cur);
+            const int32_t type = leaf->type;
+            Roots roots;
+            roots.n = 0;
+            if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(leaf->params[0], ll, roots);
+            else if (type == RSX_PRIM_BOX) {
+                const RSX_CONST_AS double *m = leaf->to_local;
+                const bool identity = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 &&
+                                      m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
+                const double prm[6] = {leaf->params[0], leaf->params[1], leaf->params[2], leaf->params[3], leaf->params[4], leaf->params[5]};
+                box_roots_uniform(prm, ll, identity, crx, cry, crz, roots);
+            } else cylinder_roots(sc.prims[leaf_id], ll, roots);
+            const int n = meets ? roots.n : 0;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                if (j < n) {
+                    const bool exiting = analytic_exiting(type, ll, roots.t[j], roots.a0[j], roots.a1[j]);
+                    // NaN roots, or anything but (enter, exit) / a lone exit of a convex solid: the stream merge answers this lane
+                    if (!(roots.t[j] == roots.t[j]) || exiting != (j == n - 1)) { if (on) result = -1; on = false; }
+                    lds_t[(2 * k + j) * WAVE + lane] = roots.t[j];
+                    lds_m[(2 * k + j) * WAVE + lane] = (roots.a0[j] & 0xff) | ((roots.a1[j] & 0xff) << 8) | ((exiting ? 1 : 0) << 16);
+                }
+            }
+            if (n == 1) lone_exit |= 1u << k;
+            nroots |= (uint32_t)n << (2 * k);
+        }
+    }
+    // "inside the solid" is the tree's truth table looked up with the "inside leaf k" bits (see csg_fast_hit)
+    uint32_t consumed = 0, inside_bits = lone_exit, solid = csg_truth_uniform(P, lone_exit);
+    for (int step = 0; step <= 2 * n_leaves && __builtin_amdgcn_ballot_w64(on) != 0ULL; ++step) {
+        int best = -1;
+        double best_t = INFINITY;
+        for (int k = 0; k < n_leaves; ++k) {
+            const uint32_t c = (consumed >> (2 * k)) & 3u, n = (nroots >> (2 * k)) & 3u;
+            const bool has = on && c < n;
+            const double t = has ? lds_t[(2 * k + (int)c) * WAVE + lane] : 0.0;
+            // exact ties go to the LATER leaf (csg.pyx:231-234), level by level
+            if (has && (best < 0 || t <= best_t)) { best = k; best_t = t; }
+        }
+        if (on && best < 0) { result = 0; on = false; }
+        if (on) {
+            const uint32_t c = (consumed >> (2 * best)) & 3u;
+            consumed += 1u << (2 * best);
+            inside_bits ^= 1u << best;                       // an enter root puts the ray inside the leaf, an exit root outside
+            const uint32_t before = solid;
+            solid = csg_truth_uniform(P, inside_bits);
+            if (solid != before) {                           // a surface of the solid (otherwise csg_valid() rejects it: next root)
+                if (!(best_t <= r.maxd)) result = 0;         // csg_identify: accepted only within the ray's reach
+                else {
+                    const int32_t m = lds_m[(2 * best + (int)c) * WAVE + lane];
+                    int32_t parity_bit = 0, leaf_of_best = 0;
+                    for (int k = 0; k < n_leaves; ++k) if (k == best) { parity_bit = P->parity[k] & 1; leaf_of_best = P->leaf[k]; }
+                    const uint32_t exiting = (uint32_t)(m >> 16) & 1u, parity = (uint32_t)parity_bit;
+                    cand.prim = uidx; cand.t = best_t;
+                    cand.a0 = (int32_t)(int8_t)(m & 0xff); cand.a1 = (int32_t)(int8_t)((m >> 8) & 0xff);
+                    cand.u = cand.v = cand.w = 0.0f;
+                    cand.leaf = leaf_of_best;
+                    cand.flags = F_VALID | ((exiting ^ parity) ? F_EXIT : 0u) | (parity ? F_FLIP : 0u);
+                    cand.hx = cand.hy = cand.hz = 0.0;
+                    result = 1;
+                }
+                on = false;
+            }
+        }
+    }
+    if (on) result = -1;                                     // (more roots than the steps allow: cannot happen; as csg_fast_hit)
+    return result;
+}
+
 // contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
 __device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
     double qx, qy, qz;

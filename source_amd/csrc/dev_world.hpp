@@ -370,7 +370,27 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                 if (gate) { UTIL_COUNT(phase_acc, 6) }
 #endif
                 if (CSG && is_csg(type)) {
-                    if (gate) {
+                    // the state-free evaluator for the whole wave at once, the tree and its operands' records over the scalar data path
+                    // (csg_fast_hit_uniform); a lane it cannot answer goes the way csg_fast_hit's -1 goes
+                    const RSX_CONST_AS CsgFast *flat = sc.csgfast ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast + uidx) : nullptr;
+                    bool answered = false;
+#ifndef RSX_NO_UNIFORM_CSG
+                    if (flat != nullptr && flat->n_leaves > 0 && mesh_stack.lds_levels >= 2 * flat->n_leaves) {
+                        Hit found;
+                        found.prim = -1;
+                        const int fast = csg_fast_hit_uniform(sc, uidx, gate, r, mesh_stack, found);
+                        if (gate && fast == 1) { cand = found; cand.prim = idx; }
+                        if (gate && fast < 0) {
+                            if constexpr (FASTONLY) work |= 0x80000000u;           // top bit of the cost counter: trace this ray again with the stream merge
+                            else {
+                                bool needs_stream = false;
+                                primitive_first_hit<CSG, false>(sc, idx, sc.prims[idx], r, mesh_stack, csg_state, cand, needs_stream);
+                            }
+                        }
+                        answered = true;
+                    }
+#endif
+                    if (!answered && gate) {
                         bool needs_stream = false;
                         primitive_first_hit<CSG, FASTONLY>(sc, idx, sc.prims[idx], r, mesh_stack, csg_state, cand, needs_stream);
                         if (FASTONLY && needs_stream) work |= 0x80000000u;        // top bit of the cost counter: trace this ray again with the stream merge
