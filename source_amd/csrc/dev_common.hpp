@@ -63,6 +63,8 @@ struct CsgFast {
     int32_t chain[CSGF_MAX_LEAVES][CSGF_MAX_CHAIN];   // primitive ids from the top node's operand down to the leaf (inclusive)
     int8_t ops[2 * CSGF_MAX_LEAVES];                  // >= 0: push inside(leaf slot); -1 union, -2 intersect, -3 subtract
     uint64_t truth[4];                                // the program's value for every combination of "inside leaf k" bits (bit = the mask)
+    int8_t guard_lo[CSGF_MAX_LEAVES], guard_hi[CSGF_MAX_LEAVES];   // leaf k lies in operand b of an Intersect / Subtract whose operand a is the leaves
+                                                      // [guard_lo, guard_hi): no root among those and k is not looked at (hi = 0: no such node)
 };
 __device__ __forceinline__ uint32_t csg_truth(const CsgFast &P, uint32_t inside_bits) { return (uint32_t)(P.truth[inside_bits >> 6] >> (inside_bits & 63u)) & 1u; }
 

@@ -300,6 +300,10 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             }
         }
         if (!prefix_alive) continue;
+        if (P.guard_hi[k] > P.guard_lo[k]) {                 // operand a of the node this leaf is (part of) operand b of has no root: not looked at
+            const uint32_t range = ((1u << (2 * P.guard_hi[k])) - 1u) & ~((1u << (2 * P.guard_lo[k])) - 1u);
+            if ((nroots & range) == 0u) continue;
+        }
         const rsx_primitive &leaf = sc.prims[P.leaf[k]];
         {
             double f, b;
@@ -410,6 +414,10 @@ __device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, c
         const int32_t leaf_id = P->leaf[k];
         const UPrim leaf = uniform_prim(sc.prims_uniform, leaf_id);
         bool meets = on && prefix_alive;
+        {
+            const int glo = P->guard_lo[k], ghi = P->guard_hi[k];    // (see csg_fast_hit)
+            if (ghi > glo) meets = meets && (nroots & (((1u << (2 * ghi)) - 1u) & ~((1u << (2 * glo)) - 1u))) != 0u;
+        }
         {
             const double lo[3] = {leaf->box_lower[0], leaf->box_lower[1], leaf->box_lower[2]}, hi[3] = {leaf->box_upper[0], leaf->box_upper[1], leaf->box_upper[2]};
             double f, b;

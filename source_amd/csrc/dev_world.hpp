@@ -175,6 +175,14 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // different round and the wave runs the evaluator once per round for a few lanes each.
     bool prefill = false;
     if constexpr (CSG && FASTONLY && CSG_MAILBOX >= 4 && !UNIFORM_ITEMS) prefill = sc.wide_csg[0] >= 0;
+    // Coherent waves (UNIFORM_ITEMS): the last CSG primitive the wave evaluated and every lane's answer. A CSG solid that sits in several
+    // world leaves is met again leaf after leaf by a ray that went through its box without hitting it (the holes of demos/csg.py's
+    // solids); Primitive.hit(ray) does not depend on the leaf, so the answer is kept instead of found again (kdtree.pyx:105-111 calls
+    // hit() once per leaf item: same ray, same result).
+    int32_t last_csg = -1;                                   // (wave-uniform)
+    double last_t = 0.0;
+    int32_t last_leaf = 0;
+    uint32_t last_meta = 0;                                  // bits 0..7 a0, 8..15 a1, 16..23 flags, 28..29: 0 not asked, 1 hit, 2 no hit, 3 stream merge
     int32_t node = 0, sp = 0;
     while (__any(active)) {
         double distance = 0;
@@ -376,11 +384,27 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                     bool answered = false;
 #ifndef RSX_NO_UNIFORM_CSG
                     if (flat != nullptr && flat->n_leaves > 0 && mesh_stack.lds_levels >= 2 * flat->n_leaves) {
-                        Hit found;
-                        found.prim = -1;
-                        const int fast = csg_fast_hit_uniform(sc, uidx, gate, r, mesh_stack, found);
-                        if (gate && fast == 1) { cand = found; cand.prim = idx; }
-                        if (gate && fast < 0) {
+                        if (uidx != last_csg) { last_csg = uidx; last_meta = 0; }
+                        const bool ask = gate && (last_meta >> 28) == 0u;
+                        if (__any(ask)) {
+                            Hit found;
+                            found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;
+                            const int fast = csg_fast_hit_uniform(sc, uidx, ask, r, mesh_stack, found);
+                            if (ask) {
+                                last_t = found.t; last_leaf = found.leaf;
+                                last_meta = ((uint32_t)found.a0 & 0xffu) | (((uint32_t)found.a1 & 0xffu) << 8) | ((found.flags & 0xffu) << 16) |
+                                            ((fast == 1 ? 1u : fast == 0 ? 2u : 3u) << 28);
+                            }
+                        }
+                        const uint32_t state = last_meta >> 28;
+                        if (gate && state == 1u) {
+                            cand.prim = idx; cand.t = last_t;
+                            cand.a0 = (int32_t)(int8_t)(last_meta & 0xffu); cand.a1 = (int32_t)(int8_t)((last_meta >> 8) & 0xffu);
+                            cand.u = cand.v = cand.w = 0.0f;
+                            cand.leaf = last_leaf; cand.flags = (last_meta >> 16) & 0xffu;
+                            cand.hx = cand.hy = cand.hz = 0.0;
+                        }
+                        if (gate && state == 3u) {
                             if constexpr (FASTONLY) work |= 0x80000000u;           // top bit of the cost counter: trace this ray again with the stream merge
                             else {
                                 bool needs_stream = false;

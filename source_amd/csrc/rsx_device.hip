@@ -654,9 +654,15 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                         f.ops[f.n_ops++] = (int8_t)k;
                     }
                 } else {
+                    const int a_lo = f.n_leaves;
                     visit(q.child_a, parity);
+                    const int a_hi = f.n_leaves;
                     visit(q.child_b, parity + (q.type == RSX_PRIM_SUBTRACT ? 1 : 0));
                     if (ok) f.ops[f.n_ops++] = q.type == RSX_PRIM_UNION ? (int8_t)-1 : q.type == RSX_PRIM_INTERSECT ? (int8_t)-2 : (int8_t)-3;
+                    // CSGPrimitive.hit at EVERY node (csg.pyx:146-150): operand a of an Intersect / Subtract without a hit -> no hit, operand b
+                    // is not looked at. The leaves of b remember a's leaf range (the innermost such node's)
+                    if (ok && q.type != RSX_PRIM_UNION)
+                        for (int k = a_hi; k < f.n_leaves; ++k) if (f.guard_hi[k] == 0) { f.guard_lo[k] = (int8_t)a_lo; f.guard_hi[k] = (int8_t)a_hi; }
                 }
                 if (i != top) chain.pop_back();
             };
