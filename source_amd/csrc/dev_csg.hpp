@@ -373,13 +373,15 @@ __device__ __forceinline__ uint32_t csg_truth_uniform(const RSX_CONST_AS CsgFast
     return (uint32_t)(w >> (inside_bits & 63u)) & 1u;
 }
 
-__device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, const Ray &r, const Stack &ms, Hit &cand) {
-    const RSX_CONST_AS CsgFast *P = (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast + uidx);
+// (the scene's tables are passed one by one: the packet walk holds the scene behind a kernel-argument pointer, the per-lane walks by value)
+__device__ int csg_fast_hit_uniform(const CsgFast *csgfast, const rsx_primitive *prims_uniform, const rsx_primitive *prims, int32_t uidx, bool want, const Ray &r,
+                                    const Stack &ms, Hit &cand) {
+    const RSX_CONST_AS CsgFast *P = (const RSX_CONST_AS CsgFast *)(unsigned long long)(csgfast + uidx);
     const int lane = threadIdx.x % WAVE;
     double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
     int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
     const int n_leaves = P->n_leaves, top_a_leaves = P->top_a_leaves, top_type = P->top_type;
-    Ray l0 = to_local_uniform(uniform_prim(sc.prims_uniform, uidx), r);
+    Ray l0 = to_local_uniform(uniform_prim(prims_uniform, uidx), r);
     l0.maxd = INFINITY;
     int result = 0;
     bool on = want;                                          // this lane is still being answered
@@ -398,7 +400,7 @@ __device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, c
             cur = l0; crx = l0rx; cry = l0ry; crz = l0rz;
             prefix_alive = true;
             for (int j = 0; j + 1 < len; ++j) {              // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
-                const UPrim node = uniform_prim(sc.prims_uniform, P->chain[k][j]);
+                const UPrim node = uniform_prim(prims_uniform, P->chain[k][j]);
                 const double lo[3] = {node->box_lower[0], node->box_lower[1], node->box_lower[2]}, hi[3] = {node->box_upper[0], node->box_upper[1], node->box_upper[2]};
                 double f, b;
                 const bool through = aabb_rcp(lo, hi, cur, crx, cry, crz, f, b);
@@ -412,7 +414,7 @@ __device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, c
             }
         }
         const int32_t leaf_id = P->leaf[k];
-        const UPrim leaf = uniform_prim(sc.prims_uniform, leaf_id);
+        const UPrim leaf = uniform_prim(prims_uniform, leaf_id);
         bool meets = on && prefix_alive;
         {
             const int glo = P->guard_lo[k], ghi = P->guard_hi[k];    // (see csg_fast_hit)
@@ -435,7 +437,7 @@ __device__ int csg_fast_hit_uniform(const DScene &sc, int32_t uidx, bool want, c
                                       m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
                 const double prm[6] = {leaf->params[0], leaf->params[1], leaf->params[2], leaf->params[3], leaf->params[4], leaf->params[5]};
                 box_roots_uniform(prm, ll, identity, crx, cry, crz, roots);
-            } else cylinder_roots(sc.prims[leaf_id], ll, roots);
+            } else cylinder_roots(prims[leaf_id], ll, roots);
             const int n = meets ? roots.n : 0;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {

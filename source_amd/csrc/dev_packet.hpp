@@ -75,16 +75,21 @@ __device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t 
 
 __host__ __device__ __forceinline__ int packet_world_levels(int wdepth) { return wdepth < PKT_WORLD_LDS_LEVELS ? wdepth : PKT_WORLD_LDS_LEVELS; }
 __host__ __device__ __forceinline__ int packet_mesh_levels(int mdepth) { return mdepth < PKT_MESH_LDS_LEVELS ? mdepth : PKT_MESH_LDS_LEVELS; }
-__host__ __device__ __forceinline__ size_t packet_lds_bytes(int wdepth, int mdepth) {       // per wave
+// csg_rows > 0 (scenes with CSG solids in the state-free evaluator's form): that many rows of (f64 root, i32 face / axis / exit) per lane
+// behind the stacks — where csg_fast_hit_uniform leaves the operands' roots (two per leaf of the biggest tree)
+__host__ __device__ __forceinline__ size_t packet_stack_bytes(int wdepth, int mdepth) {
     const size_t levels = (size_t)(packet_world_levels(wdepth) + packet_mesh_levels(mdepth));
     return (levels * WAVE * 8 + (size_t)(wdepth + mdepth) * 4 + 15) & ~(size_t)15;
+}
+__host__ __device__ __forceinline__ size_t packet_lds_bytes(int wdepth, int mdepth, int csg_rows = 0) {       // per wave
+    return packet_stack_bytes(wdepth, mdepth) + (size_t)csg_rows * WAVE * 12;
 }
 // carve the wave's LDS region and global spill region into the packet's world stack and mesh stack (the spill region is the one plan()
 // sized for the per-lane stacks: the packet keeps at least as many levels in LDS, so it needs no more)
 __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, Stack &ms) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int pw = packet_world_levels(sc.wdepth), pm = packet_mesh_levels(sc.mdepth);
-    const uint32_t base = (uint32_t)wave * (uint32_t)packet_lds_bytes(sc.wdepth, sc.mdepth);
+    const uint32_t base = (uint32_t)wave * (uint32_t)packet_lds_bytes(sc.wdepth, sc.mdepth, sc.csg_fast_rows);
     const int spill_levels = (sc.wdepth - pw) + (sc.mdepth - pm);
     const int plan_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
     const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
@@ -420,8 +425,25 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
 
 // World.hit for the packet (kdtree.pyx:73-122, boundprimitive.pyx:42-51): world_trace_wave<false, false, 1, true> with the walk above.
 // Leaf items are wave-uniform by construction (the wave is in ONE leaf); wide primitives, leaf tags and the cull as there.
-__device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work PKT_ARG) {
+// CSG: the scene has CSG solids (k_render_trace<true, 1, ..., PACKET>): a solid in the state-free evaluator's form is answered for the whole
+// wave by csg_fast_hit_uniform; a lane it cannot answer — or any lane that meets a solid without that form — raises `needs_merge` and is
+// traced again by the redo pass, as in the per-lane kernel.
+template <bool CSG = false>
+__device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work,
+                                                   bool &needs_merge PKT_ARG) {
     best.prim = -1;
+    needs_merge = false;
+    // the evaluator's rows lie behind the wave's stacks (packet_lds_bytes); the last solid evaluated and every lane's answer are kept
+    // across leaves (see world_trace_wave)
+    Stack ev;
+    ev.stage = nullptr; ev.gt = nullptr; ev.gid = nullptr;
+    ev.lds_levels = CSG ? sc->csg_fast_rows : 0;
+    ev.lds_t = (uint32_t)(((st.lds_id + (uint32_t)(sc->wdepth + sc->mdepth) * 4u) + 15u) & ~15u);
+    ev.lds_id = ev.lds_t + (uint32_t)ev.lds_levels * WAVE * 8u;
+    int32_t last_csg = -1;
+    double last_t = 0.0;
+    int32_t last_leaf = 0;
+    uint32_t last_meta = 0;
     double tmin = 0, tmax = 0;
     // 1.0 / d per axis (BoundingBox3D.intersect, boundingbox.pyx:180-245) and the branch steps' quotients both come from the refined
     // reciprocals: exact_div(1, d) and exact_div(split - o, d) are the correctly rounded quotients (dev_common.hpp)
@@ -524,6 +546,37 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                             if (mesh_trace_packet(sc, idx, gate, um, l, mesh_stack, mh, work PKT_PASS)) {
                                 cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                             }
+                        }
+                    } else if (CSG && is_csg(type)) {
+                        const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+                        double f, b;
+                        const bool gate = in && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                        if (pkt_any(gate)) {
+                            const CsgFast *table = sc->csgfast;
+                            const RSX_CONST_AS CsgFast *flat = table ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(table + idx) : nullptr;
+                            if (flat != nullptr && flat->n_leaves > 0 && ev.lds_levels >= 2 * flat->n_leaves) {
+                                if (idx != last_csg) { last_csg = idx; last_meta = 0; }
+                                const bool ask = gate && (last_meta >> 28) == 0u;
+                                if (pkt_any(ask)) {
+                                    Hit found;
+                                    found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;
+                                    const int fast = csg_fast_hit_uniform(table, sc->prims_uniform, sc->prims, idx, ask, r, ev, found);
+                                    if (ask) {
+                                        last_t = found.t; last_leaf = found.leaf;
+                                        last_meta = ((uint32_t)found.a0 & 0xffu) | (((uint32_t)found.a1 & 0xffu) << 8) | ((found.flags & 0xffu) << 16) |
+                                                    ((fast == 1 ? 1u : fast == 0 ? 2u : 3u) << 28);
+                                    }
+                                }
+                                const uint32_t state = last_meta >> 28;
+                                if (gate && state == 1u) {
+                                    cand.prim = idx; cand.t = last_t;
+                                    cand.a0 = (int32_t)(int8_t)(last_meta & 0xffu); cand.a1 = (int32_t)(int8_t)((last_meta >> 8) & 0xffu);
+                                    cand.u = cand.v = cand.w = 0.0f;
+                                    cand.leaf = last_leaf; cand.flags = (last_meta >> 16) & 0xffu;
+                                    cand.hx = cand.hy = cand.hz = 0.0;
+                                }
+                                if (gate && state == 3u) needs_merge = true;
+                            } else if (gate) needs_merge = true;               // a solid the evaluator does not serve: the redo pass
                         }
                     } else {                                                   // sphere / box / cylinder: Primitive.hit, first root
                         double t;

@@ -357,7 +357,7 @@ __device__ __attribute__((noinline)) void fused_flush_call(unsigned long long rp
 
 // PACKET: the unit's rays walk the trees together (dev_packet.hpp) — passes whose units hold a few pixels' samples.
 template <bool CSG, int MODE = 0, int STAGE_MIN = RSX_STAGE_MIN, int FUSED = 0, bool PACKET = false>     // FUSED: 0 no, 1 yes, 2 yes with several passes per call (packet kernel)
-__global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
+__global__ __launch_bounds__(WG_THREADS, !CSG ? (PACKET ? RSX_PACKET_MIN_WAVES : RSX_MIN_WAVES_PER_SIMD) : MODE == 1 ? (PACKET ? RSX_PACKET_CSG_MIN_WAVES : RSX_CSGFAST_MIN_WAVES) : RSX_CSG_MIN_WAVES)
 void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long long *ticket, FuseParams fz) {
     Stack st, ms;
     if constexpr (PACKET) wave_stacks_packet(sc, st, ms); else wave_stacks(sc, st, ms);
@@ -444,7 +444,8 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         phase_acc[0] = ph2_w0 - ph2_u0;
 #endif
         bool got;
-        if constexpr (PACKET) { static_assert(!CSG, "the packet walk serves the plain primary-ray kernel");
+        bool packet_redo = false;                                          // PACKET, CSG: this lane met a solid the state-free evaluator could not answer
+        if constexpr (PACKET) { static_assert(!CSG || MODE == 1, "CSG scenes: the packet walk is the fast pass; the redo pass walks per lane");
             unsigned long long sc_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();       // (`sc` is the first kernel argument)
             asm volatile("" : "+s"(sc_bits));
             const PScene scq = (PScene)sc_bits; 
@@ -452,12 +453,12 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             uint32_t pkc[PKC_N];
             for (int c = 0; c < PKC_N; ++c) pkc[c] = 0;
             pkc[PKC_UNITS] = 1;
-            got = world_trace_packet(valid, scq, r, st, ms, hit, work, pkc);
+            got = world_trace_packet<CSG>(valid, scq, r, st, ms, hit, work, packet_redo, pkc);
             if (lane == 0) for (int c = 0; c < PKC_N; ++c) atomicAdd(&g_pkt[c], (unsigned long long)pkc[c]);
 #elif defined(PKT_ABLATE_TRACE)
             got = false; hit.prim = -1;                                    // (timing ablation: ray generation and the record store alone)
 #else
-            got = world_trace_packet(valid, scq, r, st, ms, hit, work);
+            got = world_trace_packet<CSG>(valid, scq, r, st, ms, hit, work, packet_redo);
 #endif
         }
         else got = world_trace_wave<CSG, MODE == 1, STAGE_MIN, true>(valid, sc, r, st, ms, csg_state, hit, work, phase_acc);
@@ -474,7 +475,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         asm volatile("" : "+s"(unit));
         asm volatile("" : "+s"(rp_bits));
         const RSX_CONST_AS RenderParams *q2 = (const RSX_CONST_AS RenderParams *)rp_bits;
-        const bool redo = MODE == 1 && (work >> 31) != 0;
+        const bool redo = MODE == 1 && ((work >> 31) != 0 || packet_redo);
         work &= 0x7fffffffu;
         if (q2->measure_cost && MODE != 2 && lane == 0) {
             unsigned long long c = (unsigned long long)work;

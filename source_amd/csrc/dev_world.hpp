@@ -389,7 +389,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
                         if (__any(ask)) {
                             Hit found;
                             found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;
-                            const int fast = csg_fast_hit_uniform(sc, uidx, ask, r, mesh_stack, found);
+                            const int fast = csg_fast_hit_uniform(sc.csgfast, sc.prims_uniform, sc.prims, uidx, ask, r, mesh_stack, found);
                             if (ask) {
                                 last_t = found.t; last_leaf = found.leaf;
                                 last_meta = ((uint32_t)found.a0 & 0xffu) | (((uint32_t)found.a1 & 0xffu) << 8) | ((found.flags & 0xffu) << 16) |

@@ -74,6 +74,9 @@
 #ifndef RSX_PACKET_MIN_WAVES
 #define RSX_PACKET_MIN_WAVES 4      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace (128 registers)
 #endif
+#ifndef RSX_PACKET_CSG_MIN_WAVES
+#define RSX_PACKET_CSG_MIN_WAVES 2  // ... and of its CSG form (the state-free evaluator's registers)
+#endif
 #ifndef RSX_PACKET_MIN_SPP
 #define RSX_PACKET_MIN_SPP 16       // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp): a 64-ray
                                     // unit then holds at most four pixels. Measured on the configs[2] scene at 1024 x 1024 (trace kernel,
@@ -861,7 +864,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
     }
     UP(upload(sc, meshes.data(), meshes.size(), &d.meshes));
     d.rel = nullptr; d.rel_info = nullptr;
-    d.wsplits_bounded = splits_summary(desc->world_kd); d.pad_w = 0;
+    d.wsplits_bounded = splits_summary(desc->world_kd); d.csg_fast_rows = any_fast ? fast_levels : 0;
     for (int32_t i = 0; i < desc->n_world; ++i) {
         const rsx_primitive &p = desc->primitives[i];
         if (p.type != RSX_PRIM_MESH) continue;
@@ -1362,9 +1365,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
     // (a task list — FullFrameSampler2D shuffles its pixels, an adaptive sampler picks them — puts unrelated pixels side by side: there a
     // unit must be ONE pixel's samples for its rays to share their way through the trees)
-    const bool use_packet = !has_vol && !scene->has_csg && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
+    // (CSG scenes: the fast pass of the two — state-free evaluator — may be the packet kernel; RSX_PACKET_CSG=0 keeps the per-lane one)
+    static const bool packet_csg = [] { const char *e = std::getenv("RSX_PACKET_CSG"); return !e || std::atoi(e) != 0; }();
+    const bool use_packet = !has_vol && (!scene->has_csg || (two_pass_csg && packet_csg && !h_xyz)) && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
                             !ctx->unit_times;
-    const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
+    const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth, scene->d.csg_fast_rows) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
     const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
     // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
     // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
@@ -1510,7 +1515,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     std::memset(&fz, 0, sizeof(fz));
     // the packet kernel's grid: its stacks are smaller (one range per lane and level, no leaf staging), four waves per SIMD fit the
     // LDS — and the registers
-    const size_t plds = (size_t)WG_WAVES * packet_lds_bytes(scene->d.wdepth, scene->d.mdepth);
+    const size_t plds = (size_t)WG_WAVES * packet_lds_bytes(scene->d.wdepth, scene->d.mdepth, scene->d.csg_fast_rows);
     dim3 pgrid = l.grid;
     if (use_packet && !pipelined) {
         const long long per_cu = std::min<long long>(RSX_MAX_WG_PER_CU, (long long)((160 * 1024) / std::max<size_t>(plds, 1)));
@@ -1623,6 +1628,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+        if (use_packet) {
+            if ((rc = ensure_camera_relative(scene, desc->camera, lane.stream))) return rc;
+            const void *kernel = reinterpret_cast<const void *>(k_render_trace<true, 1, 1, 0, true>);
+            HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plds));
+            Sample *records = static_cast<Sample *>(lane.samples);
+            void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&records, (void *)&lane.ticket, (void *)&fz};
+            HIP_TRY(hipLaunchKernel(kernel, pgrid, dim3(WG_THREADS), args, plds, lane.stream));
+        } else
         hipLaunchKernelGGL((k_render_trace<true, 1>), l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
         hipLaunchKernelGGL((k_render_trace<true, 2>), dim3((unsigned)ctx->n_cus), dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);
     } else if (scene->has_csg) hipLaunchKernelGGL(k_render_trace<true>, l.grid, dim3(WG_THREADS), l.lds, lane.stream, scene->d, rp, static_cast<Sample *>(lane.samples), lane.ticket, fz);

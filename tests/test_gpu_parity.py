@@ -1418,10 +1418,14 @@ import numpy as np
 sys.path.insert(0, %r)
 from source_amd import api as ns, scenes
 world = scenes.build_c3(ns, n=24)[0]
+solids = scenes.build_csg_demo(ns)[0]                    # (CSG scenes: the packet kernel is the fast pass, the redo pass walks per lane)
 out = []
-for (nx, ny, spp) in ((72, 44, 2), (50, 61, 3), (64, 40, 5), (33, 47, 12), (40, 24, 16), (24, 24, 64)):
+for (nx, ny, spp) in ((72, 44, 2), (50, 61, 3), (64, 40, 5), (33, 47, 12), (40, 24, 16), (24, 24, 64), (-56, 40, 4), (-40, 33, 16), (-24, 24, 64)):
     pipe = ns.SpectralRadiancePipeline2D()
-    cam, _ = scenes.c3_camera(ns, world, (nx, ny), spp=spp, bins=5)
+    if nx < 0:
+        cam, _ = scenes.csg_camera(ns, solids, (-nx, ny), spp=spp, bins=5)
+    else:
+        cam, _ = scenes.c3_camera(ns, world, (nx, ny), spp=spp, bins=5)
     cam.pipelines = [pipe]
     cam.frame_sampler = ns.RectFrameSampler2D()
     cam.render_engine = ns.HipEngine(rng="philox", seed=3)
