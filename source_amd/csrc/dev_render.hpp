@@ -831,7 +831,9 @@ struct PathState {
 // STAGED: the primitive records and CSG programs are read from an LDS copy (scenes of a few dozen primitives; see render()). A
 // template parameter, not a run-time choice: a pointer that may be either makes every record access of a big scene a flat load
 // (prism-sized scene unstaged 35 -> 38 ms, Cornell box 42.5 -> 44.5 ms).
-template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false>
+// QUEUE: the instantiation can hand paths on and drain them (PathStore::queue / drain) — the forms the overlapping slices of an observe() run;
+// compiled into every form the hand-over cost a pass that never uses it 3 % (Cornell box 41.1 -> 42.7 ms: six more spilled registers).
+template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false>
 __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     DScene sc = sc_arg;
     if (STAGED || rp.world_lds > 0) {                      // stage the world tree behind the traversal stacks (see render(); STAGED implies it)
@@ -914,7 +916,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     for (;;) {
         // ---- refill idle lanes ----
         unsigned long long idle = __ballot(!active);
-        if (__builtin_expect(ps.drain != 0, 0)) {
+        if (QUEUE && __builtin_expect(ps.drain != 0, 0)) {
             // second launch of a pass: the paths the first launch's retiring waves handed on, packed 64 to a wave again
             while (idle && !exhausted) {
                 const int n_idle = __popcll(idle);
@@ -983,7 +985,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         // paths on and retires; a second, small launch (ps.drain) walks the handed-on paths of all waves, packed 64 to a wave, while the
         // places this launch gave back take the next pass's workgroups. Which wave walks a path never shows in the result (random
         // numbers, sample record and term list are keyed by pixel and sample).
-        if (__builtin_expect(exhausted && ps.queue != nullptr && !ps.drain, 0)) {
+        if (QUEUE && __builtin_expect(exhausted && ps.queue != nullptr && !ps.drain, 0)) {
             const unsigned long long live = __ballot(active);
             const int n_live = __popcll(live);
             if (n_live > 0 && n_live <= PATH_DONATE_MAX) {

@@ -1579,11 +1579,20 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 return RSX_OK;
             };
             // a launch and, behind it, the drain launch of the same kernel for the paths it handed on
-            auto launch_drained = [&](const void *kernel, dim3 grid) -> int {
-                int rc2 = launch(kernel, grid);
-                if (rc2 || !ps.queue) return rc2;
+            // (`with_queue`: the kernel's QUEUE instantiation, or null — only the forms of small scenes, staged in LDS, have one; any other
+            // form runs without the hand-over)
+            auto launch_drained = [&](const void *kernel, const void *with_queue, dim3 grid) -> int {
+                PathState *const queue = ps.queue;
+                if (!queue || !with_queue) {
+                    ps.queue = nullptr;
+                    const int rc1 = launch(kernel, grid);
+                    ps.queue = queue;
+                    return rc1;
+                }
+                int rc2 = launch(with_queue, grid);
+                if (rc2) return rc2;
                 ps.drain = 1;
-                rc2 = launch(kernel, drain_grid);
+                rc2 = launch(with_queue, drain_grid);
                 ps.drain = 0;
                 return rc2;
             };
@@ -1593,17 +1602,20 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
                 const bool staged = rp.prims_lds > 0;
                 if ((rc = launch_drained(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
-                                         staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true), l.grid))) return rc;
+                                         staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true),
+                                         !staged || rewalk ? nullptr : !vols ? PATH_KERNEL(true, 1, false, false, true, true) : PATH_KERNEL(true, 1, true, false, true, true), l.grid))) return rc;
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
                 PathState *const queue = ps.queue;
                 ps.queue = nullptr;                                            // (the redo pass — usually a handful of paths — keeps them)
                 if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
                 ps.queue = queue;
-            } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), l.grid))) return rc; }
+            } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), nullptr, l.grid))) return rc; }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
-                if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false), l.grid))) return rc;
+                if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false),
+                                         rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true, true) : nullptr, l.grid))) return rc;
             }
-            else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false), l.grid))) return rc;
+            else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false),
+                                          !rewalk && rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true, true) : nullptr, l.grid))) return rc;
 #undef PATH_KERNEL
             HIP_TRY(hipGetLastError());
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
