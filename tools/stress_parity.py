@@ -56,6 +56,8 @@ bad += run("glass", world, cam, pipe, tol=1e-12)
 world, _ = scenes.build_csg_demo(ns)
 cam, pipe = scenes.csg_camera(ns, world, (512 * K, 512 * K), spp=8, bins=5)
 bad += run("csg", world, cam, pipe)
+cam, pipe = scenes.csg_camera(ns, world, (384 * K, 384 * K), spp=16, bins=5)     # (16 spp and more: the packet walk is the fast pass)
+bad += run("csg 16spp", world, cam, pipe)
 # primary-ray mesh scenes through the render kernels (coherent-pass instantiation at 16 spp, 1-spp instantiation), whole frames
 world = scenes.build_c3(ns, n=132)[0]
 cam, pipe = scenes.c3_camera(ns, world, (256 * K, 256 * K), spp=16, bins=3)
