@@ -1624,17 +1624,20 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
             Sample cur = s[chunk0], nxt = cur;
             long long blk = ap.tail[rec_base + chunk0], nblk = blk;
             if (cn > 1) { nxt = s[chunk0 + 1]; nblk = ap.tail[rec_base + chunk0 + 1]; }
-            int j = cur.pad - 1, first = blk < ap.n_records ? 0 : 1;
+            // (the walk keeps a pointer to the term it is at and one to where the block's terms end — slot 0 of an arena block is its link —
+            // instead of forming pool + 24 (16 block + slot) at every step)
+            int first = blk < ap.n_records ? 0 : 1;
+            const PathTerm *tp = ap.pool + blk * PATH_BLOCK + (cur.pad - 1), *floor = ap.pool + blk * PATH_BLOCK + (first - 1);
             double x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
             bool live = true;
             while (live) {
-                if (j >= first) {
-                    x = apply_term(x, ap.pool[blk * PATH_BLOCK + j]);          // (term j - 1 requested before term j is applied: 5.2 -> 5.5 ms)
-                    --j;
+                if (tp > floor) {
+                    x = apply_term(x, *tp);                                    // (term j - 1 requested before term j is applied: 5.2 -> 5.5 ms)
+                    --tp;
                 } else if (first == 1) {                                       // an arena block: slot 0 links to the block before it
-                    blk = ap.pool[blk * PATH_BLOCK].table;
-                    j = PATH_BLOCK - 1;
+                    blk = floor->table;
                     first = blk < ap.n_records ? 0 : 1;
+                    tp = ap.pool + blk * PATH_BLOCK + (PATH_BLOCK - 1); floor = ap.pool + blk * PATH_BLOCK + (first - 1);
                 } else {                                                       // this sample's list is done
                     x = x * cur.weight;
                     if (ap.power) x = x * ap.sensitivity;
@@ -1642,7 +1645,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                     ++si;
                     if (si < cn) {
                         cur = nxt; blk = nblk;
-                        j = cur.pad - 1; first = blk < ap.n_records ? 0 : 1;
+                        first = blk < ap.n_records ? 0 : 1;
+                        tp = ap.pool + blk * PATH_BLOCK + (cur.pad - 1); floor = ap.pool + blk * PATH_BLOCK + (first - 1);
                         x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
                         if (si + 1 < cn) { nxt = s[chunk0 + si + 1]; nblk = ap.tail[rec_base + chunk0 + si + 1]; }
                     } else live = false;
