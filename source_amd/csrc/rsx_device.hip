@@ -78,8 +78,8 @@
 #define RSX_PACKET_CSG_MIN_WAVES 2  // ... and of its CSG form (the state-free evaluator's registers)
 #endif
 #ifndef RSX_PACKET_MIN_SPP
-#define RSX_PACKET_MIN_SPP 16       // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp): a 64-ray
-                                    // unit then holds at most four pixels. Measured on the configs[2] scene at 1024 x 1024 (trace kernel,
+#define RSX_PACKET_MIN_SPP 8        // passes with at least this many samples per pixel walk the trees as packets (dev_packet.hpp): a 64-ray
+                                    // unit then holds at most eight pixels (scenes of a few primitives: from 4, CSG scenes: always — render()). Measured on the configs[2] scene at 1024 x 1024 (trace kernel,
                                     // per-lane walk -> packet walk): 64 spp 8.2 -> 5.6 ms per 2^24 rays, 32 spp 7.2 -> 6.5, 16 spp 9.9 -> 8.8,
                                     // 8 spp 6.0 -> 5.9, 4 spp 3.2 -> 3.6, 2 spp 1.8 -> 2.4, 1 spp (8 x 8 pixel tiles) 0.85 -> 1.20: the union of
                                     // the nodes 16 or more different pixels visit outgrows what the shared walk saves. $RSX_PACKET_MIN_SPP.
@@ -1360,7 +1360,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // — round 2, per-lane walk: measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. That
     // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
     // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
-    static const int packet_min_spp = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : RSX_PACKET_MIN_SPP; }();   // 0: never
+    // From how many samples per pixel on the packet walk wins depends on the scene (tools/spp_sweep.py, 1024^2 frames): the instanced
+    // configs[2] scene from 16 (equal at 8: a unit of eight pixels straddles world leaves and instances), a single mesh (configs[1])
+    // from 4 (+21 % there, +22 % at 8, 2.2x at 32), the CSG demo at every count. RSX_PACKET_MIN_SPP pins it (0: never).
+    static const int packet_min_env = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : -1; }();
+    const int packet_min_spp = packet_min_env >= 0 ? packet_min_env : scene->has_csg ? 1 : scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP;
     static const int fuse_env = [] { const char *e = std::getenv("RSX_FUSE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
     // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
     // (a task list — FullFrameSampler2D shuffles its pixels, an adaptive sampler picks them — puts unrelated pixels side by side: there a
