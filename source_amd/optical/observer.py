@@ -848,6 +848,28 @@ class PinholeCamera(Observer2D):
             return [dict(rect=(xa, y0, min(xa + band, x1), y1)) for xa in range(x0, x1, band)]
         return [dict(tasks=tasks[a:a + per_call]) for a in range(0, len(tasks), per_call)]
 
+    def _coherent_tasks(self, tasks):
+        """Philox samples are keyed by (pixel, sample), so the order in which a pass visits its pixels never shows in the frames: a task
+        list — FullFrameSampler2D shuffles its pixels like the reference's (sampler2d.pyx:42-102), an adaptive sampler picks them — is
+        rendered as a rectangle when it is one (every pixel of its bounding box, once), else in 8 x 8 tile order, so that the 64 rays of
+        a unit lie side by side instead of all over the frame. (The MT stream of rng="stream" is consumed in task order: untouched.)
+        One conversion per observe(): the spectral slices of a pass share the list."""
+        cached = getattr(self, "_coherent_cache", None)
+        if cached is not None and cached[0] is tasks:
+            return cached[1]
+        t = np.asarray(tasks, dtype=np.int64).reshape(-1, 2)
+        out = tasks
+        if len(t):
+            x0, y0 = (int(v) for v in t.min(axis=0))
+            x1, y1 = (int(v) + 1 for v in t.max(axis=0))
+            if len(t) == (x1 - x0) * (y1 - y0) and len(np.unique(t[:, 0] * (y1 + 1) + t[:, 1])) == len(t):
+                out = RectTasks(x0, y0, x1, y1)
+            else:
+                order = np.lexsort((t[:, 0] & 7, t[:, 1] & 7, t[:, 0] >> 3, t[:, 1] >> 3))
+                out = np.ascontiguousarray(t[order].astype(np.int32))
+        self._coherent_cache = (tasks, out)
+        return out
+
     def _render_slice_device(self, tasks, slice_id, template, engine, update, update_args, update_kwargs):
         world = self.root
         if self._needs_host_materials(world, engine):
@@ -862,6 +884,8 @@ class PinholeCamera(Observer2D):
         L = _lib.lib()
         rays = C.c_uint64(0)
         offset = getattr(self, "_pass_offset", None)
+        if engine.fused and engine.rng == "philox" and not isinstance(tasks, RectTasks):
+            tasks = self._coherent_tasks(tasks)
         passes = max(1, int(getattr(engine, "passes_per_call", 1)))
         if passes > 1:
             if not engine.fused or engine.rng != "philox":

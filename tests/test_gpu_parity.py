@@ -14,7 +14,7 @@ import raysets
 from source_amd import scenes
 from source_amd._flatten import FlatScene
 
-from source_amd.optical.observer import FrameSampler2D
+from source_amd.optical.observer import FrameSampler2D, RectTasks
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1552,3 +1552,33 @@ print(" ".join(out))
         assert r.returncode == 0, mode + ": " + r.stderr[-2000:]
         digests[mode] = r.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
+
+
+def test_task_lists_render_in_coherent_order(ns):
+    """Philox frames do not depend on the order of a task list, so observe() renders a shuffled full-frame list (FullFrameSampler2D, as
+    sampler2d.pyx:42-102 builds it) as a rectangle and any other list in 8 x 8 tile order (`_coherent_tasks`): the frames must equal the
+    rectangle sampler's bit for bit — on the pixels a mask selects, and nowhere else."""
+    world = scenes.build_c3(ns, n=24)[0]
+
+    def frame(sampler, spp=5):
+        pipe = ns.SpectralRadiancePipeline2D()
+        cam, _ = scenes.c3_camera(ns, world, (56, 44), spp=spp, bins=4)
+        cam.pipelines = [pipe]
+        cam.frame_sampler = sampler
+        cam.render_engine = ns.HipEngine(rng="philox", seed=9)
+        cam.observe()
+        cam.observe()
+        return pipe.frame.mean.copy(), pipe.frame.variance.copy(), pipe.frame.samples.copy(), cam
+
+    rect = frame(ns.RectFrameSampler2D())
+    full = frame(ns.FullFrameSampler2D())
+    assert isinstance(full[3]._coherent_cache[1], RectTasks)
+    for a, b in zip(rect[:3], full[:3]):
+        assert np.array_equal(a, b) and a.max() > 0
+    mask = np.zeros((56, 44), dtype=bool)
+    mask[3:50:2, 1:40] = True
+    mask[7, 7] = True
+    part = frame(ns.FullFrameSampler2D(mask))
+    assert not isinstance(part[3]._coherent_cache[1], RectTasks)
+    for a, b in zip(rect[:3], part[:3]):
+        assert np.array_equal(a[mask], b[mask]) and not b[~mask].any()
