@@ -364,3 +364,25 @@ def test_passes_per_call_bookkeeping(ns):
     cam.render_engine = ns.HipEngine(passes_per_call=4)
     pieces = cam._pieces(cam._generate_tasks(), world)
     assert len(pieces) == 2 and pieces[0]["rect"] == (0, 0, 32, 32)    # (4 passes x 3 spp per pixel: half the frame per call)
+
+
+def test_coherent_task_order(ns):
+    """PinholeCamera._coherent_tasks (what a Philox pass does with a task list): a shuffled list of every pixel of a rectangle becomes
+    that rectangle; any other list keeps its pixels, each once, in 8 x 8 tile order; the conversion is cached per list."""
+    import random
+    from source_amd.optical.observer import RectTasks
+    cam = ns.PinholeCamera((40, 24))
+    full = [(ix, iy) for iy in range(24) for ix in range(40)]
+    random.Random(3).shuffle(full)
+    out = cam._coherent_tasks(full)
+    assert isinstance(out, RectTasks) and out.rect == (0, 0, 40, 24) and cam._coherent_tasks(full) is out
+    window = [(ix, iy) for iy in range(5, 17) for ix in range(8, 31)]
+    random.Random(4).shuffle(window)
+    assert cam._coherent_tasks(window).rect == (8, 5, 31, 17)
+    some = [t for t in full if (t[0] * 7 + t[1] * 3) % 5]
+    out = cam._coherent_tasks(some)
+    assert not isinstance(out, RectTasks) and sorted(map(tuple, out.tolist())) == sorted(some)
+    tiles = [(int(x) >> 3, int(y) >> 3) for x, y in out]
+    assert all(tiles[i] == tiles[i - 1] or tiles[i] not in tiles[:i] for i in range(1, len(tiles)))     # a tile's pixels are contiguous
+    twice = full + [(3, 3)]
+    assert not isinstance(cam._coherent_tasks(twice), RectTasks)     # (a pixel listed twice: not a rectangle)
