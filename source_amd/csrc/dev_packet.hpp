@@ -59,17 +59,24 @@ __device__ __forceinline__ double unode_split(const UNode &nd) { return __longlo
 // 4 world + 14 mesh levels are 9.3 KB per wave: sixteen waves — four per SIMD — fit a CU's 160 KB (packet_lds_bytes, wave_stacks_packet).
 #define PKT_WORLD_LDS_LEVELS 4
 #define PKT_MESH_LDS_LEVELS 14
+// the lane index, formed where it is used and opaque to the optimiser: an address built from it cannot be hoisted out of the walk (the
+// per-lane 64-bit addresses of the rarely used global stack rows and of the record ring sat in six registers through every unit)
+__device__ __forceinline__ int lane_here() {
+    int l = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    asm volatile("" : "+v"(l));
+    return l;
+}
 __device__ __forceinline__ void pstack_push(const Stack &st, int32_t sp, int32_t id, double t) {
     const int lane = (int)(threadIdx.x % WAVE);
     *reinterpret_cast<int32_t *>(smem + st.lds_id + sp * 4) = id;
-    if (sp < st.lds_levels) *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;    // (scalar branch)
-    else reinterpret_cast<double *>(st.gt)[(sp - st.lds_levels) * WAVE + lane] = t;
+    if (__builtin_expect(sp < st.lds_levels, 1)) *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;    // (scalar branch)
+    else reinterpret_cast<double *>(st.gt)[(sp - st.lds_levels) * WAVE + lane_here()] = t;
 }
 __device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
     const int lane = (int)(threadIdx.x % WAVE);
     const int32_t v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + sp * 4);
-    if (sp < st.lds_levels) t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
-    else t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + (sp - st.lds_levels) * WAVE + lane);
+    if (__builtin_expect(sp < st.lds_levels, 1)) t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
+    else t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + (sp - st.lds_levels) * WAVE + lane_here());
     id = __builtin_amdgcn_readfirstlane(v);
 }
 
@@ -340,7 +347,7 @@ __device__ __forceinline__ void packet_leaf_scan(const TriRay &q, int ix, int iy
 // (Measured and not adopted — the mesh walk as a real call, `noinline`, so that the world walk's state would sit in callee-saved
 // registers across a visit instead of being spilled piecemeal: configs[2] 27.4 -> 33.3 ms. The call's own traffic — arguments through
 // vector registers and memory, uniform values re-established with readfirstlane, the callee's saves — cost more than the spills.)
-__device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, uint32_t &work PKT_ARG) {
+__device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, int32_t &work PKT_ARG) {
     const rsx_kdnode *nodes = m->nodes;
     const float4 *leaf = m->leaf;
     const AxisDiv ad = axis_div(r);
@@ -394,7 +401,7 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
             double distance = r.maxd < tmax ? r.maxd : tmax;                   // (no range: -inf, nothing is accepted)
             int32_t closest = -1;
             float bu = 0, bv = 0, bw = 0;
-            work += (uint32_t)count;
+            work += count;
             PKT_COUNT(PKC_MLEAVES, 1)
             PKT_COUNT(PKC_TRIS, count)
             if (relative) {
@@ -429,8 +436,9 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
 // wave by csg_fast_hit_uniform; a lane it cannot answer — or any lane that meets a solid without that form — raises `needs_merge` and is
 // traced again by the redo pass, as in the per-lane kernel.
 template <bool CSG = false>
-__device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work,
+__device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const Ray &r, const Stack &st, const Stack &mesh_stack, Hit &best, uint32_t &work_out,
                                                    bool &needs_merge PKT_ARG) {
+    int32_t work = 0;                  // the unit's cost (traversal rounds): wave-uniform, counted on the scalar unit
     best.prim = -1;
     needs_merge = false;
     // the evaluator's rows lie behind the wave's stacks (packet_lds_bytes); the last solid evaluated and every lane's answer are kept
@@ -452,15 +460,22 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     // living in six registers through the mesh walks; the asm keeps the compiler from merging the copies back into one long-lived value)
     const bool all_safe = !pkt_any(ad.safe != 7);
 #define RCP3 \
-    asm volatile("" : "+v"(ad.yx), "+v"(ad.yy), "+v"(ad.yz)); \
-    const double rx = all_safe ? __builtin_fma(__builtin_fma(-r.dx, ad.yx, 1.0), ad.yx, ad.yx) : 1.0 / r.dx, \
-                 ry = all_safe ? __builtin_fma(__builtin_fma(-r.dy, ad.yy, 1.0), ad.yy, ad.yy) : 1.0 / r.dy, \
-                 rz = all_safe ? __builtin_fma(__builtin_fma(-r.dz, ad.yz, 1.0), ad.yz, ad.yz) : 1.0 / r.dz;
+    double rcp_one = 1.0; \
+    asm volatile("" : "+s"(rcp_one)); \
+    double rx = __builtin_fma(__builtin_fma(-r.dx, ad.yx, rcp_one), ad.yx, ad.yx), \
+           ry = __builtin_fma(__builtin_fma(-r.dy, ad.yy, rcp_one), ad.yy, ad.yy), \
+           rz = __builtin_fma(__builtin_fma(-r.dz, ad.yz, rcp_one), ad.yz, ad.yz); \
+    if (__builtin_expect(!all_safe, 0)) {   /* (a real branch, its operands laundered: as a select the three divisions were hoisted to the \
+                                               top of the unit and their quotients AND partial results sat in twelve registers through the walk) */ \
+        double ux = r.dx, uy = r.dy, uz = r.dz; \
+        asm volatile("" : "+v"(ux), "+v"(uy), "+v"(uz)); \
+        rx = 1.0 / ux; ry = 1.0 / uy; rz = 1.0 / uz; \
+    }
     bool enters;
     const double wlo[3] = {sc->wlower[0], sc->wlower[1], sc->wlower[2]}, whi[3] = {sc->wupper[0], sc->wupper[1], sc->wupper[2]};
     { RCP3 enters = valid && aabb_rcp(wlo, whi, r, rx, ry, rz, tmin, tmax); }
     if (!enters) tmax = PKT_EMPTY;
-    if (!pkt_any(enters)) return false;
+    if (!pkt_any(enters)) { work_out = 0; return false; }
     const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);
     const rsx_kdnode *wnodes = sc->wnodes;
     WideSet8 wide;
@@ -589,8 +604,10 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
             }
         }
         if (tmax != PKT_EMPTY) tmin = tmax;
+        work = __builtin_amdgcn_readfirstlane(work);
         if (!packet_pop(st, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
     }
+    work_out = (uint32_t)work;
     return best.prim >= 0;
 #undef RCP3
 }

@@ -371,7 +371,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
     // first, so one L2 only ever sees an eighth of the image's geometry, and steals from the other lists when its own is empty.
     const int my_xcd = xcc_id();
     int victim = -1;                   // -1: the shared list of expensive units comes first (longest-processing-time-first), then the XCD lists
-    long long batch_next = 0, batch_end = 0;   // (wave-uniform) entries of the current ticket not yet rendered
+    int32_t batch_next = 0, batch_end = 0;     // (wave-uniform; list positions stay below 2^26) entries of the current ticket not yet rendered
     for (;;) {
         // Render parameters are re-read from the kernel-argument segment at every use site of the unit loop (the pointer is
         // laundered through an empty asm): hoisted out of the loop, the camera matrix and friends sat in ~30 vector registers
@@ -396,6 +396,9 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             // address costs the wave a microsecond, and a pass of 4.2 M units through nine counters was bounded by them alone when the
             // units were cheap (7.8 ms for ray generation + record store without any traversal). Large passes only: a small pass is
             // tail-bound and hands its units out one by one.
+            // (pinned to scalar registers: left to itself the compiler kept these counters as 64-bit values in six vector registers
+            // through the walk)
+            batch_next = __builtin_amdgcn_readfirstlane(batch_next); batch_end = __builtin_amdgcn_readfirstlane(batch_end);
             if (batch_next < batch_end) tk = batch_next++;
             else while (victim < 8) {
                 const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
@@ -405,13 +408,14 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
                 if (lane == 0) mine = atomicAdd(ticket + 16 * list, take);
                 const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
                                                           (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
-                if (got < end) { tk = got; batch_next = got + 1; batch_end = got + (long long)take < end ? got + (long long)take : end; break; }
+                if (got < end) { tk = got; batch_next = (int32_t)got + 1; batch_end = (int32_t)(got + (long long)take < end ? got + (long long)take : end); break; }
                 ++victim;
             }
             if (tk < 0) break;
             unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
         }
-        const unsigned long long t_start = q->unit_times ? wall_clock64() : 0ULL;
+        // (unit timestamps — rsx_debug_unit_times — are a per-lane-walk tuning aid: a pass that has them never takes the packet kernel)
+        const unsigned long long t_start = !PACKET && q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_u0 = clock64();
 #endif
@@ -435,7 +439,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         uint32_t work = 0;
         if constexpr (PACKET) {
             // the projection weight goes to its record NOW (its two registers are then free through the walk); a and table follow the walk
-            if constexpr (FUSED != 0) fuse_ring[fuse_n * WAVE + lane].weight = weight;
+            if constexpr (FUSED != 0) fuse_ring[fuse_n * WAVE + lane_here()].weight = weight;
             else if (px.valid) samples[px.slot * q->spp + px.s].weight = weight;
             r.ox = readlane_f64(r.ox, 0); r.oy = readlane_f64(r.oy, 0); r.oz = readlane_f64(r.oz, 0);     // (the pinhole: one origin, kept in scalar registers)
         }
@@ -482,7 +486,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
             q2->unit_cost[unit] = (uint32_t)c;
         }
-        if (q2->unit_times && lane == 0) {
+        if (!PACKET && q2->unit_times && lane == 0) {
             q2->unit_times[12 * unit] = t_start;
             q2->unit_times[12 * unit + 1] = wall_clock64();
             q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
@@ -520,7 +524,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             }
         }
         if constexpr (FUSED != 0 && PACKET) {
-            Sample *rec = fuse_ring + fuse_n * WAVE + lane;                // (weight: stored before the walk)
+            Sample *rec = fuse_ring + fuse_n * WAVE + lane_here();         // (weight: stored before the walk)
             rec->a = smp.a; rec->table = smp.table; rec->pad = 0;
         }
         if constexpr (FUSED != 0) {

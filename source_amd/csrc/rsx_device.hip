@@ -1261,8 +1261,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // Path passes whose end-of-pass checks the caller collects later (rsx_defer_path_checks: the spectral slices of one observe())
     // run on the private lanes like small primary passes: the tail of a slice — a few paths bouncing inside a prism for hundreds of
     // segments — then drains while the next slice's bulk fills the chip. Their per-call inputs live in lane-owned buffers.
-    const bool deferred = has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
-    const bool pipelined = (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // (a scene whose stream-merge states live in the scene's arena — operand trees above CSG_MAX_SLOTS nodes — has ONE arena, indexed by
+    // the launch's own blockIdx: two of its passes in flight on different lanes would write each other's node states in the middle of a
+    // merge, so its passes run one after the other on the context stream)
+    const bool one_at_a_time = scene->d.csg_arena != nullptr;
+    const bool deferred = !one_at_a_time && has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    const bool pipelined = !one_at_a_time && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     // (two lanes for path passes: the path kernel fits two workgroups per CU, and each pass brings a grid of that size — the
     // next slice's workgroups move in as this slice's retire; prism, 32 slices: 3 lanes x 1 workgroup per CU 741 ms, 2 x 2 582 ms)
     // (round 3: up to eight lanes — with the trapped paths handed to a small drain launch a pass gives its workgroup places back after

@@ -1389,6 +1389,61 @@ def test_csg_trees_of_any_depth_and_size_vs_oracle(orc, ns):
     assert cam.stats["rays"] == rays
 
 
+def test_arena_csg_scene_passes_do_not_share_node_states(orc, ns):
+    """A CSG operand tree of more than 16 nodes keeps its stream-merge node states in ONE arena per scene, indexed by the launch's own
+    blockIdx (dev_csg.hpp: csg_arena_slots). Passes of such a scene must not overlap on the private lanes — the slices of one
+    observe() used to, and wrote each other's states in the middle of a merge: every one-bin slice of a 12-slice observe() against
+    the oracle, bit for bit (csg.pyx:132-234), and three more renders of the same frame."""
+    rng = np.random.RandomState(5)
+    P = ns.Point3D
+
+    def leaf(k):
+        t = ns.translate(0.22 * np.cos(0.9 * k), 0.22 * np.sin(1.3 * k), 0.08 * ((k % 5) - 2)) * ns.rotate(17.0 * k, 11.0 * k, 5.0 * k)
+        kind = k % 3
+        if kind == 0:
+            return ns.Sphere(0.25 + 0.02 * (k % 4), transform=t)
+        if kind == 1:
+            return ns.Box(P(-0.2, -0.25, -0.15), P(0.25, 0.2, 0.3), transform=t)
+        return ns.Cylinder(0.2, 0.5, transform=t)
+
+    def tree(depth):
+        if depth == 0:
+            return leaf(int(rng.randint(1000)))
+        op = [ns.Union, ns.Union, ns.Subtract, ns.Intersect][rng.randint(4)] if depth < 4 else ns.Union
+        return op(tree(depth - 1), tree(depth - 1), transform=ns.translate(*(0.08 * rng.randn(3))))
+
+    world = ns.World()
+    sf = ns.InterpolatedSF([300, 500, 800], np.array([0.2, 1.0, 0.5]))
+    for k in range(2):
+        t = tree(4)                                                              # 31 nodes, 16 leaves: the arena, no state-free form
+        t.parent, t.transform, t.material = world, ns.translate(1.3 * (k - 0.5), 0.0, 0.0), ns.UniformSurfaceEmitter(sf, 1.0 + k)
+    ns.Box(P(-4, -4, -4), P(4, 4, 4), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(0.1), 1.0))
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera((160, 96), fov=60, parent=world, pipelines=[pipe], frame_sampler=ns.RectFrameSampler2D(), transform=ns.translate(0.0, 0.1, -3.2))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = 1, 12, 12, True
+    cam.render_engine = ns.HipEngine(rng="philox", seed=12)
+    cam.observe()
+    first = np.array(pipe.frame.mean)
+    flat = world.flatten()
+    slices = cam._slice_spectrum()
+    assert len(slices) == 12
+    for k, sl in enumerate(slices):
+        keep = []
+        desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, 160, 96))
+        m, v, rays = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+        assert eq(first[:, :, k], m.reshape(96, 160).T), k
+    assert (first[:, :, 5] > 0.11).sum() > 2000                                  # the solids are in view
+    # the same again on fresh pipelines: passes in flight next to each other may not disturb one another from call to call
+    for _ in range(3):
+        pipe2 = ns.SpectralRadiancePipeline2D()
+        cam.pipelines = [pipe2]
+        cam.render_engine = ns.HipEngine(rng="philox", seed=12)
+        cam.observe()
+        assert eq(np.array(pipe2.frame.mean), first)
+
+
+
+
 def test_toolchain_divergent_loop_exit_workaround(tmp_path):
     """hipcc 7.2 miscompiles per-lane loops that the lanes of a wave leave at different turns through a `return` / `continue` in the
     middle of the body (tests/toolchain/divergent_loop_exit.hip holds both forms of one loop and says so in its output). librsx writes
