@@ -53,6 +53,7 @@ import numpy as np  # noqa: E402
 
 # /opt/skills/guides/MI355X_MICROARCH.md
 PEAK_HBM_GBS = 8000.0       # HBM3E spec peak
+WAVE_RAYS = 64              # rays of one work unit (one CDNA wavefront)
 PEAK_L2_GBS = 34500.0       # aggregate L2 bandwidth (8 XCDs)
 N_CUS, SIMDS_PER_CU, CLOCK_GHZ = 256, 4, 2.4
 PEAK_L1_GBS = N_CUS * 64 * CLOCK_GHZ          # per-CU vector cache: 64 B / clk / CU
@@ -135,6 +136,105 @@ def child_main(args):
     for _ in range(max(1, args.steps)):
         cam.observe()
     get_context().synchronize()
+
+
+def host_cores(omp_threads):
+    """The host cores this process can actually use: the affinity mask and the cgroup CPU quota (v2 cpu.max, v1 cfs_quota_us) next to
+    what os.cpu_count() and OpenMP's default say. `usable` = min(affinity, quota) — what a thread count should be compared with."""
+    info = {"os_cpu_count": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else None,
+            "omp_max_threads": int(omp_threads), "cgroup_quota_cores": None, "cgroup_cpu_max": None, "model": None}
+    try:
+        raw = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cgroup_cpu_max"] = " ".join(raw)
+        if raw and raw[0] != "max":
+            info["cgroup_quota_cores"] = round(float(raw[0]) / float(raw[1]), 2)
+    except (OSError, ValueError, IndexError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            info["cgroup_cpu_max"] = "%d %d (cgroup v1)" % (q, per)
+            if q > 0:
+                info["cgroup_quota_cores"] = round(q / per, 2)
+        except (OSError, ValueError):
+            pass
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    usable = info["affinity"] or info["os_cpu_count"] or 1
+    if info["cgroup_quota_cores"]:
+        usable = min(usable, max(1, int(info["cgroup_quota_cores"] + 0.5)))
+    info["usable"] = int(usable)
+    return info
+
+
+def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cpu_seconds, nthreads):
+    """The cpu_baseline object of the bench line (kind "port": oracle/rsx_oracle.c with OpenMP), runnable without a GPU."""
+    # bounded sample of the same workload on the host cores, same Philox samples. First WHICH cores: what the process may use
+    # (affinity mask, cgroup quota) next to what OpenMP would start by default, and a sweep over thread counts on a band of
+    # rows that grows with the count (~0.7 s each) — the baseline is the best rate of the sweep, `cores` its thread count.
+    keep = []
+    sl = cam._slice_spectrum()[SLICES // 2]
+    engine.sample_offset = 0
+    host = host_cores(nthreads)
+
+    def band_desc(rows):
+        rows = int(max(1, min(NY, rows)))
+        rect = (0, NY // 2 - rows // 2, NX, NY // 2 - rows // 2 + rows)
+        return cam.render_desc(world, None, sl, engine, keep, rect=rect), NX * rows * CAM_SPP, rows
+
+    def timed(desc, threads):
+        t0 = time.perf_counter()
+        m_, v_, nr_ = orc.render_pinhole(flat, desc, threads=threads)
+        assert np.isfinite(m_).all()
+        return time.perf_counter() - t0
+
+    cal, n_cal, _ = band_desc(2)
+    timed(cal, 1)
+    rate1 = n_cal / max(timed(cal, 1), 1e-6)
+    rows1 = max(2.0, 0.7 * rate1 / (NX * CAM_SPP))         # rows one thread renders in ~0.7 s
+    counts = sorted({1 << k for k in range(0, 12) if (1 << k) <= nthreads} | {nthreads, max(1, min(nthreads, host["usable"]))})
+    sweep = []
+    for t in counts:
+        desc_t, n_t, rows_t = band_desc(rows1 * t)
+        timed(band_desc(1)[0], t)                               # (the thread team of this size exists before the clock starts)
+        dt = min(timed(desc_t, t), timed(desc_t, t)) if n_t / rate1 / t < 0.5 else timed(desc_t, t)
+        sweep.append({"threads": t, "rays_s": round(n_t / dt, 1), "rows": rows_t, "seconds": round(dt, 3)})
+    best = max(sweep, key=lambda e: e["rays_s"])
+    best_threads, rate = best["threads"], best["rays_s"]
+    target = rate * cpu_seconds
+    saved = cam.pixel_samples
+    if target >= NX * NY * CAM_SPP:
+        n_pass = int(min(2048, max(1, round(target / (NX * NY * CAM_SPP)))))
+        cam.pixel_samples = CAM_SPP * n_pass
+        rect = (0, 0, NX, NY)
+        what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, CAM_SPP)
+        centred = False
+    else:
+        nrows = int(max(16, min(NY, target // (NX * CAM_SPP))))
+        rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
+        what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, CAM_SPP)
+        centred = True
+    if SLICES > 1:
+        what += ", one of the %d spectral slices" % SLICES
+    desc = cam.render_desc(world, None, sl, engine, keep, rect=rect)
+    n_primary = (rect[2] - rect[0]) * (rect[3] - rect[1]) * cam.pixel_samples
+    cam.pixel_samples = saved
+    tcpu = timed(desc, best_threads)
+    one = next(e for e in sweep if e["threads"] == 1)
+    cpu = {"value": round(n_primary / tcpu, 1), "unit": "primary rays/s", "cores": best_threads, "kind": "port",
+           "sample": "%s of the same workload (%d primary rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
+                     "with OpenMP on %d host threads (the best of the thread sweep), %.1f s" % (what, n_primary, best_threads, tcpu),
+           "host": host, "scaling": sweep,
+           "speedup_over_one_thread": round(n_primary / tcpu / one["rays_s"], 2),
+           "one_thread": {"value": one["rays_s"], "unit": "primary rays/s", "cores": 1,
+                          "sample": "centred band of %d rows x %d px x %d spp, %.1f s" % (one["rows"], NX, CAM_SPP, one["seconds"])}}
+    if centred:
+        cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
+    return cpu
 
 
 def collect_pmc(workload, passes, keep_dir=None, passes_per_call=0):
@@ -330,28 +430,11 @@ def main():
     # (tools/tile_balance.py). Every rank computes the same cuts from the same gathered times.
     tile_bounds = None
     if sharding == "tile" and world_size > 1 and args.tiles == "balanced":
-        tile_bounds = [(NX * r) // world_size for r in range(world_size)] + [NX]
-        engine.sample_offset = 1 << 40                      # (counters of their own: the render's first pass assigns 0 and starts there)
-        for _ in range(4):
-            cam.frame_sampler = ns.RectFrameSampler2D(rect=D.tile_rect(rank, world_size, NX, NY, tile_bounds))
-            cam.observe()
-            ctx.synchronize()
-            reps, spent = 1, 0.0
-            while True:
-                t_b = time.perf_counter()
-                for _ in range(reps):
-                    cam.observe()
-                ctx.synchronize()
-                spent = time.perf_counter() - t_b
-                if spent >= 10e-3 or reps >= 64:
-                    break
-                reps *= 4
-            times = [None] * world_size
-            dist.all_gather_object(times, spent / reps)
-            tile_bounds = [int(b) for b in D.rebalance_bounds(tile_bounds, times, NX)]
-        if pipe.frame is not None:                          # the timed passes are not part of the render: drop their frame
-            pipe.frame.release()
-            pipe.frame = None
+        def share(value):
+            values = [None] * world_size
+            dist.all_gather_object(values, value)
+            return values
+        tile_bounds = D.balance_tiles(cam, rank, world_size, share, ctx.synchronize)     # (4 timing rounds, before the warm-up)
     my_rect = D.tile_rect(rank, world_size, NX, NY, tile_bounds) if sharding == "tile" else (0, 0, NX, NY)
     cam.frame_sampler = ns.RectFrameSampler2D(rect=my_rect)
     # slice sharding: rank r renders the spectral slices [slice_bounds[r], slice_bounds[r + 1]) of every pass; they fill the bins
@@ -613,11 +696,40 @@ def main():
                             "note": "SURVEY 8d algorithmic bytes per ray x rays per launch / kernel time against the 8 TB/s HBM peak. The bytes are node / "
                                     "triangle / primitive records that the caches serve (measured HBM traffic: hbm_measured), so this fraction can exceed 1; "
                                     "it is not the ceiling that binds the kernel"}
+        # ---- the same line priced per WAVE (packet passes: dev_packet.hpp). The packet kernel fetches a node, a leaf item, a primitive or
+        # triangle record ONCE per 64-ray unit over the scalar data path, whatever the number of lanes that need it, so its algorithmic
+        # bytes are the DISTINCT records a unit's rays touch (oracle: orc_packet_counters on the 64 jittered rays of sampled pixels),
+        # plus what every unit owes: its sample records through the per-wave ring (written, then read by the flush) and the frame cells
+        # of its pixels (read + written). THIS is the HBM ceiling of the kernel that exists; the per-ray line above is SURVEY 8d's.
+        hbm_per_wave = None
+        if hbm_contract is not None and fused and WAVE_RAYS % SPP == 0:
+            ppu = WAVE_RAYS // SPP                                            # pixels per unit
+            step = max(1, int(round((NX * NY / 4096.0) ** 0.5)))              # ~4096 sampled pixels on a regular grid, whole units
+            px = np.array([(x0 + j, iy) for iy in range(step // 2, NY, step) for x0 in range((step // 2) & ~7, NX - ppu + 1, step) for j in range(ppu)], dtype=np.int32)
+            d3 = _lib.RenderDesc()
+            d3.camera = cam.device_camera()
+            u3 = np.random.RandomState(20250905).rand(2 * len(px) * SPP)
+            d3.tasks, d3.n_tasks, d3.spp, d3.uniforms = _lib.ptr(px), len(px), SPP, _lib.ptr(u3)
+            rays3 = orc.pinhole_rays(d3)
+            pc = orc.packet_counters(flat, rays3[:, 0:3], rays3[:, 3:6], group=WAVE_RAYS, threads=nthreads).mean(axis=0)
+            per_unit = dict(world_nodes=pc[0], world_leaves=pc[1], world_items=pc[2], mesh_visits=pc[3], mesh_nodes=pc[4], mesh_leaves=pc[5], triangle_records=pc[6])
+            parts = {"nodes_16B": 16.0 * (pc[0] + pc[4]), "leaf_items_4B": 4.0 * pc[2], "primitive_records_216B": 216.0 * pc[2],
+                     "triangle_records_48B": 48.0 * pc[6], "mesh_headers_96B": 96.0 * pc[3],
+                     "sample_ring_write_read": 2.0 * 24.0 * WAVE_RAYS, "frame_read_write": 40.0 * BINS * ppu, "work_list": 4.0}
+            b_unit = float(sum(parts.values()))
+            units = rays_per_step_rank / WAVE_RAYS
+            achieved_w = b_unit * units / (trace_avg * 1e-3) / 1e9
+            hbm_per_wave = {"bytes_per_unit": round(b_unit, 1), "per_unit": {k: round(float(v), 3) for k, v in per_unit.items()},
+                            "bytes": {k: round(float(v), 1) for k, v in parts.items()}, "units_per_launch": int(units),
+                            "bytes_per_launch": int(b_unit * units), "achieved": round(achieved_w, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                            "frac": round(achieved_w / PEAK_HBM_GBS, 5), "sampled_units": int(len(px) // ppu),
+                            "note": "algorithmic bytes per 64-ray unit (distinct records a packet fetches + its sample-record ring + its frame cells) x units "
+                                    "per launch / kernel time against the 8 TB/s HBM peak; compare bytes_per_launch with hbm_measured.bytes_per_launch"}
         # ---- roofline: top level = ONE ceiling, the one that binds the dominant kernel, from the counters of this run
         roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                     "kernel": kernel_prefix, "kernel_ms": round(trace_avg * my_slices, 4), "launches_per_step": my_slices,
                     "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices, 4),
-                    "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract}
+                    "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract, "hbm_per_wave": hbm_per_wave}
         if my_slices > 1:
             roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on up to eight streams and overlap, so "
                                           "the sum exceeds ms_per_step" % my_slices)
@@ -651,59 +763,7 @@ def main():
 
         cpu = None
         if not args.no_cpu_baseline and world_size == 1:       # the CPU baseline is timed at N = 1 only (the other ranks would idle at the barrier)
-            # bounded sample of the same workload on the host cores, same Philox samples: calibrate on a 16-row band, then size
-            # the sample for ~args.cpu_seconds of CPU work — whole passes when one fits, otherwise a centred band of rows
-            keep = []
-            sl = cam._slice_spectrum()[SLICES // 2]
-            engine.sample_offset = 0
-            band = (0, NY // 2 - 8, NX, NY // 2 + 8)
-            desc = cam.render_desc(world, None, sl, engine, keep, rect=band)
-            orc.render_pinhole(flat, desc, threads=nthreads)        # thread-pool warm-up
-            tcal = time.perf_counter()
-            m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
-            rate = NX * 16 * CAM_SPP / (time.perf_counter() - tcal)
-            target = rate * args.cpu_seconds
-            saved = cam.pixel_samples
-            if target >= NX * NY * CAM_SPP:
-                n_pass = int(min(2048, max(1, round(target / (NX * NY * CAM_SPP)))))
-                cam.pixel_samples = CAM_SPP * n_pass
-                rect = (0, 0, NX, NY)
-                what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, CAM_SPP)
-                centred = False
-            else:
-                nrows = int(max(16, min(NY, target // (NX * CAM_SPP))))
-                rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
-                what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, CAM_SPP)
-                centred = True
-            if SLICES > 1:
-                what += ", one of the %d spectral slices" % SLICES
-            desc = cam.render_desc(world, None, sl, engine, keep, rect=rect)
-            n_primary = (rect[2] - rect[0]) * (rect[3] - rect[1]) * cam.pixel_samples
-            cam.pixel_samples = saved
-            tcpu = time.perf_counter()
-            m, v, nr = orc.render_pinhole(flat, desc, threads=nthreads)
-            tcpu = time.perf_counter() - tcpu
-            assert np.isfinite(m).all()
-            cpu = {"value": round(n_primary / tcpu, 1), "unit": "primary rays/s", "cores": nthreads, "kind": "port",
-                   "sample": "%s of the same workload (%d primary rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
-                             "with OpenMP on %d host threads, %.1f s" % (what, n_primary, nthreads, tcpu)}
-            if centred:
-                cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
-            # ... and on ONE host thread, a sample sized for a few seconds
-            # (calibrated on its own two-row band: one thread alone runs far faster than one of 256 that share the caches and the memory)
-            cal1 = cam.render_desc(world, None, sl, engine, keep, rect=(0, NY // 2 - 1, NX, NY // 2 + 1))
-            t1 = time.perf_counter()
-            orc.render_pinhole(flat, cal1, threads=1)
-            rate1 = 2 * NX * CAM_SPP / max(time.perf_counter() - t1, 1e-6)
-            one_rows = int(max(2, min(NY, rate1 * min(4.0, args.cpu_seconds / 3) // (NX * CAM_SPP))))
-            rect1 = (0, NY // 2 - one_rows // 2, NX, NY // 2 - one_rows // 2 + one_rows)
-            desc1 = cam.render_desc(world, None, sl, engine, keep, rect=rect1)
-            t1 = time.perf_counter()
-            orc.render_pinhole(flat, desc1, threads=1)
-            t1 = time.perf_counter() - t1
-            n1 = NX * one_rows * CAM_SPP
-            cpu["one_thread"] = {"value": round(n1 / t1, 1), "unit": "primary rays/s", "cores": 1,
-                                 "sample": "centred band of %d rows x %d px x %d spp (%d primary rays), %.1f s" % (one_rows, NX, CAM_SPP, n1, t1)}
+            cpu = cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, args.cpu_seconds, nthreads)
             # the compiled Cython reference itself, measured where it can run (development container; tests/golden/time_reference.py)
             ref_path = os.path.join(ROOT, "tests", "golden", "reference_timing.json")
             if os.path.exists(ref_path):

@@ -45,6 +45,7 @@ def lib():
         L.orc_philox_uniform2.argtypes = [C.c_uint64, C.c_uint64, C.c_uint64, vp]
         L.orc_aabb_intersect.argtypes = [C.c_int64, vp, vp, vp, vp, vp]
         L.orc_hit_batch.argtypes = [C.POINTER(S.SceneDesc), C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
+        L.orc_packet_counters.argtypes = [C.POINTER(S.SceneDesc), C.c_int64, C.c_int32, vp, vp, vp, vp, C.c_int]
         L.orc_prim_hit_batch.argtypes = [C.POINTER(S.SceneDesc), C.c_int32, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp, C.c_int]
         L.orc_roots_batch.argtypes = [C.POINTER(S.SceneDesc), C.c_int32, C.c_int64, vp, vp, vp, C.c_int32, vp, vp, vp, vp]
         L.orc_contains_batch.argtypes = [C.POINTER(S.SceneDesc), C.c_int64, vp, vp]
@@ -181,6 +182,16 @@ def hit_batch(flat, origin, direction, max_distance=None, geometry=False, thread
                         p(out["uvw"]), p(out["geom"]), threads, p(cnt))
     if counters:
         out["counters"] = dict(nodes=int(cnt[0]), items=int(cnt[1]), tris=int(cnt[2]), prims=int(cnt[3]))
+    return out
+
+
+def packet_counters(flat, origin, direction, group=64, threads=1):
+    """Distinct records per group of `group` consecutive rays — what a wave walking the trees as ONE packet fetches: array
+    [n_groups, 7] = world nodes, world leaves, world leaf items, mesh trees entered, mesh nodes, non-empty mesh leaves, mesh leaf items."""
+    o, d, m, n = _rays(origin, direction, None)
+    groups = n // group
+    out = np.zeros((groups, 7), dtype=np.int64)
+    lib().orc_packet_counters(C.byref(flat.desc), groups, group, p(o), p(d), p(m), p(out), threads)
     return out
 
 

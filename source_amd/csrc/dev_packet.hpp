@@ -82,6 +82,15 @@ __device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t 
 
 __host__ __device__ __forceinline__ int packet_world_levels(int wdepth) { return wdepth < PKT_WORLD_LDS_LEVELS ? wdepth : PKT_WORLD_LDS_LEVELS; }
 __host__ __device__ __forceinline__ int packet_mesh_levels(int mdepth) { return mdepth < PKT_MESH_LDS_LEVELS ? mdepth : PKT_MESH_LDS_LEVELS; }
+// Bytes of one wave's global spill region — the stack rows that do not fit LDS, of whichever walk the launch runs: the per-lane walks
+// keep (wlds, mlds) levels in LDS and spill 12 B per lane and level, the packet keeps its own (packet_*_levels: fewer than mlds when the
+// flattened CSG trees asked for more than PKT_MESH_LDS_LEVELS) and spills 8 B. plan() allocates this stride, both carvers step by it.
+__host__ __device__ __forceinline__ size_t spill_wave_bytes(int wdepth, int wlds, int mdepth, int mlds) {
+    const int per_lane = (wdepth - wlds) + (mdepth - mlds), packet = (wdepth - packet_world_levels(wdepth)) + (mdepth - packet_mesh_levels(mdepth));
+    const size_t a = (size_t)(per_lane > 0 ? per_lane : 0) * WAVE * 12, b = (size_t)(packet > 0 ? packet : 0) * WAVE * 8;
+    const size_t need = a > b ? a : b;
+    return need > 0 ? need : (size_t)WAVE * 12;
+}
 // csg_rows > 0 (scenes with CSG solids in the state-free evaluator's form): that many rows of (f64 root, i32 face / axis / exit) per lane
 // behind the stacks — where csg_fast_hit_uniform leaves the operands' roots (two per leaf of the biggest tree)
 __host__ __device__ __forceinline__ size_t packet_stack_bytes(int wdepth, int mdepth) {
@@ -91,18 +100,13 @@ __host__ __device__ __forceinline__ size_t packet_stack_bytes(int wdepth, int md
 __host__ __device__ __forceinline__ size_t packet_lds_bytes(int wdepth, int mdepth, int csg_rows = 0) {       // per wave
     return packet_stack_bytes(wdepth, mdepth) + (size_t)csg_rows * WAVE * 12;
 }
-// carve the wave's LDS region and global spill region into the packet's world stack and mesh stack (the spill region is the one plan()
-// sized for the per-lane stacks: the packet keeps at least as many levels in LDS, so it needs no more)
+// carve the wave's LDS region and global spill region (spill_wave_bytes) into the packet's world stack and mesh stack
 __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, Stack &ms) {
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE));
     const int pw = packet_world_levels(sc.wdepth), pm = packet_mesh_levels(sc.mdepth);
     const uint32_t base = (uint32_t)wave * (uint32_t)packet_lds_bytes(sc.wdepth, sc.mdepth, sc.csg_fast_rows);
-    const int spill_levels = (sc.wdepth - pw) + (sc.mdepth - pm);
-    const int plan_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
     const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
-    char *gbase = sc.spill + gwave * (size_t)(plan_levels > 0 ? plan_levels : 1) * WAVE * 12;
-    char *gt = gbase;
-    (void)spill_levels;
+    char *gt = sc.spill + gwave * spill_wave_bytes(sc.wdepth, sc.wlds, sc.mdepth, sc.mlds);
     ws.stage = nullptr; ms.stage = nullptr;
     ws.lds_t = base; ws.lds_id = base + (uint32_t)(pw + pm) * WAVE * 8; ws.gt = gt; ws.gid = nullptr; ws.lds_levels = pw;
     ms.lds_t = base + (uint32_t)pw * WAVE * 8; ms.lds_id = ws.lds_id + (uint32_t)sc.wdepth * 4;

@@ -13,7 +13,7 @@ __device__ __forceinline__ void wave_stacks(const DScene &sc, Stack &ws, Stack &
     const uint32_t lds_t = base, lds_id = base + (uint32_t)lds_levels * WAVE * 8;
     const int spill_levels = (sc.wdepth - sc.wlds) + (sc.mdepth - sc.mlds);
     const size_t gwave = (size_t)blockIdx.x * (blockDim.x / WAVE) + wave;
-    char *gbase = sc.spill + gwave * (size_t)(spill_levels > 0 ? spill_levels : 1) * WAVE * 12;
+    char *gbase = sc.spill + gwave * spill_wave_bytes(sc.wdepth, sc.wlds, sc.mdepth, sc.mlds);
     char *gt = gbase, *gid = gbase + (size_t)spill_levels * WAVE * 8;
     float4 *stage = reinterpret_cast<float4 *>(smem + base + (size_t)lds_levels * WAVE * 12);
     ws.stage = stage; ms.stage = stage;

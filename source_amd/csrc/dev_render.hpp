@@ -339,6 +339,10 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
 // inlined into the unit loop its chains' registers competed with the walk's and cost the kernel sixteen more spilled registers.
 // (MULTI — several passes per call — is a kernel of its own: as a run-time branch in here the larger callee cost the one-pass kernel
 // 22 more spilled registers around the call and configs[2] 27.2 -> 28.4 ms)
+// (the kernel-argument layout those offsets assume — k_render_trace(DScene, RenderParams, Sample *, unsigned long long *, FuseParams): every
+// argument 8-byte aligned, so rp lies at align8(sizeof(DScene)) and fz two pointers behind align8(end of rp))
+static_assert(alignof(DScene) <= 8 && alignof(RenderParams) == 8 && alignof(FuseParams) == 8 && sizeof(Sample *) == 8 && sizeof(unsigned long long *) == 8,
+              "fused_flush_call / k_render_trace locate rp and fz in the kernel-argument segment by these alignments");
 template <bool MULTI>
 __device__ __attribute__((noinline)) void fused_flush_call(unsigned long long rp_bits_, const Sample *ring_, int u0_, int u1_, int u2_, int u3_, int n_units_, uint32_t lds_base_) {
     const Sample *ring = (const Sample *)pkt_uniform64((unsigned long long)ring_);

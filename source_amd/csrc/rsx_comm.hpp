@@ -341,8 +341,15 @@ extern "C" int rsx_allgather_bins(rsx_comm *c, double *mean, double *variance, i
     rsx_ctx *ctx = c->ctx;
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
-    const size_t P = (size_t)n_pixels, E = P * (size_t)bins;               // packed blocks of all ranks together: one frame's worth
-    const size_t need = E * 20 + 256;
+    // The packed blocks of all ranks together are one frame's worth (10.7 GB for configs[4]). They never need to exist at once: the frame
+    // travels in chunks of whole pixels — pack own bins of the chunk, one group of direct sends / receives, unpack the peers' — through a
+    // workspace of at most RSX_BINS_SCRATCH_BYTES (default 512 MB; stream order keeps a chunk's unpack ahead of the next chunk's receives;
+    // read at every call, every rank must see the same value: the chunks of a pair of ranks have to match).
+    const char *cap_env = std::getenv("RSX_BINS_SCRATCH_BYTES");
+    const size_t scratch_cap = (size_t)std::max(1ll, cap_env ? std::atoll(cap_env) : (512ll << 20));
+    const size_t per_pixel = (size_t)bins * 20;
+    const size_t chunk_pixels = std::max<size_t>(1, std::min<size_t>((size_t)n_pixels, scratch_cap / per_pixel));
+    const size_t need = chunk_pixels * per_pixel + 256;
     bool have = true;
     if (need > c->scratch_bytes) {
         if (c->scratch) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(c->scratch)); c->scratch = nullptr; c->scratch_bytes = 0; }
@@ -353,45 +360,50 @@ extern "C" int rsx_allgather_bins(rsx_comm *c, double *mean, double *variance, i
     const int arc = ranks_agree(c, have, &all_have);
     if (arc) return arc;
     if (!all_have) return rsx_fail(RSX_ENOMEM, "rsx_allgather_bins: %s could not allocate its %zu-byte packing workspace", have ? "another rank" : "this rank", need);
-    double *pm = static_cast<double *>(c->scratch), *pv = pm + E;
-    int32_t *pn = reinterpret_cast<int32_t *>(pv + E);
-    auto block_off = [&](int r) { return P * (size_t)bin_begin[r]; };      // blocks in rank order, [n_pixels][nb_r] each
-    auto block_len = [&](int r) { return P * (size_t)(bin_begin[r + 1] - bin_begin[r]); };
-    auto launch = [&](int r, int unpack) -> int {
-        const size_t len = block_len(r);
-        if (!len) return RSX_OK;
-        const dim3 grid((unsigned)((len + 255) / 256));
-        const int b0 = bin_begin[r], nb = bin_begin[r + 1] - bin_begin[r];
-        hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, mean, pm + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
-        hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, variance, pv + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
-        hipLaunchKernelGGL(k_pack_bins<int32_t>, grid, dim3(256), 0, ctx->stream, samples, pn + block_off(r), (long long)n_pixels, (int)bins, b0, nb, unpack);
-        HIP_TRY(hipGetLastError());
-        return RSX_OK;
-    };
-    int rc = launch(me, 0);
-    if (rc) return rc;
     rccl::Api &a = rccl::api();
-    {
-        GroupGuard g(a);
-        g.start();
-        const size_t my_off = block_off(me), my_len = block_len(me);
-        for (int k = 1; k < W; ++k) {
-            const int to = (me + k) % W, from = (me - k + W) % W;
-            if (my_len) {
-                RCCL_IN_GROUP(g, a.Send(pm + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
-                RCCL_IN_GROUP(g, a.Send(pv + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
-                RCCL_IN_GROUP(g, a.Send(pn + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
-            }
-            const size_t off = block_off(from), len = block_len(from);
-            if (len) {
-                RCCL_IN_GROUP(g, a.Recv(pm + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
-                RCCL_IN_GROUP(g, a.Recv(pv + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
-                RCCL_IN_GROUP(g, a.Recv(pn + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
-            }
-        }
-        rc = g.finish();
+    for (size_t p0 = 0; p0 < (size_t)n_pixels; p0 += chunk_pixels) {
+        const size_t P = std::min(chunk_pixels, (size_t)n_pixels - p0), E = P * (size_t)bins;      // this chunk: pixels [p0, p0 + P)
+        double *pm = static_cast<double *>(c->scratch), *pv = pm + E;
+        int32_t *pn = reinterpret_cast<int32_t *>(pv + E);
+        double *cm = mean + p0 * (size_t)bins, *cv = variance + p0 * (size_t)bins;
+        int32_t *cn = samples + p0 * (size_t)bins;
+        auto block_off = [&](int r) { return P * (size_t)bin_begin[r]; };      // blocks in rank order, [P][nb_r] each
+        auto block_len = [&](int r) { return P * (size_t)(bin_begin[r + 1] - bin_begin[r]); };
+        auto launch = [&](int r, int unpack) -> int {
+            const size_t len = block_len(r);
+            if (!len) return RSX_OK;
+            const dim3 grid((unsigned)((len + 255) / 256));
+            const int b0 = bin_begin[r], nb = bin_begin[r + 1] - bin_begin[r];
+            hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, cm, pm + block_off(r), (long long)P, (int)bins, b0, nb, unpack);
+            hipLaunchKernelGGL(k_pack_bins<double>, grid, dim3(256), 0, ctx->stream, cv, pv + block_off(r), (long long)P, (int)bins, b0, nb, unpack);
+            hipLaunchKernelGGL(k_pack_bins<int32_t>, grid, dim3(256), 0, ctx->stream, cn, pn + block_off(r), (long long)P, (int)bins, b0, nb, unpack);
+            HIP_TRY(hipGetLastError());
+            return RSX_OK;
+        };
+        int rc = launch(me, 0);
         if (rc) return rc;
+        {
+            GroupGuard g(a);
+            g.start();
+            const size_t my_off = block_off(me), my_len = block_len(me);
+            for (int k = 1; k < W; ++k) {
+                const int to = (me + k) % W, from = (me - k + W) % W;
+                if (my_len) {
+                    RCCL_IN_GROUP(g, a.Send(pm + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                    RCCL_IN_GROUP(g, a.Send(pv + my_off, my_len, rccl::ncclFloat64, to, c->comm, ctx->stream));
+                    RCCL_IN_GROUP(g, a.Send(pn + my_off, my_len, rccl::ncclInt32, to, c->comm, ctx->stream));
+                }
+                const size_t off = block_off(from), len = block_len(from);
+                if (len) {
+                    RCCL_IN_GROUP(g, a.Recv(pm + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                    RCCL_IN_GROUP(g, a.Recv(pv + off, len, rccl::ncclFloat64, from, c->comm, ctx->stream));
+                    RCCL_IN_GROUP(g, a.Recv(pn + off, len, rccl::ncclInt32, from, c->comm, ctx->stream));
+                }
+            }
+            rc = g.finish();
+            if (rc) return rc;
+        }
+        for (int r = 0; r < W; ++r) if (r != me && (rc = launch(r, 1))) return rc;
     }
-    for (int r = 0; r < W; ++r) if (r != me && (rc = launch(r, 1))) return rc;
     return RSX_OK;
 }

@@ -573,10 +573,14 @@ int validate_tree(const rsx_kdtree &kd, int32_t n_ids, const char *what) {
 }  // namespace
 
 extern "C" void rsx_scene_free(rsx_scene *scene) {
-    if (scene) { if (scene->rel) (void)hipFree(scene->rel); if (scene->rel_info) (void)hipFree(scene->rel_info); if (scene->rel_jobs_dev) (void)hipFree(scene->rel_jobs_dev); }
     if (!scene) return;
     (void)hipSetDevice(scene->ctx->device);
+    // nothing of the scene is freed while a pass may still read it: the private lanes first, then the context stream
+    for (TraceLane &ln : scene->ctx->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     (void)hipStreamSynchronize(scene->ctx->stream);
+    if (scene->rel) (void)hipFree(scene->rel);
+    if (scene->rel_info) (void)hipFree(scene->rel_info);
+    if (scene->rel_jobs_dev) (void)hipFree(scene->rel_jobs_dev);
     for (void *p : scene->allocs) (void)hipFree(p);
     delete scene;
 }
@@ -906,8 +910,7 @@ int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg
     if (wgs < 1) wgs = 1;
     l.grid = dim3((unsigned)wgs);
     // global spill regions: one per wave of the largest grid a lane launches (lanes run concurrently, so each has its own)
-    const int spill_levels = std::max(1, (sc->d.wdepth - sc->d.wlds) + (sc->d.mdepth - sc->d.mlds));
-    const size_t need = (size_t)sc->ctx->n_cus * RSX_MAX_WG_PER_CU * WG_WAVES * spill_levels * WAVE * 12;
+    const size_t need = (size_t)sc->ctx->n_cus * RSX_MAX_WG_PER_CU * WG_WAVES * spill_wave_bytes(sc->d.wdepth, sc->d.wlds, sc->d.mdepth, sc->d.mlds);
     if (need > lane.spill_bytes) {
         if (lane.spill) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipFree(lane.spill)); lane.spill = nullptr; lane.spill_bytes = 0; }
         HIP_TRY(hipMalloc(&lane.spill, need));
@@ -1165,6 +1168,9 @@ int ensure_camera_relative(rsx_scene *scene, const rsx_camera &cam, hipStream_t 
     hipLaunchKernelGGL(k_camera_relative, dim3((unsigned)((most + 255) / 256), (unsigned)scene->rel_jobs.size()), dim3(256), 0, stream, scene->d, cam,
                        static_cast<const RelJob *>(scene->rel_jobs_dev), static_cast<float4 *>(scene->rel), static_cast<RelInfo *>(scene->rel_info));
     HIP_TRY(hipGetLastError());
+    // The records are read by whichever lane renders with this camera next — private, non-blocking streams without an ordering against
+    // `stream` — and that lane only sees rel_valid on the host: the fill is complete before anybody is told. (Once per camera.)
+    HIP_TRY(hipStreamSynchronize(stream));
     std::memcpy(scene->rel_camera, cam.to_root, sizeof(scene->rel_camera));
     scene->rel_valid = true;
     return RSX_OK;

@@ -84,6 +84,51 @@ def rebalance_bounds(bounds, times, nx, quantum=8):
     return new
 
 
+def balance_tiles(cam, rank, world_size, allgather, synchronize, rounds=4, min_seconds=10e-3, quantum=8):
+    """Column boundaries of a tile-sharded render balanced by MEASURED tile times (what the reference's task queue does dynamically,
+    workflow.py:201-251, a static split has to do up front). Every rank times ordinary passes of its own tile of the current split —
+    with Philox counters of their own (1 << 40 ...), into a frame that is dropped afterwards — the times are shared and the cuts
+    move to the equal-cost quantiles (rebalance_bounds); `rounds` iterations bring mean / max tile time of configs[2] from 0.90 to
+    0.97 at 8 ranks (tools/tile_balance.py). Every rank computes the same cuts from the same gathered times.
+
+    cam: the observer to be sharded (HipEngine with rng='philox'; its frame sampler is left on this rank's balanced tile);
+    allgather(x) -> [x of rank 0, ..., x of rank W-1] (FrameComm.allgather_scalar, a torch.distributed all_gather_object, ...);
+    synchronize(): wait for the device (Context.synchronize). Returns the world_size + 1 boundaries."""
+    import time
+    from .optical.observer import RectFrameSampler2D
+    nx, ny = cam.pixels
+    bounds = [(nx * r) // world_size for r in range(world_size)] + [nx]
+    if world_size == 1:
+        return bounds
+    engine = cam.render_engine
+    saved = engine.sample_offset
+    engine.sample_offset = 1 << 40
+    for _ in range(rounds):
+        cam.frame_sampler = RectFrameSampler2D(rect=tile_rect(rank, world_size, nx, ny, bounds))
+        cam.observe()
+        synchronize()
+        reps, spent = 1, 0.0
+        while True:
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                cam.observe()
+            synchronize()
+            spent = time.perf_counter() - t0
+            if spent >= min_seconds or reps >= 64:
+                break
+            reps *= 4
+        times = [float(t) for t in allgather(spent / reps)]
+        bounds = [int(b) for b in rebalance_bounds(bounds, times, nx, quantum)]
+    for pipe in cam.pipelines:                              # the timed passes are not part of the render: drop their frames
+        frame = getattr(pipe, "frame", None)
+        if frame is not None:
+            frame.release()
+            pipe.frame = None
+    engine.sample_offset = saved
+    cam.frame_sampler = RectFrameSampler2D(rect=tile_rect(rank, world_size, nx, ny, bounds))
+    return bounds
+
+
 def combine_arrays(ma, va, na, mb, vb, nb):
     """Vectorised numpy restatement of _combine_samples (core/math/statsarray.pyx:780-859): returns combine(a, b)."""
     ma, va, mb, vb = (np.asarray(x, dtype=np.float64) for x in (ma, va, mb, vb))
@@ -259,6 +304,10 @@ class FrameComm:
         v = C.c_double(float(value))
         _lib.check(_lib.lib().rsx_comm_max_f64(self._h, C.byref(v)))
         return float(v.value)
+
+    def allgather_scalar(self, value):
+        """[value of rank 0, ..., value of rank W-1] on every rank (W max-reductions of one double: control-plane sized)."""
+        return [self.max(value if r == self.rank else float("-inf")) for r in range(self.world_size)]
 
     def allgather_tiles(self, frame, nx, ny, bounds=None):
         """frame: StatsArray3D whose column tile tile_rect(rank) this rank rendered; afterwards the whole frame on every rank."""

@@ -524,6 +524,7 @@ class _ObserverBase(Observer):
             return
         self._slices = slices
         self.stats = {"rays": 0, "kernel_ms": 0.0}
+        self._check_counter_layout(self.render_engine)
         self._pass_offset = self.pass_sample_offset(self.render_engine)
         # The slices fill disjoint bins of the frames, so on the device their passes need not wait for one another: a HipEngine
         # render of several slices defers the end-of-pass checks of path-traced scenes (librsx: rsx_defer_path_checks) and the
@@ -576,6 +577,16 @@ class _ObserverBase(Observer):
         self.stats["rays"] = self.stats.get("rays", 0) + rays
         for k in failed:                                    # (term arena ran out, too many volumes at a point: the ordinary retry path)
             calls[k]()
+
+    @staticmethod
+    def _check_counter_layout(engine):
+        """sample_stride = N interleaves the ranks' passes (rank r, pass p: counters (p * N + r) * pixel_samples ...); a call of K passes
+        draws K * pixel_samples consecutive counters and would run into the next rank's. The two do not compose: a sample-sharded
+        process that wants K passes per call places every call itself (engine.sample_offset =
+        distributed.rank_sample_offset(call, rank, N, K * pixel_samples), sample_stride left at 1)."""
+        if int(getattr(engine, "sample_stride", 1)) > 1 and int(getattr(engine, "passes_per_call", 1)) > 1:
+            raise ValueError("sample_stride > 1 with passes_per_call > 1: the K passes of one call would reuse the Philox counters of the next "
+                             "rank's pass; assign engine.sample_offset per call (distributed.rank_sample_offset with spp = K * pixel_samples) instead")
 
     def pass_sample_offset(self, engine):
         """First Philox sample counter of the pass about to be rendered: the engine's sample_offset plus the samples this observer's

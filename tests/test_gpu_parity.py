@@ -1444,6 +1444,65 @@ def test_arena_csg_scene_passes_do_not_share_node_states(orc, ns):
 
 
 
+@pytest.mark.parametrize("world_size", [2, 3, 8])
+def test_multi_rank_exchange_through_transport_stub(ns, tmp_path, world_size):
+    """librsx's multi-rank framebuffer exchange (csrc/rsx_comm.hpp; the reference's counterpart: the result queue of
+    workflow.py:201-251 folded by power.pyx:424-437) EXECUTED with W = 2, 3 and 8 ranks on the one GPU of the box: W processes share
+    device 0 and librsx talks to tests/stub_rccl/librccl_stub.so (RSX_RCCL_LIB) — the eleven nccl* symbols over files, group
+    semantics kept — so gather_runs' (me +- k) % W schedule, rsx_frame_segment's offsets on the device, the [W][mine] fold of
+    rsx_allreduce_frame, k_pack_bins and the chunked workspace of rsx_allgather_bins all run. Tile and slice sharding: every rank's
+    exchanged frame equals the one-process render bit for bit; sample sharding: every rank holds the same frame (bit for bit) and it
+    equals the one-process render of the same W x passes x spp samples within the merge's tolerance (the fold associates
+    differently from a sequential accumulation — 1e-12 relative on the mean, 16 eps (mean^2 + var) per merged pass on the variance),
+    sample counts exact."""
+    import shutil
+    import subprocess
+    import sys
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    stub = str(tmp_path / "librccl_stub.so")
+    subprocess.check_call([hipcc, "-shared", "-fPIC", "-O2", os.path.join(ROOT, "tests", "stub_rccl", "rccl_stub.cpp"), "-o", stub])
+    modes = "tile,tile_balanced,sample,slice,slice_chunked"
+    env = dict(os.environ, RSX_RCCL_LIB=stub, RSX_STUB_DIR=str(tmp_path), RSX_DEVICE="0", RSX_STUB_TIMEOUT_S="240")
+    procs = []
+    for r in range(world_size):
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stub_rccl", "worker.py"), str(r), str(world_size), str(tmp_path), modes],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-1500:] for o in outs)
+    # the one-process renders
+    NX, NY, SPP, BINS, PASSES = 72, 40, 3, 6, 2
+
+    def single(slices, passes, spp_offsets):
+        world, mesh, box = scenes.build_c2(ns, n=24)
+        cam, pipe = scenes.c2_camera(ns, world, (NX, NY), spp=SPP, bins=BINS)
+        cam.spectral_rays = slices
+        cam.render_engine = ns.HipEngine(rng="philox", seed=77)
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        for off in spp_offsets:
+            cam.render_engine.sample_offset = off
+            cam.observe()
+        f = pipe.frame
+        return np.array(f.mean), np.array(f.variance), np.array(f.samples)
+
+    ref_tile = single(1, PASSES, [p * SPP for p in range(PASSES)])
+    ref_slice = single(BINS, PASSES, [p * SPP for p in range(PASSES)])
+    ref_sample = single(1, PASSES * world_size, [k * SPP for k in range(PASSES * world_size)])       # the same counters, all on one rank
+    load = lambda mode, r: np.load(str(tmp_path / ("%s_rank%d.npz" % (mode, r))))
+    for r in range(world_size):
+        for mode, ref in (("tile", ref_tile), ("tile_balanced", ref_tile), ("slice", ref_slice), ("slice_chunked", ref_slice)):
+            got = load(mode, r)
+            assert eq(got["mean"], ref[0]) and eq(got["variance"], ref[1]) and eq(got["samples"], ref[2]), (mode, r)
+        got = load("sample", r)
+        first = load("sample", 0)
+        assert eq(got["mean"], first["mean"]) and eq(got["variance"], first["variance"]) and eq(got["samples"], first["samples"]), r
+    got = load("sample", 0)
+    assert eq(got["samples"], ref_sample[2]) and (got["samples"] == PASSES * world_size * SPP).all()
+    assert np.allclose(got["mean"], ref_sample[0], rtol=1e-12, atol=0.0)
+    eps = np.finfo(np.float64).eps
+    assert (np.abs(got["variance"] - ref_sample[1]) <= 16 * eps * (ref_sample[0] ** 2 + ref_sample[1]) * (PASSES * world_size)).all()
+    assert ref_tile[0].max() > 0 and ref_slice[0].max() > 0
+
+
 def test_toolchain_divergent_loop_exit_workaround(tmp_path):
     """hipcc 7.2 miscompiles per-lane loops that the lanes of a wave leave at different turns through a `return` / `continue` in the
     middle of the body (tests/toolchain/divergent_loop_exit.hip holds both forms of one loop and says so in its output). librsx writes

@@ -364,6 +364,17 @@ def test_passes_per_call_bookkeeping(ns):
     cam.render_engine = ns.HipEngine(passes_per_call=4)
     pieces = cam._pieces(cam._generate_tasks(), world)
     assert len(pieces) == 2 and pieces[0]["rect"] == (0, 0, 32, 32)    # (4 passes x 3 spp per pixel: half the frame per call)
+    # sample_stride interleaves the ranks' single passes; K passes per call would run into the next rank's counters: refused, loudly
+    cam.render_engine = ns.HipEngine(passes_per_call=4, sample_stride=2, sample_offset=3)
+    with pytest.raises(ValueError, match="sample_stride"):
+        cam._check_counter_layout(cam.render_engine)
+    cam._check_counter_layout(ns.HipEngine(passes_per_call=4))
+    cam._check_counter_layout(ns.HipEngine(sample_stride=2, sample_offset=3))
+    # ... the documented way: every call placed by hand, blocks of K x spp counters per rank
+    from source_amd import distributed as D
+    K, spp, N = 4, 3, 2
+    blocks = sorted((D.rank_sample_offset(call, rank, N, K * spp), K * spp) for call in range(3) for rank in range(N))
+    assert all(blocks[i][0] + blocks[i][1] == blocks[i + 1][0] for i in range(len(blocks) - 1)) and blocks[0][0] == 0
 
 
 def test_coherent_task_order(ns):
