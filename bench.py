@@ -602,6 +602,8 @@ def main():
     sync()
     barrier()
     sync()
+    from source_amd.optical import observer as observer_mod
+    calls_before = observer_mod.LIBRARY_CALLS[0]
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -628,9 +630,13 @@ def main():
 
     # per-launch kernel durations of the timed steps (HIP events recorded by librsx on its launch stream): one library call per
     # spectral slice; a fused pass (Welford inside the trace kernel) has no second kernel
-    n_hist = max(1, min(args.steps * my_slices, 512))
+    # (small passes are batched — HipEngine.auto_batch: K observe() calls, one library call — so a launch may cover several steps)
+    calls_timed = max(1, observer_mod.LIBRARY_CALLS[0] - calls_before)
+    n_hist = max(1, min(calls_timed, 512))
     trace_ms, accum_ms = ctx.render_history(n_hist)
     trace_avg, accum_avg = float(np.mean(trace_ms)), float(np.mean(accum_ms))
+    steps_per_launch = args.steps * my_slices / calls_timed       # 1 unless passes were batched
+    rays_per_launch = rays_per_step_rank / my_slices * steps_per_launch
     fused = accum_avg < 0.05                               # (two back-to-back event records: microseconds)
 
     out = None
@@ -697,7 +703,7 @@ def main():
             b_ray, per_ray = ray_bytes(cnt, len(tasks))
             if fused:
                 b_ray += 40.0 * BINS / SPP - 24.0
-            achieved = b_ray * rays_per_step_rank / (trace_avg * 1e-3) / 1e9
+            achieved = b_ray * rays_per_launch * my_slices / (trace_avg * 1e-3) / 1e9
             hbm_contract = {"bytes_per_ray": round(b_ray, 1), "per_ray": {k: round(v, 3) for k, v in per_ray.items()}, "achieved": round(achieved, 2),
                             "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBS, 5),
                             "note": "SURVEY 8d algorithmic bytes per ray x rays per launch / kernel time against the 8 TB/s HBM peak. The bytes are node / "
@@ -724,7 +730,7 @@ def main():
                      "triangle_records_48B": 48.0 * pc[6], "mesh_headers_96B": 96.0 * pc[3],
                      "sample_ring_write_read": 2.0 * 24.0 * WAVE_RAYS, "frame_read_write": 40.0 * BINS * ppu, "work_list": 4.0}
             b_unit = float(sum(parts.values()))
-            units = rays_per_step_rank / WAVE_RAYS
+            units = rays_per_launch / WAVE_RAYS
             achieved_w = b_unit * units / (trace_avg * 1e-3) / 1e9
             hbm_per_wave = {"bytes_per_unit": round(b_unit, 1), "per_unit": {k: round(float(v), 3) for k, v in per_unit.items()},
                             "bytes": {k: round(float(v), 1) for k, v in parts.items()}, "units_per_launch": int(units),
@@ -734,14 +740,16 @@ def main():
                                     "per launch / kernel time against the 8 TB/s HBM peak; compare bytes_per_launch with hbm_measured.bytes_per_launch"}
         # ---- roofline: top level = ONE ceiling, the one that binds the dominant kernel, from the counters of this run
         roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
-                    "kernel": kernel_prefix, "kernel_ms": round(trace_avg * my_slices, 4), "launches_per_step": my_slices,
+                    "kernel": kernel_prefix, "kernel_ms": round(trace_avg * my_slices / steps_per_launch, 4), "launches_per_step": round(my_slices / steps_per_launch, 4),
+                    "kernel_ms_per_launch": round(trace_avg, 4), "steps_per_launch": round(steps_per_launch, 3), "rays_per_launch": int(rays_per_launch),
                     "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices, 4),
                     "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract, "hbm_per_wave": hbm_per_wave}
         if my_slices > 1:
             roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on up to eight streams and overlap, so "
                                           "the sum exceeds ms_per_step" % my_slices)
         if not args.no_pmc and world_size == 1:
-            table, note = collect_pmc(args.workload, 3 if SLICES == 1 else 1, args.pmc_keep, PPC)
+            # (batched small passes: the child renders the timed region's own number of steps, so that its launches are the timed ones)
+            table, note = collect_pmc(args.workload, args.steps if steps_per_launch > 1 else (3 if SLICES == 1 else 1), args.pmc_keep, PPC)
             if table is None:
                 roofline["pmc_error"] = note
             else:

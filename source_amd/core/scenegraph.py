@@ -8,6 +8,8 @@ objects they flatten the scenegraph once (source_amd/_flatten.py), upload it to 
 traversal kernels through librsx (include/rsx.h). A GEOMETRY change invalidates the device scene the same
 way it invalidates the reference's accelerator (world.pyx:220-238).
 """
+import weakref
+
 from .math import AffineMatrix3D, Point3D, Vector3D
 
 
@@ -315,6 +317,7 @@ class World(Node):
         self._rebuild_accelerator = True
         self._device_scene = None
         self._accelerator = HipAccelerator(self)
+        self._lazy_observers = weakref.WeakSet()            # observers holding accepted, not yet submitted passes (_settle_observers)
         super().__init__(None, None, name)
 
     @property
@@ -350,6 +353,7 @@ class World(Node):
         return list(self._observers)
 
     def _register(self, node):                              # world.pyx:196-207
+        self._settle_observers()
         if isinstance(node, Primitive):
             self._primitives.append(node)
             self._rebuild_accelerator = True
@@ -357,6 +361,7 @@ class World(Node):
             self._observers.append(node)
 
     def _deregister(self, node):                            # world.pyx:209-218
+        self._settle_observers()
         if isinstance(node, Primitive):
             self._primitives.remove(node)
             self._rebuild_accelerator = True
@@ -364,8 +369,16 @@ class World(Node):
             self._observers.remove(node)
 
     def _change(self, node, change):                        # world.pyx:220-238
+        self._settle_observers()
         if change is GEOMETRY:
             self._rebuild_accelerator = True
+
+    def _settle_observers(self):
+        """Passes that observers have accepted but not yet submitted (PinholeCamera batches small passes) are rendered before the
+        scenegraph changes under them."""
+        for obs in list(self._lazy_observers):
+            self._lazy_observers.discard(obs)
+            obs._flush_lazy()
 
     # -- device scene management ---------------------------------------------------------------
     def flatten(self):

@@ -13,6 +13,14 @@ from .core.math import Normal3D, Point3D
 from .core.scenegraph import Intersection, MeshIntersection
 
 _contexts = {}
+pending_observers = weakref.WeakSet()      # observers holding accepted, not yet submitted passes (optical/observer.py: _lazy_pass)
+
+
+def settle_observers():
+    """Renders the passes observers have accepted but not yet submitted (small passes are batched into one library call)."""
+    for obs in list(pending_observers):
+        pending_observers.discard(obs)
+        obs._flush_lazy()
 
 
 class DeviceContext:
@@ -50,6 +58,7 @@ class DeviceContext:
         _lib.check(_lib.lib().rsx_set_stream(self._h, C.c_void_p(hip_stream) if hip_stream else None))
 
     def synchronize(self):
+        settle_observers()                                  # (work an observer is still holding back counts as issued)
         _lib.check(_lib.lib().rsx_synchronize(self._h))
 
     def defer_path_checks(self, on):

@@ -369,6 +369,25 @@ def test_philox_frame_vs_oracle_full_size(orc, ns):
 
 
 
+@pytest.mark.parametrize("spp", [12, 16])
+def test_packet_form_frame_vs_oracle_directly(orc, ns, spp):
+    """The packet walk (dev_packet.hpp) tied to the oracle WITHOUT the per-lane kernel in between: whole frames of the instanced
+    scene of configs[2] and of the single-mesh scene of configs[1] at 12 samples per pixel (units cut across pixels, separate
+    Welford kernel) and 16 (four pixels per unit, Welford fused into the trace kernel) — mean and variance equal the oracle's
+    bit for bit (kdtree3d.pyx:609-700, mesh.pyx:506-713, statsarray.pyx:743-776 per ray of each packet)."""
+    for build, camera, size in ((lambda: scenes.build_c3(ns, n=40)[0], scenes.c3_camera, (160, 96)), (lambda: scenes.build_c2(ns, n=48)[0], scenes.c2_camera, (128, 96))):
+        world = build()
+        cam, pipe = camera(ns, world, size, spp=spp, bins=7)
+        cam.render_engine = ns.HipEngine(rng="philox", seed=23, auto_batch=False)
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.observe()
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0) + size)
+        m, v, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+        assert eq(pipe.frame.mean, m.reshape(size[1], size[0], 7).transpose(1, 0, 2)) and eq(pipe.frame.variance, v.reshape(size[1], size[0], 7).transpose(1, 0, 2))
+        assert (pipe.frame.samples == spp).all() and pipe.frame.variance.max() > 0
+
+
 def _full_size_properties(orc, ns, world, cam, pipe, make_camera, strip_rows, spp, seed):
     """Shared body of the BASELINE full-size checks: one Philox pass on the device, then
       (1) every frame element holds exactly spp samples, mean finite,
@@ -996,7 +1015,7 @@ def test_pipelining_does_not_change_frames():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     digests = []
     for depth in ("1", "3", "4"):
-        env = dict(os.environ, RSX_PIPELINE=depth, KB_WARM="20")
+        env = dict(os.environ, RSX_PIPELINE=depth, KB_WARM="20", RSX_AUTO_BATCH="0")      # (every pass its own launch: that is what is under test)
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "kbench.py"), "100", "c2"], env=env, capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         digests.append(json.loads(out.stdout.strip().splitlines()[-1])["digest"])
@@ -1501,6 +1520,66 @@ def test_multi_rank_exchange_through_transport_stub(ns, tmp_path, world_size):
     eps = np.finfo(np.float64).eps
     assert (np.abs(got["variance"] - ref_sample[1]) <= 16 * eps * (ref_sample[0] ** 2 + ref_sample[1]) * (PASSES * world_size)).all()
     assert ref_tile[0].max() > 0 and ref_slice[0].max() > 0
+
+
+def test_auto_batched_passes_equal_separate_passes(orc, ns):
+    """HipEngine.auto_batch (on by default): consecutive small observe() calls are held back and submitted as one library call. The
+    frames must be those of the separate passes bit for bit — whatever ends a batch: a full unit (64 / spp passes), a read of the
+    frame, ctx.synchronize(), a scenegraph change, a changed camera or engine setting — and one batch is also checked directly against
+    the oracle (observer.pyx:265-309 called K times, power.pyx:424-437 merging each pass)."""
+    from source_amd.device import get_context
+
+    def run(auto, spp, script):
+        world, mesh, box = scenes.build_c2(ns, n=24)
+        cam, pipe = scenes.c2_camera(ns, world, (96, 64), spp=spp, bins=5)
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=3, auto_batch=auto)
+        seen = []
+        for step in script:
+            if step == "observe":
+                cam.observe()
+                assert cam.stats["rays"] == 96 * 64 * spp
+            elif step == "read":
+                seen.append(np.array(pipe.frame.mean).sum())
+            elif step == "sync":
+                get_context().synchronize()
+            elif step == "move":
+                mesh.transform = ns.translate(0.01, 0.0, 0.0) * (mesh.transform or ns.translate(0, 0, 0))
+            elif step == "camera":
+                cam.fov = 40
+            elif step == "offset":
+                cam.render_engine.sample_offset = 1000
+            elif step == "shuffled":
+                cam.frame_sampler = ns.FullFrameSampler2D()
+        f = pipe.frame
+        return np.array(f.mean), np.array(f.variance), np.array(f.samples), seen, world, cam, pipe
+
+    scripts = {
+        1: ["observe"] * 70 + ["read"] + ["observe"] * 3 + ["sync"] + ["observe"] * 5 + ["move"] + ["observe"] * 4 + ["camera"] + ["observe"] * 3
+           + ["offset"] + ["observe"] * 6 + ["shuffled"] + ["observe"] * 5,
+        2: ["observe"] * 33 + ["move"] + ["observe"] * 2 + ["read"] + ["observe"] * 31,
+        16: ["observe"] * 9,
+    }
+    for spp, script in scripts.items():
+        a = run(True, spp, script)
+        b = run(False, spp, script)
+        assert eq(a[0], b[0]) and eq(a[1], b[1]) and eq(a[2], b[2]) and a[3] == b[3], spp
+        assert (a[2] == spp * script.count("observe")).all()
+    # one batch against the oracle: 4 passes of 2 spp = the pixel's samples 0 .. 7, merged pass by pass
+    m, v, n, _, world, cam, pipe = run(True, 2, ["observe"] * 4)
+    flat = world.flatten()
+    from source_amd import distributed as D
+    om = ov = on = None
+    for p in range(4):
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 96, 64), sample_offset=2 * p)
+        pm, pv, rays = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+        pm, pv = pm.reshape(64, 96, 5).transpose(1, 0, 2), pv.reshape(64, 96, 5).transpose(1, 0, 2)
+        if om is None:
+            om, ov, on = pm, pv, np.full(pm.shape, 2, dtype=np.int32)
+        else:
+            om, ov, on = D.combine_arrays(om, ov, on, pm, np.maximum(pv, 0.0), np.full(pm.shape, 2, dtype=np.int32))
+    assert eq(n, on) and np.allclose(m, om, rtol=1e-13, atol=0) and np.allclose(v, ov, rtol=1e-9, atol=1e-300)
 
 
 def test_toolchain_divergent_loop_exit_workaround(tmp_path):
