@@ -1621,7 +1621,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
                 PathState *const queue = ps.queue;
                 ps.queue = nullptr;                                            // (the redo pass — usually a handful of paths — keeps them)
-                if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), l.grid))) return rc;
+                // The redo pass carries the stream merge: one wave per SIMD, a whole register file per wave — each of its workgroups has to
+                // wait for a CU whose SIMDs have drained completely, behind the persistent workgroups of the other slices in flight, and
+                // the slice's k_accumulate waits behind it. It usually finds a handful of paths (units are strided over whatever grid
+                // there is), so among overlapping slices it brings a small grid: few places to wait for. RSX_REDO_GRID pins the size.
+                static const int redo_grid_env = [] { const char *e = std::getenv("RSX_REDO_GRID"); return e ? std::atoi(e) : 0; }();
+                const unsigned redo_wgs = redo_grid_env > 0 ? (unsigned)redo_grid_env : deferred ? 32u : l.grid.x;
+                if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), dim3(std::min(l.grid.x, redo_wgs))))) return rc;
                 ps.queue = queue;
             } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), nullptr, l.grid))) return rc; }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass

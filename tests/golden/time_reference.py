@@ -5,7 +5,8 @@ the oracle's rays/s measured on the GPU box (bench.py cpu_baseline, kind "port")
 
     bash tests/golden/build_reference.sh && python tests/golden/time_reference.py [pixels] [c2|c3] [spp]
 
-Scene: BASELINE configs[1] (c2: 69 432-triangle mesh) or configs[2] (c3: 15 instances of it + floor box), pinhole camera,
+Scene: BASELINE configs[1] (c2: 69 432-triangle mesh), configs[2] (c3: 15 instances of it + floor box) or configs[0]'s Cornell box
+(c1: path traced; the rates are primary rays per second), pinhole camera,
 `pixels` x `pixels`, `spp` samples / pixel, 15 bins. The result is merged into tests/golden/reference_timing.json (committed:
 bench.py reports it as cpu_baseline.reference next to the oracle's rate on the GPU box).
 """
@@ -27,7 +28,7 @@ import raysect  # noqa: E402
 from raysect.core import SerialEngine, MulticoreEngine, Point3D, Vector3D, translate, rotate  # noqa: E402
 from raysect.primitive import Mesh, Sphere, Box, Cylinder, Union, Intersect, Subtract  # noqa: E402
 from raysect.optical import World, ConstantSF, InterpolatedSF  # noqa: E402
-from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter  # noqa: E402
+from raysect.optical.material import AbsorbingSurface, UniformSurfaceEmitter, Lambert, Dielectric, Sellmeier  # noqa: E402
 from raysect.optical.material.debug import Light  # noqa: E402
 from raysect.optical.observer import PinholeCamera, FullFrameSampler2D, SpectralRadiancePipeline2D, SpectralPowerPipeline2D  # noqa: E402
 
@@ -38,6 +39,7 @@ REFNS = types.SimpleNamespace(
     World=World, Mesh=Mesh, Sphere=Sphere, Box=Box, Cylinder=Cylinder, Union=Union, Intersect=Intersect, Subtract=Subtract,
     Point3D=Point3D, Vector3D=Vector3D, translate=translate, rotate=rotate, ConstantSF=ConstantSF, InterpolatedSF=InterpolatedSF,
     AbsorbingSurface=AbsorbingSurface, UniformSurfaceEmitter=UniformSurfaceEmitter, Light=Light, PinholeCamera=PinholeCamera,
+    Lambert=Lambert, Dielectric=Dielectric, Sellmeier=Sellmeier,
     FullFrameSampler2D=FullFrameSampler2D, SpectralRadiancePipeline2D=SpectralRadiancePipeline2D,
     SpectralPowerPipeline2D=SpectralPowerPipeline2D)
 
@@ -48,6 +50,9 @@ out = {"workload": wl, "pixels": px, "spp": spp, "host_cpus": os.cpu_count(), "w
 
 
 def build(api):
+    if wl == "c1":                                          # the Cornell box of configs[0]: path traced (rays/s below = PRIMARY rays/s)
+        world = scenes.build_cornell(api)[0]
+        return world, scenes.cornell_camera(api, world, (px, px), spp=spp, bins=15)
     if wl == "c3":
         world = scenes.build_c3(api, n=132)[0]
         return world, scenes.c3_camera(api, world, (px, px), spp=spp, bins=15)
@@ -71,7 +76,7 @@ for threads in (1, 8):
     orc.render_pinhole(flat, desc, threads=threads)
     t0 = time.perf_counter()
     m, v, rays = orc.render_pinhole(flat, desc, threads=threads)
-    out["oracle_%d_threads_rays_per_s" % threads] = round(rays / (time.perf_counter() - t0), 1)
+    out["oracle_%d_threads_rays_per_s" % threads] = round(px * px * spp / (time.perf_counter() - t0), 1)
 out["oracle_1_over_reference_serial"] = round(out["oracle_1_threads_rays_per_s"] / out["reference_serial_rays_per_s"], 2)
 out["oracle_8_over_reference_multicore_8"] = round(out["oracle_8_threads_rays_per_s"] / out["reference_multicore_8_rays_per_s"], 2)
 print(json.dumps(out))
