@@ -486,6 +486,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) wide.t[j] = -1.0;
     wide.faces[0] = wide.faces[1] = 0;
+#ifndef PKT_ABLATE_WIDE                                  // (timing ablation: results are wrong)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (sc->wide[j] >= 0) {
@@ -495,6 +496,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
             wide.faces[0] |= (uint32_t)f << (8 * j);
         }
     }
+#endif
     double t_cull = INFINITY;
 #pragma unroll
     for (int j = 0; j < 2; ++j) if (wide.t[j] >= 0.0 && wide.t[j] < t_cull) t_cull = wide.t[j];

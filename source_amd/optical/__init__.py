@@ -41,6 +41,8 @@ class World(_CoreWorld):
 
     # -- the sampling half of the ImportanceManager, host form (world.pyx:130-230): what a material's evaluate_surface calls ------
     def _spheres_cached(self):
+        if getattr(self, "_important_frozen", False):       # (inside one host-callback render: the scene cannot change between two hits)
+            return self._important
         key = (id(self._device_scene), self._rebuild_accelerator, tuple(id(p.material) for p in self._primitives),
                tuple(getattr(p.material, "importance", 0.0) for p in self._primitives))
         if getattr(self, "_important_key", None) != key:

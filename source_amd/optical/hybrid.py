@@ -149,6 +149,9 @@ class WaveScheduler:
             self.rays += 1
         saved = ray_module._scheduler
         ray_module._scheduler = self
+        if hasattr(self.world, "_spheres_cached"):
+            self.world._spheres_cached()                    # (validated once; frozen while materials are being evaluated)
+            self.world._important_frozen = True
         try:
             while self.need_hit:
                 batch, self.need_hit = self.need_hit, []
@@ -176,6 +179,7 @@ class WaveScheduler:
                         stack.append(n.parent)
         finally:
             ray_module._scheduler = saved
+            self.world._important_frozen = False
         return self.results
 
 

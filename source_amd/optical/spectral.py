@@ -77,8 +77,11 @@ class SpectralFunction:
     def integrate(self, min_wavelength, max_wavelength):
         raise NotImplementedError("Virtual method integrate() not implemented.")
 
-    def average(self, min_wavelength, max_wavelength):
-        return self.integrate(min_wavelength, max_wavelength) / (max_wavelength - min_wavelength)
+    def average(self, min_wavelength, max_wavelength):     # :135-169, with the reference's one-entry cache (a dielectric asks per hit)
+        key = (float(min_wavelength), float(max_wavelength))
+        if getattr(self, "_average_key", None) != key:
+            self._average_key, self._average_cache = key, self.integrate(min_wavelength, max_wavelength) / (max_wavelength - min_wavelength)
+        return self._average_cache
 
     def sample_mv(self, min_wavelength, max_wavelength, bins):
         return self.sample(min_wavelength, max_wavelength, bins)
