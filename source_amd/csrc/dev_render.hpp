@@ -28,6 +28,12 @@ __device__ __forceinline__ void philox2(uint64_t seed, uint64_t pixel, uint64_t 
 #ifndef RSX_LPT_MAX_UNITS
 #define RSX_LPT_MAX_UNITS (1 << 18)   // passes with more 64-ray units than this are not re-ordered
 #endif
+// Per-unit timestamps (rsx_debug_unit_times: start, end, workgroup of every 64-ray unit) exist in tuning builds only (-DRSX_UNIT_STAMPS=1,
+// and whenever a profile build asks for its counters): carried through the walk, the start stamp and the buffer tests cost the
+// per-lane kernels registers in every production pass.
+#ifndef RSX_UNIT_STAMPS
+#define RSX_UNIT_STAMPS (RSX_PHASE_PROF || RSX_UTIL_PROF)
+#endif
 struct RenderParams {
     rsx_camera cam;
     const rsx_material *materials;
@@ -419,7 +425,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));   // wave-uniform: keep it scalar
         }
         // (unit timestamps — rsx_debug_unit_times — are a per-lane-walk tuning aid: a pass that has them never takes the packet kernel)
-        const unsigned long long t_start = !PACKET && q->unit_times ? wall_clock64() : 0ULL;
+        const unsigned long long t_start = RSX_UNIT_STAMPS && !PACKET && q->unit_times ? wall_clock64() : 0ULL;
 #if RSX_PHASE_PROF == 2
         const unsigned long long ph2_u0 = clock64();
 #endif
@@ -490,7 +496,7 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
             if (c > 0x7fffffffULL) c = 0x7fffffffULL;
             q2->unit_cost[unit] = (uint32_t)c;
         }
-        if (!PACKET && q2->unit_times && lane == 0) {
+        if (RSX_UNIT_STAMPS && !PACKET && q2->unit_times && lane == 0) {
             q2->unit_times[12 * unit] = t_start;
             q2->unit_times[12 * unit + 1] = wall_clock64();
             q2->unit_times[12 * unit + 2] = ((unsigned long long)blockIdx.x << 8) | (threadIdx.x / WAVE);
