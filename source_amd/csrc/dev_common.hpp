@@ -38,6 +38,8 @@ struct DScene {
     const rsx_primitive *prims_uniform;   // = prims in global memory: what the scalar data path reads (the path kernel may point `prims` at an LDS copy)
     struct NodeSt *csg_arena;             // node states of the CSG stream merge for trees too big for the kernels' private arrays, or null:
     int32_t csg_arena_slots, csg_arena_lanes;   // [csg_arena_lanes][csg_arena_slots] (dev_csg.hpp: csg_slots)
+    int32_t wide_plain;        // bit j: wide[j] is a box without any transform (a floor, an enclosing emitter): the packet walk answers it in a form
+                               // specialised for rays that agree in the signs of their direction (dev_packet.hpp: plain_box_first_root)
     int32_t wsplits_bounded, csg_fast_rows;   // every split of the world tree lies inside [wlower, wupper] (packet_space, dev_packet.hpp);
                                           // LDS rows the state-free CSG evaluator needs: two per leaf of the scene's biggest flattened tree (0: none)
     const float4 *rel;                    // camera-relative leaf records of the mesh instances (dev_packet.hpp: RelInfo), or null

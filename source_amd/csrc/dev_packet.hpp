@@ -434,6 +434,51 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
     return hit;
 }
 
+// First root of a PLAIN box (DScene::wide_plain: no transform, so the ray in the box's space IS the world ray) for a packet whose rays
+// agree in the sign of every direction component, none of them zero — the rays of one pixel, nearly always. With uniform signs which
+// bound of a slab is the near one is a scalar fact: box_slab_rcp's / slab_rcp's `d != 0`, `d > 0` arms are resolved once for the wave
+// and both the BoundPrimitive gate (boundingbox.pyx:180-245, on the padded bounding box blo / bhi) and Box.hit (box.pyx:149-200, on the
+// box's own extents lo / hi) become straight lines of the same operations in the same order — the products (bound - origin) *
+// (1.0 / direction), merged with the reference's strict comparisons in axis order (the first axis wins a tie).
+// Out as analytic_first_root: t = -1, faces = 0 when there is no root.
+__device__ __forceinline__ void plain_box_first_root(const double (&blo)[3], const double (&bhi)[3], const double (&lo)[3], const double (&hi)[3], bool want,
+                                                     const Ray &r, double rx, double ry, double rz, bool neg_x, bool neg_y, bool neg_z, double &t, int32_t &faces) {
+    t = -1.0; faces = 0;
+    {   // the gate: aabb_rcp on the bounding box
+        double front = -INFINITY, back = INFINITY, a, b;
+        a = ((neg_x ? bhi[0] : blo[0]) - r.ox) * rx; b = ((neg_x ? blo[0] : bhi[0]) - r.ox) * rx;
+        if (a > front) front = a;
+        if (b < back) back = b;
+        a = ((neg_y ? bhi[1] : blo[1]) - r.oy) * ry; b = ((neg_y ? blo[1] : bhi[1]) - r.oy) * ry;
+        if (a > front) front = a;
+        if (b < back) back = b;
+        a = ((neg_z ? bhi[2] : blo[2]) - r.oz) * rz; b = ((neg_z ? blo[2] : bhi[2]) - r.oz) * rz;
+        if (a > front) front = a;
+        if (b < back) back = b;
+        want = want && !(front > back) && !(front < 0.0 && back < 0.0);
+    }
+    // Box.hit: faces packed as analytic_first_root returns them, (face + 1) | (axis + 1) << 4
+    const double nx = ((neg_x ? hi[0] : lo[0]) - r.ox) * rx, fx = ((neg_x ? lo[0] : hi[0]) - r.ox) * rx;
+    const double ny = ((neg_y ? hi[1] : lo[1]) - r.oy) * ry, fy = ((neg_y ? lo[1] : hi[1]) - r.oy) * ry;
+    const double nz = ((neg_z ? hi[2] : lo[2]) - r.oz) * rz, fz = ((neg_z ? lo[2] : hi[2]) - r.oz) * rz;
+    const int32_t near_x = ((neg_x ? UPPER_FACE : LOWER_FACE) + 1) | (1 << 4), far_x = ((neg_x ? LOWER_FACE : UPPER_FACE) + 1) | (1 << 4);
+    const int32_t near_y = ((neg_y ? UPPER_FACE : LOWER_FACE) + 1) | (2 << 4), far_y = ((neg_y ? LOWER_FACE : UPPER_FACE) + 1) | (2 << 4);
+    const int32_t near_z = ((neg_z ? UPPER_FACE : LOWER_FACE) + 1) | (3 << 4), far_z = ((neg_z ? LOWER_FACE : UPPER_FACE) + 1) | (3 << 4);
+    double near_t = -INFINITY, far_t = INFINITY;
+    int32_t nf = 0, ff = 0;                                // (NO_FACE, axis -1)
+    if (nx > near_t) { near_t = nx; nf = near_x; }
+    if (fx < far_t) { far_t = fx; ff = far_x; }
+    if (ny > near_t) { near_t = ny; nf = near_y; }
+    if (fy < far_t) { far_t = fy; ff = far_y; }
+    if (nz > near_t) { near_t = nz; nf = near_z; }
+    if (fz < far_t) { far_t = fz; ff = far_z; }
+    // pick_roots with the ray's own reach
+    if (want && !(near_t > far_t) && !(near_t > r.maxd || far_t < 0.0)) {
+        if (near_t >= 0.0) { t = near_t; faces = nf; }
+        else if (far_t <= r.maxd) { t = far_t; faces = ff; }
+    }
+}
+
 // World.hit for the packet (kdtree.pyx:73-122, boundprimitive.pyx:42-51): world_trace_wave<false, false, 1, true> with the walk above.
 // Leaf items are wave-uniform by construction (the wave is in ONE leaf); wide primitives, leaf tags and the cull as there.
 // CSG: the scene has CSG solids (k_render_trace<true, 1, ..., PACKET>): a solid in the state-free evaluator's form is answered for the whole
@@ -486,16 +531,32 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
 #pragma unroll
     for (int j = 0; j < 8; ++j) wide.t[j] = -1.0;
     wide.faces[0] = wide.faces[1] = 0;
+#ifdef RSX_ASM_MARKS
+    asm volatile("; MARK wide begin");
+#endif
 #ifndef PKT_ABLATE_WIDE                                  // (timing ablation: results are wrong)
+    // (signs of the direction components: wave-uniform and non-zero for the rays of a pixel, except where a pixel straddles an axis)
+    const lanemask m_negx = pkt_mask(r.dx < 0.0), m_negy = pkt_mask(r.dy < 0.0), m_negz = pkt_mask(r.dz < 0.0);
+    const bool signs_uniform = (m_negx == 0ULL || m_negx == ~0ULL) && (m_negy == 0ULL || m_negy == ~0ULL) && (m_negz == 0ULL || m_negz == ~0ULL) &&
+                               !pkt_any(r.dx == 0.0 || r.dy == 0.0 || r.dz == 0.0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (sc->wide[j] >= 0) {
             int32_t f = 0;
             RCP3
+            if (signs_uniform && ((sc->wide_plain >> j) & 1)) {
+                const UPrim wp = uniform_prim(sc->prims_uniform, sc->wide[j]);
+                const double blo[3] = {wp->box_lower[0], wp->box_lower[1], wp->box_lower[2]}, bhi[3] = {wp->box_upper[0], wp->box_upper[1], wp->box_upper[2]};
+                const double plo[3] = {wp->params[0], wp->params[1], wp->params[2]}, phi[3] = {wp->params[3], wp->params[4], wp->params[5]};
+                plain_box_first_root(blo, bhi, plo, phi, enters, r, rx, ry, rz, m_negx != 0ULL, m_negy != 0ULL, m_negz != 0ULL, wide.t[j], f);
+            } else
             analytic_first_root(sc->prims, uniform_prim(sc->prims_uniform, sc->wide[j]), sc->wide[j], enters, r, rx, ry, rz, wide.t[j], f);
             wide.faces[0] |= (uint32_t)f << (8 * j);
         }
     }
+#endif
+#ifdef RSX_ASM_MARKS
+    asm volatile("; MARK wide end");
 #endif
     double t_cull = INFINITY;
 #pragma unroll

@@ -756,6 +756,15 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
             for (size_t k = 0; k < cand.size() && k < 8; ++k) d.wide[k] = cand[k];
         }
+        d.wide_plain = 0;
+        for (int k = 0; k < 8; ++k) {
+            if (d.wide[k] < 0) continue;
+            const rsx_primitive &wp = desc->primitives[d.wide[k]];
+            static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+            bool plain = wp.type == RSX_PRIM_BOX;
+            for (int c = 0; plain && c < 12; ++c) plain = wp.to_local[c] == ident[c];      // (numerically: -0.0 entries leave x * 1 + y * 0 + z * 0 + 0 = x as well)
+            if (plain) d.wide_plain |= 1 << k;
+        }
         for (int32_t &w : d.wide_csg) w = -1;
         if (any_fast && !std::getenv("RSX_NO_WIDE_CSG")) {
             std::vector<int32_t> cand;
