@@ -345,6 +345,29 @@ __device__ __forceinline__ void packet_leaf_scan(const TriRay &q, int ix, int iy
     }
 }
 
+// aabb_rcp (dev_common.hpp; BoundingBox3D.intersect, boundingbox.pyx:180-245) for a packet whose rays agree in the sign of every direction
+// component, none of them zero: slab_rcp's `d != 0` / `d > 0` arms are resolved once for the wave (neg_* scalar), the rest is the same
+// operations in the same order. `uniform` false (wave-uniform): the general form.
+__device__ __forceinline__ bool aabb_rcp_signed(bool uniform, bool neg_x, bool neg_y, bool neg_z, const double *lo, const double *hi, const Ray &r,
+                                                double rx, double ry, double rz, double &front, double &back) {
+    if (!uniform) return aabb_rcp(lo, hi, r, rx, ry, rz, front, back);
+    front = -INFINITY;
+    back = INFINITY;
+    double a, b;
+    a = ((neg_x ? hi[0] : lo[0]) - r.ox) * rx; b = ((neg_x ? lo[0] : hi[0]) - r.ox) * rx;
+    if (a > front) front = a;
+    if (b < back) back = b;
+    a = ((neg_y ? hi[1] : lo[1]) - r.oy) * ry; b = ((neg_y ? lo[1] : hi[1]) - r.oy) * ry;
+    if (a > front) front = a;
+    if (b < back) back = b;
+    a = ((neg_z ? hi[2] : lo[2]) - r.oz) * rz; b = ((neg_z ? lo[2] : hi[2]) - r.oz) * rz;
+    if (a > front) front = a;
+    if (b < back) back = b;
+    if (front > back) return false;
+    if (front < 0.0 && back < 0.0) return false;
+    return true;
+}
+
 // MeshData.trace (mesh.pyx:506-563) for the packet: `m` and the ray space are wave-uniform, `want` = the lane's ray passed the
 // BoundPrimitive gate. Leaves of any size are walked the same way: every record comes in once over the scalar data path (the next one
 // while this one is tested) and every lane with a range tests it — in leaf order, strict `<`: the reference's own loop.
@@ -361,8 +384,10 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
         const double lo[3] = {m->lower[0], m->lower[1], m->lower[2]}, hi[3] = {m->upper[0], m->upper[1], m->upper[2]};
         const double rx = exact_div(1.0, r.dx, ad.yx, ad.safe & 1), ry = exact_div(1.0, r.dy, ad.yy, (ad.safe >> 1) & 1),
                      rz = exact_div(1.0, r.dz, ad.yz, (ad.safe >> 2) & 1);
-        if (!(want && aabb_rcp(lo, hi, r, rx, ry, rz, tmin, tmax))) tmax = PKT_EMPTY;       // kdtree3d.pyx:589-607
         ps = packet_space(r, ad, lo, hi, want, m->splits_bounded);
+        const bool uniform = (ps.neg[0] == 0ULL || ps.neg[0] == ~0ULL) && (ps.neg[1] == 0ULL || ps.neg[1] == ~0ULL) && (ps.neg[2] == 0ULL || ps.neg[2] == ~0ULL) &&
+                             !pkt_any(r.dx == 0.0 || r.dy == 0.0 || r.dz == 0.0);
+        if (!(want && aabb_rcp_signed(uniform, ps.neg[0] != 0ULL, ps.neg[1] != 0ULL, ps.neg[2] != 0ULL, lo, hi, r, rx, ry, rz, tmin, tmax))) tmax = PKT_EMPTY;       // kdtree3d.pyx:589-607
     }
     if (!pkt_any(tmax != PKT_EMPTY)) return false;
     PKT_COUNT(PKC_MVISITS, 1)
@@ -522,7 +547,12 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     }
     bool enters;
     const double wlo[3] = {sc->wlower[0], sc->wlower[1], sc->wlower[2]}, whi[3] = {sc->wupper[0], sc->wupper[1], sc->wupper[2]};
-    { RCP3 enters = valid && aabb_rcp(wlo, whi, r, rx, ry, rz, tmin, tmax); }
+    // (signs of the direction components: wave-uniform and non-zero for the rays of a pixel, except where a pixel straddles an axis)
+    const lanemask m_negx = pkt_mask(r.dx < 0.0), m_negy = pkt_mask(r.dy < 0.0), m_negz = pkt_mask(r.dz < 0.0);
+    const bool signs_uniform = (m_negx == 0ULL || m_negx == ~0ULL) && (m_negy == 0ULL || m_negy == ~0ULL) && (m_negz == 0ULL || m_negz == ~0ULL) &&
+                               !pkt_any(r.dx == 0.0 || r.dy == 0.0 || r.dz == 0.0);
+    const bool neg_x = m_negx != 0ULL, neg_y = m_negy != 0ULL, neg_z = m_negz != 0ULL;
+    { RCP3 enters = valid && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, wlo, whi, r, rx, ry, rz, tmin, tmax); }
     if (!enters) tmax = PKT_EMPTY;
     if (!pkt_any(enters)) { work_out = 0; return false; }
     const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);
@@ -535,10 +565,6 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     asm volatile("; MARK wide begin");
 #endif
 #ifndef PKT_ABLATE_WIDE                                  // (timing ablation: results are wrong)
-    // (signs of the direction components: wave-uniform and non-zero for the rays of a pixel, except where a pixel straddles an axis)
-    const lanemask m_negx = pkt_mask(r.dx < 0.0), m_negy = pkt_mask(r.dy < 0.0), m_negz = pkt_mask(r.dz < 0.0);
-    const bool signs_uniform = (m_negx == 0ULL || m_negx == ~0ULL) && (m_negy == 0ULL || m_negy == ~0ULL) && (m_negz == 0ULL || m_negz == ~0ULL) &&
-                               !pkt_any(r.dx == 0.0 || r.dy == 0.0 || r.dz == 0.0);
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         if (sc->wide[j] >= 0) {
@@ -548,7 +574,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                 const UPrim wp = uniform_prim(sc->prims_uniform, sc->wide[j]);
                 const double blo[3] = {wp->box_lower[0], wp->box_lower[1], wp->box_lower[2]}, bhi[3] = {wp->box_upper[0], wp->box_upper[1], wp->box_upper[2]};
                 const double plo[3] = {wp->params[0], wp->params[1], wp->params[2]}, phi[3] = {wp->params[3], wp->params[4], wp->params[5]};
-                plain_box_first_root(blo, bhi, plo, phi, enters, r, rx, ry, rz, m_negx != 0ULL, m_negy != 0ULL, m_negz != 0ULL, wide.t[j], f);
+                plain_box_first_root(blo, bhi, plo, phi, enters, r, rx, ry, rz, neg_x, neg_y, neg_z, wide.t[j], f);
             } else
             analytic_first_root(sc->prims, uniform_prim(sc->prims_uniform, sc->wide[j]), sc->wide[j], enters, r, rx, ry, rz, wide.t[j], f);
             wide.faces[0] |= (uint32_t)f << (8 * j);
@@ -615,7 +641,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                     if (type == RSX_PRIM_MESH) {
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                         double f, b;
-                        const bool gate = in && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                        const bool gate = in && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
 #ifdef PKT_ABLATE_MESH
                         if (false) {                                           // (timing ablation: results are wrong)
 #else
@@ -632,7 +658,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                     } else if (CSG && is_csg(type)) {
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                         double f, b;
-                        const bool gate = in && aabb_rcp(lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                        const bool gate = in && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, lo, hi, r, rx, ry, rz, f, b);      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
                         if (pkt_any(gate)) {
                             const CsgFast *table = sc->csgfast;
                             const RSX_CONST_AS CsgFast *flat = table ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(table + idx) : nullptr;
