@@ -256,8 +256,21 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
         if constexpr (!MULTI) {
             double m = value(0), v = 0;
             const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
+            // the operands of sample i + 1 (and the table id of sample i + 2, which the table read of i + 1 needs) are requested while the
+            // recurrence of sample i runs: read at the point of use, a step was three LDS round trips in a row (table id -> a, table row ->
+            // weight, behind a branch on the id) in front of twelve dependent f64 operations
+            auto at = [&](int i) { return base + (i < spp ? i : spp - 1); };
+            int32_t tab_n = l_tab[at(1)], tab_nn = l_tab[at(2)];
+            double a_n = l_a[at(1)], w_n = l_w[at(1)], t_n = tables[(tab_n < 0 ? 0 : tab_n) * bins + b];
             for (int i = 1; i < spp; ++i) {                                   // _add_sample, as k_accumulate's step(): divisors over the scalar data path,
-                const double x = value(i);                                    // both quotients by exact_div's shortcut, one wave-level range test per step
+                const int32_t tab_c = tab_n;                                  // both quotients by exact_div's shortcut, one wave-level range test per step
+                const double a_c = a_n, w_c = w_n, t_c = t_n;
+                tab_n = tab_nn; tab_nn = l_tab[at(i + 2)];
+                a_n = l_a[at(i + 1)]; w_n = l_w[at(i + 1)]; t_n = tables[(tab_n < 0 ? 0 : tab_n) * bins + b];
+                double x = a_c * t_c;                                         // x = (a * table[bin]) * weight [* sensitivity], absorbers (table < 0) give 0
+                x = tab_c < 0 ? 0.0 : x;
+                x = x * w_c;
+                x = x * scale;
                 const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
                 const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
                 const double pm = m, pv = v;
