@@ -1281,7 +1281,15 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // merge, so its passes run one after the other on the context stream)
     const bool one_at_a_time = scene->d.csg_arena != nullptr;
     const bool deferred = !one_at_a_time && has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
-    const bool pipelined = !one_at_a_time && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // (a call of several passes — rsx_render_desc.passes, what batched small passes arrive as — runs alone as well: on the context stream it
+    // may take the fused form, the recurrence and its K frame merges inside the packet kernel; on a private lane it would need
+    // k_accumulate's multi-pass form, which costs four times the trace of a 16-pass batch of configs[1]. RSX_BATCH_ALONE=0: as before)
+    static const bool batch_alone = [] { const char *e = std::getenv("RSX_BATCH_ALONE"); return !e || std::atoi(e) != 0; }();
+    // (desc->spp is the widened count here: passes x samples per pass; the packet walk's threshold as further down, without its env override)
+    const bool batch_fusable = batch_alone && passes > 1 && !has_vol && !scene->has_csg && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
+                               desc->spp >= (scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP) && fmean && !h_mean && !h_xyz;
+    const bool pipelined = !one_at_a_time && !batch_fusable && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 &&
+                           n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     // (two lanes for path passes: the path kernel fits two workgroups per CU, and each pass brings a grid of that size — the
     // next slice's workgroups move in as this slice's retire; prism, 32 slices: 3 lanes x 1 workgroup per CU 741 ms, 2 x 2 582 ms)
     // (round 3: up to eight lanes — with the trapped paths handed to a small drain launch a pass gives its workgroup places back after
