@@ -207,10 +207,10 @@ class StatsArray3D:
     def _settle(self):
         """Passes an observer has accepted but not yet submitted (PinholeCamera: consecutive small passes are batched into one
         library call) are rendered before anybody looks at — or replaces — the frame."""
-        owner = getattr(self, "_lazy_owner", None)
-        owner = owner() if owner is not None else None
-        if owner is not None:
-            owner._flush_lazy()
+        owners = getattr(self, "_lazy_owners", None)
+        if owners:
+            for owner in list(owners):                      # (several observers may accumulate into one pipeline's frame)
+                owner._flush_lazy()
 
     def _device(self, context, settle=True):
         """Device pointers of the frame (allocated and uploaded on first use)."""
@@ -853,6 +853,15 @@ class PinholeCamera(Observer2D):
             pend = None
         if sig is None:
             return False
+        if pend is not None:
+            # material parameters changed in place (no scenegraph notification: `emitter.scale = 2`) since the batch began? The pending
+            # calls hold the materials and spectral tables of their own moment; a pass that would send other bytes starts a new batch
+            keep = []
+            first, last = getattr(engine, "slice_range", None) or (0, len(templates))
+            probe = self.render_desc(world, None, self._slices[first], engine, keep, rect=(0, 0, 1, 1), sample_offset=0)
+            if self._material_bytes(probe, keep) != pend["materials"]:
+                self._flush_lazy()
+                pend = None
         if pend is None:
             # the library calls of this pass, built now — materials, tables, camera, Philox keys are those of THIS moment — and kept;
             # later passes of the batch only raise their `passes` count
@@ -872,10 +881,13 @@ class PinholeCamera(Observer2D):
                         desc = self.render_desc(world, None, sl, engine, keep, rect=piece["rect"], sample_offset=offset)
                         desc.power = 1 if pipe.power else 0
                         calls.append(dict(desc=desc, keep=keep, frame=pipe.frame, offset=sl.offset))
-            pend = self._lazy = dict(sig=sig, first=offset, count=0, calls=calls, scene=scene, rays=sum(c["desc"].n_tasks for c in calls) * spp // max(1, len(self._pipelines)))
-            me = weakref.ref(self)
+            pend = self._lazy = dict(sig=sig, first=offset, count=0, calls=calls, scene=scene, rays=sum(c["desc"].n_tasks for c in calls) * spp // max(1, len(self._pipelines)),
+                                     materials=self._material_bytes(calls[0]["desc"], calls[0]["keep"]))
             for pipe in self._pipelines:
-                pipe.frame._lazy_owner = me
+                owners = getattr(pipe.frame, "_lazy_owners", None)
+                if owners is None:
+                    owners = pipe.frame._lazy_owners = weakref.WeakSet()
+                owners.add(self)
             world._lazy_observers.add(self)
             from .. import device
             device.pending_observers.add(self)
@@ -884,6 +896,12 @@ class PinholeCamera(Observer2D):
         if pend["count"] * spp >= 64:
             self._flush_lazy()
         return True
+
+    @staticmethod
+    def _material_bytes(desc, keep):
+        """The material records and spectral tables a render call sends (render_desc puts both at the head of `keep`)."""
+        mat_arr, tab = keep[0], keep[1]
+        return bytes(mat_arr) + tab.tobytes()
 
     def _flush_lazy(self):
         """Submits the pending passes: one library call per (slice, block of pixels, pipeline) with passes = the number accepted."""

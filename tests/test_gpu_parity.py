@@ -1551,12 +1551,14 @@ def test_auto_batched_passes_equal_separate_passes(orc, ns):
                 cam.render_engine.sample_offset = 1000
             elif step == "shuffled":
                 cam.frame_sampler = ns.FullFrameSampler2D()
+            elif step == "brighter":                       # a material parameter changed in place: no scenegraph notification
+                box.material.scale = box.material.scale * 1.5
         f = pipe.frame
         return np.array(f.mean), np.array(f.variance), np.array(f.samples), seen, world, cam, pipe
 
     scripts = {
         1: ["observe"] * 70 + ["read"] + ["observe"] * 3 + ["sync"] + ["observe"] * 5 + ["move"] + ["observe"] * 4 + ["camera"] + ["observe"] * 3
-           + ["offset"] + ["observe"] * 6 + ["shuffled"] + ["observe"] * 5,
+           + ["offset"] + ["observe"] * 6 + ["shuffled"] + ["observe"] * 5 + ["brighter"] + ["observe"] * 3,
         2: ["observe"] * 33 + ["move"] + ["observe"] * 2 + ["read"] + ["observe"] * 31,
         16: ["observe"] * 9,
     }
