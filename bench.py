@@ -743,7 +743,7 @@ def main():
         roofline = {"bound": None, "achieved": None, "peak": None, "unit": None, "frac": None, "traffic": None,
                     "kernel": kernel_prefix, "kernel_ms": round(trace_avg * my_slices / steps_per_launch, 4), "launches_per_step": round(my_slices / steps_per_launch, 4),
                     "kernel_ms_per_launch": round(trace_avg, 4), "steps_per_launch": round(steps_per_launch, 3), "rays_per_launch": int(rays_per_launch),
-                    "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices, 4),
+                    "accumulate_kernel_ms": None if fused else round(accum_avg * my_slices / steps_per_launch, 4),
                     "welford": "fused into the trace kernel" if fused else "k_accumulate", "hbm_contract": hbm_contract, "hbm_per_wave": hbm_per_wave}
         if my_slices > 1:
             roofline["kernel_ms_note"] = ("sum over the %d launches of a step (one per spectral slice); the slices run on up to eight streams and overlap, so "
