@@ -114,6 +114,9 @@ __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, 
 }
 
 #define PKT_EMPTY (-INFINITY)
+#ifndef RSX_STEP_UNIFORM_ORIGIN
+#define RSX_STEP_UNIFORM_ORIGIN 1
+#endif
 
 // a value that is the same in every lane, declared so to the compiler (it then lives in scalar registers)
 __device__ __forceinline__ unsigned long long pkt_uniform64(unsigned long long v) {
@@ -198,7 +201,14 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
     // crosses the plane inside its range: not (:686) "plane > max_range or plane <= 0" (a lane without a range: plane <= -inf fails)
     const lanemask m_cross = pkt_mask(plane > 0.0) & pkt_mask(plane <= tmax);
     lanemask m_far = m_cross & pkt_mask(plane < tmin);                     // (:690) far child only
+    // (the packet's rays leave ONE point — the pinhole, or its image in a mesh's space: the callers hold the origin in scalar registers —
+    // and all 64 lanes are active in the walks, so m_lt is empty or full by construction: testing it for that cost every step a 64-bit
+    // add and a vector compare, 24.1 -> 23.2 ms on configs[2] without them. RSX_STEP_UNIFORM_ORIGIN=0 restores the test)
+#if RSX_STEP_UNIFORM_ORIGIN
+    if (__builtin_expect(m_eq == 0ULL, 1)) {
+#else
     if (__builtin_expect(m_eq == 0ULL && (m_lt == 0ULL || m_lt == ~0ULL), 1)) {
+#endif
         // Every lane has the same near child — rays from one origin that does not lie on the plane: the visit order is a scalar fact.
         const bool lower_near = m_lt != 0ULL;
         const int32_t near_id = lower_near ? lower : upper, far_id = lower_near ? upper : lower;
@@ -415,12 +425,18 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
     int32_t node = 0, sp = 0;
     for (;;) {
         UNode nd = load_node_u(nodes, node);
+#ifdef RSX_ASM_MARKS
+        asm volatile("; MARK mesh steps begin");
+#endif
         while (nd.type >= 0) {
             node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0 PKT_PASS);
             nd = load_node_u(nodes, node);
             work += 1;
             PKT_COUNT(PKC_MSTEPS, 1)
         }
+#ifdef RSX_ASM_MARKS
+        asm volatile("; MARK mesh steps end");
+#endif
 #ifdef PKT_ABLATE_TRIS
         const int32_t count = 0;                                               // (timing ablation: results are wrong)
 #else
