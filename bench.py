@@ -211,7 +211,7 @@ def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cp
         dt = min(timed(desc_t, t), timed(desc_t, t)) if n_t / rate1 / t < 0.5 else timed(desc_t, t)
         sweep.append({"threads": t, "rays_s": round(n_t / dt, 1), "rows": rows_t, "seconds": round(dt, 3)})
     top = max(e["rays_s"] for e in sweep)
-    best = min((e for e in sweep if e["rays_s"] >= 0.95 * top), key=lambda e: e["threads"])     # (the fewest threads that reach the best rate: beyond the quota more threads only time-slice)
+    best = min((e for e in sweep if e["rays_s"] >= 0.90 * top), key=lambda e: e["threads"])     # (the fewest threads that reach the best rate: beyond the quota more threads only time-slice)
     best_threads, rate = best["threads"], best["rays_s"]
     target = rate * cpu_seconds
     saved = cam.pixel_samples
