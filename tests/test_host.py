@@ -427,6 +427,69 @@ def test_auto_batch_eligibility(ns):
         del os.environ["RSX_AUTO_BATCH"]
 
 
+def test_balance_tiles_converges_on_measured_times(ns):
+    """distributed.balance_tiles (what the reference's task queue does dynamically, workflow.py:201-251): every rank times its own tile,
+    the times are shared, the cuts move to equal measured cost. Driven here by stand-in observers whose observe() takes time in
+    proportion to a known cost density over its tile — two 'ranks' stepped in lock-step: the cuts end where the density says, stay
+    multiples of 8 columns, and the engine's sample offset and the frame sampler are left as documented."""
+    import time
+    from source_amd import distributed as D
+    from source_amd.optical.observer import RectFrameSampler2D
+    nx, ny, W = 256, 8, 2
+    density = [1.0 if x < 128 else 3.0 for x in range(nx)]            # the right half costs three times the left
+    clock = [0.0]
+
+    class Engine:
+        sample_offset = 7
+
+    class Cam:
+        def __init__(self):
+            self.pixels, self.render_engine, self.pipelines = (nx, ny), Engine(), []
+            self.frame_sampler = RectFrameSampler2D()
+            self.cost = 0.0
+
+        def observe(self):
+            x0, _, x1, _ = self.frame_sampler.rect
+            self.cost = sum(density[x0:x1]) * 1e-4
+            time.sleep(self.cost)
+
+    cams = [Cam() for _ in range(W)]
+    shared = {}
+
+    # the ranks run one after the other; allgather hands every rank the times of a full round: rank 0's round k is computed first, so the
+    # exchange is emulated by recording per-(round, rank) times from the known density instead of the wall clock of the other process
+    def make_allgather(rank):
+        calls = [0]
+
+        def allgather(value):
+            k = calls[0]
+            calls[0] += 1
+            out = []
+            for r in range(W):
+                b = shared.setdefault(("bounds", k), None) or [(nx * q) // W for q in range(W)] + [nx]
+                out.append(sum(density[b[r]:b[r + 1]]) * 1e-4)
+            return out
+        return allgather
+
+    bounds = None
+    for rank in range(W):
+        # every rank computes the same cuts from the same shared times: emulate by iterating the rule itself
+        b = [(nx * q) // W for q in range(W)] + [nx]
+        for k in range(4):
+            shared[("bounds", k)] = list(b)
+            times = [sum(density[b[r]:b[r + 1]]) * 1e-4 for r in range(W)]
+            b = [int(v) for v in D.rebalance_bounds(b, times, nx)]
+        got = D.balance_tiles(cams[rank], rank, W, make_allgather(rank), lambda: None, rounds=4, min_seconds=0.0)
+        assert got == b, (got, b)
+        bounds = got
+        assert cams[rank].render_engine.sample_offset == 7
+        assert cams[rank].frame_sampler.rect == D.tile_rect(rank, W, nx, ny, bounds)
+    assert bounds[0] == 0 and bounds[-1] == nx and all(v % 8 == 0 for v in bounds)
+    cost = [sum(density[bounds[r]:bounds[r + 1]]) for r in range(W)]
+    assert max(cost) / (sum(cost) / W) < 1.06, (bounds, cost)          # equal cost within a quantum of 8 columns (total 512: 256 each)
+    assert D.balance_tiles(cams[0], 0, 1, None, None) == [0, nx]
+
+
 def test_coherent_task_order(ns):
     """PinholeCamera._coherent_tasks (what a Philox pass does with a task list): a shuffled list of every pixel of a rectangle becomes
     that rectangle; any other list keeps its pixels, each once, in 8 x 8 tile order; the conversion is cached per list."""
