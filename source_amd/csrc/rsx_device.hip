@@ -754,6 +754,18 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 if ((t == RSX_PRIM_SPHERE || t == RSX_PRIM_BOX || t == RSX_PRIM_CYLINDER) && leaves[(size_t)i] >= 2) cand.push_back(i);
             }
             std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
+            // A room of at most eight analytic primitives (a Cornell box): the ones that sit in a single leaf take the slots that are
+            // left (never the first two: those are what the two-slot kernels answer for every ray), so that EVERY leaf is tagged and
+            // every subtree can be culled against the nearest answer — a walk of such a world touches no primitive record at all.
+            // (Cornell box: the ceiling light sits in one leaf; a quarter of the Lambert samples aim at it.)
+            if (!std::getenv("RSX_NO_WIDE_ALL") && cand.size() >= 2 && desc->n_world <= 8) {
+                bool all_analytic = true;
+                for (int32_t i = 0; i < desc->n_world; ++i) {
+                    const int32_t t = desc->primitives[i].type;
+                    all_analytic = all_analytic && (t == RSX_PRIM_SPHERE || t == RSX_PRIM_BOX || t == RSX_PRIM_CYLINDER);
+                }
+                if (all_analytic) for (int32_t i = 0; i < desc->n_world; ++i) if (leaves[(size_t)i] == 1) cand.push_back(i);
+            }
             for (size_t k = 0; k < cand.size() && k < 8; ++k) d.wide[k] = cand[k];
         }
         d.wide_plain = 0;
