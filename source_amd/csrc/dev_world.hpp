@@ -116,6 +116,9 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
 #ifndef RSX_WORLD_CULL
 #define RSX_WORLD_CULL 1
 #endif
+#ifndef RSX_WIDE_PER_LANE
+#define RSX_WIDE_PER_LANE 1           // eight-slot kernels: the box slots' roots per lane, after wave-uniform gates (world_trace_wave)
+#endif
 #ifndef RSX_CSG_MAILBOX
 #define RSX_CSG_MAILBOX 4
 #endif
@@ -146,12 +149,57 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
 #if RSX_PHASE_PROF == 2
     const unsigned long long ph2_wd0 = clock64();
 #endif
+    // Scattered rays (eight slots): a ray inside a room passes the BoundPrimitive gate of two or three of its walls, yet a wave-uniform
+    // test per slot finds the roots of all eight boxes for as long as ANY lane passes each gate — a fifth of the lanes on each.
+    // So the gates of the box slots run wave-uniform (scalar-loaded boxes, full width) and leave each lane a mask of the boxes it
+    // has to answer; the roots are then found round by round, every lane on ITS next box (its record read per lane). Same
+    // arithmetic per (ray, box) as analytic_first_root: the gate, Point3D / Vector3D.transform, Box.hit's slabs.
+    uint32_t lane_boxes = 0;
 #pragma unroll
     for (int j = 0; j < WIDE_N; ++j) {
         if (sc.wide[j] >= 0) {                              // (wave-uniform)
+            const UPrim up = uniform_prim(sc.prims_uniform, sc.wide[j]);
+            if (WIDE_N == 8 && RSX_WIDE_PER_LANE && up->type == RSX_PRIM_BOX) {
+                const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+                double f, b;
+                if (active && aabb_rcp(lo, hi, r, rx, ry, rz, f, b)) lane_boxes |= 1u << j;
+                continue;
+            }
             int32_t f = 0;
-            analytic_first_root(sc.prims, uniform_prim(sc.prims_uniform, sc.wide[j]), sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
+            analytic_first_root(sc.prims, up, sc.wide[j], active, r, rx, ry, rz, wide.t[j], f);
             wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
+        }
+    }
+    if constexpr (WIDE_N == 8 && RSX_WIDE_PER_LANE) {
+        while (__any(lane_boxes != 0u)) {
+            const bool have = lane_boxes != 0u;
+            const int slot = have ? __builtin_ctz(lane_boxes) : 0;
+            lane_boxes &= lane_boxes - 1u;
+            int32_t idx = sc.wide[0];
+#pragma unroll
+            for (int q = 1; q < 8; ++q) if (slot == q) idx = sc.wide[q];
+            if (have) {
+                const rsx_primitive &p = sc.prims[idx];
+                const double *m = p.to_local;
+                Ray l;
+                double w = 1.0;                                               // (to_local_uniform's shortcut: an affine matrix has w == 1 exactly)
+                if (!(m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0)) { w = m[12] * r.ox + m[13] * r.oy + m[14] * r.oz + m[15]; w = 1.0 / w; }
+                l.ox = (m[0] * r.ox + m[1] * r.oy + m[2] * r.oz + m[3]) * w;
+                l.oy = (m[4] * r.ox + m[5] * r.oy + m[6] * r.oz + m[7]) * w;
+                l.oz = (m[8] * r.ox + m[9] * r.oy + m[10] * r.oz + m[11]) * w;
+                l.dx = m[0] * r.dx + m[1] * r.dy + m[2] * r.dz;
+                l.dy = m[4] * r.dx + m[5] * r.dy + m[6] * r.dz;
+                l.dz = m[8] * r.dx + m[9] * r.dy + m[10] * r.dz;
+                l.maxd = r.maxd;
+                Roots roots;
+                box_roots(p, l, roots);
+                if (roots.n > 0) {
+                    const uint32_t f = (uint32_t)((roots.a0[0] + 1) | ((roots.a1[0] + 1) << 4));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) if (slot == q) wide.t[q] = roots.t[0];
+                    if (slot < 4) wide.faces[0] |= f << (8 * slot); else wide.faces[1] |= f << (8 * (slot - 4));
+                }
+            }
         }
     }
     // the nearest of those answers: subtrees that hold wide primitives only and end before it are not entered (world_step)
