@@ -1151,6 +1151,15 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             pp_t3 = clock64();
 #endif
             ++segments;
+            // What the scattering materials' arms have in common runs once, outside them (the arms run one after the other for
+            // whatever lanes each has): the scattering draw of this depth before them — Lambert's (h1, h2) or, with important
+            // primitives, its (choose, pick); the Dielectric's reflect / transmit draw — and, behind them, the daughter's roulette
+            // and the term it leaves in the list.
+            double scatter1 = 0.0, scatter2 = 0.0;
+            if (!abandoned && segments < PATH_MAX_SEGMENTS && (mat.type == RSX_MAT_LAMBERT || mat.type == RSX_MAT_DIELECTRIC))
+                philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
+            bool daughter = false, lambert_term = false;
+            double term_a = 1.0, term_b = 1.0;                                // (a = b = 1: the replay multiplies every term's a and b in)
             if (abandoned) {}
             else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
             else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
@@ -1186,8 +1195,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 double h1, h2, sx, sy, sz, pdf_important = 0.0;
                 bool from_important = false;
                 if (mis) {
-                    double choose, pick;
-                    philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), choose, pick);
+                    const double choose = scatter1, pick = scatter2;
                     philox2(q->seed, rng_pixel | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
                     from_important = choose < q->important_path_weight;
                     double wx, wy, wz;
@@ -1220,7 +1228,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
                 } else {
                     double sn, cs;
-                    philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                    h1 = scatter1; h2 = scatter2;
                     const double rad = sqrt(h1);
                     portable_sincos(2.0 * M_PI * h2, sn, cs);
                     sx = rad * cs; sy = rad * sn;
@@ -1237,11 +1245,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
                     r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
                     r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                    ++depth;
-                    ++spawned; ++path_spawned;
-                    const int alive = roulette();
-                    if (!alive) active = false;
-                    push(pdf, rcp, mat.table, alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
+                    daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
                 }
             } else if (mat.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:159-262
                 double ix, iy, iz;
@@ -1265,11 +1269,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     const double reflectivity = 0.5 * (ra * ra + rb * rb);
                     const double transmission = 1 - reflectivity;
                     if (transmission_only) reflect = false;
-                    else {
-                        double k1, k2;
-                        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), k1, k2);
-                        reflect = !(k1 < transmission);
-                    }
+                    else reflect = !(scatter1 < transmission);
                 }
                 if (reflect && transmission_only) active = false;             // total internal reflection without a reflected ray: zero spectrum
                 else {
@@ -1281,11 +1281,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     } else from = inside ? g.outside : g.inside;
                     xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
                     xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
-                    ++depth;
-                    ++spawned; ++path_spawned;
-                    const int alive = roulette();
-                    if (!alive) active = false;
-                    else if (alive == 2) push(1.0, 1.0, mat.table, TERM_NORM);       // (a = b = 1: the replay multiplies every term's a and b in)
+                    daughter = true;
                 }
             } else {
                 if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
@@ -1297,6 +1293,14 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     smp.table = mat.table;
                 }
                 active = false;
+            }
+            if (daughter) {                                                   // ray.pyx:380-388: the daughter exists (and counts) before its roulette
+                ++depth;
+                ++spawned; ++path_spawned;
+                const int alive = roulette();
+                if (!alive) active = false;
+                // Lambert: the term is left whatever the roulette says; Dielectric: only the roulette's 1 / (1 - p)
+                if (lambert_term || alive == 2) push(term_a, term_b, mat.table, !lambert_term ? TERM_NORM : alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
             }
         }
 #if RSX_PHASE_PROF == 3
