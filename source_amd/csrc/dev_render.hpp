@@ -914,7 +914,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
     smp.a = 0; smp.weight = 0; smp.table = -1; smp.pad = 0;
 #if RSX_PHASE_PROF == 3
-    unsigned long long pp_acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
+    unsigned long long pp_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
 #endif
     auto push = [&](double a, double b, int32_t table, int32_t kind) {
         if (pos == PATH_BLOCK) {
@@ -1321,7 +1321,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         }
     }
 #if RSX_PHASE_PROF == 3
-    if (lane == 0 && q->unit_times) for (int k = 0; k < 10; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
+    if (lane == 0 && q->unit_times) for (int k = 0; k < 13; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
 #endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
     for (int o = 32; o > 0; o >>= 1) spawned += __shfl_xor(spawned, o);

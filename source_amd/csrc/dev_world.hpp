@@ -155,6 +155,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // has to answer; the roots are then found round by round, every lane on ITS next box (its record read per lane). Same
     // arithmetic per (ray, box) as analytic_first_root: the gate, Point3D / Vector3D.transform, Box.hit's slabs.
     uint32_t lane_boxes = 0;
+#if RSX_PHASE_PROF == 3
+    const unsigned long long ph3_w0 = clock64();
+#endif
 #pragma unroll
     for (int j = 0; j < WIDE_N; ++j) {
         if (sc.wide[j] >= 0) {                              // (wave-uniform)
@@ -170,8 +173,15 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             wide.faces[j >> 2] |= (uint32_t)f << (8 * (j & 3));
         }
     }
+#if RSX_PHASE_PROF == 3
+    const unsigned long long ph3_w1 = clock64();
+    if (phase_acc) phase_acc[9] += ph3_w1 - ph3_w0;
+#endif
     if constexpr (WIDE_N == 8 && RSX_WIDE_PER_LANE) {
         while (__any(lane_boxes != 0u)) {
+#if RSX_PHASE_PROF == 3
+            if (phase_acc) { phase_acc[11] += 1; phase_acc[12] += __popcll(__ballot(lane_boxes != 0u)); }
+#endif
             const bool have = lane_boxes != 0u;
             const int slot = have ? __builtin_ctz(lane_boxes) : 0;
             lane_boxes &= lane_boxes - 1u;
@@ -202,6 +212,9 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
             }
         }
     }
+#if RSX_PHASE_PROF == 3
+    if (phase_acc) phase_acc[10] += clock64() - ph3_w1;
+#endif
     // the nearest of those answers: subtrees that hold wide primitives only and end before it are not entered (world_step)
     double t_cull = INFINITY;
 #pragma unroll

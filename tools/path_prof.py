@@ -42,3 +42,5 @@ for name, v in zip(("refill / ray generation", "world_trace_wave", "hit geometry
     print("%-30s %.3f" % (name, v / tot))
 print("segment rounds %.4g, live lanes per round %.1f" % (c[7], c[6] / max(c[7], 1)))
 print("inside world_trace_wave: descents %.3f of it; %.1f leaf-visit rounds per segment round" % (c[5] / max(c[1], 1), c[8] / max(c[7], 1)))
+print("  before the walk: gates and wave-uniform answers %.3f of it, per-lane box rounds %.3f of it (%.2f rounds per segment round, %.1f lanes per round)" % (
+    c[9] / max(c[1], 1), c[10] / max(c[1], 1), c[11] / max(c[7], 1), c[12] / max(c[11], 1)))
