@@ -782,6 +782,14 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             std::vector<int32_t> cand;
             for (int32_t i = 0; i < desc->n_world; ++i) if (fast[(size_t)i].n_leaves > 0 && leaves[(size_t)i] >= 2) cand.push_back(i);
             std::stable_sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) { return leaves[(size_t)a] > leaves[(size_t)b]; });
+            // (as above: when every CSG solid with a flattened program fits the four slots, the single-leaf ones are answered in the
+            // same round before the traversal — the subtree of a solid most scattered rays aim at, a prism of importance 9, can then
+            // be culled like the others)
+            if (!std::getenv("RSX_NO_WIDE_ALL")) {
+                size_t n_programs = 0;
+                for (int32_t i = 0; i < desc->n_world; ++i) if (fast[(size_t)i].n_leaves > 0 && leaves[(size_t)i] >= 1) ++n_programs;
+                if (!cand.empty() && n_programs <= 4) for (int32_t i = 0; i < desc->n_world; ++i) if (fast[(size_t)i].n_leaves > 0 && leaves[(size_t)i] == 1) cand.push_back(i);
+            }
             for (size_t k = 0; k < cand.size() && k < 4; ++k) d.wide_csg[k] = cand[k];
         }
         // Device copies of the world nodes. A leaf whose items are ALL wide primitives (most leaves of a scene with a floor and an
