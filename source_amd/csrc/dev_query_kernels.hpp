@@ -64,7 +64,7 @@ void k_hit_batch(DScene sc, long long n, const double *origin, const double *dir
         }
         Hit h;
         uint32_t work = 0;
-        const bool hit = world_trace_wave<CSG, MODE == 1>(valid, sc, r, st, ms, csg_state, h, work);
+        const bool hit = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, CSG && MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(valid, sc, r, st, ms, csg_state, h, work);
         if (!valid) continue;
         if constexpr (MODE == 1) { if (work >> 31) { out.prim[i] = HIT_REDO; continue; } }
         out.prim[i] = hit ? h.prim : -1;

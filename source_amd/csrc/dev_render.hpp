@@ -1043,9 +1043,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         pp_acc[6] += __popcll(__ballot(active)); pp_acc[7] += 1;
 #endif
 #if RSX_PHASE_PROF == 3
-        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, CSG ? 2 : 8>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
 #else
-        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, CSG ? 2 : 8>(active, sc, r, st, ms, csg_state, hit, work);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(active, sc, r, st, ms, csg_state, hit, work);
 #endif
 #if RSX_PHASE_PROF == 3
         const unsigned long long pp1 = clock64();

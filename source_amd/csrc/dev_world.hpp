@@ -122,6 +122,9 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
 #ifndef RSX_CSG_MAILBOX
 #define RSX_CSG_MAILBOX 4
 #endif
+#ifndef RSX_CSG_WIDE
+#define RSX_CSG_WIDE 4                // analytic wide slots of the CSG kernels that answer the wide CSG solids before the traversal (2 or 4)
+#endif
 template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false, int WIDE_N = 2, int CSG_MAILBOX = RSX_CSG_MAILBOX>
 __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
@@ -138,9 +141,11 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
     // Primitives that sit in several world leaves (the reference tests a primitive again in every leaf the ray visits,
     // kdtree.pyx:99-116; the answer is the same each time): their first root is computed once, here. configs[2]: the floor box and
     // the enclosing emitter are met 4.4 times per primary ray.
-    static_assert(WIDE_N == 2 || WIDE_N == 8, "two tagged copies of the world nodes exist: for two and for eight wide slots");
+    static_assert(WIDE_N == 2 || WIDE_N == 8 || (CSG && WIDE_N == RSX_CSG_WIDE), "two tagged copies of the world nodes exist: for two slots and for eight (CSG scenes: RSX_CSG_WIDE)");
     // (CSG kernels with the mailbox: the copy whose cull bits count the CSG primitives answered in the round before the traversal)
     constexpr bool CSG_ANSWERED = CSG && FASTONLY && CSG_MAILBOX >= 4 && !UNIFORM_ITEMS;
+    static_assert(!CSG_ANSWERED || WIDE_N == RSX_CSG_WIDE, "the CSG-answered copy of the world nodes is tagged for RSX_CSG_WIDE slots");
+    static_assert(!CSG || CSG_ANSWERED || WIDE_N == 2, "the other kernels of a CSG scene walk the two-slot copy");
     const rsx_kdnode *wnodes = (WIDE_N == 8 || CSG_ANSWERED) ? sc.wnodes_scatter : sc.wnodes;
     WideSet8 wide;
 #pragma unroll

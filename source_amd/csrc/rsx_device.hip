@@ -766,6 +766,23 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 }
                 if (all_analytic) for (int32_t i = 0; i < desc->n_world; ++i) if (leaves[(size_t)i] == 1) cand.push_back(i);
             }
+            // A CSG scene's path and query kernels answer RSX_CSG_WIDE analytic slots (registers): when all its analytic primitives
+            // fit, the single-leaf ones come in from slot two on (a hole in slot one is fine: -1 matches nothing) — the prism scene's
+            // floor, slit light and top light; with its four solids in the wide_csg slots every leaf of it is answered.
+            if (!std::getenv("RSX_NO_WIDE_ALL") && sc->has_csg && !cand.empty()) {
+                size_t n_analytic = 0;
+                for (int32_t i = 0; i < desc->n_world; ++i) {
+                    const int32_t t = desc->primitives[i].type;
+                    if ((t == RSX_PRIM_SPHERE || t == RSX_PRIM_BOX || t == RSX_PRIM_CYLINDER) && leaves[(size_t)i] >= 1) ++n_analytic;
+                }
+                if (n_analytic <= (size_t)RSX_CSG_WIDE) {
+                    while (cand.size() < 2) cand.push_back(-1);
+                    for (int32_t i = 0; i < desc->n_world; ++i) {
+                        const int32_t t = desc->primitives[i].type;
+                        if ((t == RSX_PRIM_SPHERE || t == RSX_PRIM_BOX || t == RSX_PRIM_CYLINDER) && leaves[(size_t)i] == 1) cand.push_back(i);
+                    }
+                }
+            }
             for (size_t k = 0; k < cand.size() && k < 8; ++k) d.wide[k] = cand[k];
         }
         d.wide_plain = 0;
@@ -799,7 +816,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         for (int n_slots : {2, 8}) {
             // (a CSG scene has no eight-slot kernels: its second copy serves the kernels that answer the wide CSG primitives before
             // the traversal — two slots for the leaf tags, and cull bits that count those CSG primitives as answered too)
-            const int tag_slots = (n_slots == 8 && sc->has_csg) ? 2 : n_slots;
+            const int tag_slots = (n_slots == 8 && sc->has_csg) ? RSX_CSG_WIDE : n_slots;
             const bool csg_answered = n_slots == 8 && sc->has_csg;
             std::vector<rsx_kdnode> wnodes(desc->world_kd.nodes, desc->world_kd.nodes + desc->world_kd.n_nodes);
             for (rsx_kdnode &nd : wnodes) {
