@@ -914,7 +914,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
     r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
     smp.a = 0; smp.weight = 0; smp.table = -1; smp.pad = 0;
 #if RSX_PHASE_PROF == 3
-    unsigned long long pp_acc[13] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
+    unsigned long long pp_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
 #endif
     auto push = [&](double a, double b, int32_t table, int32_t kind) {
         if (pos == PATH_BLOCK) {
@@ -1158,6 +1158,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
             double scatter1 = 0.0, scatter2 = 0.0;
             if (!abandoned && segments < PATH_MAX_SEGMENTS && (mat.type == RSX_MAT_LAMBERT || mat.type == RSX_MAT_DIELECTRIC))
                 philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
+#if RSX_PHASE_PROF == 3
+            pp_acc[18] += clock64() - pp_t3;
+#endif
             bool daughter = false, lambert_term = false;
             double term_a = 1.0, term_b = 1.0;                                // (a = b = 1: the replay multiplies every term's a and b in)
             if (abandoned) {}
@@ -1167,6 +1170,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
                 ++spawned; ++path_spawned;
             } else if (mat.type == RSX_MAT_LAMBERT) {
+#if RSX_PHASE_PROF == 3
+                const unsigned long long ppl0 = clock64();
+#endif
                 // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
                 // normal.pyx:346-370); the normal faces the incident side
                 const double *from = g.exiting ? g.inside : g.outside;
@@ -1247,7 +1253,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
                     daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
                 }
+#if RSX_PHASE_PROF == 3
+                pp_acc[13] += clock64() - ppl0; pp_acc[14] += 1;
+#endif
             } else if (mat.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:159-262
+#if RSX_PHASE_PROF == 3
+                const unsigned long long ppd0 = clock64();
+#endif
                 double ix, iy, iz;
                 xform_vector(p.to_local, r.dx, r.dy, r.dz, ix, iy, iz);
                 normalise3(ix, iy, iz);
@@ -1283,6 +1295,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                     xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
                     daughter = true;
                 }
+#if RSX_PHASE_PROF == 3
+                pp_acc[15] += clock64() - ppd0; pp_acc[16] += 1;
+#endif
             } else {
                 if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
                 else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
@@ -1294,6 +1309,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 }
                 active = false;
             }
+#if RSX_PHASE_PROF == 3
+            const unsigned long long ppt0 = clock64();
+#endif
             if (daughter) {                                                   // ray.pyx:380-388: the daughter exists (and counts) before its roulette
                 ++depth;
                 ++spawned; ++path_spawned;
@@ -1302,6 +1320,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
                 // Lambert: the term is left whatever the roulette says; Dielectric: only the roulette's 1 / (1 - p)
                 if (lambert_term || alive == 2) push(term_a, term_b, mat.table, !lambert_term ? TERM_NORM : alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
             }
+#if RSX_PHASE_PROF == 3
+            pp_acc[17] += clock64() - ppt0;
+#endif
         }
 #if RSX_PHASE_PROF == 3
         {
@@ -1321,7 +1342,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAV
         }
     }
 #if RSX_PHASE_PROF == 3
-    if (lane == 0 && q->unit_times) for (int k = 0; k < 13; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
+    if (lane == 0 && q->unit_times) for (int k = 0; k < 20; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
 #endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
     for (int o = 32; o > 0; o >>= 1) spawned += __shfl_xor(spawned, o);

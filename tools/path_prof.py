@@ -44,3 +44,8 @@ print("segment rounds %.4g, live lanes per round %.1f" % (c[7], c[6] / max(c[7],
 print("inside world_trace_wave: descents %.3f of it; %.1f leaf-visit rounds per segment round" % (c[5] / max(c[1], 1), c[8] / max(c[7], 1)))
 print("  before the walk: gates and wave-uniform answers %.3f of it, per-lane box rounds %.3f of it (%.2f rounds per segment round, %.1f lanes per round)" % (
     c[9] / max(c[1], 1), c[10] / max(c[1], 1), c[11] / max(c[7], 1), c[12] / max(c[11], 1)))
+# (the accumulators are lane 0's: inside a divergent arm they count the rounds in which lane 0 took the arm — the time is scaled by that share)
+la, di = c[14] / max(c[7], 1), c[16] / max(c[7], 1)
+print("  inside material + bookkeeping: lane 0 is in the Lambert arm in %.2f of the rounds, in the Dielectric arm in %.2f" % (la, di))
+print("    Lambert arm ~%.2f of it, Dielectric arm ~%.2f, roulette and term ~%.2f, before the arms (scattering draw, first use of the material record) %.2f" % (
+    c[13] / max(c[4], 1) / max(la, 1e-9), c[15] / max(c[4], 1) / max(di, 1e-9), c[17] / max(c[4], 1) / max(la + di, 1e-9), c[18] / max(c[4], 1)))
