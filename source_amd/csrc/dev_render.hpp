@@ -717,7 +717,15 @@ __device__ __noinline__ double portable_pow(double x, double y) {
 }
 
 // ImportanceManager.sample (world.pyx:150-188): pick = the selection uniform, (ua, ub) = the direction pair in the reference's draw order
-__device__ void important_sample(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double pick, double ua, double ub,
+#ifndef RSX_IMPORTANT_INLINE
+#define RSX_IMPORTANT_INLINE 1
+#endif
+#if RSX_IMPORTANT_INLINE
+#define RSX_IMP_INLINE __forceinline__
+#else
+#define RSX_IMP_INLINE
+#endif
+__device__ RSX_IMP_INLINE void important_sample(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double pick, double ua, double ub,
                                  double &wx, double &wy, double &wz) {
     int index = 0;
     while (index < n - 1 && !(pick < spheres[index].cdf)) ++index;            // find_index(cdf, u) + 1
@@ -759,7 +767,7 @@ __device__ void important_sample(const rsx_important_sphere *spheres, int n, dou
 }
 
 // ImportanceManager.pdf (world.pyx:190-230)
-__device__ double important_pdf(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double wx, double wy, double wz) {
+__device__ RSX_IMP_INLINE double important_pdf(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double wx, double wy, double wz) {
     double pdf_all = 0;
     for (int i = 0; i < n; ++i) {
         const rsx_important_sphere sp = spheres[i];

@@ -126,7 +126,7 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
 #define RSX_CSG_WIDE 4                // analytic wide slots of the CSG kernels that answer the wide CSG solids before the traversal (2 or 4)
 #endif
 template <bool CSG, bool FASTONLY = false, int STAGE_MIN = RSX_STAGE_MIN, bool UNIFORM_ITEMS = false, int WIDE_N = 2, int CSG_MAILBOX = RSX_CSG_MAILBOX>
-__device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
+__device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, const Stack &st, const Stack &mesh_stack, NodeSt *csg_state, Hit &best,
                                  uint32_t &work, unsigned long long *phase_acc = nullptr) {
     best.prim = -1;
     double tmin = 0, tmax = 0;
@@ -510,7 +510,7 @@ __device__ bool world_trace_wave(bool valid, const DScene &sc, const Ray &r, con
 }
 
 template <bool CSG>
-__device__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
+__device__ __forceinline__ void finalise(const DScene &sc, const Ray &r, const Hit &h, Geom &g) {
     const rsx_primitive &p = sc.prims[h.prim];
     if constexpr (CSG) {
         if (is_csg(p.type)) { csg_geom(sc, r, h, g); return; }

@@ -10,8 +10,9 @@ head -n "$n" "$R/source_amd/csrc/rsx_device.hip" | sed "s#\"../../include/rsx.h\
 echo "template __global__ void $1;" >> /tmp/probe/probe.hip
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -Wno-unused-value --cuda-device-only -gline-tables-only $2 \
     -Rpass-analysis=kernel-resource-usage -S /tmp/probe/probe.hip -o /tmp/probe/probe.s 2>&1 \
-  | grep -E 'error|remark' | sed 's/.*remark: //; s/ \[-Rpass.*//' | grep -E "error|Function Name|VGPRs|AGPRs|Scratch|Occupancy" | paste - - - - - - \
+  | tee /tmp/probe/compile.log | grep -E 'error|remark' | sed 's/.*remark: //; s/ \[-Rpass.*//' | grep -E "error|Function Name|VGPRs|AGPRs|Scratch|Occupancy" | paste - - - - - - \
   | grep -E "${3:-k_render_trace|k_accumulate|fused_flush}" | sed 's/Function Name: //; s/ScratchSize \[bytes\/lane\]/scratch/; s/Occupancy \[waves\/SIMD\]/occ/' | cut -c1-260
+grep -E ' error: ' /tmp/probe/compile.log | head -5
 python3 - <<'PY'
 import re, collections
 cur = None; files = {}; out = collections.Counter(); fn = None
@@ -28,4 +29,11 @@ tot = collections.Counter()
 for (fn, kind, loc), n in sorted(out.items(), key=lambda kv: (kv[0][0], kv[0][2] or ('', 0), kv[0][1])):
     print("  %-40s %-5s %3d dwords at %s:%s" % (fn, kind, n, loc[0] if loc else '?', loc[1] if loc else '?')); tot[(fn, kind)] += n
 print(dict(tot))
+# device functions left out of line (a call passes struct arguments through scratch: world_trace_wave once went 34 -> 61 ms that way)
+import subprocess
+funcs = [l.split()[1].rstrip(',') for l in open('/tmp/probe/probe.s') if l.strip().startswith('.type') and '@function' in l]
+calls = [f for f in funcs if 'k_render' not in f and 'k_accumulate' not in f and 'k_hit' not in f]
+if calls:
+    out = subprocess.run(['c++filt'] + calls, capture_output=True, text=True).stdout.split('\n')
+    print("out of line:", "; ".join(o.split('(')[0] for o in out if o))
 PY
