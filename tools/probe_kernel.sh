@@ -31,8 +31,8 @@ for (fn, kind, loc), n in sorted(out.items(), key=lambda kv: (kv[0][0], kv[0][2]
 print(dict(tot))
 # device functions left out of line (a call passes struct arguments through scratch: world_trace_wave once went 34 -> 61 ms that way)
 import subprocess
-funcs = [l.split()[1].rstrip(',') for l in open('/tmp/probe/probe.s') if l.strip().startswith('.type') and '@function' in l]
-calls = [f for f in funcs if 'k_render' not in f and 'k_accumulate' not in f and 'k_hit' not in f]
+funcs = [l.split()[1].split(',')[0] for l in open('/tmp/probe/probe.s') if l.strip().startswith('.type') and '@function' in l]
+calls = [f for f in funcs if not re.match(r'_Z\d+k_', f)]
 if calls:
     out = subprocess.run(['c++filt'] + calls, capture_output=True, text=True).stdout.split('\n')
     print("out of line:", "; ".join(o.split('(')[0] for o in out if o))
