@@ -49,7 +49,31 @@ spp = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 out = {"workload": wl, "pixels": px, "spp": spp, "host_cpus": os.cpu_count(), "where": "development container (8 vCPU Xeon 2.1 GHz), compiled Cython reference"}
 
 
+class UserLambert(Lambert):
+    """c1user: what a Raysect user's own material costs IN THE REFERENCE — the Cornell box's walls as a Python subclass of the compiled
+    Lambert with evaluate_shading written in Python (the counterpart of tools/host_material_rate.py's `user` case on the device)."""
+
+    def __init__(self, reflectivity=None):
+        super().__init__(reflectivity)
+        self.refl = reflectivity                            # (the compiled class keeps its own copy private)
+
+    def evaluate_shading(self, world, ray, s_incoming, s_outgoing, w_reflection_origin, w_transmission_origin, back_face,
+                         world_to_surface, surface_to_world, intersection):
+        pdf = s_outgoing.z * 0.3183098861837907 if s_outgoing.z > 0 else 0.0
+        if pdf == 0.0:
+            return ray.new_spectrum()
+        spectrum = ray.spawn_daughter(w_reflection_origin, s_outgoing.transform(surface_to_world)).trace(world)
+        spectrum.samples[:] *= self.refl.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins)   # (mul_array / mul_scalar are cdef:
+        spectrum.samples[:] *= pdf                                                                                #  a Python material uses numpy)
+        return spectrum
+
+
 def build(api):
+    if wl == "c1user":
+        if api is REFNS:
+            api = types.SimpleNamespace(**dict(vars(REFNS), Lambert=UserLambert))
+        world, prims = scenes.build_cornell(api)
+        return world, scenes.cornell_camera(api, world, (px, px), spp=spp, bins=15)
     if wl == "c1":                                          # the Cornell box of configs[0]: path traced (rays/s below = PRIMARY rays/s)
         world = scenes.build_cornell(api)[0]
         return world, scenes.cornell_camera(api, world, (px, px), spp=spp, bins=15)
@@ -68,6 +92,13 @@ for name, engine in (("reference_serial", SerialEngine()), ("reference_multicore
     cam.observe()
     out[name + "_rays_per_s"] = round(px * px * spp / (time.perf_counter() - t0), 1)
 
+if wl == "c1user":                                          # (no oracle leg: the oracle has no user materials)
+    print(json.dumps(out))
+    path = os.path.join(HERE, "reference_timing.json")
+    table = json.load(open(path)) if os.path.exists(path) else {}
+    table[wl] = out
+    json.dump(table, open(path, "w"), indent=1, sort_keys=True)
+    sys.exit(0)
 world, (cam, pipe) = build(ns)
 flat = world.flatten()
 keep = []
