@@ -858,6 +858,14 @@ struct PathState {
 #ifndef RSX_PATH_MIN_WAVES
 #define RSX_PATH_MIN_WAVES 2
 #endif
+#ifndef RSX_REDO_MIN_WAVES
+// The redo pass of a CSG scene (the stream merge) usually finds a handful of paths, so its own speed does not matter; when it can
+// START does: built for one wave per SIMD (256 + 143 registers) each of its workgroups needs a CU whose SIMDs have drained completely,
+// behind the persistent workgroups of the other slices in flight, and the slice's k_accumulate waits behind it (2.4 ms on average
+// per configs[4] slice). Capped for two waves per SIMD (181 registers spilled, 7 KB scratch) it moves in as soon as one path wave
+// retires: configs[4] 1.72 -> 1.67 s per pass.
+#define RSX_REDO_MIN_WAVES 2
+#endif
 // VOLS = the scene has materials with a volume contribution (volume emitters, dielectrics): only then is the per-segment
 // world.contains() pass compiled in (its CSG form, a depth-unrolled recursion, costs the CSG instantiation a wave per SIMD).
 // REWALK: the instantiation a pass is traced again with when a path met more overlapping volumes than the registers keep
@@ -869,7 +877,7 @@ struct PathState {
 // QUEUE: the instantiation can hand paths on and drain them (PathStore::queue / drain) — the forms the overlapping slices of an observe() run;
 // compiled into every form the hand-over cost a pass that never uses it 3 % (Cornell box 41.1 -> 42.7 ms: six more spilled registers).
 template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false>
-__global__ __launch_bounds__(WG_THREADS, CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+__global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES : CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     DScene sc = sc_arg;
     if (STAGED || rp.world_lds > 0) {                      // stage the world tree behind the traversal stacks (see render(); STAGED implies it)
         int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
