@@ -1508,6 +1508,7 @@ __global__ __launch_bounds__(1024) void k_order_units(uint32_t *cost, uint32_t *
         const uint32_t c = cost[i];
         const int list = unit_list(i, c, mean, tiles_x, spp);
         order[atomicAdd(&offset[list][flat && list ? 0 : cost_bucket(c)], 1u)] = (uint32_t)i;
+        if (flat) cost[i] = 0u;                            // (path passes measure every pass: consumed here, zero for the next one — no memset)
     }
 }
 
@@ -1536,7 +1537,17 @@ struct AccumParams {
     int32_t passes, pad_passes;         // consecutive passes of spp samples per pixel in the records (rsx_render_desc.passes; 1 = the usual case)
     const unsigned int *abort_flags;    // deferred path passes: PathStore::flags of the trace kernel — a pass whose arena ran out (bit 0), that hit the
                                         // segment guard (1) or met too many volumes at a point (2) is left out of the frame and rendered again by the caller
+    unsigned int *zero;                 // scheduling state of the lane's trace kernels that this kernel leaves zeroed for their next pass, like the
+    long long zero_n;                   // tickets (the redo mask of a CSG path pass): zero_n words, or 0
 };
+
+// The tickets (two sets: the second serves the redo pass of a CSG path pass) and the words at `zero` are re-armed here for the lane's next
+// pass: every hipMemsetAsync between the launches of an overlapping slice waits ~0.3 ms for a free place on a chip full of persistent
+// path workgroups. Stream order: the trace kernels that used them have finished.
+__device__ __forceinline__ void accumulate_rearm(const AccumParams &ap, long long gid) {
+    if (gid < 18 && ap.ticket) ap.ticket[16 * gid] = 0ULL;
+    for (long long z = gid; z < ap.zero_n; z += (long long)gridDim.x * blockDim.x) ap.zero[z] = 0u;
+}
 
 __global__ void k_fill_acc_consts(double *consts, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1573,7 +1584,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     }
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * ap.bins;
-    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;   // stream order: the trace kernel that used the tickets has finished
+    accumulate_rearm(ap, gid);
     if (gid >= total) return;
     if (ap.abort_flags && (*ap.abort_flags & 7u)) return;
     long long p;
@@ -1813,7 +1824,7 @@ template <int VOL>                      // 0 = no path terms, 1 = path terms, 2 
 __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_table0, double delta) {
     const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = ap.n_tasks * 3;
-    if (gid < 9 && ap.ticket) ap.ticket[16 * gid] = 0ULL;
+    accumulate_rearm(ap, gid);
     if (gid >= total) return;
     const long long p = gid / 3;
     const int c = (int)(gid % 3);

@@ -162,6 +162,8 @@ struct TraceLane {
     hipStream_t stream = nullptr;
     unsigned long long *ticket = nullptr;
     bool ticket_armed = false;         // ticket is known to be zero on the stream (left so by k_accumulate)
+    long long cost_zeroed = 0;         // units of unit_cost known to be zero on the stream (left so by k_order_units after a path pass), 0 = unknown
+    long long redo_zeroed = 0;         // units of the redo mask known to be zero on the stream (left so by k_accumulate), 0 = unknown
     void *spill = nullptr;             // global spill regions for the traversal stacks
     size_t spill_bytes = 0;
     uint32_t *unit_cost = nullptr, *unit_order = nullptr, *n_work = nullptr;   // longest-first scheduling state
@@ -326,7 +328,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         if (ln != &ctx->main && ++lane_no >= std::max(ctx->pipeline_depth, ctx->path_lanes)) continue;      // only the lanes in use get a stream (= an HSA queue)
         if (ln != &ctx->main && ctx->pipeline_depth < 2) continue;
         if (ln != &ctx->main) HIP_TRY(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&ln->ticket, 9 * 16 * sizeof(unsigned long long)));   // one ticket per XCD list, a cache line apart
+        HIP_TRY(hipMalloc(&ln->ticket, 2 * 9 * 16 * sizeof(unsigned long long)));   // one ticket per XCD list, a cache line apart; two sets (the second: the redo pass of a CSG path pass)
         HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
     }
@@ -967,7 +969,7 @@ int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg
 }
 
 int reset_ticket(TraceLane &lane) {
-    HIP_TRY(hipMemsetAsync(lane.ticket, 0, 9 * 16 * sizeof(unsigned long long), lane.stream));
+    HIP_TRY(hipMemsetAsync(lane.ticket, 0, 2 * 9 * 16 * sizeof(unsigned long long), lane.stream));
     lane.ticket_armed = false;          // whoever launches next dirties it again
     return RSX_OK;
 }
@@ -1445,7 +1447,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const bool fused = fuse_enabled && (passes == 1 || use_packet) && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
                        !ctx->unit_times && wave_lds >= fuse_fixed;
     if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
-    if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
+    {
+        void *const redo_before = lane.redo;
+        if (two_pass_csg && (rc = lane_buffer(lane.redo, lane.redo_bytes, (size_t)n_units_all * 8))) return rc;
+        if (lane.redo != redo_before) lane.redo_zeroed = 0;
+    }
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;
     if (has_vol) {
@@ -1500,6 +1506,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             if (lane.unit_cost) HIP_TRY(hipFree(lane.unit_cost));
             if (lane.unit_order) HIP_TRY(hipFree(lane.unit_order));
             lane.unit_capacity = (size_t)n_units + (size_t)n_units / 8 + 64;
+            lane.cost_zeroed = 0;
             HIP_TRY(hipMalloc(&lane.unit_cost, lane.unit_capacity * 4));
             HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4));
             if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 64));
@@ -1516,6 +1523,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (!(lane.order_units == n_units && lane.cost_signature == sig)) {
             lane.sorts_done = 0;
             HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
+            lane.cost_zeroed = n_units;
             {   // no costs yet: natural order per XCD list, laid out by all CUs (k_order_natural_*)
                 const int n_blocks = (int)((n_units + ORDER_BLOCK_UNITS - 1) / ORDER_BLOCK_UNITS);
                 if ((rc = lane_buffer(lane.order_counts, lane.order_counts_bytes, (size_t)n_blocks * 8 * 4 + 64))) return rc;
@@ -1547,7 +1555,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             lane.order_units = n_units;                      // the list stays valid
         }
         if (want_order) lane.sorts_done++;
-        if (want_order && has_vol) HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));   // (after the sort that consumed them)
+        // (path passes measure in every pass: k_order_units zeroes the costs it consumed, so only a list of unknown state is cleared here)
+        if (want_order && has_vol && lane.cost_zeroed != n_units) HIP_TRY(hipMemsetAsync(lane.unit_cost, 0, (size_t)n_units * 4, lane.stream));
+        if (rp.measure_cost) lane.cost_zeroed = 0;
         lane.order_units = want_order ? 0 : n_units;
         order_n = n_units;
         lane.cost_units = n_units;
@@ -1640,9 +1650,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 ps.queue = static_cast<PathState *>(lane.path_queue); ps.queue_cap = (unsigned int)cap;
             }
             const dim3 drain_grid(std::min<unsigned>(l.grid.x, 128u));
-            auto launch = [&](const void *kernel, dim3 grid) -> int {
+            auto launch = [&](const void *kernel, dim3 grid, int ticket_set = 0) -> int {
                 HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
-                void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&lane.ticket, (void *)&ps};
+                unsigned long long *tickets = lane.ticket + (size_t)ticket_set * 9 * 16;
+                void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&tickets, (void *)&ps};
                 HIP_TRY(hipLaunchKernel(kernel, grid, dim3(WG_THREADS), args, l.lds, lane.stream));
                 return RSX_OK;
             };
@@ -1667,13 +1678,14 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 #define PATH_KERNEL(...) reinterpret_cast<const void *>(k_render_trace_path<__VA_ARGS__>)
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
-                HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
+                // (the mask is left zeroed by the k_accumulate of the lane's previous pass over as many units, the second ticket set too)
+                if (lane.redo_zeroed != n_units_all) HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
+                lane.redo_zeroed = 0;
                 const bool staged = rp.prims_lds > 0;
                 if ((rc = launch_drained(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
                                          staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true),
                                          !staged || rewalk ? nullptr : !vols ? PATH_KERNEL(true, 1, false, false, true, true) : PATH_KERNEL(true, 1, true, false, true, true), l.grid))) return rc;
-                if ((rc = reset_ticket(lane))) return rc;                      // the redo pass walks the same work lists
-                PathState *const queue = ps.queue;
+                PathState *const queue = ps.queue;                             // (the redo pass walks the same work lists: with the second ticket set)
                 ps.queue = nullptr;                                            // (the redo pass — usually a handful of paths — keeps them)
                 // The redo pass carries the stream merge: one wave per SIMD, a whole register file per wave — each of its workgroups has to
                 // wait for a CU whose SIMDs have drained completely, behind the persistent workgroups of the other slices in flight, and
@@ -1681,7 +1693,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 // there is), so among overlapping slices it brings a small grid: few places to wait for. RSX_REDO_GRID pins the size.
                 static const int redo_grid_env = [] { const char *e = std::getenv("RSX_REDO_GRID"); return e ? std::atoi(e) : 0; }();
                 const unsigned redo_wgs = redo_grid_env > 0 ? (unsigned)redo_grid_env : deferred ? 32u : l.grid.x;
-                if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), dim3(std::min(l.grid.x, redo_wgs))))) return rc;
+                if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), dim3(std::min(l.grid.x, redo_wgs)), 1))) return rc;
                 ps.queue = queue;
             } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), nullptr, l.grid))) return rc; }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
@@ -1756,6 +1768,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
         HIP_TRY(hipGetLastError());
         lane.order_units = order_n;
+        if (has_vol) lane.cost_zeroed = order_n;
     }
     if (pipelined) HIP_TRY(hipStreamWaitEvent(ctx->stream, lane.traced, 0));   // the merge runs on the ctx stream, in call order
 
@@ -1779,6 +1792,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     ap.roulette_norm = 1 / (1 - desc->ray_extinction_prob);      // ray.pyx:388
     ap.abort_flags = deferred ? lane.overflow : nullptr;
     ap.consts = ctx->acc_consts;
+    ap.zero = nullptr; ap.zero_n = 0;
+    if (two_pass_csg && has_vol && !fused) {                // the redo mask of this pass: consumed; zero for the lane's next one
+        ap.zero = static_cast<unsigned int *>(lane.redo); ap.zero_n = 2 * n_units_all;
+        lane.redo_zeroed = n_units_all;
+    }
     lane.ticket_armed = true;
     const long long total = (long long)T * (long long)B;
     HP_MARK(2)
