@@ -56,7 +56,9 @@
 #define RSX_MAX_WG_PER_CU 8
 #endif
 #define STAGE_BYTES (WAVE * 52)     // per-wave leaf staging area: 64 x (48-byte triangle record + 4-byte id)
+#ifndef RSX_MAX_LANES
 #define RSX_MAX_LANES 8
+#endif
 #ifndef RSX_RENDER_WG_PER_CU
 #define RSX_RENDER_WG_PER_CU 1
 #endif
