@@ -920,15 +920,18 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     bool exhausted = false;
     // per-lane path state
     bool active = false;
+    // (kept narrow: the kernel lives at 256 registers, and every value that stays live through the walk is a spill elsewhere — record and
+    // block ids stay below 2^31 (render()), a pixel index below 2^32, and of the sample record only the weight is known before the
+    // path ends: the emitter's (a, table) are found in its last round)
     Ray r;
-    Sample smp;
-    long long record = 0, blk = 0;
-    uint64_t rng_pixel = 0, rng_sample = 0;
+    double smp_weight = 0;
+    int32_t record = 0, blk = 0;
+    uint32_t rng_pixel_lo = 0;
+    uint64_t rng_sample = 0;
     int pos = 0, depth = 0, segments = 0;
-    unsigned long long spawned = 0;                        // rays this lane traced or spawned (the reference's ray_count statistic)
+    unsigned int spawned = 0;                              // rays this lane traced or spawned (the reference's ray_count statistic)
     uint32_t work = 0;
     r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
-    smp.a = 0; smp.weight = 0; smp.table = -1; smp.pad = 0;
 #if RSX_PHASE_PROF == 3
     unsigned long long pp_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
 #endif
@@ -938,13 +941,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
             PathTerm link;
             link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
-            blk = ps.n_records + nb;
-            ps.pool[blk * PATH_BLOCK] = link;
+            blk = (int32_t)(ps.n_records + nb);
+            ps.pool[(long long)blk * PATH_BLOCK] = link;
             pos = 1;
         }
         PathTerm t;
         t.a = a; t.b = b; t.table = table; t.kind = kind;
-        ps.pool[blk * PATH_BLOCK + pos] = t;
+        ps.pool[(long long)blk * PATH_BLOCK + pos] = t;
         ++pos;
     };
     // Russian roulette of a freshly spawned daughter (ray.pyx:382-388): 0 = extinguished, 1 = alive, 2 = alive and its result is
@@ -953,7 +956,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         if (depth < q->ray_min_depth) return 1;
         if (depth >= q->ray_max_depth) return 0;
         double k1, k2;
-        philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
+        philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
         return k1 < q->ray_extinction_prob ? 0 : 2;
     };
     for (;;) {
@@ -971,7 +974,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
                 if (!active && rank < take) {
                     const PathState stt = ps.queue[start + (unsigned int)rank];
-                    r = stt.r; smp = stt.smp; record = stt.record; blk = stt.blk; rng_pixel = stt.rng_pixel; rng_sample = stt.rng_sample;
+                    r = stt.r; smp_weight = stt.smp.weight; record = (int32_t)stt.record; blk = (int32_t)stt.blk; rng_pixel_lo = (uint32_t)stt.rng_pixel; rng_sample = stt.rng_sample;
                     pos = stt.pos; depth = stt.depth; segments = stt.segments; ray_unit = stt.ray_unit;
                     if constexpr (MODE == 1) { path_spawned = stt.path_spawned; ray_slot = stt.ray_slot; }       // (what a path leaves to the redo pass)
                     active = true;
@@ -1007,14 +1010,14 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 if constexpr (MODE == 2) wanted = wanted && ((q->redo_mask[unit] >> (cursor + rank)) & 1ULL);
                 if (wanted) {
                     ray_unit = (int)unit; ray_slot = cursor + rank; path_spawned = 0;
-                    rng_pixel = (uint64_t)px.ix * (uint64_t)q->cam.ny + (uint64_t)px.iy; rng_sample = q->sample_offset + (uint64_t)px.s;
+                    rng_pixel_lo = (uint32_t)px.ix * (uint32_t)q->cam.ny + (uint32_t)px.iy; rng_sample = q->sample_offset + (uint64_t)px.s;
                     double u1, u2;
                     if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
-                    else philox2(q->seed, rng_pixel, rng_sample, u1, u2);
+                    else philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample, u1, u2);
                     double weight;
                     camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
-                    smp.a = 0.0; smp.weight = weight; smp.table = -1; smp.pad = 0;
-                    record = px.slot * q->spp + px.s;
+                    smp_weight = weight;
+                    record = (int32_t)(px.slot * q->spp + px.s);
                     blk = record; pos = 0; depth = 0; segments = 0;
                     ++spawned; ++path_spawned;
                     active = true;
@@ -1038,7 +1041,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 if (base + (unsigned int)n_live <= ps.queue_cap) {
                     if (active) {
                         PathState stt;
-                        stt.r = r; stt.smp = smp; stt.record = record; stt.blk = blk; stt.rng_pixel = rng_pixel; stt.rng_sample = rng_sample;
+                        stt.r = r; stt.smp.a = 0.0; stt.smp.weight = smp_weight; stt.smp.table = -1; stt.smp.pad = 0;
+                        stt.record = record; stt.blk = blk; stt.rng_pixel = (uint64_t)rng_pixel_lo; stt.rng_sample = rng_sample;
                         stt.path_spawned = 0; stt.ray_slot = 0;
                         if constexpr (MODE == 1) { stt.path_spawned = path_spawned; stt.ray_slot = ray_slot; }
                         stt.pos = pos; stt.depth = depth; stt.segments = segments; stt.ray_unit = ray_unit; stt.pad = 0;
@@ -1053,6 +1057,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         const bool was_active = active;
         Hit hit;
         work = 0;
+        double end_a = 0.0;                                                   // the sample record's emitter, if this round ends the path at one
+        int32_t end_table = -1;
 #if RSX_PHASE_PROF == 3
         const unsigned long long pp0 = clock64();
         pp_acc[0] += pp0 - pp_mark;                           // refill
@@ -1071,7 +1077,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         if constexpr (MODE == 1) {
             if (active && (work >> 31)) {                                     // this path needs the stream merge: hand it to the redo pass
                 atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
-                spawned -= path_spawned;
+                spawned -= (unsigned int)path_spawned;
                 abandoned = true;
                 active = false;
             }
@@ -1158,7 +1164,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             if constexpr (MODE == 1) {
                 if (contains_needs_stream) {                                  // a CSG volume without a flattened program: redo pass
                     atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
-                    spawned -= path_spawned;
+                    spawned -= (unsigned int)path_spawned;
                     abandoned = true;
                     active = false;
                 }
@@ -1173,7 +1179,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             // and the term it leaves in the list.
             double scatter1 = 0.0, scatter2 = 0.0;
             if (!abandoned && segments < PATH_MAX_SEGMENTS && (mat.type == RSX_MAT_LAMBERT || mat.type == RSX_MAT_DIELECTRIC))
-                philox2(q->seed, rng_pixel, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
+                philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
 #if RSX_PHASE_PROF == 3
             pp_acc[18] += clock64() - pp_t3;
 #endif
@@ -1218,7 +1224,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 bool from_important = false;
                 if (mis) {
                     const double choose = scatter1, pick = scatter2;
-                    philox2(q->seed, rng_pixel | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                    philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
                     from_important = choose < q->important_path_weight;
                     double wx, wy, wz;
                     if (from_important) {
@@ -1315,13 +1321,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 pp_acc[15] += clock64() - ppd0; pp_acc[16] += 1;
 #endif
             } else {
-                if (mat.type == RSX_MAT_UNIFORM_EMITTER) { smp.a = mat.scale; smp.table = mat.table; }
+                if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
                 else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
                     double lx, ly, lz;
                     xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
                     const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
-                    smp.a = mat.scale * (dot > 0 ? dot : 0.0);
-                    smp.table = mat.table;
+                    end_a = mat.scale * (dot > 0 ? dot : 0.0);
+                    end_table = mat.table;
                 }
                 active = false;
             }
@@ -1352,7 +1358,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
 #ifndef RSX_NO_PATHCOST
             if (q->measure_cost) atomicMax(q->unit_cost + ray_unit, (uint32_t)segments + 1u);   // the unit's longest path: next pass's schedule
 #endif
-            smp.pad = pos;
+            Sample smp;
+            smp.a = end_a; smp.weight = smp_weight; smp.table = end_table; smp.pad = pos;
             samples[record] = smp;
             ps.tail[record] = (int32_t)blk;
         }
@@ -1361,8 +1368,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     if (lane == 0 && q->unit_times) for (int k = 0; k < 20; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
 #endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
-    for (int o = 32; o > 0; o >>= 1) spawned += __shfl_xor(spawned, o);
-    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ps.flags) + 1, spawned);
+    unsigned long long spawned_wave = spawned;
+    for (int o = 32; o > 0; o >>= 1) spawned_wave += __shfl_xor(spawned_wave, o);
+    if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ps.flags) + 1, spawned_wave);
 }
 
 // Self-test of exact_div(): bit equality with the compiler's IEEE division over pseudo-random and adversarial operand pairs.

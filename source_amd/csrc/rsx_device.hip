@@ -1457,6 +1457,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // path terms: every ray owns one PATH_BLOCK-slot block; longer paths chain blocks out of a shared arena
     size_t arena_blocks = 0;
     if (has_vol) {
+        // (the path kernel keeps a path's pixel index — the Philox counter's first word — in 32 bits)
+        if ((unsigned long long)desc->camera.nx * (unsigned long long)desc->camera.ny > 0xffffffffULL)
+            return rsx_fail(RSX_EUNSUPPORTED, "render: path-traced passes address at most 2^32 camera pixels (%d x %d asked for)", desc->camera.nx, desc->camera.ny);
         arena_blocks = std::max<size_t>((size_t)1 << 16, (has_scatter ? 2 : 1) * S);
         if (const char *e = std::getenv("RSX_PATH_ARENA")) arena_blocks = (size_t)std::max(0ll, std::atoll(e));
         const size_t pool_bytes = (S + arena_blocks) * PATH_BLOCK * sizeof(PathTerm);
