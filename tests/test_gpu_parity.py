@@ -1748,6 +1748,11 @@ print(" ".join(out))
         r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_PATH_DONATE=mode), capture_output=True, text=True, timeout=900)
         assert r.returncode == 0, mode + ": " + r.stderr[-2000:]
         digests[mode] = r.stdout.strip().splitlines()[-1]
+    # the same four scenes with the >= 2-leaf rule for the wide slots (RSX_NO_WIDE_ALL=1: single-leaf primitives are met in their leaf
+    # instead of answered before the walk — rsx_scene_create): when a primitive is asked never shows in a frame
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_NO_WIDE_ALL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, "RSX_NO_WIDE_ALL: " + r.stderr[-2000:]
+    digests["no_wide_all"] = r.stdout.strip().splitlines()[-1]
     assert len(set(digests.values())) == 1, digests
 
 
