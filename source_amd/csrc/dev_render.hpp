@@ -725,32 +725,42 @@ __device__ __noinline__ double portable_pow(double x, double y) {
 #else
 #define RSX_IMP_INLINE
 #endif
-__device__ RSX_IMP_INLINE void important_sample(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double pick, double ua, double ub,
-                                 double &wx, double &wy, double &wz) {
+// ImportanceManager.sample in two halves, so that the caller finds sin / cos of the azimuth ONCE for the lanes that sample an important
+// sphere and the lanes that sample the cosine lobe (both are 2 pi times one of the draws): important_pick chooses the sphere and says
+// which draw the azimuth takes (`cone`: the first; a point inside the sphere, like the cosine lobe, the second); important_direction
+// finishes with sin / cos of that azimuth. Same operations per lane as the one-piece form had.
+struct ImportantPick {
+    double dx, dy, dz, distance, radius;
+    bool cone;
+};
+__device__ RSX_IMP_INLINE ImportantPick important_pick(const rsx_important_sphere *spheres, int n, double ox, double oy, double oz, double pick) {
     int index = 0;
     while (index < n - 1 && !(pick < spheres[index].cdf)) ++index;            // find_index(cdf, u) + 1
     const rsx_important_sphere sp = spheres[index];
-    double dx = sp.centre[0] - ox, dy = sp.centre[1] - oy, dz = sp.centre[2] - oz;
-    const double distance = sqrt(dx * dx + dy * dy + dz * dz);
-    double sn, cs;
-    if (distance == 0 || distance < sp.radius) {                              // vector_sphere
+    ImportantPick k;
+    k.dx = sp.centre[0] - ox; k.dy = sp.centre[1] - oy; k.dz = sp.centre[2] - oz;
+    k.distance = sqrt(k.dx * k.dx + k.dy * k.dy + k.dz * k.dz);
+    k.radius = sp.radius;
+    k.cone = !(k.distance == 0 || k.distance < sp.radius);
+    return k;
+}
+__device__ RSX_IMP_INLINE void important_direction(const ImportantPick &k, double ua, double ub, double sn, double cs, double &wx, double &wy, double &wz) {
+    double dx = k.dx, dy = k.dy, dz = k.dz;
+    if (!k.cone) {                                                            // vector_sphere (azimuth 2 pi ub)
         const double z = 1.0 - 2.0 * ua;
         const double r2 = 1.0 - z * z;
         const double r = sqrt(r2 > 0 ? r2 : 0);
-        portable_sincos(2.0 * M_PI * ub, sn, cs);
         wx = r * cs; wy = r * sn; wz = z;
         return;
     }
-    const double angular_radius = portable_asin(sp.radius / distance);
+    const double angular_radius = portable_asin(k.radius / k.distance);
     double theta = angular_radius * 180 / M_PI;                               // vector_cone_uniform(degrees)
     theta *= 0.017453292519943295;
-    const double phi = 2.0 * M_PI * ua;
-    double cos_theta, unused;
+    double cos_theta, unused;                                                 // (azimuth 2 pi ua)
     portable_sincos(theta, unused, cos_theta);
     const double z = ub * (1 - cos_theta) + cos_theta;
     const double r2 = 1.0 - z * z;
     const double r = sqrt(r2 > 0 ? r2 : 0);
-    portable_sincos(phi, sn, cs);
     const double sx = r * cs, sy = r * sn, sz = z;
     normalise3(dx, dy, dz);
     double nx = dx, ny = dy, nz = dz;                                         // direction.orthogonal()
@@ -1227,8 +1237,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                     philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
                     from_important = choose < q->important_path_weight;
                     double wx, wy, wz;
+                    ImportantPick picked;
+                    picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
+                    if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
+                    double sn, cs;                                            // one azimuth for every lane: 2 pi h1 (a cone) or 2 pi h2 (inside a sphere; the cosine lobe)
+                    portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
                     if (from_important) {
-                        important_sample(q->important, q->n_important, hx, hy, hz, pick, h1, h2, wx, wy, wz);
+                        important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
                         // s_outgoing = w_outgoing.transform(primitive_to_surface.mul(world_to_primitive))
                         const double *wtp = p.to_local;
                         double wts[9];
@@ -1243,9 +1258,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                         sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
                     }
                     if (!from_important) {
-                        double sn, cs;
                         const double rad = sqrt(h1);
-                        portable_sincos(2.0 * M_PI * h2, sn, cs);
                         sx = rad * cs; sy = rad * sn;
                         const double sz2 = 1.0 - sx * sx - sy * sy;
                         sz = sqrt(sz2 > 0 ? sz2 : 0);
