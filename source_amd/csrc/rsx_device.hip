@@ -1654,7 +1654,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 if ((rc = lane_buffer(lane.path_queue, lane.path_queue_bytes, cap * sizeof(PathState)))) return rc;
                 ps.queue = static_cast<PathState *>(lane.path_queue); ps.queue_cap = (unsigned int)cap;
             }
-            const dim3 drain_grid(std::min<unsigned>(l.grid.x, 128u));
+            // (the drain launch: 32 workgroups — the handed-on paths of a 1 M-path slice fill a few hundred waves at first and a handful for
+            // most of its 13 ms; a bigger grid only holds more places that the other slices' bulk launches could use. configs[4], paths/s:
+            // 8 workgroups 3.19e8, 16 3.31e8, 24 3.34e8, 32 3.37e8, 48 3.28e8, 64 3.29e8, 128 3.23e8, 256 3.21e8, 512 3.17e8. RSX_DRAIN_GRID pins it)
+            static const int drain_grid_env = [] { const char *e = std::getenv("RSX_DRAIN_GRID"); return e ? std::atoi(e) : 0; }();
+            const dim3 drain_grid(std::min<unsigned>(l.grid.x, drain_grid_env > 0 ? (unsigned)drain_grid_env : 32u));
             auto launch = [&](const void *kernel, dim3 grid, int ticket_set = 0) -> int {
                 HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
                 unsigned long long *tickets = lane.ticket + (size_t)ticket_set * 9 * 16;
