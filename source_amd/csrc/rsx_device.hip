@@ -1574,7 +1574,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
     // A pipelined (small, tail-bound) pass takes one workgroup per CU and the neighbouring lane's pass fills the idle CUs.
     int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
-    if (deferred) wg_cap = RSX_PATH_MIN_WAVES;
+    // (the overlapping slices of an observe(): ONE workgroup per CU and launch — eight lanes keep the two places of every CU taken, and a
+    // bulk launch that brings two per CU holds the second place through its tail; configs[4]: 3.37e8 -> 3.49e8 paths/s. RSX_PATH_WG pins it)
+    static const int path_wg_env = [] { const char *e = std::getenv("RSX_PATH_WG"); return e ? std::atoi(e) : 0; }();
+    if (deferred) wg_cap = path_wg_env > 0 ? std::min(path_wg_env, RSX_PATH_MIN_WAVES) : 1;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
     rp.world_lds = 0; rp.prims_lds = 0;
