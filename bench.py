@@ -364,6 +364,28 @@ def frame_digest(frame):
     return h.hexdigest()[:32]
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves — the command the driver would
+    have used (torch.distributed.run, one process per GPU, rendezvous on 127.0.0.1 at a free port) with this process's own
+    arguments — and pass rank 0's JSON line through. The torchrun form keeps working: with RANK in the environment this is skipped."""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")         # (the host driver supports dmabuf IPC only: RCCL needs it between processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 1) // args.gpus)))
+    r = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    sys.stdout.write(r.stdout if not lines else lines[-1] + "\n")
+    sys.stdout.flush()
+    if r.returncode != 0:
+        raise SystemExit(r.returncode)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -388,6 +410,8 @@ def main():
     args = ap.parse_args()
     if args.child:
         return child_main(args)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        return self_launch(args)
     W = WORKLOADS[args.workload]
     NX, NY, CAM_SPP = W["nx"], W["ny"], W["spp"]
     PPC = args.passes_per_call or W.get("passes_per_call", 1)   # passes per observe() (HipEngine.passes_per_call)
@@ -404,7 +428,8 @@ def main():
         import torch
         import torch.distributed as dist
         local_rank = local_rank % max(1, torch.cuda.device_count())     # more ranks than GPUs (--collective host): share
-        torch.cuda.set_device(local_rank)
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local_rank)
         if collective == "torch":
             with stdout_to_stderr():
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -412,6 +437,14 @@ def main():
             with stdout_to_stderr():                          # (gloo announces its peers on stdout)
                 dist.init_process_group("gloo")               # control plane only: rendezvous, barriers, the RCCL unique id
         world_size = dist.get_world_size()
+    if os.environ.get("RSX_BENCH_RENDEZVOUS_ONLY"):           # test aid (no GPU needed): the launch plumbing up to the first barrier
+        if dist is not None:
+            dist.barrier()
+        if rank == 0:
+            print(json.dumps({"rendezvous_only": True, "n_gpus": world_size, "steps": args.steps, "warmup": args.warmup}), flush=True)
+        if dist is not None:
+            dist.destroy_process_group()
+        return 0
     sharding = "none" if world_size == 1 and not distributed else (("slice" if SLICES >= 8 else "tile") if args.sharding == "auto" else args.sharding)
     if sharding == "slice" and SLICES < world_size:
         raise SystemExit("--sharding slice needs at least one spectral slice per rank (workload %s has %d)" % (args.workload, SLICES))

@@ -306,6 +306,15 @@ int rsx_render_pinhole_frame(rsx_scene *scene, const rsx_render_desc *desc, doub
 int rsx_defer_path_checks(rsx_ctx *ctx, int32_t on);
 int rsx_collect_path_checks(rsx_ctx *ctx, int32_t *failed_calls, int32_t capacity, int32_t *n_failed, uint64_t *ray_count);
 
+/* How the render calls of path-traced scenes (Ray.trace with scattering materials, optical/ray.pyx:338-455) are scheduled on the device.
+ * mode 1: level by level — one launch per path segment over lists of live paths filed by the material arm they wait for (a wave runs
+ * ONE arm on 64 paths that all need it, then walks their daughters' segments); mode 0: one persistent kernel in which every lane carries a path from its camera ray to its end; mode -1:
+ * the library's default (the one-kernel form, which measures faster on MI355X today; $RSX_WAVEFRONT=1 makes it mode 1 for calls of at
+ * least $RSX_WF_MIN_PATHS paths that no other call overlaps).
+ * min_paths < 0 keeps the default threshold. Frames are identical either way: the random numbers, sample record and term list of a
+ * path are keyed by (pixel, sample), never by the lane or launch that renders it. */
+int rsx_set_path_stages(rsx_ctx *ctx, int32_t mode, int64_t min_paths);
+
 /* XYZPixelProcessor (optical/observer/pipeline/rgb.pyx:534-562) for one spectral slice: every sample's spectrum (times its
  * projection weight) is projected on the CIE XYZ curves resampled over the slice (spectrum_to_ciexyz, optical/colour.pyx:158-187:
  * sum over bins of delta_wavelength * sample[bin] * resampled_xyz[bin, c]), times camera.sensitivity, and the three channels go

@@ -137,6 +137,7 @@ SYMBOLS = [
     ("rsx_comm_free", None, [_vp]),
     ("rsx_comm_barrier", C.c_int, [_vp]),
     ("rsx_comm_max_f64", C.c_int, [_vp, C.POINTER(C.c_double)]),
+    ("rsx_set_path_stages", C.c_int, [_vp, C.c_int32, C.c_int64]),
     ("rsx_defer_path_checks", C.c_int, [_vp, C.c_int32]),
     ("rsx_collect_path_checks", C.c_int, [_vp, _vp, C.c_int32, _vp, _vp]),
     ("rsx_allgather_frame", C.c_int, [_vp, _vp, _vp, _vp, _vp]),
@@ -147,7 +148,7 @@ SYMBOLS = [
 ]
 # Entry points an A/B build of an earlier revision ($RSX_LIB, tools/ab.sh) may lack: callers test `has(name)` before using them.
 # Any other missing symbol is ABI drift between include/rsx.h and the binary and stops the load, whichever library was named.
-OPTIONAL_WITH_RSX_LIB = {"rsx_frame_segment", "rsx_allgather_bins", "rsx_comm_size"}
+OPTIONAL_WITH_RSX_LIB = {"rsx_frame_segment", "rsx_allgather_bins", "rsx_comm_size", "rsx_set_path_stages"}
 
 _lib = None
 

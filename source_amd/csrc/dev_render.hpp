@@ -1381,7 +1381,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     if (lane == 0 && q->unit_times) for (int k = 0; k < 20; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
 #endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
-    unsigned long long spawned_wave = spawned;
+    // (a lane of the drain launch that abandons a handed-on path takes off rays other lanes counted: the lane's count is signed)
+    unsigned long long spawned_wave = (unsigned long long)(long long)(int)spawned;
     for (int o = 32; o > 0; o >>= 1) spawned_wave += __shfl_xor(spawned_wave, o);
     if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(ps.flags) + 1, spawned_wave);
 }

@@ -148,6 +148,7 @@ extern "C" const char *rsx_version(void) { return "librsx 0.1 (gfx950)"; }
 #include "dev_packet.hpp"
 #include "dev_query_kernels.hpp"
 #include "dev_render.hpp"
+#include "dev_wavefront.hpp"
 #include "dev_selftest.hpp"
 
 // ---------------------------------------------------------------------------------------------------
@@ -184,6 +185,8 @@ struct TraceLane {
     size_t ring_bytes = 0;
     void *path_queue = nullptr;        // path passes: PathState records handed from the first launch's retiring waves to the drain launch
     size_t path_queue_bytes = 0;
+    void *wf_paths = nullptr, *wf_hits = nullptr, *wf_lists = nullptr, *wf_counts = nullptr;   // path passes in stages (dev_wavefront.hpp)
+    size_t wf_paths_bytes = 0, wf_hits_bytes = 0, wf_lists_bytes = 0, wf_counts_bytes = 0;
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
@@ -222,6 +225,8 @@ struct rsx_ctx {
     void *staging;             // pinned host mirror of small query workspaces: one copy in, one copy out per call
     size_t staging_bytes;
     // rsx_defer_path_checks: path passes run on the private lanes and their end-of-pass checks are collected later
+    int32_t wf_mode = -1;                          // rsx_set_path_stages
+    long long wf_min_paths = -1;
     bool defer_path = false;
     int32_t deferred_calls = 0;                    // path passes issued since deferral was switched on
     std::vector<int32_t> deferred_failed;          // ... of which these must be rendered again (term arena ran out, too many volumes at a point)
@@ -354,7 +359,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     for (TraceLane &l8 : ctx->lanes) all_lanes.push_back(&l8);
     for (TraceLane *ln : all_lanes) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, ln->wf_paths, ln->wf_hits, ln->wf_lists, ln->wf_counts, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -1331,6 +1336,17 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                                desc->spp >= (scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP) && fmean && !h_mean && !h_xyz;
     const bool pipelined = !one_at_a_time && !batch_fusable && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 &&
                            n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // Scattering passes can run level by level (dev_wavefront.hpp: one launch per path segment over lists of live paths filed by material
+    // arm) instead of in the one persistent kernel. Measured on the Cornell box (round 5, profiles/r05_wf_*): lane utilisation 0.42 -> 0.64,
+    // a third fewer vector instructions, and 31.2 ms against 28.1 — the arm's 3.5 us per 64-path iteration come back as exposed memory
+    // latency (list entry -> path record -> atomic, behind the iteration's own stores on the in-order vector-memory counter) at two waves per
+    // SIMD. So the form is opt-in (rsx_set_path_stages / RSX_WAVEFRONT=1) until its loads are moved off the critical path; never for the
+    // overlapping slices of one observe() (their host never waits for a launch; the levels read counts back between batches) or a CSG scene
+    // without the state-free evaluator.
+    static const int wf_env = [] { const char *e = std::getenv("RSX_WAVEFRONT"); return e ? std::atoi(e) : 0; }();
+    static const long long wf_min_paths = [] { const char *e = std::getenv("RSX_WF_MIN_PATHS"); return e ? std::atoll(e) : (1LL << 18); }();
+    const bool use_wf = (ctx->wf_mode < 0 ? wf_env != 0 : ctx->wf_mode != 0) && has_scatter && !deferred && (!scene->has_csg || two_pass_csg) &&
+                        (long long)S >= (ctx->wf_min_paths >= 0 ? ctx->wf_min_paths : wf_min_paths) && (!ctx->unit_times || RSX_PHASE_PROF == 3);
     // (two lanes for path passes: the path kernel fits two workgroups per CU, and each pass brings a grid of that size — the
     // next slice's workgroups move in as this slice's retire; prism, 32 slices: 3 lanes x 1 workgroup per CU 741 ms, 2 x 2 582 ms)
     // (round 3: up to eight lanes — with the trapped paths handed to a small drain launch a pass gives its workgroup places back after
@@ -1547,7 +1563,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // and record the longest path of each unit (atomicMax in k_render_trace_path); spectral slices of one observe() share camera and
         // units, so slice k + 1 starts the units that held slice k's longest paths first.
         static const int path_lpt = [] { const char *e = std::getenv("RSX_PATH_LPT"); return e ? std::atoi(e) : 2; }();
-        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && (has_vol ? path_lpt > 0 : !two_pass_csg);
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && (has_vol ? path_lpt > 0 && !use_wf : !two_pass_csg);
         rp.measure_cost = want_order ? 1 : 0;
         if (has_vol && path_lpt == 1) want_order = false;           // (measure, do not re-order: tuning aid)
         // Primary-ray passes over the same units cost the same from pass to pass (the rays differ only by their jitter): the list
@@ -1643,6 +1659,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // a four times larger one — before its records are merged into the frame (one host round trip per path pass, small next
         // to the pass itself). RSX_PATH_ARENA pins the size instead.
         bool rewalk = false;                                 // second form of the kernels: any number of volumes at a point (slower)
+        bool wf_off = false;                                 // the level-by-level form gave up (a sub-list overflowed: cannot happen, checked anyway): the one-kernel form renders the pass
         for (int attempt = 0;; ++attempt) {
             PathStore ps;
             ps.pool = static_cast<PathTerm *>(lane.terms); ps.tail = static_cast<int32_t *>(lane.tail); ps.n_records = (long long)S;
@@ -1687,6 +1704,76 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 ps.drain = 0;
                 return rc2;
             };
+            // The pass level by level (dev_wavefront.hpp), chunk by chunk: level 0 makes a chunk's paths and walks their first segment, every
+            // further launch runs the material arms of the segments the previous one walked and walks the daughters' segments; after a
+            // batch of levels the counts of live paths are read back, and once they are few the one-kernel form's drain launch walks them to
+            // their ends (`drain_kernel`; without one the levels run until no path is left).
+            auto run_staged = [&](const void *level_kernel, const void *drain_kernel) -> int {
+                static const long long chunk_env = [] { const char *e = std::getenv("RSX_WF_CHUNK"); return e ? std::atoll(e) : (1LL << 25); }();
+                static const int first_levels = [] { const char *e = std::getenv("RSX_WF_LEVELS"); return e ? std::min(32, std::max(1, std::atoi(e))) : 12; }();
+                static const long long drain_below = [] { const char *e = std::getenv("RSX_WF_DRAIN_BELOW"); return e ? std::atoll(e) : (1LL << 15); }();
+                const int more_levels = 8, rows = 64;
+                const long long chunk_units = std::max<long long>(1, std::min<long long>(n_units_all, chunk_env / WAVE));
+                const size_t chunk_n = (size_t)chunk_units * WAVE;
+                const long long lds_per_cu = (long long)((160 * 1024) / std::max<size_t>(l.lds + 2048, 1));
+                const long long level_wgs = (long long)ctx->n_cus * std::max<long long>(1, std::min<long long>(RSX_WF_MIN_WAVES, lds_per_cu));
+                // a sub-list takes what the waves of one number modulo WF_SUB file: their share of the chunk's paths plus one partial chunk per
+                // wave and segment (see wf_append: checked on the device as well)
+                const size_t sub_stride = ((chunk_n / WF_SUB + 63) & ~(size_t)63) + 64 * ((size_t)(level_wgs * WG_WAVES) / WF_SUB + 2) + 64 * (WF_SEGS / WF_SUB + 1) + 4096;
+                const size_t list_entries = (size_t)WF_SEGS * sub_stride;
+                if ((rc = lane_buffer(lane.wf_paths, lane.wf_paths_bytes, chunk_n * sizeof(WfPath))) ||
+                    (scene->has_csg && (rc = lane_buffer(lane.wf_hits, lane.wf_hits_bytes, chunk_n * sizeof(Hit)))) ||
+                    (rc = lane_buffer(lane.wf_lists, lane.wf_lists_bytes, 2 * list_entries * 4)) || (rc = lane_buffer(lane.wf_counts, lane.wf_counts_bytes, (size_t)rows * WF_SEGS * 4))) return rc;
+                const size_t queue_cap = std::max<size_t>((size_t)1 << 16, chunk_n / 8);
+                PathState *const queue_before = ps.queue; const unsigned int cap_before = ps.queue_cap;
+                if (drain_kernel) {
+                    if ((rc = lane_buffer(lane.path_queue, lane.path_queue_bytes, queue_cap * sizeof(PathState)))) return rc;
+                    ps.queue = static_cast<PathState *>(lane.path_queue); ps.queue_cap = (unsigned int)queue_cap;
+                }
+                HIP_TRY(hipFuncSetAttribute(level_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
+                WfStore wf;
+                wf.paths = static_cast<WfPath *>(lane.wf_paths); wf.csg_hits = static_cast<Hit *>(lane.wf_hits);
+                uint32_t *const lists = static_cast<uint32_t *>(lane.wf_lists), *const counts = static_cast<uint32_t *>(lane.wf_counts);
+                wf.sub_stride = (uint32_t)sub_stride; wf.pad = 0;
+                std::vector<uint32_t> row(WF_SEGS);
+                for (long long first_unit = 0; first_unit < n_units_all; first_unit += chunk_units) {
+                    const long long units = std::min<long long>(chunk_units, n_units_all - first_unit);
+                    wf.n = units * WAVE; wf.first_unit = first_unit;
+                    HIP_TRY(hipMemsetAsync(counts, 0, (size_t)rows * WF_SEGS * 4, lane.stream));
+                    long long live = units * WAVE;                          // (upper bound until the first counts come back)
+                    for (int level = 0, batch = first_levels;; batch = more_levels) {
+                        for (int b = 0; b < batch; ++b, ++level) {
+                            wf.cnt_in = level == 0 ? nullptr : counts + (size_t)((level - 1) % rows) * WF_SEGS;
+                            wf.cnt_out = counts + (size_t)(level % rows) * WF_SEGS;
+                            wf.list_in = lists + (size_t)((level + 1) & 1) * list_entries; wf.list_out = lists + (size_t)(level & 1) * list_entries;
+                            const long long wave_chunks = (live + WAVE - 1) / WAVE + (level == 0 ? 0 : WF_SEGS), need_wgs = (wave_chunks + WG_WAVES - 1) / WG_WAVES;
+                            void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&wf, (void *)&ps};
+                            HIP_TRY(hipLaunchKernel(level_kernel, dim3((unsigned)std::max<long long>(1, std::min(level_wgs, need_wgs))), dim3(WG_THREADS), args, l.lds, lane.stream));
+                        }
+                        HIP_TRY(hipMemcpyAsync(row.data(), counts + (size_t)((level - 1) % rows) * WF_SEGS, WF_SEGS * 4, hipMemcpyDeviceToHost, lane.stream));
+                        HIP_TRY(hipStreamSynchronize(lane.stream));
+                        live = 0;
+                        for (uint32_t v : row) live += v;
+                        if (live == 0) break;
+                        if (drain_kernel && (size_t)live <= queue_cap && live <= drain_below) {
+                            wf.cnt_in = counts + (size_t)((level - 1) % rows) * WF_SEGS; wf.list_in = lists + (size_t)((level + 1) & 1) * list_entries;
+                            hipLaunchKernelGGL(k_wf_to_queue, dim3((unsigned)std::min<long long>(1024, (live + 255) / 256)), dim3(256), 0, lane.stream, wf, ps);
+                            ps.drain = 1;
+                            const long long drain_wgs = std::min<long long>((long long)l.grid.x, (live + WG_THREADS - 1) / WG_THREADS);
+                            const int rc_d = launch(drain_kernel, dim3((unsigned)std::max<long long>(1, drain_wgs)));
+                            ps.drain = 0;
+                            if (rc_d) return rc_d;
+                            break;
+                        }
+                        // the rows the next batch counts in: zero again (all but the one that holds the live counts)
+                        for (int b = 0; b < more_levels; ++b) HIP_TRY(hipMemsetAsync(counts + (size_t)((level + b) % rows) * WF_SEGS, 0, WF_SEGS * 4, lane.stream));
+                    }
+                }
+                ps.queue = queue_before; ps.queue_cap = cap_before;
+                HIP_TRY(hipGetLastError());
+                return RSX_OK;
+            };
+#define WF_LEVEL(...) reinterpret_cast<const void *>(k_wf_level<__VA_ARGS__>)
 #define PATH_KERNEL(...) reinterpret_cast<const void *>(k_render_trace_path<__VA_ARGS__>)
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
@@ -1694,6 +1781,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 if (lane.redo_zeroed != n_units_all) HIP_TRY(hipMemsetAsync(lane.redo, 0, (size_t)n_units_all * 8, lane.stream));
                 lane.redo_zeroed = 0;
                 const bool staged = rp.prims_lds > 0;
+                if (use_wf && !rewalk && !wf_off) {
+                    if (!vols) rc = staged ? run_staged(WF_LEVEL(true, 1, false, true), PATH_KERNEL(true, 1, false, false, true, true)) : run_staged(WF_LEVEL(true, 1, false, false), nullptr);
+                    else rc = staged ? run_staged(WF_LEVEL(true, 1, true, true), PATH_KERNEL(true, 1, true, false, true, true)) : run_staged(WF_LEVEL(true, 1, true, false), nullptr);
+                    if (rc) return rc;
+                } else
                 if ((rc = launch_drained(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
                                          staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true),
                                          !staged || rewalk ? nullptr : !vols ? PATH_KERNEL(true, 1, false, false, true, true) : PATH_KERNEL(true, 1, true, false, true, true), l.grid))) return rc;
@@ -1708,6 +1800,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 if ((rc = launch(rewalk ? PATH_KERNEL(true, 2, true, true) : PATH_KERNEL(true, 2), dim3(std::min(l.grid.x, redo_wgs)), 1))) return rc;
                 ps.queue = queue;
             } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), nullptr, l.grid))) return rc; }
+            else if (use_wf && !rewalk && !wf_off) {
+                const bool staged = rp.prims_lds > 0;
+                if (rp.n_vol_emitters == 0) rc = staged ? run_staged(WF_LEVEL(false, 0, false, true), PATH_KERNEL(false, 0, false, false, true, true)) : run_staged(WF_LEVEL(false, 0, false, false), nullptr);
+                else rc = staged ? run_staged(WF_LEVEL(false, 0, true, true), PATH_KERNEL(false, 0, true, false, true, true)) : run_staged(WF_LEVEL(false, 0, true, false), nullptr);
+                if (rc) return rc;
+            }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
                 if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false),
                                          rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true, true) : nullptr, l.grid))) return rc;
@@ -1715,6 +1813,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false),
                                           !rewalk && rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true, true) : nullptr, l.grid))) return rc;
 #undef PATH_KERNEL
+#undef WF_LEVEL
             HIP_TRY(hipGetLastError());
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
             if (deferred) break;                             // (the flags are read when the caller collects; k_accumulate leaves a failed pass out of the frame)
@@ -1722,8 +1821,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             unsigned int flags = 0;
             HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
             HIP_TRY(hipStreamSynchronize(lane.stream));
-            const bool grow = (flags & 1u) && has_scatter && !std::getenv("RSX_PATH_ARENA"), again = (flags & 4u) && !rewalk;
-            if (!grow && !again) break;
+            const bool grow = (flags & 1u) && has_scatter && !std::getenv("RSX_PATH_ARENA"), again = (flags & 4u) && !rewalk, refile = (flags & 8u) && !wf_off;
+            if (!grow && !again && !refile) break;
+            if (refile) wf_off = true;
             if (again) rewalk = true;
             if (grow) {
                 const size_t bigger = arena_blocks * 4, pool_bytes = (S + bigger) * PATH_BLOCK * sizeof(PathTerm);
@@ -1885,12 +1985,20 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: the path-term arena (%zu blocks of %d terms) ran out; render fewer rays per call or raise RSX_PATH_ARENA", arena_blocks, PATH_BLOCK - 1);
         if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a path crossed more than %d surfaces (limit of this build)", PATH_MAX_SEGMENTS);
         if (flags & 4u) return rsx_fail(RSX_EUNSUPPORTED, "render: more than %d volume emitters overlap at one point (limit of this build)", PATH_VOL_OVERLAP);
+        if (flags & 8u) return rsx_fail(RSX_EHIP, "render: a path list of the level-by-level form overflowed (internal error; RSX_WAVEFRONT=0 renders the pass with the one-kernel form)");
     }
     // frame form: asynchronous — the pooled workspace stays alive in the ctx, stream order protects reuse
     return RSX_OK;
 }
 
 }  // namespace
+
+extern "C" int rsx_set_path_stages(rsx_ctx *ctx, int32_t mode, int64_t min_paths) {
+    if (!ctx || mode < -1 || mode > 1) return rsx_fail(RSX_EINVAL, "rsx_set_path_stages: bad arguments");
+    ctx->wf_mode = mode;
+    ctx->wf_min_paths = min_paths < 0 ? -1 : (long long)min_paths;
+    return RSX_OK;
+}
 
 extern "C" int rsx_defer_path_checks(rsx_ctx *ctx, int32_t on) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "rsx_defer_path_checks: null context");

@@ -61,6 +61,10 @@ class DeviceContext:
         settle_observers()                                  # (work an observer is still holding back counts as issued)
         _lib.check(_lib.lib().rsx_synchronize(self._h))
 
+    def set_path_stages(self, mode=-1, min_paths=-1):
+        """How path-traced passes are scheduled (rsx_set_path_stages): 1 in stages, 0 one persistent kernel, -1 the library's default."""
+        _lib.check(_lib.lib().rsx_set_path_stages(self._h, int(mode), int(min_paths)))
+
     def defer_path_checks(self, on):
         """Spectral slices of one observe(): path passes return without their end-of-pass round trip until collect_path_checks()."""
         _lib.check(_lib.lib().rsx_defer_path_checks(self._h, 1 if on else 0))

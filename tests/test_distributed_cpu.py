@@ -156,3 +156,22 @@ def test_combine_arrays_matches_reference(golden):
     g = golden("f09_stats")
     m, v, n = D.combine_arrays(g["ma"], g["va"], g["na"], g["mb"], np.maximum(g["vb"], 0), g["nb"])
     assert np.array_equal(np.stack([m, v, n.astype(float)], axis=1), g["comb"])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` WITHOUT torch.distributed.run around it (what a driver that launches N = 1 as `python bench.py --gpus 1`
+    may well do for N = 2): bench.py re-executes itself under torch.distributed.run on 127.0.0.1 at a free port, the two ranks meet
+    (gloo control plane) and rank 0's line comes back through the parent. No GPU here: RSX_BENCH_RENDEZVOUS_ONLY stops every rank after
+    the first barrier (the GPU suite runs the same self-launch through a whole two-rank bench, test_bench_self_launch_two_ranks_one_gpu)."""
+    import json
+    import subprocess
+    env = dict(os.environ, RSX_BENCH_RENDEZVOUS_ONLY="1")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--collective", "host"],
+                       cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["rendezvous_only"] is True

@@ -1327,6 +1327,26 @@ def test_bench_distributed_paths_start_on_rccl(workload, sharding):
         assert cfg["slice_bounds"] == [0, 16]
 
 
+def test_bench_self_launch_two_ranks_one_gpu():
+    """`python bench.py --gpus 2 --collective host` with no launcher around it: bench.py starts its two ranks itself (torch.distributed.run
+    on 127.0.0.1 at a free port), both render their tile on this one GPU, the frame is exchanged over the host route and checked against
+    a one-GPU render inside the run; rank 0's line comes back with n_gpus = 2."""
+    import json
+    import subprocess
+    import sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-pmc", "--no-cpu-baseline",
+                        "--workload", "c2", "--collective", "host"], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["sharding"] == "tile"
+    assert d["config"].get("frame_digest_equals_single_gpu") is True
+
+
 def test_csg_trees_of_any_depth_and_size_vs_oracle(orc, ns):
     """CSG operand trees beyond the former limits (5 nested levels, 16 nodes; csg.pyx:132-234 recurses without a bound): a 12-level
     Union chain, a 14-level mixed chain, and random trees of 33 - 70 nodes — first hits with full geometry, next_intersection
@@ -1784,3 +1804,52 @@ def test_task_lists_render_in_coherent_order(ns):
     assert not isinstance(part[3]._coherent_cache[1], RectTasks)
     for a, b in zip(rect[:3], part[:3]):
         assert np.array_equal(a[mask], b[mask]) and not b[~mask].any()
+
+
+def test_staged_path_passes_equal_the_one_kernel_form(orc, ns):
+    """Path-traced passes level by level (dev_wavefront.hpp: one launch per path segment over lists of live paths filed by material arm,
+    the last paths handed to the drain launch or walked level by level) against the one-kernel form on the same calls: frames and Ray.ray_count
+    identical — Lambert with a volume emitter and a CSG solid (two-pass), clear and tinted glass (attenuation terms), the Cornell box
+    with importance sampling, the prism scene (state-free CSG evaluator + redo pass) — and two of them against the oracle directly.
+    One spectral slice per observe(): several slices overlap on private lanes and keep the one-kernel form."""
+    from source_amd.device import get_context
+    ctx = get_context()
+
+    def cases():
+        world, _ = scenes.build_lambert(ns)
+        yield "lambert", world, scenes.lambert_camera(ns, world, (96, 80), 8, 5, (0.01, 3, 500)), True
+        world, _ = scenes.build_lambert(ns, with_volume=False, csg=False)
+        yield "lambert_plain", world, scenes.lambert_camera(ns, world, (64, 48), 6, 6, (0.3, 1, 4)), False
+        for clear in (True, False):
+            world, _ = scenes.build_glass(ns, unit_transmission=clear)
+            yield "glass_%s" % clear, world, scenes.glass_camera(ns, world, (96, 72), 6, 6, 1, (0.01, 3, 500) if clear else (0.1, 2, 20)), not clear
+        world, _ = scenes.build_cornell(ns)
+        yield "cornell", world, scenes.cornell_camera(ns, world, (128, 96), 4, 6), False
+        world, _ = scenes.build_prism(ns)
+        yield "prism", world, scenes.prism_camera(ns, world, (96, 64), 4, 4, 1), False
+
+    try:
+        for name, world, (cam, pipe), against_oracle in cases():
+            cam.frame_sampler = ns.RectFrameSampler2D()
+            pipe.accumulate = False                                # (every observe() starts a fresh frame)
+            frames = []
+            for mode in (1, 0):
+                ctx.set_path_stages(mode, 0 if mode else -1)
+                cam.render_engine = ns.HipEngine(rng="philox", seed=41)
+                cam.observe()
+                frames.append((pipe.frame.mean.copy(), pipe.frame.variance.copy(), pipe.frame.samples.copy(), cam.stats["rays"]))
+                cam.render_engine.sample_offset = 0
+            assert eq(frames[0][0], frames[1][0]) and eq(frames[0][1], frames[1][1]) and eq(frames[0][2], frames[1][2]), name
+            assert frames[0][3] == frames[1][3], (name, frames[0][3], frames[1][3])
+            assert (frames[0][0] > 0).mean() > 0.05, name
+            if against_oracle:
+                w, h = cam.pixels
+                sl = cam._slice_spectrum()[0]
+                keep = []
+                desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+                om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+                assert eq(frames[0][0], om.reshape(h, w, sl.bins).transpose(1, 0, 2)) and eq(frames[0][1], ov.reshape(h, w, sl.bins).transpose(1, 0, 2)), name
+                assert frames[0][3] == n_rays, name
+            cam.parent = None
+    finally:
+        ctx.set_path_stages(-1, -1)

@@ -44,6 +44,12 @@ print("segment rounds %.4g, live lanes per round %.1f" % (c[7], c[6] / max(c[7],
 print("inside world_trace_wave: descents %.3f of it; %.1f leaf-visit rounds per segment round" % (c[5] / max(c[1], 1), c[8] / max(c[7], 1)))
 print("  before the walk: gates and wave-uniform answers %.3f of it, per-lane box rounds %.3f of it (%.2f rounds per segment round, %.1f lanes per round)" % (
     c[9] / max(c[1], 1), c[10] / max(c[1], 1), c[11] / max(c[7], 1), c[12] / max(c[11], 1)))
+if c[36] + c[44] > 0:                                    # the level-by-level form (dev_wavefront.hpp) rendered the pass
+    for name, o in (("level 0", 40), ("levels >= 1", 32)):
+        t = c[o:o + 4].sum()
+        if t > 0:
+            print("%-12s iterations %.4g, live lanes %.1f, lanes that go on %.1f; clocks per iteration %.0f: entry + path record %.3f, arm %.3f, walk %.3f, filing %.3f" % (
+                name, c[o + 4], c[o + 5] / max(c[o + 4], 1), c[o + 6] / max(c[o + 4], 1), t / max(c[o + 4], 1), c[o] / t, c[o + 1] / t, c[o + 2] / t, c[o + 3] / t))
 # (the accumulators are lane 0's: inside a divergent arm they count the rounds in which lane 0 took the arm — the time is scaled by that share)
 la, di = c[14] / max(c[7], 1), c[16] / max(c[7], 1)
 print("  inside material + bookkeeping: lane 0 is in the Lambert arm in %.2f of the rounds, in the Dielectric arm in %.2f" % (la, di))
