@@ -181,15 +181,22 @@ def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cp
     engine.sample_offset = 0
     host = host_cores(nthreads)
 
-    def band_desc(rows):
-        # (more rows than the frame has: whole frames of several passes' samples — a sample must outlast the cgroup's accounting period,
-        # or threads beyond the quota look free: 64 threads rendered a 13 ms frame at 5x the rate the box sustains)
+    def spread_desc(rows):
+        """`rows` pixel rows spread evenly over the frame (every sample of the sweep and the reported value is cut the same way, so they
+        time the same kind of work: a centred band is the densest part of the frame and ran 25 % below the whole-frame rate in round 4).
+        More rows than the frame has: whole frames of several passes' samples — a sample must outlast the cgroup's accounting period, or
+        threads beyond the quota look free."""
         reps = int(max(1, -(-int(rows) // NY)))
         rows = int(max(1, min(NY, rows)))
-        rect = (0, NY // 2 - rows // 2, NX, NY // 2 - rows // 2 + rows)
         saved_spp = cam.pixel_samples
         cam.pixel_samples = CAM_SPP * reps
-        d = cam.render_desc(world, None, sl, engine, keep, rect=rect)
+        if rows >= NY:
+            d = cam.render_desc(world, None, sl, engine, keep, rect=(0, 0, NX, NY))
+        else:
+            ys = np.unique(np.floor((np.arange(rows) + 0.5) * NY / rows).astype(np.int64))
+            rows = int(len(ys))
+            tasks = [(x, int(y)) for y in ys for x in range(NX)]
+            d = cam.render_desc(world, tasks, sl, engine, keep)
         cam.pixel_samples = saved_spp
         return d, NX * rows * CAM_SPP * reps, rows * reps
 
@@ -199,49 +206,37 @@ def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cp
         assert np.isfinite(m_).all()
         return time.perf_counter() - t0
 
-    cal, n_cal, _ = band_desc(2)
+    cal, n_cal, _ = spread_desc(2)
     timed(cal, 1)
     rate1 = n_cal / max(timed(cal, 1), 1e-6)
     rows1 = max(2.0, 0.7 * rate1 / (NX * CAM_SPP))         # rows one thread renders in ~0.7 s
-    counts = sorted({1 << k for k in range(0, 12) if (1 << k) <= nthreads} | {nthreads, max(1, min(nthreads, host["usable"]))})
+    # thread counts: powers of two up to twice what the process may use (affinity mask and cgroup quota: beyond that more threads only
+    # time-slice — round 4 spent 68 s of the driver's 98 on 128- and 256-thread points under a 16-core quota)
+    cap = int(max(1, min(nthreads, 2 * host["usable"])))
+    counts = sorted({1 << k for k in range(0, 12) if (1 << k) <= cap} | {cap, max(1, min(cap, host["usable"]))})
     sweep = []
     for t in counts:
-        desc_t, n_t, rows_t = band_desc(rows1 * t)
-        timed(band_desc(1)[0], t)                               # (the thread team of this size exists before the clock starts)
+        desc_t, n_t, rows_t = spread_desc(rows1 * t)
+        timed(spread_desc(1)[0], t)                             # (the thread team of this size exists before the clock starts)
         dt = min(timed(desc_t, t), timed(desc_t, t)) if n_t / rate1 / t < 0.5 else timed(desc_t, t)
         sweep.append({"threads": t, "rays_s": round(n_t / dt, 1), "rows": rows_t, "seconds": round(dt, 3)})
-    top = max(e["rays_s"] for e in sweep)
-    best = min((e for e in sweep if e["rays_s"] >= 0.90 * top), key=lambda e: e["threads"])     # (the fewest threads that reach the best rate: beyond the quota more threads only time-slice)
+    best = max(sweep, key=lambda e: e["rays_s"])                # the baseline is the best configuration measured, nothing less
+    fewest = min((e for e in sweep if e["rays_s"] >= 0.90 * best["rays_s"]), key=lambda e: e["threads"])
     best_threads, rate = best["threads"], best["rays_s"]
-    target = rate * cpu_seconds
-    saved = cam.pixel_samples
-    if target >= NX * NY * CAM_SPP:
-        n_pass = int(min(2048, max(1, round(target / (NX * NY * CAM_SPP)))))
-        cam.pixel_samples = CAM_SPP * n_pass
-        rect = (0, 0, NX, NY)
-        what = "%d full %dx%d passes of %d spp" % (n_pass, NX, NY, CAM_SPP)
-        centred = False
-    else:
-        nrows = int(max(16, min(NY, target // (NX * CAM_SPP))))
-        rect = (0, NY // 2 - nrows // 2, NX, NY // 2 - nrows // 2 + nrows)
-        what = "centred band of %d of %d rows x %d px x %d spp" % (nrows, NY, NX, CAM_SPP)
-        centred = True
+    desc, n_primary, rows_final = spread_desc(rate * cpu_seconds / (NX * CAM_SPP))
+    what = ("%d full %dx%d passes of %d spp" % (rows_final // NY, NX, NY, CAM_SPP)) if rows_final >= NY else \
+           ("%d of %d rows, spread evenly over the frame, x %d px x %d spp" % (rows_final, NY, NX, CAM_SPP))
     if SLICES > 1:
         what += ", one of the %d spectral slices" % SLICES
-    desc = cam.render_desc(world, None, sl, engine, keep, rect=rect)
-    n_primary = (rect[2] - rect[0]) * (rect[3] - rect[1]) * cam.pixel_samples
-    cam.pixel_samples = saved
     tcpu = timed(desc, best_threads)
     one = next(e for e in sweep if e["threads"] == 1)
     cpu = {"value": round(n_primary / tcpu, 1), "unit": "primary rays/s", "cores": best_threads, "kind": "port",
            "sample": "%s of the same workload (%d primary rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
-                     "with OpenMP on %d host threads (the best of the thread sweep), %.1f s" % (what, n_primary, best_threads, tcpu),
-           "host": host, "scaling": sweep,
+                     "with OpenMP on %d host threads (the best of the thread sweep, whose samples are cut the same way), %.1f s" % (what, n_primary, best_threads, tcpu),
+           "host": host, "scaling": sweep, "fewest_threads_within_10_percent": fewest["threads"],
            "speedup_over_one_thread": round(n_primary / tcpu / one["rays_s"], 2),
            "one_thread": {"value": one["rays_s"], "unit": "primary rays/s", "cores": 1,
-                          "sample": "centred band of %d rows x %d px x %d spp, %.1f s" % (one["rows"], NX, CAM_SPP, one["seconds"])}}
-    if centred:
-        cpu["sample_note"] = "a centred band is the densest part of the frame: the whole-frame CPU rate would be higher, so GPU / CPU ratios from this value flatter the GPU"
+                          "sample": "%d rows spread over the frame x %d px x %d spp, %.1f s" % (one["rows"], NX, CAM_SPP, one["seconds"])}}
     return cpu
 
 
@@ -764,12 +759,18 @@ def main():
                      "triangle_records_48B": 48.0 * pc[6], "mesh_headers_96B": 96.0 * pc[3],
                      "sample_ring_write_read": 2.0 * 24.0 * WAVE_RAYS, "frame_read_write": 40.0 * BINS * ppu, "work_list": 4.0}
             b_unit = float(sum(parts.values()))
+            # what a unit OWES whatever the kernel's design: the scene records its rays touch and its pixels' frame cells, read and written
+            # once. The sample-record ring is the design's own detour (the records could in principle stay on chip), so it is left out here.
+            b_owed = b_unit - parts["sample_ring_write_read"]
             units = rays_per_launch / WAVE_RAYS
             achieved_w = b_unit * units / (trace_avg * 1e-3) / 1e9
             hbm_per_wave = {"bytes_per_unit": round(b_unit, 1), "per_unit": {k: round(float(v), 3) for k, v in per_unit.items()},
                             "bytes": {k: round(float(v), 1) for k, v in parts.items()}, "units_per_launch": int(units),
                             "bytes_per_launch": int(b_unit * units), "achieved": round(achieved_w, 2), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                             "frac": round(achieved_w / PEAK_HBM_GBS, 5), "sampled_units": int(len(px) // ppu),
+                            "compulsory": {"bytes_per_unit": round(b_owed, 1), "bytes_per_launch": int(b_owed * units),
+                                           "achieved": round(b_owed * units / (trace_avg * 1e-3) / 1e9, 2), "frac": round(b_owed * units / (trace_avg * 1e-3) / 1e9 / PEAK_HBM_GBS, 5),
+                                           "note": "scene records + frame cells only (no sample-record ring): what is owed, next to what the design spends"},
                             "note": "algorithmic bytes per 64-ray unit (distinct records a packet fetches + its sample-record ring + its frame cells) x units "
                                     "per launch / kernel time against the 8 TB/s HBM peak; compare bytes_per_launch with hbm_measured.bytes_per_launch"}
         # ---- roofline: top level = ONE ceiling, the one that binds the dominant kernel, from the counters of this run

@@ -201,6 +201,10 @@ const char *rsx_version(void);
 /* Launch all kernels of this ctx on an external HIP stream (e.g. torch's current stream); NULL = own stream. */
 int rsx_set_stream(rsx_ctx *ctx, void *hip_stream);
 int rsx_synchronize(rsx_ctx *ctx);
+/* Non-blocking: *idle = 1 when everything issued on the context (its stream and its render lanes) has completed, 0 while work is in
+ * flight. The host layer uses it to decide when to submit the small passes it is holding back (HipEngine.auto_batch): an idle device is
+ * handed what there is, a busy one lets the batch grow. */
+int rsx_idle(rsx_ctx *ctx, int32_t *idle);
 /* Duration (ms, HIP events on the launch stream) of the most recent kernel launched through this ctx. */
 int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms);
 /* Durations (ms) of the two kernels of the most recent render call: sample trace and per-bin accumulation. */
@@ -213,7 +217,8 @@ int rsx_render_history(rsx_ctx *ctx, int32_t n, float *trace_ms, float *accumula
 int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t seed, uint64_t *mismatches);
 /* Tuning aid: when dev_buffer != NULL the next render calls write, per 64-ray work unit, {start, end} wall_clock64 ticks
  * (100 MHz) and the (workgroup << 8 | wave) that processed it into dev_buffer[n_units][12] (u64; slots 3.. are per-phase
- * cycle counters in RSX_PHASE_PROF builds). NULL switches it off. */
+ * cycle counters in RSX_PHASE_PROF builds). NULL switches it off. Tuning builds only (-DRSX_UNIT_STAMPS=1 / -DRSX_PHASE_PROF / -DRSX_UTIL_PROF):
+ * a production build compiles the stamps out and answers a non-NULL buffer with RSX_EUNSUPPORTED. */
 int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer);
 /* Timeline of the last n render calls: t[n][4] = trace begin, trace end, merge begin, merge end in ms since the first of them. */
 int rsx_render_timeline(rsx_ctx *ctx, int32_t n, float *t);
@@ -280,6 +285,24 @@ int rsx_roots_batch(rsx_scene *scene, int32_t primitive, int64_t n, const double
 /* World.contains for a batch of points (world.pyx:149-168 -> kdtree.pyx:126-162):
  * inside[n, n_world] = 1 where world primitive j contains point i. Host buffers. */
 int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *points, uint8_t *inside);
+
+/* ---- one ray, one point: the host side (SURVEY.md 8b "Who calls it: World.hit (n = 1 -> CPU lib)") ---------------------------------
+ * World.hit(ray) / World.contains(point) / Ray.trace of ONE ray from Python (core/scenegraph/world.pyx:125-168 over
+ * core/acceleration/kdtree.pyx:73-162): a device round trip per ray costs ~70 us, the reference answers in ~1 us. These entry points
+ * answer such calls on the host from the same flattened arrays the device scene is created from — the same operations in the same
+ * order as the kernels (hit ids, distances, barycentrics and geometry are the device's, bit for bit). They exist for the single-ray
+ * API only: render calls, batch queries and the bench never use them; a scene with CSG primitives is refused (RSX_EUNSUPPORTED: the
+ * caller goes to rsx_hit_batch / rsx_contains_batch). No device is needed. Arguments as rsx_hit_batch / rsx_contains_batch (host
+ * pointers; max_distance, t, exiting, tri, uvw, geom may be NULL). */
+typedef struct rsx_host_scene rsx_host_scene;
+int rsx_host_scene_create(const rsx_scene_desc *desc, rsx_host_scene **out);   /* copies what it needs from desc */
+void rsx_host_scene_free(rsx_host_scene *scene);
+int rsx_hit_host(const rsx_host_scene *scene, int64_t n, const double *origin, const double *direction, const double *max_distance,
+                 int32_t *prim, double *t, uint8_t *exiting, int32_t *tri, float *uvw, double *geom);
+/* one ray through two pointers: in[7] = origin, direction, max_distance; out[19] = primitive id (-1: none), t, exiting, triangle (-1: not a
+ * mesh), u, v, w, then hit / inside / outside point and normal (12 values, as rsx_hit_batch's geom) */
+int rsx_hit_host_one(const rsx_host_scene *scene, const double *in, double *out);
+int rsx_contains_host(const rsx_host_scene *scene, int64_t n, const double *points, uint8_t *inside);
 
 /* One spectral slice of Observer.observe(): _render_pixel for every task (observer.pyx:363-419) —
  * pinhole ray generation, Ray.trace (optical/ray.pyx:338-401) with closed-form materials, per-pixel

@@ -97,6 +97,7 @@ SYMBOLS = [
     ("rsx_version", C.c_char_p, []),
     ("rsx_set_stream", C.c_int, [_vp, _vp]),
     ("rsx_synchronize", C.c_int, [_vp]),
+    ("rsx_idle", C.c_int, [_vp, C.POINTER(C.c_int32)]),
     ("rsx_last_kernel_ms", C.c_int, [_vp, C.POINTER(C.c_float)]),
     ("rsx_last_render_ms", C.c_int, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("rsx_render_history", C.c_int, [_vp, C.c_int32, _vp, _vp]),
@@ -124,6 +125,11 @@ SYMBOLS = [
     ("rsx_hit_batch_dev", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rsx_roots_batch", C.c_int, [_vp, C.c_int32, C.c_int64, _vp, _vp, _vp, C.c_int32, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rsx_contains_batch", C.c_int, [_vp, C.c_int64, _vp, _vp]),
+    ("rsx_host_scene_create", C.c_int, [C.POINTER(SceneDesc), C.POINTER(_vp)]),
+    ("rsx_host_scene_free", None, [_vp]),
+    ("rsx_hit_host", C.c_int, [_vp, C.c_int64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    ("rsx_hit_host_one", C.c_int, [_vp, _vp, _vp]),
+    ("rsx_contains_host", C.c_int, [_vp, C.c_int64, _vp, _vp]),
     ("rsx_render_pinhole", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, C.POINTER(C.c_uint64)]),
     ("rsx_render_pinhole_frame", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, _vp, _vp, C.c_int32, C.c_int32, C.POINTER(C.c_uint64)]),
     ("rsx_render_pinhole_xyz", C.c_int, [_vp, C.POINTER(RenderDesc), _vp, C.c_double, _vp, _vp, C.POINTER(C.c_uint64)]),
@@ -148,7 +154,7 @@ SYMBOLS = [
 ]
 # Entry points an A/B build of an earlier revision ($RSX_LIB, tools/ab.sh) may lack: callers test `has(name)` before using them.
 # Any other missing symbol is ABI drift between include/rsx.h and the binary and stops the load, whichever library was named.
-OPTIONAL_WITH_RSX_LIB = {"rsx_frame_segment", "rsx_allgather_bins", "rsx_comm_size", "rsx_set_path_stages"}
+OPTIONAL_WITH_RSX_LIB = {"rsx_frame_segment", "rsx_allgather_bins", "rsx_comm_size", "rsx_set_path_stages", "rsx_idle", "rsx_host_scene_create", "rsx_host_scene_free", "rsx_hit_host", "rsx_hit_host_one", "rsx_contains_host"}
 
 _lib = None
 

@@ -412,7 +412,7 @@ class World(Node):
         scene = self.build_accelerator()
         if not isinstance(self._accelerator, HipAccelerator):
             return self._accelerator.contains(point)
-        flags = scene.contains_batch([[point.x, point.y, point.z]])[0]
+        flags = scene.contains_single(point)
         order = scene.flat.contains_order(point)
         return [self._primitives[i] for i in order if flags[i]]
 

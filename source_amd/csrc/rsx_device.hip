@@ -408,6 +408,22 @@ extern "C" int rsx_synchronize(rsx_ctx *ctx) {
     return RSX_OK;
 }
 
+extern "C" int rsx_idle(rsx_ctx *ctx, int32_t *idle) {
+    if (!ctx || !idle) return rsx_fail(RSX_EINVAL, "rsx_idle: null argument");
+    HIP_TRY(hipSetDevice(ctx->device));
+    *idle = 1;
+    for (TraceLane &ln : ctx->lanes) {
+        if (!ln.in_flight) continue;
+        const hipError_t e = hipStreamQuery(ln.stream);
+        if (e == hipErrorNotReady) { *idle = 0; return RSX_OK; }
+        if (e != hipSuccess) return rsx_fail(RSX_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    }
+    const hipError_t e = hipStreamQuery(ctx->stream);
+    if (e == hipErrorNotReady) *idle = 0;
+    else if (e != hipSuccess) return rsx_fail(RSX_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    return RSX_OK;
+}
+
 extern "C" int rsx_last_kernel_ms(rsx_ctx *ctx, float *ms) {
     if (!ctx || !ms) return rsx_fail(RSX_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
@@ -458,6 +474,10 @@ extern "C" int rsx_selftest_exact_division(rsx_ctx *ctx, uint64_t n, uint64_t se
 
 extern "C" int rsx_debug_unit_times(rsx_ctx *ctx, void *dev_buffer) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
+    // (production builds compile the stamps out — they cost the per-lane kernels registers in every pass: a buffer would stay unwritten and
+    // only change which kernels the passes take. Switching it off is always allowed.)
+    if (dev_buffer && !RSX_UNIT_STAMPS)
+        return rsx_fail(RSX_EUNSUPPORTED, "rsx_debug_unit_times: this build has no unit stamps (build librsx with -DRSX_UNIT_STAMPS=1, -DRSX_PHASE_PROF=.. or -DRSX_UTIL_PROF=1)");
     ctx->unit_times = static_cast<unsigned long long *>(dev_buffer);
     return RSX_OK;
 }
@@ -1327,13 +1347,38 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // merge, so its passes run one after the other on the context stream)
     const bool one_at_a_time = scene->d.csg_arena != nullptr;
     const bool deferred = !one_at_a_time && has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // Fused form (dev_render.hpp, "Welford in the trace kernel"): a pass that runs alone on the context stream, merges into a frame,
+    // has closed-form materials only and whole pixels per 64-ray unit keeps its sample records in per-wave rings
+    // — round 2, per-lane walk: measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. That
+    // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
+    // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
+    // From how many samples per pixel on the packet walk wins depends on the scene (tools/spp_sweep.py, 1024^2 frames): the instanced
+    // configs[2] scene from 16 (equal at 8: a unit of eight pixels straddles world leaves and instances), a single mesh (configs[1])
+    // from 4 (+21 % there, +22 % at 8, 2.2x at 32), the CSG demo at every count. RSX_PACKET_MIN_SPP pins it (0: never).
+    static const int packet_min_env = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : -1; }();
+    const int packet_min_spp = packet_min_env >= 0 ? packet_min_env : scene->has_csg ? 1 : scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP;
+    static const int fuse_env = [] { const char *e = std::getenv("RSX_FUSE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
+    // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
+    // (a task list — FullFrameSampler2D shuffles its pixels, an adaptive sampler picks them — puts unrelated pixels side by side: there a
+    // unit must be ONE pixel's samples for its rays to share their way through the trees)
+    // (CSG scenes: the fast pass of the two — state-free evaluator — may be the packet kernel; RSX_PACKET_CSG=0 keeps the per-lane one)
+    static const bool packet_csg = [] { const char *e = std::getenv("RSX_PACKET_CSG"); return !e || std::atoi(e) != 0; }();
+    const bool use_packet = !has_vol && (!scene->has_csg || (two_pass_csg && packet_csg && !h_xyz)) && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
+                            !ctx->unit_times;
+    const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth, scene->d.csg_fast_rows) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
+    const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
+    // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
+    // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
+    const bool fuse_enabled = fuse_env < 0 ? use_packet : fuse_env != 0;
+    // (what decides the fused form apart from "runs alone": batch_fusable below takes multi-pass calls off the pipelined lanes exactly when this holds)
+    const bool fusable = fuse_enabled && (passes == 1 || use_packet) && fmean && !h_mean && !has_vol && !scene->has_csg && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
+                         !ctx->unit_times && wave_lds >= fuse_fixed;
     // (a call of several passes — rsx_render_desc.passes, what batched small passes arrive as — runs alone as well: on the context stream it
     // may take the fused form, the recurrence and its K frame merges inside the packet kernel; on a private lane it would need
     // k_accumulate's multi-pass form, which costs four times the trace of a 16-pass batch of configs[1]. RSX_BATCH_ALONE=0: as before)
     static const bool batch_alone = [] { const char *e = std::getenv("RSX_BATCH_ALONE"); return !e || std::atoi(e) != 0; }();
     // (desc->spp is the widened count here: passes x samples per pass; the packet walk's threshold as further down, without its env override)
-    const bool batch_fusable = batch_alone && passes > 1 && !has_vol && !scene->has_csg && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
-                               desc->spp >= (scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP) && fmean && !h_mean && !h_xyz;
+    const bool batch_fusable = batch_alone && passes > 1 && fusable && !h_xyz;
     const bool pipelined = !one_at_a_time && !batch_fusable && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 &&
                            n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     // Scattering passes can run level by level (dev_wavefront.hpp: one launch per path segment over lists of live paths filed by material
@@ -1355,7 +1400,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     const size_t lane_bytes = S * (sizeof(Sample) + (size_t)PATH_BLOCK * sizeof(PathTerm) * 5 / 4 + 4) + 1;
     const int path_lanes = (int)std::max<size_t>(2, std::min<size_t>((size_t)ctx->path_lanes, ((size_t)48 << 30) / lane_bytes));
     TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % path_lanes] : pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
-    if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
+    // (a pass that runs alone waits for the private lanes' traces. Their `in_flight` stays set: the lane's merge kernel sits on the ctx
+    // stream and may still be reading the lane's sample records — the lane's next pass must wait for `merged` before it overwrites them.
+    // Clearing the flag here let a pipelined pass that followed a lone one race its lane's previous merge: round 5, found by submitting
+    // partial batches of small passes eagerly, tools/r5_eager_repro.py.)
+    if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) HIP_TRY(hipStreamSynchronize(ln.stream));
     if ((rc = settle_lane(ctx, lane))) return rc;          // (a deferred pass this lane ran before: its buffers are about to be reused)
 
     // materials and the importance manager's spheres share one small buffer: [materials][spheres]
@@ -1439,31 +1488,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         }
         return RSX_OK;
     };
-    // Fused form (dev_render.hpp, "Welford in the trace kernel"): a pass that runs alone on the context stream, merges into a frame,
-    // has closed-form materials only and whole pixels per 64-ray unit keeps its sample records in per-wave rings
-    // — round 2, per-lane walk: measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. That
-    // trace kernel is bound by instruction issue (VALU busy 0.75), so the recurrence finds no idle slots to hide in, and inside the
-    // wave it runs at 60 of 64 lanes plus the staging; the 6.4 GB it saves were never the bound (HBM at 2 % of peak).
-    // From how many samples per pixel on the packet walk wins depends on the scene (tools/spp_sweep.py, 1024^2 frames): the instanced
-    // configs[2] scene from 16 (equal at 8: a unit of eight pixels straddles world leaves and instances), a single mesh (configs[1])
-    // from 4 (+21 % there, +22 % at 8, 2.2x at 32), the CSG demo at every count. RSX_PACKET_MIN_SPP pins it (0: never).
-    static const int packet_min_env = [] { const char *e = std::getenv("RSX_PACKET_MIN_SPP"); return e ? std::atoi(e) : -1; }();
-    const int packet_min_spp = packet_min_env >= 0 ? packet_min_env : scene->has_csg ? 1 : scene->d.n_world <= 4 ? 4 : RSX_PACKET_MIN_SPP;
-    static const int fuse_env = [] { const char *e = std::getenv("RSX_FUSE"); return e ? (std::atoi(e) != 0 ? 1 : 0) : -1; }();
-    // few pixels per 64-ray unit: the wave walks the trees as one packet (dev_packet.hpp), with its own, smaller LDS layout
-    // (a task list — FullFrameSampler2D shuffles its pixels, an adaptive sampler picks them — puts unrelated pixels side by side: there a
-    // unit must be ONE pixel's samples for its rays to share their way through the trees)
-    // (CSG scenes: the fast pass of the two — state-free evaluator — may be the packet kernel; RSX_PACKET_CSG=0 keeps the per-lane one)
-    static const bool packet_csg = [] { const char *e = std::getenv("RSX_PACKET_CSG"); return !e || std::atoi(e) != 0; }();
-    const bool use_packet = !has_vol && (!scene->has_csg || (two_pass_csg && packet_csg && !h_xyz)) && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
-                            !ctx->unit_times;
-    const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth, scene->d.csg_fast_rows) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
-    const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
-    // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:
-    // configs[2] 24.5 + 5.3 ms as two kernels, 27.9 ms fused — off otherwise; RSX_FUSE=0 / 1 forces either)
-    const bool fuse_enabled = fuse_env < 0 ? use_packet : fuse_env != 0;
-    const bool fused = fuse_enabled && (passes == 1 || use_packet) && fmean && !h_mean && !has_vol && !scene->has_csg && !pipelined && desc->spp <= WAVE && WAVE % desc->spp == 0 &&
-                       !ctx->unit_times && wave_lds >= fuse_fixed;
+    const bool fused = fusable && !pipelined;
     if (!fused && (rc = lane_buffer(lane.samples, lane.samples_bytes, S * sizeof(Sample)))) return rc;
     {
         void *const redo_before = lane.redo;
@@ -1836,6 +1861,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         }
     } else if (two_pass_csg) {
         // fast pass (state-free CSG evaluator, several waves per SIMD), then the redo pass for the rays it could not finish
+        lane.redo_zeroed = 0;                              // (the fast pass writes every unit's mask: whatever a path pass left zeroed is not zero any more)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void *>(k_render_trace<true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l.lds));
         if (use_packet) {

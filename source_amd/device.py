@@ -13,7 +13,9 @@ from .core.math import Normal3D, Point3D
 from .core.scenegraph import Intersection, MeshIntersection
 
 _contexts = {}
-pending_observers = weakref.WeakSet()      # observers holding accepted, not yet submitted passes (optical/observer.py: _lazy_pass)
+# observers holding accepted, not yet submitted passes (optical/observer.py: _lazy_pass). Strong references on purpose: a camera that goes
+# out of scope with passes pending must still deliver them into the pipeline frames its user keeps (it leaves the set when it has).
+pending_observers = set()
 
 
 def settle_observers():
@@ -60,6 +62,14 @@ class DeviceContext:
     def synchronize(self):
         settle_observers()                                  # (work an observer is still holding back counts as issued)
         _lib.check(_lib.lib().rsx_synchronize(self._h))
+
+    def idle(self):
+        """True when nothing issued on this context is still running (non-blocking; passes observers hold back are not "issued")."""
+        if not _lib.has("rsx_idle"):
+            return False
+        flag = C.c_int32(0)
+        _lib.check(_lib.lib().rsx_idle(self._h, C.byref(flag)))
+        return bool(flag.value)
 
     def set_path_stages(self, mode=-1, min_paths=-1):
         """How path-traced passes are scheduled (rsx_set_path_stages): 1 in stages, 0 one persistent kernel, -1 the library's default."""
@@ -153,7 +163,23 @@ class DeviceScene:
             return i
         return Intersection(*args)
 
+    def host_scene(self):
+        """The host-side twin for single rays and points (HostScene), or None for a scene the host side refuses (CSG primitives)."""
+        h = getattr(self, "_host", None)
+        if h is None:
+            has_csg = any(r["type"] in (_lib.PRIM_UNION, _lib.PRIM_INTERSECT, _lib.PRIM_SUBTRACT) for r in self.flat.records)
+            h = self._host = HostScene(self.flat) if (not has_csg and _lib.has("rsx_hit_host")) else False
+        return h or None
+
     def hit_single(self, ray):
+        host = self.host_scene()
+        if host is not None:                                # one ray: answered on the host (a device round trip per ray costs ~70 us)
+            o, d = ray.origin, ray.direction
+            r1 = host.hit_one(o.x, o.y, o.z, d.x, d.y, d.z, ray.max_distance)
+            if r1 is None:
+                return None
+            prim, t, ex, tri, uvw, g = r1
+            return self._intersection(ray, self.flat.records[prim]["obj"], t, ex, tri, uvw, g)
         r = self.hit_batch([[ray.origin.x, ray.origin.y, ray.origin.z]], [[ray.direction.x, ray.direction.y, ray.direction.z]],
                            [ray.max_distance], geometry=True)
         if r["prim"][0] < 0:
@@ -190,11 +216,71 @@ class DeviceScene:
         _lib.check(_lib.lib().rsx_contains_batch(self._h, p.shape[0], _lib.ptr(p), _lib.ptr(inside)))
         return inside[:, :self.flat.n_world]
 
+    def contains_single(self, point):
+        host = self.host_scene()
+        if host is not None:
+            return host.contains_batch([[point.x, point.y, point.z]])[0]
+        return self.contains_batch([[point.x, point.y, point.z]])[0]
+
     def prim_contains(self, index, point):
-        return self.contains_batch([[point.x, point.y, point.z]])[0][index]
+        return self.contains_single(point)[index]
 
 
 _private_scenes = weakref.WeakKeyDictionary()
+
+
+class HostScene:
+    """rsx_host_scene wrapper: World.hit / World.contains for single rays and points on the host (include/rsx.h, "one ray, one point").
+    Built from the same FlatScene the device scene is; needs no GPU. Scenes with CSG primitives are refused by the library
+    (RsxError): the callers then take the device path."""
+
+    def __init__(self, flat):
+        self.flat = flat
+        self._h = C.c_void_p()
+        _lib.check(_lib.lib().rsx_host_scene_create(C.byref(flat.desc), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            _lib.lib().rsx_host_scene_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def hit_batch(self, origin, direction, max_distance=None, geometry=False):
+        o, d = _f64(origin).reshape(-1, 3), _f64(direction).reshape(-1, 3)
+        n = o.shape[0]
+        m = np.full(n, np.inf) if max_distance is None else _f64(np.broadcast_to(max_distance, (n,)))
+        out = dict(prim=np.empty(n, dtype=np.int32), t=np.empty(n), exiting=np.empty(n, dtype=np.uint8),
+                   tri=np.empty(n, dtype=np.int32), uvw=np.empty((n, 3), dtype=np.float32),
+                   geom=np.empty((n, 12)) if geometry else None)
+        _lib.check(_lib.lib().rsx_hit_host(self._h, n, _lib.ptr(o), _lib.ptr(d), _lib.ptr(m), _lib.ptr(out["prim"]), _lib.ptr(out["t"]),
+                                           _lib.ptr(out["exiting"]), _lib.ptr(out["tri"]), _lib.ptr(out["uvw"]), _lib.ptr(out["geom"])))
+        return out
+
+    def contains_batch(self, points):
+        pts = _f64(points).reshape(-1, 3)
+        inside = np.zeros((pts.shape[0], max(1, self.flat.n_world)), dtype=np.uint8)
+        _lib.check(_lib.lib().rsx_contains_host(self._h, pts.shape[0], _lib.ptr(pts), _lib.ptr(inside)))
+        return inside[:, :self.flat.n_world]
+
+    def hit_one(self, ox, oy, oz, dx, dy, dz, max_distance):
+        """One ray through two preallocated ctypes buffers (no numpy on the way): (prim, t, exiting, tri, (u, v, w), geom[12]) or None."""
+        b = getattr(self, "_one", None)
+        if b is None:
+            b = self._one = ((C.c_double * 7)(), (C.c_double * 19)(), _lib.lib().rsx_hit_host_one)
+        i, o, call = b
+        i[0], i[1], i[2], i[3], i[4], i[5], i[6] = ox, oy, oz, dx, dy, dz, max_distance
+        rc = call(self._h, i, o)
+        if rc:
+            _lib.check(rc)
+        if o[0] < 0:
+            return None
+        v = o[:]
+        return int(v[0]), v[1], int(v[2]), int(v[3]), (v[4], v[5], v[6]), v[7:19]
 
 
 def _geometry_versions(prim):

@@ -67,8 +67,8 @@ class HipEngine(RenderEngine):
     ``auto_batch`` (default on): small consecutive passes need no opt-in. An observe() whose pass is small (pixel_samples < 64, a
     rectangle of pixels, accumulating spectral pipelines, closed-form materials, this engine in its default Philox form) returns at
     once; up to 64 / pixel_samples such calls in a row are submitted as ONE library call — exactly the call passes_per_call would
-    make, so the frames are those of the separate passes, bit for bit — when the batch is full or the moment anything reads or
-    replaces a frame, synchronises the context, changes the scenegraph, or changes what the next pass would render. The reference's
+    make, so the frames are those of the separate passes, bit for bit — when the batch is full, when the device runs idle, or the moment
+    anything reads or replaces a frame, synchronises the context, changes the scenegraph, or changes what the next pass would render. The reference's
     usual loop (`while not camera.render_complete: camera.observe()` with a display or a save per pass) reads the frame every pass
     and sees no difference; a loop that only accumulates runs several times faster (configs[1]: 2.5 -> ~9 G rays/s).
 
@@ -101,6 +101,9 @@ class HipEngine(RenderEngine):
         # small (pixel_samples < 64) are accepted at once and submitted together — as the ONE library call passes_per_call would have
         # made — when the batch fills a 64-ray unit per pixel, or as soon as anything looks at the frames (see PinholeCamera._lazy_pass)
         self.auto_batch = (os.environ.get("RSX_AUTO_BATCH", "1") != "0") if auto_batch is None else bool(auto_batch)
+        # (a partial batch is submitted as soon as the device is idle — rsx_idle — instead of waiting to be full; RSX_EAGER_BATCH=0: only full
+        # batches and reads submit. How many passes a library call carries never shows in the frames.)
+        self.eager_batch = os.environ.get("RSX_EAGER_BATCH", "1") != "0"
         self.last_kernel_ms = None
 
     def worker_count(self):
@@ -856,10 +859,8 @@ class PinholeCamera(Observer2D):
         if pend is not None:
             # material parameters changed in place (no scenegraph notification: `emitter.scale = 2`) since the batch began? The pending
             # calls hold the materials and spectral tables of their own moment; a pass that would send other bytes starts a new batch
-            keep = []
-            first, last = getattr(engine, "slice_range", None) or (0, len(templates))
-            probe = self.render_desc(world, None, self._slices[first], engine, keep, rect=(0, 0, 1, 1), sample_offset=0)
-            if self._material_bytes(probe, keep) != pend["materials"]:
+            # (every slice the batch renders: a spectral function edited only at the wavelengths of a later slice must be seen too)
+            if self._all_material_bytes(world, engine, len(templates)) != pend["materials"]:
                 self._flush_lazy()
                 pend = None
         if pend is None:
@@ -882,7 +883,7 @@ class PinholeCamera(Observer2D):
                         desc.power = 1 if pipe.power else 0
                         calls.append(dict(desc=desc, keep=keep, frame=pipe.frame, offset=sl.offset))
             pend = self._lazy = dict(sig=sig, first=offset, count=0, calls=calls, scene=scene, rays=sum(c["desc"].n_tasks for c in calls) * spp // max(1, len(self._pipelines)),
-                                     materials=self._material_bytes(calls[0]["desc"], calls[0]["keep"]))
+                                     materials=self._all_material_bytes(world, engine, len(templates)))
             for pipe in self._pipelines:
                 owners = getattr(pipe.frame, "_lazy_owners", None)
                 if owners is None:
@@ -893,9 +894,22 @@ class PinholeCamera(Observer2D):
             device.pending_observers.add(self)
         pend["count"] += 1
         self.stats = {"rays": pend["rays"], "kernel_ms": 0.0}
-        if pend["count"] * spp >= 64:
+        # A full batch goes out at once; a partial one goes out the moment the device has nothing to do (the first passes of a loop, a
+        # loop of fewer passes than a batch holds: 20 batched passes used to be a 16-pass launch after sixteen observe() calls of host
+        # time and a 4-pass launch at the read — three times their kernel time). While the device is busy the batch keeps growing.
+        if pend["count"] * spp >= 64 or (getattr(engine, "eager_batch", True) and pend["scene"].context.idle()):
             self._flush_lazy()
         return True
+
+    def _all_material_bytes(self, world, engine, n_slices):
+        """The material records and spectral tables of every slice the engine renders, as one byte string (the batch's staleness probe)."""
+        first, last = getattr(engine, "slice_range", None) or (0, n_slices)
+        parts = []
+        for slice_id in range(first, last):
+            keep = []
+            probe = self.render_desc(world, None, self._slices[slice_id], engine, keep, rect=(0, 0, 1, 1), sample_offset=0)
+            parts.append(self._material_bytes(probe, keep))
+        return b"".join(parts)
 
     @staticmethod
     def _material_bytes(desc, keep):

@@ -510,3 +510,85 @@ def test_coherent_task_order(ns):
     assert all(tiles[i] == tiles[i - 1] or tiles[i] not in tiles[:i] for i in range(1, len(tiles)))     # a tile's pixels are contiguous
     twice = full + [(3, 3)]
     assert not isinstance(cam._coherent_tasks(twice), RectTasks)     # (a pixel listed twice: not a rectangle)
+
+
+def test_host_walk_single_rays_against_golden_vectors(orc, ns, golden, m70k):
+    """rsx_hit_host / rsx_contains_host (csrc/rsx_hostwalk.cpp: the host side of World.hit / World.contains for single rays, SURVEY.md 8b
+    "n = 1 -> CPU lib") against the reference's own vectors, no GPU involved: the mesh ray classes of F04 (ids, t, u, v, w, exiting,
+    geometry; vertex / edge rays, origins on the surface, max_distance short / exact / long), the analytic primitives of F05 (first
+    root, full geometry, contains), the edge worlds of F11 (empty world, coincident primitives, t == max_distance, axis-parallel
+    grazing rays) — and against the pinned oracle on a mixed world of instanced meshes and analytic primitives. Scenes with CSG
+    primitives (F06 / F07's worlds) are refused loudly: their single rays go to the device."""
+    import raysets
+    from source_amd import scenes, _lib
+    from source_amd._flatten import FlatScene
+    from source_amd.device import HostScene
+    import test_oracle_golden as T
+    # F04: the 69 432-triangle mesh as a one-primitive world
+    g = golden("f04_mesh")
+    mesh, v, t = m70k
+    host = HostScene(FlatScene([mesh]))
+    sets = {"grid": raysets.pinhole_grid(96), "outside": raysets.random_outside(6000, 41), "outside_raw": raysets.random_outside(2000, 42, unit=False),
+            "interior": raysets.random_interior(4000, 43), "vertices": raysets.through_vertices(v, 4000, 44), "edges": raysets.along_edges(v, t, 3000, 45),
+            "axis": raysets.axis_aligned(3000, 46, 0.1, v)}
+    for name, (o, d, m) in sets.items():
+        r = host.hit_batch(o, d, m, geometry=True)
+        hit = T._check_mesh(r, g, name)
+        if name + "_extra" in g:
+            assert eq(r["geom"][hit], g[name + "_extra"][hit]), name
+    T._check_mesh(host.hit_batch(g["surf_o"], g["surf_d"]), g, "surf")
+    o, d, _ = sets["outside"]
+    T._check_mesh(host.hit_batch(o[g["maxd_idx"]], d[g["maxd_idx"]], g["maxd_m"]), g, "maxd")
+    assert eq(host.contains_batch(raysets.points(4000, 49, 0.1))[:, 0], g["contains"])
+    # F05: sphere / box / cylinder, transformed and not: World.hit of a one-primitive world = the primitive's first root
+    g = golden("f05_primitives")
+    for k, (name, prim) in enumerate(T._prims(ns).items()):
+        host = HostScene(FlatScene([prim]))
+        o, d, m = raysets.primitive_rays(3000, 70 + k)
+        r = host.hit_batch(o, d, m, geometry=True)
+        ref = g[name][:, 0, :]                               # Primitive.hit's first root: t, exiting, hit, inside, outside, normal
+        hit = r["prim"] >= 0
+        # World.hit puts the BoundPrimitive gate and the tree's bounds in front of Primitive.hit (boundprimitive.pyx:42-51): some rays the bare
+        # cylinder answers (along its axis, from its caps) never reach it in a world. Where the world answers, it is the primitive's root ...
+        assert not np.isnan(ref[hit, 0]).any() and hit.sum() > 0.5 * (~np.isnan(ref[:, 0])).sum(), name
+        assert eq(r["t"][hit], ref[hit, 0]) and eq(r["exiting"][hit], ref[hit, 1]) and eq(r["geom"][hit], ref[hit, 2:]), name
+        # ... and which rays it answers is what the pinned oracle's World.hit says
+        w = orc.hit_batch(FlatScene([prim]), o, d, m, geometry=True)
+        assert eq(r["prim"], w["prim"]) and eq(r["t"][hit], w["t"][hit]) and eq(r["geom"][hit], w["geom"][hit]), name
+        assert eq(host.contains_batch(raysets.points(2000, 90 + k, 1.2))[:, 0], g[name + "_contains"]), name
+    # F11: the edge semantics of SURVEY.md Appendix B
+    g = golden("f11_edges")
+    for name, (world, prims) in scenes.build_edge_worlds(ns).items():
+        host = HostScene(world.flatten())
+        o, d, m = scenes.edge_rays(name)
+        T._check_world(host.hit_batch(o, d, m, geometry=True), g[name + "_idx"], g[name + "_rec"])
+        assert eq(host.contains_batch(np.concatenate([o, o + 0.25 * d])), g[name + "_contains"]), name
+    # instanced meshes + analytic primitives in one world, against the pinned oracle (smoothing normals, transforms, the world tree)
+    world = ns.World()
+    vs, ts = scenes.displaced_sphere(24, radius=0.5)
+    ts6 = np.concatenate([ts, ts], axis=1)                     # (vertex-normal indices = vertex indices)
+    base = ns.Mesh(vs, ts6, normals=scenes.vertex_normals(vs, ts), smoothing=True, closed=True, parent=world, transform=ns.translate(-0.7, 0.1, 0.2) * ns.rotate(20, 30, 40))
+    base.instance(parent=world, transform=ns.translate(0.8, -0.2, 0.1) * ns.rotate(-50, 10, 5))
+    ns.Sphere(0.4, world, ns.translate(0.0, 0.9, -0.3))
+    ns.Box(ns.Point3D(-2, -2, -1.6), ns.Point3D(2, 2, -1.5), world)
+    ns.Cylinder(0.25, 1.1, world, ns.translate(0.1, -0.9, -0.4) * ns.rotate(0, 70, 0))
+    flat = world.flatten()
+    host = HostScene(flat)
+    o, d, m = raysets.scene_rays(20000, 321, 6.0, 2.2)
+    a, b = host.hit_batch(o, d, m, geometry=True), orc.hit_batch(flat, o, d, m, geometry=True)
+    assert eq(a["prim"], b["prim"]) and (a["prim"] >= 0).mean() > 0.2
+    hit = b["prim"] >= 0
+    for key in ("t", "exiting", "tri", "uvw", "geom"):
+        assert eq(a[key][hit], b[key][hit]), key
+    pts = raysets.points(6000, 322, 1.5)
+    assert eq(host.contains_batch(pts), orc.contains_batch(flat, pts))
+    # single-ray form through preallocated buffers = the batch form
+    one = host.hit_one(*o[0], *d[0], float(m[0]))
+    assert (one is None) == (a["prim"][0] < 0) and (one is None or (one[0] == a["prim"][0] and one[1] == a["t"][0] and eq(one[5], a["geom"][0])))
+    # CSG worlds are the device's: loud refusal, no silent substitute
+    for build in (scenes.build_csg_demo, scenes.build_mixed):
+        host = HostScene(build(ns)[0].flatten())
+        with pytest.raises(_lib.RsxError):
+            host.hit_batch([[0, 0, -4]], [[0, 0, 1]])
+        with pytest.raises(_lib.RsxError):
+            host.contains_batch([[0, 0, 0]])
