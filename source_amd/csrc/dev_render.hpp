@@ -857,6 +857,32 @@ struct PathState {
 #define PATH_DONATE_MAX 32          // a wave out of new rays with this many live paths or fewer hands them on and retires
 #endif
 
+// Term blocks beyond a path's first come out of a shared arena. One RETURNED atomic per block — all on one address, and behind the
+// in-order vector-memory counter, so the lane waits for every store it issued before — stalled nearly every round of a wave (64 lanes, a
+// block every 15 terms: some lane needs one in 99 % of the rounds). A wave reserves ARENA_BATCH blocks at a time and hands them out
+// from a counter pair in LDS (`res` = {next, end} of this wave, zero at kernel start): the atomic runs every ~16th round. Called by
+// whatever lanes are active at the call site; `need` marks the ones that want a block. Which block a list continues in never shows
+// in a result. (What a batch has left when the next is reserved is abandoned: the arena holds two blocks per path.)
+#define ARENA_BATCH 64
+__device__ __forceinline__ unsigned int arena_block(const PathStore &ps, bool need, volatile uint32_t *res) {
+    const unsigned long long m = __ballot(need);
+    unsigned int base = 0;
+    const int lane = threadIdx.x % WAVE;
+    const int leader = m ? __ffsll((long long)m) - 1 : 0;
+    if (m != 0ULL && lane == leader) {
+        const unsigned int want = (unsigned int)__popcll(m);
+        unsigned int next = res[0], end = res[1];
+        if (next + want > end) {
+            next = atomicAdd(ps.arena_next, (unsigned int)ARENA_BATCH);
+            end = next + ARENA_BATCH;
+        }
+        base = next;
+        res[0] = next + want; res[1] = end;
+    }
+    base = (unsigned int)__builtin_amdgcn_readlane((int)base, leader);
+    return base + (unsigned int)__popcll(m & ((1ULL << lane) - 1ULL));
+}
+
 // Lanes are refilled: a lane whose path has ended takes the next ray of the wave's current 64-ray unit (a new unit when that one is
 // used up), so a wave keeps all its lanes on live paths instead of waiting for the longest of 64 (path lengths are geometric: the
 // longest of 64 is several times the mean). Which lane renders which ray never shows in the result — random numbers, sample record
@@ -888,6 +914,9 @@ struct PathState {
 // compiled into every form the hand-over cost a pass that never uses it 3 % (Cornell box 41.1 -> 42.7 ms: six more spilled registers).
 template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false>
 __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES : CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+    __shared__ uint32_t arena_res[2 * WG_WAVES];           // arena_block: the blocks each wave has reserved
+    if (threadIdx.x < 2 * WG_WAVES) arena_res[threadIdx.x] = 0;
+    __syncthreads();
     DScene sc = sc_arg;
     if (STAGED || rp.world_lds > 0) {                      // stage the world tree behind the traversal stacks (see render(); STAGED implies it)
         int4 *dst = reinterpret_cast<int4 *>(smem + rp.world_lds);
@@ -946,19 +975,25 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     unsigned long long pp_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
 #endif
     auto push = [&](double a, double b, int32_t table, int32_t kind) {
-        if (pos == PATH_BLOCK) {
-            const unsigned int nb = atomicAdd(ps.arena_next, 1u);
-            if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
-            PathTerm link;
-            link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
-            blk = (int32_t)(ps.n_records + nb);
-            ps.pool[(long long)blk * PATH_BLOCK] = link;
-            pos = 1;
+        const bool full = pos == PATH_BLOCK;
+        const unsigned int nb = arena_block(ps, full, arena_res + 2 * (threadIdx.x / WAVE));
+        bool room = true;
+        if (full) {
+            if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); room = false; }
+            else {
+                PathTerm link;
+                link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
+                blk = (int32_t)(ps.n_records + nb);
+                ps.pool[(long long)blk * PATH_BLOCK] = link;
+                pos = 1;
+            }
         }
-        PathTerm t;
-        t.a = a; t.b = b; t.table = table; t.kind = kind;
-        ps.pool[(long long)blk * PATH_BLOCK + pos] = t;
-        ++pos;
+        if (room) {
+            PathTerm t;
+            t.a = a; t.b = b; t.table = table; t.kind = kind;
+            ps.pool[(long long)blk * PATH_BLOCK + pos] = t;
+            ++pos;
+        }
     };
     // Russian roulette of a freshly spawned daughter (ray.pyx:382-388): 0 = extinguished, 1 = alive, 2 = alive and its result is
     // scaled by 1 / (1 - extinction_prob)

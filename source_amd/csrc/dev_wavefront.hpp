@@ -90,11 +90,265 @@ __device__ __forceinline__ void wf_finish(Sample *samples, const PathStore &ps, 
     ps.tail[record] = blk;
 }
 
+// The material arm of one path segment for the lanes of a wave that all wait for the same arm (`arm`: WF_NULL / WF_LAMBERT /
+// WF_DIELECTRIC / WF_END): k_render_trace_path's material stage — hit geometry, the volumes around the segment's origin, the surface,
+// the daughter's roulette and the term it leaves — on the path registers `p`. On return `active` says whether the path goes on (p.r is
+// then the daughter ray); a path that ended has its sample record written.
+struct WfRegs {
+    Ray r;
+    int32_t blk, record;
+    int pos, depth, segments;
+    uint32_t rng_pixel_lo;
+    uint64_t rng_sample;
+    unsigned int path_spawned;
+    double weight;
+};
+template <bool CSG, int MODE, bool VOLS>
+__device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS RenderParams *q, const PathStore &ps, Sample *samples, const Stack &ms, volatile uint32_t *arena_wave,
+                                       int arm, const Hit &hit, int ray_unit, int ray_slot, WfRegs &p_, bool &active, long long &spawned) {
+    Ray &r = p_.r;
+    int32_t &blk = p_.blk; const int32_t record = p_.record;
+    int &pos = p_.pos, &depth = p_.depth, &segments = p_.segments;
+    const uint32_t rng_pixel_lo = p_.rng_pixel_lo;
+    const uint64_t rng_sample = p_.rng_sample;
+    unsigned int &path_spawned = p_.path_spawned;
+    const double weight = p_.weight;
+    auto push = [&](double a, double b, int32_t table, int32_t kind) {
+        const bool full = pos == PATH_BLOCK;
+        const unsigned int nb = arena_block(ps, full, arena_wave);       // (dev_render.hpp: blocks reserved per wave)
+        bool room = true;
+        if (full) {
+            if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); room = false; }
+            else {
+                PathTerm link;
+                link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
+                blk = (int32_t)(ps.n_records + nb);
+                ps.pool[(long long)blk * PATH_BLOCK] = link;
+                pos = 1;
+            }
+        }
+        if (room) {
+            PathTerm t;
+            t.a = a; t.b = b; t.table = table; t.kind = kind;
+            ps.pool[(long long)blk * PATH_BLOCK + pos] = t;
+            ++pos;
+        }
+    };
+    auto roulette = [&]() -> int {                                         // ray.pyx:382-388
+        if (depth < q->ray_min_depth) return 1;
+        if (depth >= q->ray_max_depth) return 0;
+        double k1, k2;
+        philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
+        return k1 < q->ray_extinction_prob ? 0 : 2;
+    };
+    const bool was_active = active;
+    bool abandoned = false;
+    double end_a = 0.0;
+    int32_t end_table = -1;
+    if (active) {
+        const rsx_primitive &p = sc.prims[hit.prim];
+        const rsx_material mat = q->materials[p.material];
+        Geom g;
+        finalise<CSG>(sc, r, hit, g);
+        double hx, hy, hz;                                            // hit_point.transform(primitive_to_world)
+        xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
+        // volume emitters containing this segment's origin (Ray._sample_volumes, ray.pyx:422-455), newest first: the list is replayed backwards
+        double v_len[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_scale[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
+        int32_t v_table[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_kind[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
+        int n_vol = 0;
+        bool contains_needs_stream = false;
+        if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
+            const int32_t vm_id = sc.prims[idx].material;
+            const int32_t vt = q->materials[vm_id].type;
+            return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || (vt == RSX_MAT_DIELECTRIC && q->materials[vm_id].light_dir[2] == 0.0);
+        }, [&](int32_t idx) {
+            const rsx_primitive &vp = sc.prims[idx];
+            const rsx_material vm = q->materials[vp.material];
+            double length;
+            bool skip = false;
+            if (vm.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:300-328: world-space length
+                const double vx = r.ox - hx, vy = r.oy - hy, vz = r.oz - hz;
+                length = sqrt(vx * vx + vy * vy + vz * vz);
+            } else {
+                double sx, sy, sz, ex, ey, ez;
+                xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
+                xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
+                const double vx = sx - ex, vy = sy - ey, vz = sz - ez;
+                length = sqrt(vx * vx + vy * vy + vz * vz);
+                skip = length == 0;                                   // homogeneous.pyx:92-94
+            }
+            if (!skip) {
+                if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u);    // more volumes at a point than the registers keep: the pass is traced again by the one-kernel REWALK form
+#pragma unroll
+                for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
+                v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
+                ++n_vol;
+            }
+        });
+#pragma unroll
+        for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
+        if constexpr (MODE == 1) {
+            if (contains_needs_stream) {                              // a CSG volume without a flattened program: redo pass
+                atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
+                spawned -= (long long)path_spawned;
+                abandoned = true;
+                active = false;
+            }
+        }
+        ++segments;
+        double scatter1 = 0.0, scatter2 = 0.0;
+        if (!abandoned && segments < PATH_MAX_SEGMENTS && (arm == WF_LAMBERT || arm == WF_DIELECTRIC))
+            philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
+        bool daughter = false, lambert_term = false;
+        double term_a = 1.0, term_b = 1.0;
+        if (abandoned) {}
+        else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
+        else if (arm == WF_NULL) {                                    // null surface: carry on from the far side (material.pyx:118-147)
+            // (selects, not a pointer into the record: a pointer chosen at run time sends the whole Geom to scratch)
+            const double fx = g.exiting ? g.outside[0] : g.inside[0], fy = g.exiting ? g.outside[1] : g.inside[1], fz = g.exiting ? g.outside[2] : g.inside[2];
+            xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
+            ++spawned; ++path_spawned;
+        } else if (arm == WF_LAMBERT) {                               // lambert.pyx:76-104 under ContinuousBSDF.evaluate_surface, material.pyx:286-361
+            const double fx = g.exiting ? g.inside[0] : g.outside[0], fy = g.exiting ? g.inside[1] : g.outside[1], fz = g.exiting ? g.inside[2] : g.outside[2];
+            double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
+            if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
+            double ux = nx, uy = ny, uz = nz;
+            normalise3(ux, uy, uz);
+            double vx = 1, vy = 0, vz = 0;
+            if (fabs(ux * vx + uy * vy + uz * vz) > 0.5) { vx = 0; vy = 1; }
+            const double m = ux * vx + uy * vy + uz * vz;
+            double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
+            normalise3(tx, ty, tz);
+            const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
+            const double *a = p.to_root;
+            double stw[9];
+#pragma unroll
+            for (int ii = 0; ii < 3; ++ii) {
+                stw[3 * ii + 0] = a[4 * ii] * tx + a[4 * ii + 1] * ty + a[4 * ii + 2] * tz + a[4 * ii + 3] * 0.0;
+                stw[3 * ii + 1] = a[4 * ii] * bx + a[4 * ii + 1] * by + a[4 * ii + 2] * bz + a[4 * ii + 3] * 0.0;
+                stw[3 * ii + 2] = a[4 * ii] * nx + a[4 * ii + 1] * ny + a[4 * ii + 2] * nz + a[4 * ii + 3] * 0.0;
+            }
+            const bool mis = q->n_important > 0;
+            double h1, h2, sx, sy, sz, pdf_important = 0.0;
+            bool from_important = false;
+            if (mis) {
+                const double choose = scatter1, pick = scatter2;
+                philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                from_important = choose < q->important_path_weight;
+                double wx, wy, wz;
+                ImportantPick picked;
+                picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
+                if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
+                double sn, cs;
+                portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
+                if (from_important) {
+                    important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
+                    const double *wtp = p.to_local;
+                    double wts[9];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                        wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                        wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                    }
+                    sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
+                    sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
+                    sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
+                }
+                if (!from_important) {
+                    const double rad = sqrt(h1);
+                    sx = rad * cs; sy = rad * sn;
+                    const double sz2 = 1.0 - sx * sx - sy * sy;
+                    sz = sqrt(sz2 > 0 ? sz2 : 0);
+                    wx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                    wy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                    wz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                }
+                pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
+            } else {
+                double sn, cs;
+                h1 = scatter1; h2 = scatter2;
+                const double rad = sqrt(h1);
+                portable_sincos(2.0 * M_PI * h2, sn, cs);
+                sx = rad * cs; sy = rad * sn;
+                const double sz2 = 1.0 - sx * sx - sy * sy;
+                sz = sqrt(sz2 > 0 ? sz2 : 0);
+            }
+            const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;         // HemisphereCosineSampler.pdf
+            const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
+            const double rcp = 1.0 / pdf_all;                         // div_scalar (spectrum.pyx:459-467)
+            if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }
+            else {
+                xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
+                r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
+            }
+        } else if (arm == WF_DIELECTRIC) {                            // dielectric.pyx:159-262
+            double ix, iy, iz;
+            xform_vector(p.to_local, r.dx, r.dy, r.dz, ix, iy, iz);
+            normalise3(ix, iy, iz);
+            double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
+            normalise3(nx, ny, nz);
+            const double c1 = -(nx * ix + ny * iy + nz * iz);
+            const bool inside = c1 < 0.0;
+            const double n1 = inside ? mat.scale : mat.light_dir[0], n2 = inside ? mat.light_dir[0] : mat.scale;
+            const bool transmission_only = mat.light_dir[1] != 0.0;
+            const double gamma = n1 / n2;
+            const double c2s = 1 - (gamma * gamma) * (1 - c1 * c1);
+            bool reflect = true;
+            double ox = 0, oy = 0, oz = 0;
+            if (c2s > 0) {
+                const double temp = inside ? gamma * c1 + sqrt(c2s) : gamma * c1 - sqrt(c2s);
+                ox = gamma * ix + temp * nx; oy = gamma * iy + temp * ny; oz = gamma * iz + temp * nz;
+                const double ci = c1, ct = -(nx * ox + ny * oy + nz * oz);
+                const double ra = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct), rb = (n1 * ct - n2 * ci) / (n1 * ct + n2 * ci);
+                const double reflectivity = 0.5 * (ra * ra + rb * rb);
+                const double transmission = 1 - reflectivity;
+                if (transmission_only) reflect = false;
+                else reflect = !(scatter1 < transmission);
+            }
+            if (reflect && transmission_only) active = false;         // total internal reflection without a reflected ray: zero spectrum
+            else {
+                if (reflect) {
+                    const double temp = 2 * c1;
+                    ox = ix + temp * nx; oy = iy + temp * ny; oz = iz + temp * nz;
+                }
+                const bool from_inside = reflect == inside;           // reflect: the side the ray came from; transmit: the far side
+                const double fx = from_inside ? g.inside[0] : g.outside[0], fy = from_inside ? g.inside[1] : g.outside[1], fz = from_inside ? g.inside[2] : g.outside[2];
+                xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
+                xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
+                daughter = true;
+            }
+        } else {                                                      // optical/ray.pyx:391-393: the path ends at this surface
+            if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
+            else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
+                double lx, ly, lz;
+                xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                end_a = mat.scale * (dot > 0 ? dot : 0.0);
+                end_table = mat.table;
+            }
+            active = false;
+        }
+        if (daughter) {                                               // ray.pyx:380-388: the daughter exists (and counts) before its roulette
+            ++depth;
+            ++spawned; ++path_spawned;
+            const int alive = roulette();
+            if (!alive) active = false;
+            if (lambert_term || alive == 2) push(term_a, term_b, mat.table, !lambert_term ? TERM_NORM : alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
+        }
+    }
+    if (was_active && !active && !abandoned) wf_finish(samples, ps, record, blk, pos, weight, end_a, end_table);
+}
 template <bool CSG, int MODE = 0, bool VOLS = true, bool STAGED = false>
 __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScene sc_arg, RenderParams rp, Sample *samples, WfStore wf, PathStore ps) {
     static_assert(!CSG || MODE == 1, "CSG scenes: the staged form is the fast pass (state-free evaluator); the redo pass is k_render_trace_path<true, 2>");
     __shared__ uint32_t seg_first[WF_SEGS + 1];            // first chunk of every (arm, sub-list) segment of list_in
     __shared__ uint32_t seg_count[WF_SEGS];                // ... and its length
+    __shared__ uint32_t arena_res[2 * WG_WAVES];           // arena_block: the blocks each wave has reserved
+    if (threadIdx.x < 2 * WG_WAVES) arena_res[threadIdx.x] = 0;
     const unsigned long long rp_bits = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(DScene) + 7) & ~(size_t)7);
     const RSX_CONST_AS RenderParams *q = (const RSX_CONST_AS RenderParams *)rp_bits;
     (void)rp;
@@ -143,10 +397,9 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
         lo = __builtin_amdgcn_readfirstlane(lo);
         i0 = (uint32_t)(c - (long long)seg_first[lo]) * WAVE;
     };
-    // The slot numbers of a wave's NEXT chunk are requested while it works on the current one, and the two lines of those paths
-    // are touched (one dword each, into the L2) before the current chunk's walk: list entry -> path record -> primitive record is a chain
-    // of dependent loads, and at two waves per SIMD nobody else hides it (first measurement of this kernel: vector ALU 0.50 busy, waves
-    // waiting 0.48 of their cycles).
+    // The slot numbers of a wave's NEXT chunk are requested while it works on the current one. (Touching the two lines of those paths
+    // before the current chunk's walk, to have them in the L2 when they are wanted, was measured and dropped: -0.9 k clocks at the top
+    // of an iteration, +2.6 k in the walk, whose few scratch reloads then wait behind the touches on the in-order memory counter.)
     int lo_next = 0;
     bool active_next = false;
     uint32_t slot_next = 0;
@@ -179,14 +432,16 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
         unsigned long long pp_mark = clock64();
 #endif
         WfPath &path = wf.paths[slot];
-        Ray r;
+        WfRegs pr;
+        Ray &r = pr.r;
         r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
-        int32_t blk = 0, record = 0;
-        int pos = 0, depth = 0, segments = 0;
-        uint32_t rng_pixel_lo = 0;
-        uint64_t rng_sample = 0;
-        unsigned int path_spawned = 0;
-        double weight = 0;
+        int32_t &blk = pr.blk, &record = pr.record;
+        int &pos = pr.pos, &depth = pr.depth, &segments = pr.segments;
+        uint32_t &rng_pixel_lo = pr.rng_pixel_lo;
+        uint64_t &rng_sample = pr.rng_sample;
+        unsigned int &path_spawned = pr.path_spawned;
+        double &weight = pr.weight;
+        blk = 0; record = 0; pos = 0; depth = 0; segments = 0; rng_pixel_lo = 0; rng_sample = 0; path_spawned = 0; weight = 0;
         const int ray_unit = (int)(wf.first_unit + (long long)(slot / WAVE)), ray_slot = (int)(slot % WAVE);    // where the path's primary ray came from
         if (first) {
             const UnitPixel px = unit_pixel(q, wf.first_unit + c, lane);
@@ -206,237 +461,19 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
             blk = path.blk; pos = path.pos; depth = path.depth; segments = path.segments;
             record = path.record; rng_pixel_lo = path.rng_pixel_lo; rng_sample = path.rng_sample; weight = path.weight; path_spawned = path.path_spawned;
         }
-        auto push = [&](double a, double b, int32_t table, int32_t kind) {
-            if (pos == PATH_BLOCK) {
-                const unsigned int nb = atomicAdd(ps.arena_next, 1u);
-                if (nb >= ps.arena_blocks) { atomicOr(ps.flags, 1u); return; }
-                PathTerm link;
-                link.a = 0; link.b = 0; link.table = (int32_t)blk; link.kind = TERM_LINK;
-                blk = (int32_t)(ps.n_records + nb);
-                ps.pool[(long long)blk * PATH_BLOCK] = link;
-                pos = 1;
-            }
-            PathTerm t;
-            t.a = a; t.b = b; t.table = table; t.kind = kind;
-            ps.pool[(long long)blk * PATH_BLOCK + pos] = t;
-            ++pos;
-        };
-        auto roulette = [&]() -> int {                                         // ray.pyx:382-388
-            if (depth < q->ray_min_depth) return 1;
-            if (depth >= q->ray_max_depth) return 0;
-            double k1, k2;
-            philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth) << 48), k1, k2);
-            return k1 < q->ray_extinction_prob ? 0 : 2;
-        };
         WF_STAMP(0)
 #if RSX_PHASE_PROF == 3
         pp[4] += 1; pp[5] += __popcll(__ballot(active));
 #endif
         // ---- the material arm of the segment the previous level walked ----
         if (!first) {
-            const bool was_active = active;
-            bool abandoned = false;
-            double end_a = 0.0;
-            int32_t end_table = -1;
+            Hit hit;
+            hit.prim = -1;
             if (active) {
-                Hit hit;
                 if constexpr (CSG) hit = wf.csg_hits[slot];
                 else { hit.t = path.t; hit.prim = path.prim; hit.a0 = path.a0; hit.a1 = path.a1; hit.u = path.u; hit.v = path.v; hit.w = path.w; hit.leaf = 0; hit.flags = 0; hit.hx = hit.hy = hit.hz = 0; }
-                const rsx_primitive &p = sc.prims[hit.prim];
-                const rsx_material mat = q->materials[p.material];
-                Geom g;
-                finalise<CSG>(sc, r, hit, g);
-                double hx, hy, hz;                                            // hit_point.transform(primitive_to_world)
-                xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
-                // volume emitters containing this segment's origin (Ray._sample_volumes, ray.pyx:422-455), newest first: the list is replayed backwards
-                double v_len[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_scale[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
-                int32_t v_table[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_kind[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
-                int n_vol = 0;
-                bool contains_needs_stream = false;
-                if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
-                    const int32_t vm_id = sc.prims[idx].material;
-                    const int32_t vt = q->materials[vm_id].type;
-                    return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || (vt == RSX_MAT_DIELECTRIC && q->materials[vm_id].light_dir[2] == 0.0);
-                }, [&](int32_t idx) {
-                    const rsx_primitive &vp = sc.prims[idx];
-                    const rsx_material vm = q->materials[vp.material];
-                    double length;
-                    bool skip = false;
-                    if (vm.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:300-328: world-space length
-                        const double vx = r.ox - hx, vy = r.oy - hy, vz = r.oz - hz;
-                        length = sqrt(vx * vx + vy * vy + vz * vz);
-                    } else {
-                        double sx, sy, sz, ex, ey, ez;
-                        xform_point(vp.to_local, hx, hy, hz, sx, sy, sz);
-                        xform_point(vp.to_local, r.ox, r.oy, r.oz, ex, ey, ez);
-                        const double vx = sx - ex, vy = sy - ey, vz = sz - ez;
-                        length = sqrt(vx * vx + vy * vy + vz * vz);
-                        skip = length == 0;                                   // homogeneous.pyx:92-94
-                    }
-                    if (!skip) {
-                        if (n_vol == PATH_VOL_OVERLAP) atomicOr(ps.flags, 4u);    // more volumes at a point than the registers keep: the pass is traced again by the one-kernel REWALK form
-#pragma unroll
-                        for (int j = PATH_VOL_OVERLAP - 1; j > 0; --j) { v_len[j] = v_len[j - 1]; v_scale[j] = v_scale[j - 1]; v_table[j] = v_table[j - 1]; v_kind[j] = v_kind[j - 1]; }
-                        v_len[0] = length; v_scale[0] = vm.scale; v_table[0] = vm.table; v_kind[0] = vm.type == RSX_MAT_DIELECTRIC ? TERM_ATTEN : TERM_VOL;
-                        ++n_vol;
-                    }
-                });
-#pragma unroll
-                for (int j = 0; j < PATH_VOL_OVERLAP; ++j) if (j < n_vol) push(v_len[j], v_scale[j], v_table[j], v_kind[j]);
-                if constexpr (MODE == 1) {
-                    if (contains_needs_stream) {                              // a CSG volume without a flattened program: redo pass
-                        atomicOr(q->redo_mask + ray_unit, 1ULL << ray_slot);
-                        spawned -= (long long)path_spawned;
-                        abandoned = true;
-                        active = false;
-                    }
-                }
-                ++segments;
-                double scatter1 = 0.0, scatter2 = 0.0;
-                if (!abandoned && segments < PATH_MAX_SEGMENTS && (arm == WF_LAMBERT || arm == WF_DIELECTRIC))
-                    philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample | ((uint64_t)(2 * depth + 1) << 48), scatter1, scatter2);
-                bool daughter = false, lambert_term = false;
-                double term_a = 1.0, term_b = 1.0;
-                if (abandoned) {}
-                else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
-                else if (arm == WF_NULL) {                                    // null surface: carry on from the far side (material.pyx:118-147)
-                    // (selects, not a pointer into the record: a pointer chosen at run time sends the whole Geom to scratch)
-                    const double fx = g.exiting ? g.outside[0] : g.inside[0], fy = g.exiting ? g.outside[1] : g.inside[1], fz = g.exiting ? g.outside[2] : g.inside[2];
-                    xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
-                    ++spawned; ++path_spawned;
-                } else if (arm == WF_LAMBERT) {                               // lambert.pyx:76-104 under ContinuousBSDF.evaluate_surface, material.pyx:286-361
-                    const double fx = g.exiting ? g.inside[0] : g.outside[0], fy = g.exiting ? g.inside[1] : g.outside[1], fz = g.exiting ? g.inside[2] : g.outside[2];
-                    double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
-                    if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
-                    double ux = nx, uy = ny, uz = nz;
-                    normalise3(ux, uy, uz);
-                    double vx = 1, vy = 0, vz = 0;
-                    if (fabs(ux * vx + uy * vy + uz * vz) > 0.5) { vx = 0; vy = 1; }
-                    const double m = ux * vx + uy * vy + uz * vz;
-                    double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
-                    normalise3(tx, ty, tz);
-                    const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
-                    const double *a = p.to_root;
-                    double stw[9];
-#pragma unroll
-                    for (int ii = 0; ii < 3; ++ii) {
-                        stw[3 * ii + 0] = a[4 * ii] * tx + a[4 * ii + 1] * ty + a[4 * ii + 2] * tz + a[4 * ii + 3] * 0.0;
-                        stw[3 * ii + 1] = a[4 * ii] * bx + a[4 * ii + 1] * by + a[4 * ii + 2] * bz + a[4 * ii + 3] * 0.0;
-                        stw[3 * ii + 2] = a[4 * ii] * nx + a[4 * ii + 1] * ny + a[4 * ii + 2] * nz + a[4 * ii + 3] * 0.0;
-                    }
-                    const bool mis = q->n_important > 0;
-                    double h1, h2, sx, sy, sz, pdf_important = 0.0;
-                    bool from_important = false;
-                    if (mis) {
-                        const double choose = scatter1, pick = scatter2;
-                        philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
-                        from_important = choose < q->important_path_weight;
-                        double wx, wy, wz;
-                        ImportantPick picked;
-                        picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
-                        if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
-                        double sn, cs;
-                        portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
-                        if (from_important) {
-                            important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
-                            const double *wtp = p.to_local;
-                            double wts[9];
-#pragma unroll
-                            for (int j = 0; j < 3; ++j) {
-                                wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                                wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                                wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                            }
-                            sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
-                            sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
-                            sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
-                        }
-                        if (!from_important) {
-                            const double rad = sqrt(h1);
-                            sx = rad * cs; sy = rad * sn;
-                            const double sz2 = 1.0 - sx * sx - sy * sy;
-                            sz = sqrt(sz2 > 0 ? sz2 : 0);
-                            wx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                            wy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                            wz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                        }
-                        pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
-                    } else {
-                        double sn, cs;
-                        h1 = scatter1; h2 = scatter2;
-                        const double rad = sqrt(h1);
-                        portable_sincos(2.0 * M_PI * h2, sn, cs);
-                        sx = rad * cs; sy = rad * sn;
-                        const double sz2 = 1.0 - sx * sx - sy * sy;
-                        sz = sqrt(sz2 > 0 ? sz2 : 0);
-                    }
-                    const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;         // HemisphereCosineSampler.pdf
-                    const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
-                    const double rcp = 1.0 / pdf_all;                         // div_scalar (spectrum.pyx:459-467)
-                    if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }
-                    else {
-                        xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
-                        r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                        r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                        r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                        daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
-                    }
-                } else if (arm == WF_DIELECTRIC) {                            // dielectric.pyx:159-262
-                    double ix, iy, iz;
-                    xform_vector(p.to_local, r.dx, r.dy, r.dz, ix, iy, iz);
-                    normalise3(ix, iy, iz);
-                    double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
-                    normalise3(nx, ny, nz);
-                    const double c1 = -(nx * ix + ny * iy + nz * iz);
-                    const bool inside = c1 < 0.0;
-                    const double n1 = inside ? mat.scale : mat.light_dir[0], n2 = inside ? mat.light_dir[0] : mat.scale;
-                    const bool transmission_only = mat.light_dir[1] != 0.0;
-                    const double gamma = n1 / n2;
-                    const double c2s = 1 - (gamma * gamma) * (1 - c1 * c1);
-                    bool reflect = true;
-                    double ox = 0, oy = 0, oz = 0;
-                    if (c2s > 0) {
-                        const double temp = inside ? gamma * c1 + sqrt(c2s) : gamma * c1 - sqrt(c2s);
-                        ox = gamma * ix + temp * nx; oy = gamma * iy + temp * ny; oz = gamma * iz + temp * nz;
-                        const double ci = c1, ct = -(nx * ox + ny * oy + nz * oz);
-                        const double ra = (n1 * ci - n2 * ct) / (n1 * ci + n2 * ct), rb = (n1 * ct - n2 * ci) / (n1 * ct + n2 * ci);
-                        const double reflectivity = 0.5 * (ra * ra + rb * rb);
-                        const double transmission = 1 - reflectivity;
-                        if (transmission_only) reflect = false;
-                        else reflect = !(scatter1 < transmission);
-                    }
-                    if (reflect && transmission_only) active = false;         // total internal reflection without a reflected ray: zero spectrum
-                    else {
-                        if (reflect) {
-                            const double temp = 2 * c1;
-                            ox = ix + temp * nx; oy = iy + temp * ny; oz = iz + temp * nz;
-                        }
-                        const bool from_inside = reflect == inside;           // reflect: the side the ray came from; transmit: the far side
-                        const double fx = from_inside ? g.inside[0] : g.outside[0], fy = from_inside ? g.inside[1] : g.outside[1], fz = from_inside ? g.inside[2] : g.outside[2];
-                        xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
-                        xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
-                        daughter = true;
-                    }
-                } else {                                                      // optical/ray.pyx:391-393: the path ends at this surface
-                    if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
-                    else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
-                        double lx, ly, lz;
-                        xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
-                        const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
-                        end_a = mat.scale * (dot > 0 ? dot : 0.0);
-                        end_table = mat.table;
-                    }
-                    active = false;
-                }
-                if (daughter) {                                               // ray.pyx:380-388: the daughter exists (and counts) before its roulette
-                    ++depth;
-                    ++spawned; ++path_spawned;
-                    const int alive = roulette();
-                    if (!alive) active = false;
-                    if (lambert_term || alive == 2) push(term_a, term_b, mat.table, !lambert_term ? TERM_NORM : alive == 2 ? TERM_LAMBERT_NORM : TERM_LAMBERT);
-                }
             }
-            if (was_active && !active && !abandoned) wf_finish(samples, ps, record, blk, pos, weight, end_a, end_table);
+            wf_arm<CSG, MODE, VOLS>(sc, q, ps, samples, ms, arena_res + 2 * (threadIdx.x / WAVE), arm, hit, ray_unit, ray_slot, pr, active, spawned);
         }
         // ---- the next segment: Ray.trace's world.hit for every path that goes on ----
         WF_STAMP(1)
@@ -444,11 +481,6 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
         pp[6] += __popcll(__ballot(active));
 #endif
         int next_key = -1;
-        uint32_t touch0 = 0, touch1 = 0;
-        if (have_next && active_next) {
-            const volatile uint32_t *line = reinterpret_cast<const volatile uint32_t *>(wf.paths + slot_next);
-            touch0 = line[0]; touch1 = line[16];
-        }
         if (__any(active)) {
             Hit hit;
             uint32_t work = 0;
@@ -486,7 +518,6 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
                 }
             }
         }
-        asm volatile("" :: "v"(touch0), "v"(touch1));
         WF_STAMP(2)
         // file the paths that go on: lane k < WF_KEYS reserves list k's entries (ONE atomic instruction per chunk for all the lists)
         {

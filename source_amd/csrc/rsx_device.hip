@@ -1501,7 +1501,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // (the path kernel keeps a path's pixel index — the Philox counter's first word — in 32 bits)
         if ((unsigned long long)desc->camera.nx * (unsigned long long)desc->camera.ny > 0xffffffffULL)
             return rsx_fail(RSX_EUNSUPPORTED, "render: path-traced passes address at most 2^32 camera pixels (%d x %d asked for)", desc->camera.nx, desc->camera.ny);
-        arena_blocks = std::max<size_t>((size_t)1 << 16, (has_scatter ? 2 : 1) * S);
+        // (two blocks per path for the lists themselves; a third because waves take blocks ARENA_BATCH at a time — arena_block, dev_render.hpp —
+        // and a wave that needs one block holds sixty-four)
+        arena_blocks = std::max<size_t>((size_t)1 << 17, (has_scatter ? 3 : 1) * S);
         if (const char *e = std::getenv("RSX_PATH_ARENA")) arena_blocks = (size_t)std::max(0ll, std::atoll(e));
         const size_t pool_bytes = (S + arena_blocks) * PATH_BLOCK * sizeof(PathTerm);
         if (S + arena_blocks >= ((size_t)1 << 31) || pool_bytes > ((size_t)48 << 30))
