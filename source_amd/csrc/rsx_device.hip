@@ -1590,7 +1590,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // and record the longest path of each unit (atomicMax in k_render_trace_path); spectral slices of one observe() share camera and
         // units, so slice k + 1 starts the units that held slice k's longest paths first.
         static const int path_lpt = [] { const char *e = std::getenv("RSX_PATH_LPT"); return e ? std::atoi(e) : 2; }();
-        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && (has_vol ? path_lpt > 0 && !use_wf : !two_pass_csg);
+        // (a call of several passes — batched small passes — is as many times the units of one and balances by itself; the one-workgroup sort
+        // behind it cost a 16-pass batch of configs[1] 0.25 - 0.8 ms next to a 1.3 ms kernel: profiles/r05a_c2_kernel_stats.csv)
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && passes == 1 && (has_vol ? path_lpt > 0 && !use_wf : !two_pass_csg);
         rp.measure_cost = want_order ? 1 : 0;
         if (has_vol && path_lpt == 1) want_order = false;           // (measure, do not re-order: tuning aid)
         // Primary-ray passes over the same units cost the same from pass to pass (the rays differ only by their jitter): the list

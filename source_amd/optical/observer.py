@@ -104,6 +104,10 @@ class HipEngine(RenderEngine):
         # (a partial batch is submitted as soon as the device is idle — rsx_idle — instead of waiting to be full; RSX_EAGER_BATCH=0: only full
         # batches and reads submit. How many passes a library call carries never shows in the frames.)
         self.eager_batch = os.environ.get("RSX_EAGER_BATCH", "1") != "0"
+        # samples per pixel a partial batch must hold to go out early. Swept on configs[1] (tools/r5_observe_times.py; rays/s at 20 / 64 / 200
+        # observe() calls): never 3.9 / 6.4 / 8.5e9, from 16 on 4.7 / 7.5 / 8.5e9, from 4 or 8 on 5.2 / 5.5 / 2.0e9 — small batches are served by
+        # launches that cost four times as much per pass, and new batch sizes meet first-use costs (80 ms stalls in the timed loop)
+        self.eager_min = int(os.environ.get("RSX_EAGER_MIN", "16"))
         self.last_kernel_ms = None
 
     def worker_count(self):
@@ -897,7 +901,10 @@ class PinholeCamera(Observer2D):
         # A full batch goes out at once; a partial one goes out the moment the device has nothing to do (the first passes of a loop, a
         # loop of fewer passes than a batch holds: 20 batched passes used to be a 16-pass launch after sixteen observe() calls of host
         # time and a 4-pass launch at the read — three times their kernel time). While the device is busy the batch keeps growing.
-        if pend["count"] * spp >= 64 or (getattr(engine, "eager_batch", True) and pend["scene"].context.idle()):
+        # (only power-of-two batches of at least eager_min samples per pixel: anything smaller is cut into launches of 1, 2, 4 passes that
+        # cost 0.4 ms per pass where a 16-pass launch takes 0.1 — profiles/r05a_c2_kernel_stats.csv)
+        count = pend["count"]
+        if count * spp >= 64 or (getattr(engine, "eager_batch", True) and count * spp >= getattr(engine, "eager_min", 16) and count & (count - 1) == 0 and pend["scene"].context.idle()):
             self._flush_lazy()
         return True
 
