@@ -496,13 +496,15 @@ __device__ int csg_fast_hit_uniform(const CsgFast *csgfast, const rsx_primitive 
 }
 
 // contains(): csg.pyx:350-353, :448-451, :570-573 over BoundPrimitive.contains (box gate + primitive.contains)
+// MESHES false: the caller knows the scene holds no mesh (the ray cast and its registers are left out)
+template <bool MESHES = true>
 __device__ bool leaf_contains(const DScene &sc, const rsx_primitive &p, double px, double py, double pz, Stack mesh_stack) {
     double qx, qy, qz;
     xform_point(p.to_local, px, py, pz, qx, qy, qz);
     if (p.type == RSX_PRIM_SPHERE) return (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
     if (p.type == RSX_PRIM_BOX) return aabb_contains(p.params, p.params + 3, qx, qy, qz);
     if (p.type == RSX_PRIM_CYLINDER) return (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
-    if (p.type == RSX_PRIM_MESH) {
+    if constexpr (MESHES) if (p.type == RSX_PRIM_MESH) {
         const DMesh &m = sc.meshes[p.mesh];
         if (!m.closed) return false;
         Ray zr;

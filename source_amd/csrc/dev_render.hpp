@@ -803,7 +803,7 @@ __device__ RSX_IMP_INLINE double important_pdf(const rsx_important_sphere *spher
 // whose bounding box and surface contain the point
 // FASTONLY (fast pass of a CSG scene): CSG primitives are tested with the flattened program; one without a program makes the
 // caller abandon the path to the redo pass (needs_stream).
-template <bool CSG, bool FASTONLY, typename W, typename F>
+template <bool CSG, bool FASTONLY, bool MESHES = true, typename W, typename F>
 __device__ __forceinline__ void world_contains_each(const DScene &sc, double px, double py, double pz, const Stack &ms, bool &needs_stream, W want, F f) {
     if (!aabb_contains(sc.wlower, sc.wupper, px, py, pz)) return;
     int32_t node = 0;
@@ -823,9 +823,9 @@ __device__ __forceinline__ void world_contains_each(const DScene &sc, double px,
                 if (is_csg(p.type)) {
                     if (sc.csgfast && sc.csgfast[idx].n_leaves > 0) in = csg_fast_contains(sc, idx, px, py, pz, ms);
                     else { in = false; needs_stream = true; }
-                } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+                } else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains<MESHES>(sc, p, px, py, pz, ms);
             } else if constexpr (CSG) in = node_contains(sc, idx, px, py, pz, ms);
-            else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz, ms);
+            else in = aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains<MESHES>(sc, p, px, py, pz, ms);
             if (in) f(idx);
         }
     }
@@ -912,8 +912,16 @@ __device__ __forceinline__ unsigned int arena_block(const PathStore &ps, bool ne
 // (prism-sized scene unstaged 35 -> 38 ms, Cornell box 42.5 -> 44.5 ms).
 // QUEUE: the instantiation can hand paths on and drain them (PathStore::queue / drain) — the forms the overlapping slices of an observe() run;
 // compiled into every form the hand-over cost a pass that never uses it 3 % (Cornell box 41.1 -> 42.7 ms: six more spilled registers).
-template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false>
-__global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES : CSG && MODE != 1 ? 1 : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
+// MESHES false: the form for scenes without a mesh primitive (render() picks it). The wave-cooperative mesh walk and its triangle
+// test held the register peak of every path instantiation (235 registers live there against ~200 elsewhere) whether or not a path
+// ever reached a mesh; without them the plain form fits three waves per SIMD (168 registers, 328 B scratch: Cornell box 28.3 ->
+// 24.6 ms per pass, two waves 25.9), the CSG forms stay at two (three waves spill the flattened evaluator: prism pass 333 -> 487 ms)
+// and gain from the shorter code alone (357 -> 333 ms).
+#ifndef RSX_PATH_NOMESH_MIN_WAVES
+#define RSX_PATH_NOMESH_MIN_WAVES 3
+#endif
+template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false, bool MESHES = true>
+__global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES : CSG && MODE != 1 ? 1 : !CSG && !MESHES ? RSX_PATH_NOMESH_MIN_WAVES : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     __shared__ uint32_t arena_res[2 * WG_WAVES];           // arena_block: the blocks each wave has reserved
     if (threadIdx.x < 2 * WG_WAVES) arena_res[threadIdx.x] = 0;
     __syncthreads();
@@ -1110,9 +1118,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         pp_acc[6] += __popcll(__ballot(active)); pp_acc[7] += 1;
 #endif
 #if RSX_PHASE_PROF == 3
-        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2, RSX_CSG_MAILBOX, MESHES>(active, sc, r, st, ms, csg_state, hit, work, pp_acc);
 #else
-        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(active, sc, r, st, ms, csg_state, hit, work);
+        const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2, RSX_CSG_MAILBOX, MESHES>(active, sc, r, st, ms, csg_state, hit, work);
 #endif
 #if RSX_PHASE_PROF == 3
         const unsigned long long pp1 = clock64();
@@ -1132,7 +1140,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             const rsx_primitive &p = sc.prims[hit.prim];
             const rsx_material mat = q->materials[p.material];
             Geom g;
-            finalise<CSG>(sc, r, hit, g);
+            finalise<CSG, MESHES>(sc, r, hit, g);
             double hx, hy, hz;                                                // hit_point.transform(primitive_to_world)
             xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
 #if RSX_PHASE_PROF == 3
@@ -1144,7 +1152,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             int32_t v_table[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_kind[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
             int n_vol = 0;
             bool contains_needs_stream = false;
-            if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
+            if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1, MESHES>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
                 const int32_t vm_id = sc.prims[idx].material;                         // every other evaluate_volume leaves the spectrum unchanged
                 const int32_t vt = q->materials[vm_id].type;                          // (light_dir[2] != 0: a dielectric of unit transmission — render())
                 return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || (vt == RSX_MAT_DIELECTRIC && q->materials[vm_id].light_dir[2] == 0.0);
@@ -1182,7 +1190,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 for (int want = n_vol - PATH_VOL_OVERLAP - 1; want >= 0; --want) {
                     int seen = 0;
                     bool dummy = false;
-                    world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, dummy, [&](int32_t idx) {
+                    world_contains_each<CSG, MODE == 1, MESHES>(sc, r.ox, r.oy, r.oz, ms, dummy, [&](int32_t idx) {
                         const int32_t vm_id = sc.prims[idx].material;
                         const int32_t vt = q->materials[vm_id].type;
                         return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || (vt == RSX_MAT_DIELECTRIC && q->materials[vm_id].light_dir[2] == 0.0);

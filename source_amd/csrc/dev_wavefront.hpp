@@ -103,7 +103,7 @@ struct WfRegs {
     unsigned int path_spawned;
     double weight;
 };
-template <bool CSG, int MODE, bool VOLS>
+template <bool CSG, int MODE, bool VOLS, bool MESHES = true>
 __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS RenderParams *q, const PathStore &ps, Sample *samples, const Stack &ms, volatile uint32_t *arena_wave,
                                        int arm, const Hit &hit, int ray_unit, int ray_slot, WfRegs &p_, bool &active, long long &spawned) {
     Ray &r = p_.r;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS Rend
         const rsx_primitive &p = sc.prims[hit.prim];
         const rsx_material mat = q->materials[p.material];
         Geom g;
-        finalise<CSG>(sc, r, hit, g);
+        finalise<CSG, MESHES>(sc, r, hit, g);
         double hx, hy, hz;                                            // hit_point.transform(primitive_to_world)
         xform_point(p.to_root, g.hit[0], g.hit[1], g.hit[2], hx, hy, hz);
         // volume emitters containing this segment's origin (Ray._sample_volumes, ray.pyx:422-455), newest first: the list is replayed backwards
@@ -157,7 +157,7 @@ __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS Rend
         int32_t v_table[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_kind[PATH_VOL_OVERLAP] = {0, 0, 0, 0};
         int n_vol = 0;
         bool contains_needs_stream = false;
-        if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
+        if constexpr (VOLS) if (q->n_vol_emitters) world_contains_each<CSG, MODE == 1, MESHES>(sc, r.ox, r.oy, r.oz, ms, contains_needs_stream, [&](int32_t idx) {
             const int32_t vm_id = sc.prims[idx].material;
             const int32_t vt = q->materials[vm_id].type;
             return vt == RSX_MAT_UNIFORM_VOLUME_EMITTER || (vt == RSX_MAT_DIELECTRIC && q->materials[vm_id].light_dir[2] == 0.0);
@@ -342,7 +342,7 @@ __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS Rend
     }
     if (was_active && !active && !abandoned) wf_finish(samples, ps, record, blk, pos, weight, end_a, end_table);
 }
-template <bool CSG, int MODE = 0, bool VOLS = true, bool STAGED = false>
+template <bool CSG, int MODE = 0, bool VOLS = true, bool STAGED = false, bool MESHES = true>
 __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScene sc_arg, RenderParams rp, Sample *samples, WfStore wf, PathStore ps) {
     static_assert(!CSG || MODE == 1, "CSG scenes: the staged form is the fast pass (state-free evaluator); the redo pass is k_render_trace_path<true, 2>");
     __shared__ uint32_t seg_first[WF_SEGS + 1];            // first chunk of every (arm, sub-list) segment of list_in
@@ -473,7 +473,7 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
                 if constexpr (CSG) hit = wf.csg_hits[slot];
                 else { hit.t = path.t; hit.prim = path.prim; hit.a0 = path.a0; hit.a1 = path.a1; hit.u = path.u; hit.v = path.v; hit.w = path.w; hit.leaf = 0; hit.flags = 0; hit.hx = hit.hy = hit.hz = 0; }
             }
-            wf_arm<CSG, MODE, VOLS>(sc, q, ps, samples, ms, arena_res + 2 * (threadIdx.x / WAVE), arm, hit, ray_unit, ray_slot, pr, active, spawned);
+            wf_arm<CSG, MODE, VOLS, MESHES>(sc, q, ps, samples, ms, arena_res + 2 * (threadIdx.x / WAVE), arm, hit, ray_unit, ray_slot, pr, active, spawned);
         }
         // ---- the next segment: Ray.trace's world.hit for every path that goes on ----
         WF_STAMP(1)
@@ -484,7 +484,7 @@ __global__ __launch_bounds__(WG_THREADS, RSX_WF_MIN_WAVES) void k_wf_level(DScen
         if (__any(active)) {
             Hit hit;
             uint32_t work = 0;
-            const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2>(active, sc, r, st, ms, csg_state, hit, work);
+            const bool got = world_trace_wave<CSG, MODE == 1, RSX_STAGE_MIN, false, !CSG ? 8 : MODE == 1 && RSX_CSG_MAILBOX >= 4 ? RSX_CSG_WIDE : 2, RSX_CSG_MAILBOX, MESHES>(active, sc, r, st, ms, csg_state, hit, work);
             if (active) {
                 bool abandoned = false;
                 if constexpr (MODE == 1) abandoned = (work >> 31) != 0;

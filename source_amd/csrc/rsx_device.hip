@@ -227,6 +227,7 @@ struct rsx_ctx {
     // rsx_defer_path_checks: path passes run on the private lanes and their end-of-pass checks are collected later
     int32_t wf_mode = -1;                          // rsx_set_path_stages
     long long wf_min_paths = -1;
+    bool path_general = false;                     // rsx_set_path_stages mode 2 / 3: scenes without a mesh keep the kernel forms that carry the mesh walk
     bool defer_path = false;
     int32_t deferred_calls = 0;                    // path passes issued since deferral was switched on
     std::vector<int32_t> deferred_failed;          // ... of which these must be rendered again (term arena ran out, too many volumes at a point)
@@ -1804,6 +1805,11 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             };
 #define WF_LEVEL(...) reinterpret_cast<const void *>(k_wf_level<__VA_ARGS__>)
 #define PATH_KERNEL(...) reinterpret_cast<const void *>(k_render_trace_path<__VA_ARGS__>)
+            // the staged forms (scenes of a few dozen primitives) come with and without the mesh walk: see k_render_trace_path, MESHES
+#define PATH_STAGED(c, m, v, qd) (nomesh ? PATH_KERNEL(c, m, v, false, true, qd, false) : PATH_KERNEL(c, m, v, false, true, qd))
+#define WF_STAGED(c, m, v) (nomesh ? WF_LEVEL(c, m, v, true, false) : WF_LEVEL(c, m, v, true))
+            static const bool path_meshes_always = [] { const char *e = std::getenv("RSX_PATH_MESHES"); return e && std::atoi(e) != 0; }();   // (A/B and the parity test of the two forms)
+            const bool nomesh = scene->d.n_meshes == 0 && !path_meshes_always && !ctx->path_general;       // (rsx_scene_create: a mesh primitive needs a mesh record)
             if (two_pass_csg) {
                 const bool vols = rp.n_vol_emitters > 0;
                 // (the mask is left zeroed by the k_accumulate of the lane's previous pass over as many units, the second ticket set too)
@@ -1811,13 +1817,13 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                 lane.redo_zeroed = 0;
                 const bool staged = rp.prims_lds > 0;
                 if (use_wf && !rewalk && !wf_off) {
-                    if (!vols) rc = staged ? run_staged(WF_LEVEL(true, 1, false, true), PATH_KERNEL(true, 1, false, false, true, true)) : run_staged(WF_LEVEL(true, 1, false, false), nullptr);
-                    else rc = staged ? run_staged(WF_LEVEL(true, 1, true, true), PATH_KERNEL(true, 1, true, false, true, true)) : run_staged(WF_LEVEL(true, 1, true, false), nullptr);
+                    if (!vols) rc = staged ? run_staged(WF_STAGED(true, 1, false), PATH_STAGED(true, 1, false, true)) : run_staged(WF_LEVEL(true, 1, false, false), nullptr);
+                    else rc = staged ? run_staged(WF_STAGED(true, 1, true), PATH_STAGED(true, 1, true, true)) : run_staged(WF_LEVEL(true, 1, true, false), nullptr);
                     if (rc) return rc;
                 } else
-                if ((rc = launch_drained(!vols ? (staged ? PATH_KERNEL(true, 1, false, false, true) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
-                                         staged ? PATH_KERNEL(true, 1, true, false, true) : PATH_KERNEL(true, 1, true),
-                                         !staged || rewalk ? nullptr : !vols ? PATH_KERNEL(true, 1, false, false, true, true) : PATH_KERNEL(true, 1, true, false, true, true), l.grid))) return rc;
+                if ((rc = launch_drained(!vols ? (staged ? PATH_STAGED(true, 1, false, false) : PATH_KERNEL(true, 1, false)) : rewalk ? PATH_KERNEL(true, 1, true, true) :
+                                         staged ? PATH_STAGED(true, 1, true, false) : PATH_KERNEL(true, 1, true),
+                                         !staged || rewalk ? nullptr : !vols ? PATH_STAGED(true, 1, false, true) : PATH_STAGED(true, 1, true, true), l.grid))) return rc;
                 PathState *const queue = ps.queue;                             // (the redo pass walks the same work lists: with the second ticket set)
                 ps.queue = nullptr;                                            // (the redo pass — usually a handful of paths — keeps them)
                 // The redo pass carries the stream merge: one wave per SIMD, a whole register file per wave — each of its workgroups has to
@@ -1831,16 +1837,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             } else if (scene->has_csg) { if ((rc = launch_drained(rewalk ? PATH_KERNEL(true, 0, true, true) : PATH_KERNEL(true), nullptr, l.grid))) return rc; }
             else if (use_wf && !rewalk && !wf_off) {
                 const bool staged = rp.prims_lds > 0;
-                if (rp.n_vol_emitters == 0) rc = staged ? run_staged(WF_LEVEL(false, 0, false, true), PATH_KERNEL(false, 0, false, false, true, true)) : run_staged(WF_LEVEL(false, 0, false, false), nullptr);
-                else rc = staged ? run_staged(WF_LEVEL(false, 0, true, true), PATH_KERNEL(false, 0, true, false, true, true)) : run_staged(WF_LEVEL(false, 0, true, false), nullptr);
+                if (rp.n_vol_emitters == 0) rc = staged ? run_staged(WF_STAGED(false, 0, false), PATH_STAGED(false, 0, false, true)) : run_staged(WF_LEVEL(false, 0, false, false), nullptr);
+                else rc = staged ? run_staged(WF_STAGED(false, 0, true), PATH_STAGED(false, 0, true, true)) : run_staged(WF_LEVEL(false, 0, true, false), nullptr);
                 if (rc) return rc;
             }
             else if (rp.n_vol_emitters == 0) {            // nothing with a volume contribution (clear glass counts as nothing): the form without the world.contains() pass
-                if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true) : PATH_KERNEL(false, 0, false),
-                                         rp.prims_lds > 0 ? PATH_KERNEL(false, 0, false, false, true, true) : nullptr, l.grid))) return rc;
+                if ((rc = launch_drained(rp.prims_lds > 0 ? PATH_STAGED(false, 0, false, false) : PATH_KERNEL(false, 0, false),
+                                         rp.prims_lds > 0 ? PATH_STAGED(false, 0, false, true) : nullptr, l.grid))) return rc;
             }
-            else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true) : PATH_KERNEL(false),
-                                          !rewalk && rp.prims_lds > 0 ? PATH_KERNEL(false, 0, true, false, true, true) : nullptr, l.grid))) return rc;
+            else if ((rc = launch_drained(rewalk ? PATH_KERNEL(false, 0, true, true) : rp.prims_lds > 0 ? PATH_STAGED(false, 0, true, false) : PATH_KERNEL(false),
+                                          !rewalk && rp.prims_lds > 0 ? PATH_STAGED(false, 0, true, true) : nullptr, l.grid))) return rc;
+#undef PATH_STAGED
+#undef WF_STAGED
 #undef PATH_KERNEL
 #undef WF_LEVEL
             HIP_TRY(hipGetLastError());
@@ -2024,8 +2032,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 }  // namespace
 
 extern "C" int rsx_set_path_stages(rsx_ctx *ctx, int32_t mode, int64_t min_paths) {
-    if (!ctx || mode < -1 || mode > 1) return rsx_fail(RSX_EINVAL, "rsx_set_path_stages: bad arguments");
-    ctx->wf_mode = mode;
+    if (!ctx || mode < -1 || mode > 3) return rsx_fail(RSX_EINVAL, "rsx_set_path_stages: bad arguments");
+    ctx->wf_mode = mode < 0 ? -1 : (mode & 1);
+    ctx->path_general = mode >= 2;
     ctx->wf_min_paths = min_paths < 0 ? -1 : (long long)min_paths;
     return RSX_OK;
 }

@@ -72,7 +72,8 @@ class DeviceContext:
         return bool(flag.value)
 
     def set_path_stages(self, mode=-1, min_paths=-1):
-        """How path-traced passes are scheduled (rsx_set_path_stages): 1 in stages, 0 one persistent kernel, -1 the library's default."""
+        """How path-traced passes are scheduled (rsx_set_path_stages): 1 in stages, 0 one persistent kernel, -1 the library's default;
+        2 / 3 = 0 / 1 with the kernel forms that carry the mesh walk kept for scenes without a mesh (A/B, tests)."""
         _lib.check(_lib.lib().rsx_set_path_stages(self._h, int(mode), int(min_paths)))
 
     def defer_path_checks(self, on):

@@ -1872,14 +1872,15 @@ def test_staged_path_passes_equal_the_one_kernel_form(orc, ns):
             cam.frame_sampler = ns.RectFrameSampler2D()
             pipe.accumulate = False                                # (every observe() starts a fresh frame)
             frames = []
-            for mode in (1, 0):
-                ctx.set_path_stages(mode, 0 if mode else -1)
+            for mode in (1, 0, 3, 2):                              # (2 / 3: the forms with the mesh walk, which none of these scenes needs)
+                ctx.set_path_stages(mode, 0 if mode & 1 else -1)
                 cam.render_engine = ns.HipEngine(rng="philox", seed=41)
                 cam.observe()
                 frames.append((pipe.frame.mean.copy(), pipe.frame.variance.copy(), pipe.frame.samples.copy(), cam.stats["rays"]))
                 cam.render_engine.sample_offset = 0
-            assert eq(frames[0][0], frames[1][0]) and eq(frames[0][1], frames[1][1]) and eq(frames[0][2], frames[1][2]), name
-            assert frames[0][3] == frames[1][3], (name, frames[0][3], frames[1][3])
+            for other in frames[1:]:
+                assert eq(frames[0][0], other[0]) and eq(frames[0][1], other[1]) and eq(frames[0][2], other[2]), name
+                assert frames[0][3] == other[3], (name, frames[0][3], other[3])
             assert (frames[0][0] > 0).mean() > 0.05, name
             if against_oracle:
                 w, h = cam.pixels
