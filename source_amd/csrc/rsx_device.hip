@@ -1028,8 +1028,11 @@ int query_workspace(rsx_ctx *ctx, std::initializer_list<size_t> sizes, Carver &c
     return RSX_OK;
 }
 
-// One synchronous query = inputs up, kernel, outputs back. For small workspaces (<= 1 MiB) both directions go through the ctx's
-// pinned mirror of the workspace: one transfer each way instead of one per array (World.hit(ray) is a batch of one).
+// One synchronous query = inputs up, kernel, outputs back. Workspaces up to 256 MiB go both ways through the ctx's pinned mirror of
+// the workspace: one transfer each way instead of one per array (World.hit(ray) is a batch of one), and the caller's pageable arrays
+// are never a DMA target. The second half matters to the host-callback render path (optical/hybrid.py), whose parent process answers
+// the ray waves of forked material workers: pageable transfers into heap pages still shared copy-on-write with 16 busy children
+// cost 3 ms per call instead of 0.2 (tools/r5_hybrid_workers.py); through the mirror the call no longer depends on who shares the pages.
 struct QueryIO {
     rsx_ctx *ctx;
     char *ws_begin, *ws_end;
@@ -1040,12 +1043,19 @@ struct QueryIO {
 
     int begin(rsx_ctx *c, void *first, char *end) {
         ctx = c; ws_begin = static_cast<char *>(first); ws_end = end;
-        staged = (size_t)(ws_end - ws_begin) <= ((size_t)1 << 20);
-        if (staged && ctx->staging_bytes < ((size_t)1 << 20)) {
+        const size_t need = (size_t)(ws_end - ws_begin);
+        staged = need <= ((size_t)256 << 20);
+        if (staged && ctx->staging_bytes < need) {
+            size_t bytes = std::max(ctx->staging_bytes, (size_t)1 << 20);
+            while (bytes < need) bytes *= 2;
             if (ctx->staging) HIP_TRY(hipHostFree(ctx->staging));
             ctx->staging = nullptr; ctx->staging_bytes = 0;
-            HIP_TRY(hipHostMalloc(&ctx->staging, (size_t)1 << 20, hipHostMallocDefault));
-            ctx->staging_bytes = (size_t)1 << 20;
+            if (hipHostMalloc(&ctx->staging, bytes, hipHostMallocDefault) != hipSuccess) {      // (no pinned memory left: pageable transfers)
+                (void)hipGetLastError();
+                ctx->staging = nullptr; staged = false;
+                return RSX_OK;
+            }
+            ctx->staging_bytes = bytes;
         }
         return RSX_OK;
     }

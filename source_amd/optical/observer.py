@@ -80,7 +80,7 @@ class HipEngine(RenderEngine):
     """
 
     def __init__(self, rng="philox", seed=0, fused=True, timing=False, sample_offset=0, host_materials=False, sample_stride=1, slice_range=None,
-                 passes_per_call=1, auto_batch=None):
+                 passes_per_call=1, auto_batch=None, per_node_materials=False, host_workers=None):
         if rng not in ("philox", "stream"):
             raise ValueError("rng must be 'philox' or 'stream'")
         # multi-process renders (source_amd/distributed.py). sample_stride = N with sample_offset = rank * pixel_samples: pass p of this
@@ -91,6 +91,11 @@ class HipEngine(RenderEngine):
         self.rng, self.seed, self.fused = rng, int(seed), bool(fused)
         self.host_materials = bool(host_materials)    # True: evaluate every material on the host (source_amd/optical/hybrid.py) even when
                                                       # all of them have device lowerings — scenes with a user-written material always do
+        # host-callback path only (hybrid.py). per_node_materials: call every material per node through the plugin API instead of the
+        # library's array forms (what a user-written evaluate_surface gets anyway; a test aid). host_workers: processes that evaluate
+        # Python materials (None: min(cores, 16); 1: in this process) — see hybrid.render_slice
+        self.per_node_materials = bool(per_node_materials)
+        self.host_workers = None if host_workers is None else max(1, int(host_workers))
         self.timing = bool(timing)          # True: read back HIP-event kernel times after each library call (one stream sync per call:
                                             # a tuning aid, it defeats the pipelined render lanes)
         self.sample_offset = int(sample_offset)

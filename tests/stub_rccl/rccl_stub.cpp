@@ -10,7 +10,14 @@
 // blocking copies and returns — later work on the stream sees them). Sends never block (so a group of sends and receives cannot
 // deadlock whatever the order of the peers); a receive that waits longer than RSX_STUB_TIMEOUT_S (default 120) fails.
 //
-// build: hipcc -shared -fPIC -O2 tests/stub_rccl/rccl_stub.cpp -o librccl_stub.so
+// RSX_STUB_ASYNC=1 (with RSX_STUB_DELAY_MS, default 20): the point-to-point groups complete ASYNCHRONOUSLY, like the real library's —
+// ncclGroupEnd returns at once; a helper thread waits for the work enqueued on the stream before the group (an event), sleeps the
+// delay, moves the bytes over its own non-blocking stream and only then releases the caller's stream, which has been parked behind
+// a one-lane kernel spinning on a pinned flag. So the receive buffers change well after the call has returned, and only work that
+// is ordered behind the group ON THE GROUP'S STREAM may read them: a consumer on another stream, a host read without a
+// synchronisation, or a send buffer recycled too early shows up as a wrong frame (the synchronous form hides all three).
+//
+// build: hipcc -shared -fPIC -O2 tests/stub_rccl/rccl_stub.cpp -o librccl_stub.so -lpthread
 #include <hip/hip_runtime.h>
 
 #include <fcntl.h>
@@ -18,11 +25,16 @@
 #include <time.h>
 #include <unistd.h>
 
+#include <atomic>
+#include <condition_variable>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace {
@@ -98,25 +110,134 @@ int collect(const std::string &name, void *data, size_t bytes, bool remove) {
     return kSuccess;
 }
 
-int run(std::vector<Op> &ops) {
-    // everything enqueued on the streams before the group comes first
-    for (const Op &op : ops) if (hipStreamSynchronize(op.stream) != hipSuccess) return kUnhandledCudaError;
+// copies on `copier` (a non-blocking stream of the helper thread) when given, else blocking copies
+int copy_down(void *host, const void *dev, size_t bytes, hipStream_t copier) {
+    if (!bytes) return kSuccess;
+    if (!copier) return hipMemcpy(host, dev, bytes, hipMemcpyDeviceToHost) == hipSuccess ? kSuccess : kUnhandledCudaError;
+    if (hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, copier) != hipSuccess) return kUnhandledCudaError;
+    return hipStreamSynchronize(copier) == hipSuccess ? kSuccess : kUnhandledCudaError;
+}
+int copy_up(void *dev, const void *host, size_t bytes, hipStream_t copier) {
+    if (!bytes) return kSuccess;
+    if (!copier) return hipMemcpy(dev, host, bytes, hipMemcpyHostToDevice) == hipSuccess ? kSuccess : kUnhandledCudaError;
+    if (hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, copier) != hipSuccess) return kUnhandledCudaError;
+    return hipStreamSynchronize(copier) == hipSuccess ? kSuccess : kUnhandledCudaError;
+}
+
+int transfer(std::vector<Op> &ops, hipStream_t copier) {
     std::vector<char> host;
     for (const Op &op : ops) {                                   // all sends first: they never wait
         if (op.kind != 0) continue;
         host.resize(op.bytes);
-        if (op.bytes && hipMemcpy(host.data(), op.buf, op.bytes, hipMemcpyDeviceToHost) != hipSuccess) return kUnhandledCudaError;
-        const int rc = publish(p2p_name(op.comm, op.comm->rank, op.peer, op.comm->sent[(size_t)op.peer]++), host.data(), op.bytes);
+        int rc = copy_down(host.data(), op.buf, op.bytes, copier);
+        if (rc) return rc;
+        rc = publish(p2p_name(op.comm, op.comm->rank, op.peer, op.comm->sent[(size_t)op.peer]++), host.data(), op.bytes);
         if (rc) return rc;
     }
     for (const Op &op : ops) {
         if (op.kind != 1) continue;
         host.resize(op.bytes);
-        const int rc = collect(p2p_name(op.comm, op.peer, op.comm->rank, op.comm->received[(size_t)op.peer]++), host.data(), op.bytes, true);
+        int rc = collect(p2p_name(op.comm, op.peer, op.comm->rank, op.comm->received[(size_t)op.peer]++), host.data(), op.bytes, true);
         if (rc) return rc;
-        if (op.bytes && hipMemcpy(op.buf, host.data(), op.bytes, hipMemcpyHostToDevice) != hipSuccess) return kUnhandledCudaError;
+        rc = copy_up(op.buf, host.data(), op.bytes, copier);
+        if (rc) return rc;
     }
     return kSuccess;
+}
+
+// ---- asynchronous completion (RSX_STUB_ASYNC=1) ---------------------------------------------------------------------------------------
+__global__ void k_park(volatile int *flag) {
+    // holds the stream until the helper thread has moved the group's bytes (or ~60 s have passed: a dead helper must not hang the GPU)
+    const long long t0 = wall_clock64();
+    while (__atomic_load_n(const_cast<int *>(flag), __ATOMIC_RELAXED) == 0) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 6000000000LL) break;
+    }
+}
+
+struct Job { std::vector<Op> ops; hipEvent_t before; int *flag; };
+
+struct Helper {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<Job> jobs;
+    std::thread thread;
+    std::atomic<int> failed{0};
+    bool started = false, stop = false, busy = false;
+    int device = 0;
+    int *flags = nullptr;                                       // pinned, one int per group in flight (ring)
+    size_t next_flag = 0;
+    static constexpr size_t kFlags = 4096;
+
+    void loop() {
+        (void)hipSetDevice(device);
+        hipStream_t copier = nullptr;
+        if (hipStreamCreateWithFlags(&copier, hipStreamNonBlocking) != hipSuccess) { failed = kUnhandledCudaError; copier = nullptr; }
+        const char *e = getenv("RSX_STUB_DELAY_MS");
+        const int delay_ms = e ? atoi(e) : 20;
+        for (;;) {
+            Job job;
+            {
+                std::unique_lock<std::mutex> lock(m);
+                cv.wait(lock, [&] { return stop || !jobs.empty(); });
+                if (jobs.empty()) break;
+                job = std::move(jobs.front());
+                jobs.pop_front();
+                busy = true;
+            }
+            int rc = hipEventSynchronize(job.before) == hipSuccess ? kSuccess : kUnhandledCudaError;      // the stream's earlier work
+            usleep((useconds_t)delay_ms * 1000);
+            if (!rc && copier) rc = transfer(job.ops, copier);
+            if (rc) { failed = rc; fprintf(stderr, "rccl_stub (async): a group failed with %d\n", rc); }
+            __atomic_store_n(job.flag, 1, __ATOMIC_RELEASE);    // releases the caller's stream
+            (void)hipEventDestroy(job.before);
+            { std::lock_guard<std::mutex> lock(m); busy = false; }
+            cv.notify_all();
+        }
+        if (copier) (void)hipStreamDestroy(copier);
+    }
+
+    int submit(std::vector<Op> &ops) {
+        if (failed) return failed;
+        std::lock_guard<std::mutex> lock(m);
+        if (!started) {
+            if (hipGetDevice(&device) != hipSuccess) return kUnhandledCudaError;
+            if (hipHostMalloc(reinterpret_cast<void **>(&flags), kFlags * sizeof(int), hipHostMallocDefault) != hipSuccess) return kUnhandledCudaError;
+            memset(flags, 0, kFlags * sizeof(int));
+            thread = std::thread([this] { loop(); });
+            thread.detach();                                    // (lives as long as the process; the object itself is never destroyed)
+            started = true;
+        }
+        Job job;
+        job.flag = flags + (next_flag++ % kFlags);
+        __atomic_store_n(job.flag, 0, __ATOMIC_RELEASE);
+        const hipStream_t stream = ops.front().stream;
+        for (const Op &op : ops) if (op.stream != stream) return kInvalidArgument;      // (librsx issues a group on one stream)
+        if (hipEventCreateWithFlags(&job.before, hipEventDisableTiming) != hipSuccess) return kUnhandledCudaError;
+        if (hipEventRecord(job.before, stream) != hipSuccess) return kUnhandledCudaError;
+        hipLaunchKernelGGL(k_park, dim3(1), dim3(1), 0, stream, job.flag);
+        if (hipGetLastError() != hipSuccess) return kUnhandledCudaError;
+        job.ops = std::move(ops);
+        jobs.push_back(std::move(job));
+        cv.notify_all();
+        return kSuccess;
+    }
+
+    void drain() {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&] { return jobs.empty() && !busy; });
+    }
+};
+
+Helper &g_helper = *new Helper();
+bool async_mode() { static const bool on = [] { const char *e = getenv("RSX_STUB_ASYNC"); return e && *e && *e != '0'; }(); return on; }
+
+int run(std::vector<Op> &ops) {
+    if (ops.empty()) return kSuccess;
+    if (async_mode()) return g_helper.submit(ops);
+    // everything enqueued on the streams before the group comes first
+    for (const Op &op : ops) if (hipStreamSynchronize(op.stream) != hipSuccess) return kUnhandledCudaError;
+    return transfer(ops, nullptr);
 }
 
 int submit(const Op &op) {
@@ -168,6 +289,7 @@ int ncclCommInitRank(ncclComm_t *comm, int n_ranks, ncclUniqueId id, int rank) {
 
 int ncclCommDestroy(ncclComm_t c) {
     if (!c) return kSuccess;
+    if (async_mode() && g_helper.started) g_helper.drain();
     // (this rank's files of the last two collective rounds stay: a slower rank may not have read them yet — a few bytes each, in the
     // test's own directory)
     delete c;
@@ -213,6 +335,7 @@ int ncclRecv(void *buf, size_t count, int type, int peer, ncclComm_t c, hipStrea
 int ncclBroadcast(const void *send, void *recv, size_t count, int type, int root, ncclComm_t c, hipStream_t stream) {
     const size_t w = type_bytes(type);
     if (!c || !w || root < 0 || root >= c->n) return kInvalidArgument;
+    if (async_mode() && g_helper.started) g_helper.drain();     // (collectives stay synchronous: after the groups issued before them)
     if (hipStreamSynchronize(stream) != hipSuccess) return kUnhandledCudaError;
     std::vector<char> host(count * w);
     if (c->rank == root) {
@@ -234,6 +357,7 @@ int ncclBroadcast(const void *send, void *recv, size_t count, int type, int root
 int ncclAllReduce(const void *send, void *recv, size_t count, int type, int op, ncclComm_t c, hipStream_t stream) {
     const size_t w = type_bytes(type);
     if (!c || !w || (type != 8 && type != 7 && type != 2 && type != 4)) return kInvalidArgument;
+    if (async_mode() && g_helper.started) g_helper.drain();
     if (hipStreamSynchronize(stream) != hipSuccess) return kUnhandledCudaError;
     const uint64_t seq = c->collectives++;
     // a rank publishes round s only after it has read every rank's round s - 1, so once this rank begins round s everybody is done

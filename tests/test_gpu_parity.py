@@ -1524,7 +1524,7 @@ def test_arena_csg_scene_passes_do_not_share_node_states(orc, ns):
 
 
 
-@pytest.mark.parametrize("world_size", [2, 3, 8])
+@pytest.mark.parametrize("world_size", [2, 3, 8, -3])
 def test_multi_rank_exchange_through_transport_stub(ns, tmp_path, world_size):
     """librsx's multi-rank framebuffer exchange (csrc/rsx_comm.hpp; the reference's counterpart: the result queue of
     workflow.py:201-251 folded by power.pyx:424-437) EXECUTED with W = 2, 3 and 8 ranks on the one GPU of the box: W processes share
@@ -1534,15 +1534,22 @@ def test_multi_rank_exchange_through_transport_stub(ns, tmp_path, world_size):
     exchanged frame equals the one-process render bit for bit; sample sharding: every rank holds the same frame (bit for bit) and it
     equals the one-process render of the same W x passes x spp samples within the merge's tolerance (the fold associates
     differently from a sequential accumulation — 1e-12 relative on the mean, 16 eps (mean^2 + var) per merged pass on the variance),
-    sample counts exact."""
+    sample counts exact.
+    world_size -3 = three ranks with the stub's ASYNCHRONOUS completion (RSX_STUB_ASYNC=1): ncclGroupEnd returns at once and the
+    bytes land 20 ms after the stream's earlier work has finished, moved by another thread over another stream while the caller's
+    stream is parked — what a consumer on a different stream, a host read without a synchronisation or a send buffer recycled too
+    early would get wrong."""
     import shutil
     import subprocess
     import sys
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     stub = str(tmp_path / "librccl_stub.so")
-    subprocess.check_call([hipcc, "-shared", "-fPIC", "-O2", os.path.join(ROOT, "tests", "stub_rccl", "rccl_stub.cpp"), "-o", stub])
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-O2", os.path.join(ROOT, "tests", "stub_rccl", "rccl_stub.cpp"), "-o", stub, "-lpthread"])
     modes = "tile,tile_balanced,sample,slice,slice_chunked"
     env = dict(os.environ, RSX_RCCL_LIB=stub, RSX_STUB_DIR=str(tmp_path), RSX_DEVICE="0", RSX_STUB_TIMEOUT_S="240")
+    if world_size < 0:
+        world_size = -world_size
+        env.update(RSX_STUB_ASYNC="1", RSX_STUB_DELAY_MS="20")
     procs = []
     for r in range(world_size):
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "stub_rccl", "worker.py"), str(r), str(world_size), str(tmp_path), modes],
