@@ -120,6 +120,9 @@ __device__ __forceinline__ void wave_stacks_packet(const DScene &sc, Stack &ws, 
 #ifndef RSX_STEP_UNIFORM_ORIGIN
 #define RSX_STEP_UNIFORM_ORIGIN 1
 #endif
+#ifndef RSX_STEP_PREFETCH
+#define RSX_STEP_PREFETCH 0
+#endif
 
 // a value that is the same in every lane, declared so to the compiler (it then lives in scalar registers)
 __device__ __forceinline__ unsigned long long pkt_uniform64(unsigned long long v) {
@@ -443,8 +446,19 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
         asm volatile("; MARK mesh steps begin");
 #endif
         while (nd.type >= 0) {
+#if RSX_STEP_PREFETCH
+            // both children are asked for before the step: the next node's record is a dependent scalar load (the constant cache answers in
+            // ~100 cycles, L2 in several hundred) at the end of every step otherwise — here it travels under the step's own arithmetic
+            const int32_t lower_id = node + 1;
+            const UNode nl = load_node_u(nodes, lower_id), nu = load_node_u(nodes, nd.count);
+            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0, m_have PKT_PASS);
+            const bool took_lower = node == lower_id;
+            nd.type = took_lower ? nl.type : nu.type; nd.count = took_lower ? nl.count : nu.count;
+            nd.lo = took_lower ? nl.lo : nu.lo; nd.hi = took_lower ? nl.hi : nu.hi;
+#else
             node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0, m_have PKT_PASS);
             nd = load_node_u(nodes, node);
+#endif
             work += 1;
             PKT_COUNT(PKC_MSTEPS, 1)
         }
@@ -626,8 +640,17 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
         m_have = pkt_mask(tmax != PKT_EMPTY);
         UNode nd = load_node_u(wnodes, node);
         while (nd.type >= 0) {
+#if RSX_STEP_PREFETCH >= 2
+            const int32_t lower_id = node + 1;
+            const UNode nl = load_node_u(wnodes, lower_id), nu = load_node_u(wnodes, nd.count);
+            node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, sp, t_cull, m_have PKT_PASS);
+            const bool took_lower = node == lower_id;
+            nd.type = took_lower ? nl.type : nu.type; nd.count = took_lower ? nl.count : nu.count;
+            nd.lo = took_lower ? nl.lo : nu.lo; nd.hi = took_lower ? nl.hi : nu.hi;
+#else
             node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, sp, t_cull, m_have PKT_PASS);
             nd = load_node_u(wnodes, node);
+#endif
             work += 1;
             PKT_COUNT(PKC_WSTEPS, 1)
         }

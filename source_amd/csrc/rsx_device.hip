@@ -1390,7 +1390,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     static const bool batch_alone = [] { const char *e = std::getenv("RSX_BATCH_ALONE"); return !e || std::atoi(e) != 0; }();
     // (desc->spp is the widened count here: passes x samples per pass; the packet walk's threshold as further down, without its env override)
     const bool batch_fusable = batch_alone && passes > 1 && fusable && !h_xyz;
-    const bool pipelined = !one_at_a_time && !batch_fusable && (deferred || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 &&
+    // A path pass of its own (one slice per observe(): the Cornell box) also renders on a private lane — two of them, used in turn: its replay
+    // (k_accumulate over the term lists, on the context stream) then runs beside the NEXT pass's path kernel instead of in front of it, and
+    // the end-of-pass check waits for the lane's stream only. The check itself stays where it was: the pass is known to be complete before
+    // its merge is enqueued, passes merge in call order, frames are those of the un-pipelined form bit for bit.
+    // Measured (round 5, Cornell box 1024^2 x 16 spp, bench.py --workload c1): 30.61 ms per pass without, 31.10 with — the next pass's
+    // persistent workgroups take every register the replay's waves would need, so the two still run one after the other. Opt-in
+    // (RSX_PATH_PIPELINE=1) until the path kernel leaves room.
+    static const bool path_pipeline = [] { const char *e = std::getenv("RSX_PATH_PIPELINE"); return e && std::atoi(e) != 0; }();
+    const size_t solo_lane_bytes = S * (sizeof(Sample) + (size_t)PATH_BLOCK * sizeof(PathTerm) * 5 / 4 + 4) + 1;
+    const bool solo_path = path_pipeline && !deferred && !one_at_a_time && has_vol && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && !ctx->timing &&
+                           n_units_all <= (long long)RSX_LPT_MAX_UNITS && 2 * solo_lane_bytes <= ((size_t)64 << 30);
+    const bool pipelined = !one_at_a_time && !batch_fusable && (deferred || solo_path || (!h_mean && !has_vol && !two_pass_csg)) && ctx->pipeline_depth > 1 &&
                            n_units_all <= (long long)RSX_LPT_MAX_UNITS;
     // Scattering passes can run level by level (dev_wavefront.hpp: one launch per path segment over lists of live paths filed by material
     // arm) instead of in the one persistent kernel. Measured on the Cornell box (round 5, profiles/r05_wf_*): lane utilisation 0.42 -> 0.64,
@@ -1410,7 +1421,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // term blocks, 0.4 KB per path: the lanes in use stay below 48 GB)
     const size_t lane_bytes = S * (sizeof(Sample) + (size_t)PATH_BLOCK * sizeof(PathTerm) * 5 / 4 + 4) + 1;
     const int path_lanes = (int)std::max<size_t>(2, std::min<size_t>((size_t)ctx->path_lanes, ((size_t)48 << 30) / lane_bytes));
-    TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % path_lanes] : pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
+    TraceLane &lane = deferred ? ctx->lanes[ctx->deferred_calls % path_lanes] : solo_path ? ctx->lanes[ctx->render_calls % 2] :
+                      pipelined ? ctx->lanes[ctx->render_calls % ctx->pipeline_depth] : ctx->main;
     // (a pass that runs alone waits for the private lanes' traces. Their `in_flight` stays set: the lane's merge kernel sits on the ctx
     // stream and may still be reading the lane's sample records — the lane's next pass must wait for `merged` before it overwrites them.
     // Clearing the flag here let a pipelined pass that followed a lone one race its lane's previous merge: round 5, found by submitting
@@ -1629,7 +1641,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // pipelined passes share the chip: each takes RSX_RENDER_WG_PER_CU workgroups per CU so that the other lane's pass, the merge
     // kernel and the sort always find free slots (a persistent grid that filled every slot would serialise them behind its tail)
     // A pipelined (small, tail-bound) pass takes one workgroup per CU and the neighbouring lane's pass fills the idle CUs.
-    int wg_cap = pipelined ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
+    int wg_cap = pipelined && !solo_path ? RSX_RENDER_WG_PER_CU : RSX_MAX_WG_PER_CU;
     // (the overlapping slices of an observe(): ONE workgroup per CU and launch — eight lanes keep the two places of every CU taken, and a
     // bulk launch that brings two per CU holds the second place through its tail; configs[4]: 3.37e8 -> 3.49e8 paths/s. RSX_PATH_WG pins it)
     static const int path_wg_env = [] { const char *e = std::getenv("RSX_PATH_WG"); return e ? std::atoi(e) : 0; }();
@@ -2022,14 +2034,12 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (ray_count) *ray_count = ~0ULL;                 // "deferred": the count comes with rsx_collect_path_checks
     } else
     if (has_vol) {                                          // a ray that ran out of term slots or segments must not go unnoticed
-        unsigned int flags = 0;
-        HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (ray_count) {
-            unsigned long long spawned = 0;
-            HIP_TRY(hipMemcpy(&spawned, reinterpret_cast<unsigned long long *>(lane.overflow) + 1, sizeof(spawned), hipMemcpyDeviceToHost));
-            *ray_count = spawned;
-        }
+        const hipStream_t check = solo_path ? lane.stream : ctx->stream;      // (solo_path: the merge on the ctx stream is not waited for)
+        unsigned long long words[2] = {0, 0};                                 // [0] low half: flags, [1]: rays spawned
+        HIP_TRY(hipMemcpyAsync(words, lane.overflow, sizeof(words), hipMemcpyDeviceToHost, check));
+        HIP_TRY(hipStreamSynchronize(check));
+        const unsigned int flags = (unsigned int)(words[0] & 0xFFFFFFFFull);
+        if (ray_count) *ray_count = words[1];
         if (flags & 1u) return rsx_fail(RSX_EUNSUPPORTED, "render: the path-term arena (%zu blocks of %d terms) ran out; render fewer rays per call or raise RSX_PATH_ARENA", arena_blocks, PATH_BLOCK - 1);
         if (flags & 2u) return rsx_fail(RSX_EUNSUPPORTED, "render: a path crossed more than %d surfaces (limit of this build)", PATH_MAX_SEGMENTS);
         if (flags & 4u) return rsx_fail(RSX_EUNSUPPORTED, "render: more than %d volume emitters overlap at one point (limit of this build)", PATH_VOL_OVERLAP);

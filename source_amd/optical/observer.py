@@ -492,7 +492,8 @@ class RGBAdaptiveSampler2D(FrameSampler2D):
         percentile_error = np.percentile(normalised[mask], (1 - self.fraction) * 100)
         cutoff = max(self.cutoff, percentile_error)
         need = mask & ((samples.min(axis=2) < min_samples) | (normalised > cutoff))
-        tasks = [(int(x), int(y)) for x, y in zip(*np.nonzero(need))]    # x outer, y inner
+        xs, ys = np.nonzero(need)                           # x outer, y inner
+        tasks = list(zip(xs.tolist(), ys.tolist()))
         pyrandom.shuffle(tasks)
         return tasks
 
