@@ -182,7 +182,7 @@ typedef struct rsx_render_desc {
      * (probability(important_path_weight), sphere selection), the same block with bit 63 of the pixel word set = the direction pair. */
     const rsx_important_sphere *important;
     int32_t n_important;
-    int32_t passes;                   /* 0 / 1: one pass. K > 1 (rsx_render_pinhole_frame, RSX_RNG_PHILOX, scenes without path terms): K consecutive
+    int32_t passes;                   /* 0 / 1: one pass. K > 1 (rsx_render_pinhole_frame, RSX_RNG_PHILOX; path-traced scenes included): K consecutive
                                        * passes of spp samples per pixel in this one call — the frame K calls with sample_offset advanced by spp
                                        * each time would leave (Observer.observe() called K times, observer.pyx:265-309), bit for bit. */
     double important_path_weight;     /* Ray.important_path_weight */

@@ -1753,21 +1753,31 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         v = exact_div(pv * c + (x - pm) * (x - m), dm, ym, true);
         dm = dn;
     };
-    if constexpr (VOL != 0 && STAGED && !MULTI) {
+    if constexpr (VOL != 0 && STAGED) {
         // Path passes. The lanes of a wave are the bins of four or five pixels, and the lists of those pixels' samples differ in length
         // (path lengths are geometric): walked sample by sample, every lane waited for the longest list of every sample and 0.4 of the
         // lane-slots did work. Here every lane walks ITS lists one after the other — a step is one term of whatever sample the lane
         // has reached — over ACC_PATH_CHUNK samples at a time, leaving each sample's value in LDS; the Welford steps of the chunk then
         // run for all lanes together (their divisors depend on the sample index alone and come over the scalar data path).
         // Same operations in the same order per (pixel, bin); the loop has one exit (see the toolchain note in dev_csg.hpp).
+        // MULTI (rsx_render_desc.passes = K): the pixel's K * spp records are K passes — per pass the recurrence from its first sample
+        // and the frame merge, in pass order, the frame cell in registers between the merges: the frame of K calls.
         double *acc_xs = acc_tab + (tab_lds ? ap.n_tables * ap.bins : 1);      // [ACC_PATH_CHUNK][blockDim.x]
-        const long long rec_base = p * ap.spp;
+        const int n_pass_v = MULTI ? ap.passes : 1;
+        const size_t ff = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+        double fm_v = 0, fv_v = 0;
+        int fn_v = 0;
+        if (MULTI && ap.fmean) { fm_v = ap.fmean[ff]; fv_v = ap.fvar[ff]; fn_v = ap.fn[ff]; }
+        for (int pass = 0; pass < n_pass_v; ++pass) {
+        const Sample *sp = s + (long long)pass * ap.spp;
+        const long long rec_base = (p * n_pass_v + pass) * ap.spp;
+        m = 0; v = 0; dm = 1.0;
         for (int chunk0 = 0; chunk0 < ap.spp; chunk0 += ACC_PATH_CHUNK) {
             const int cn = ap.spp - chunk0 < ACC_PATH_CHUNK ? ap.spp - chunk0 : ACC_PATH_CHUNK;     // (wave-uniform)
             int si = 0;
-            Sample cur = s[chunk0], nxt = cur;
+            Sample cur = sp[chunk0], nxt = cur;
             long long blk = ap.tail[rec_base + chunk0], nblk = blk;
-            if (cn > 1) { nxt = s[chunk0 + 1]; nblk = ap.tail[rec_base + chunk0 + 1]; }
+            if (cn > 1) { nxt = sp[chunk0 + 1]; nblk = ap.tail[rec_base + chunk0 + 1]; }
             // (the walk keeps a pointer to the term it is at and one to where the block's terms end — slot 0 of an arena block is its link —
             // instead of forming pool + 24 (16 block + slot) at every step)
             int first = blk < ap.n_records ? 0 : 1;
@@ -1792,7 +1802,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                         first = blk < ap.n_records ? 0 : 1;
                         tp = ap.pool + blk * PATH_BLOCK + (cur.pad - 1); floor = ap.pool + blk * PATH_BLOCK + (first - 1);
                         x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
-                        if (si + 1 < cn) { nxt = s[chunk0 + si + 1]; nblk = ap.tail[rec_base + chunk0 + si + 1]; }
+                        if (si + 1 < cn) { nxt = sp[chunk0 + si + 1]; nblk = ap.tail[rec_base + chunk0 + si + 1]; }
                     } else live = false;
                 }
             }
@@ -1801,9 +1811,22 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
                 if (chunk0 + i == 0) { m = xi; v = 0; } else step(xi, chunk0 + i);
             }
         }
+        if constexpr (MULTI) {
+            if (ap.fmean) {
+                if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
+                double mt, vt;
+                int nt;
+                combine_samples_uniform(fm_v, fv_v, fn_v, m, v, ap.spp, mt, vt, nt, consts, ACC_CONSTS_ENTRIES);
+                fm_v = mt; fv_v = vt; fn_v = nt;
+            }
+        }
+        }
+        if constexpr (MULTI) {
+            if (ap.fmean) { ap.fmean[ff] = fm_v; ap.fvar[ff] = fv_v; ap.fn[ff] = fn_v; }
+            return;
+        }
         if (ap.mean) { ap.mean[k * ap.bins + b] = m; ap.variance[k * ap.bins + b] = v; }
         if (ap.fmean) {
-            const size_t ff = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
             if (v < 0) v = 0;                                                     // statsarray.pyx:649-650
             double mt, vt;
             int nt;

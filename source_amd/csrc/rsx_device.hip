@@ -33,6 +33,8 @@
 #include <tuple>
 #include <vector>
 #include <functional>
+#include <map>
+#include <unordered_map>
 
 #include "../../include/rsx.h"
 #include "rsx_internal.h"
@@ -224,6 +226,12 @@ struct rsx_ctx {
     size_t pool_bytes[POOL_SLOTS];
     void *staging;             // pinned host mirror of small query workspaces: one copy in, one copy out per call
     size_t staging_bytes;
+    // Device blocks released by scenes and frames, kept for the next scene / frame (cached_alloc / cached_release below): on this
+    // runtime a hipFree in a process of a few GB costs ~80 ms, and a host program that builds a second world meets one for every buffer
+    // of the first whenever Python's collector gets round to it (tools/r5_path_batches_diag.py: two or three 85 ms calls among 2 ms ones).
+    std::multimap<size_t, void *> cache_free;
+    std::unordered_map<void *, size_t> cache_size;
+    size_t cache_bytes = 0;
     // rsx_defer_path_checks: path passes run on the private lanes and their end-of-pass checks are collected later
     int32_t wf_mode = -1;                          // rsx_set_path_stages
     long long wf_min_paths = -1;
@@ -366,6 +374,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
         if (ln->merged) (void)hipEventDestroy(ln->merged);
     }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
+    for (auto &e : ctx->cache_free) (void)hipFree(e.second);
     if (ctx->acc_consts) (void)hipFree(ctx->acc_consts);
     if (ctx->staging) (void)hipHostFree(ctx->staging);
     for (hipEvent_t e : {ctx->ev0, ctx->ev1, ctx->ev2}) if (e) (void)hipEventDestroy(e);
@@ -498,18 +507,54 @@ extern "C" int rsx_render_timeline(rsx_ctx *ctx, int32_t n, float *t) {
     return RSX_OK;
 }
 
+namespace {
+// A block of at least `bytes`: a released one of up to twice the size when the cache holds one, else hipMalloc. The caller owns the
+// stream order: blocks are released only after the streams that used them have been synchronised (rsx_scene_free, rsx_dev_free).
+int cached_alloc(rsx_ctx *ctx, void **out, size_t bytes) {
+    bytes = (std::max<size_t>(bytes, 16) + 255) & ~(size_t)255;
+    auto it = ctx->cache_free.lower_bound(bytes);
+    if (it != ctx->cache_free.end() && it->first <= 2 * bytes + 4096) {
+        *out = it->second;
+        ctx->cache_bytes -= it->first;
+        ctx->cache_free.erase(it);
+        return RSX_OK;
+    }
+    if (hipMalloc(out, bytes) != hipSuccess) {                 // out of memory: give the cache back and try once more
+        (void)hipGetLastError();
+        for (auto &e : ctx->cache_free) { ctx->cache_size.erase(e.second); (void)hipFree(e.second); }
+        ctx->cache_free.clear(); ctx->cache_bytes = 0;
+        HIP_TRY(hipMalloc(out, bytes));
+    }
+    ctx->cache_size[*out] = bytes;
+    return RSX_OK;
+}
+
+void cached_release(rsx_ctx *ctx, void *p) {
+    if (!p) return;
+    auto it = ctx->cache_size.find(p);
+    if (it == ctx->cache_size.end()) { (void)hipFree(p); return; }
+    const size_t bytes = it->second;
+    if (bytes <= ((size_t)1 << 30) && ctx->cache_bytes + bytes <= ((size_t)8 << 30)) {
+        ctx->cache_free.emplace(bytes, p);
+        ctx->cache_bytes += bytes;
+        return;
+    }
+    ctx->cache_size.erase(it);
+    (void)hipFree(p);
+}
+}  // namespace
+
 extern "C" int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr) {
     if (!ctx || !dptr) return rsx_fail(RSX_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMalloc(dptr, bytes ? bytes : 16));
-    return RSX_OK;
+    return cached_alloc(ctx, dptr, bytes);
 }
 
 extern "C" int rsx_dev_free(rsx_ctx *ctx, void *dptr) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
-    HIP_TRY(hipFree(dptr));
+    cached_release(ctx, dptr);
     return RSX_OK;
 }
 
@@ -543,7 +588,8 @@ template <typename T>
 int upload(rsx_scene *sc, const T *host, size_t count, const T **dev) {
     void *d = nullptr;
     const size_t bytes = std::max<size_t>(count * sizeof(T), 16) + 64;   // slack: traversal reads node pairs (id, id+1)
-    HIP_TRY(hipMalloc(&d, bytes));
+    const int rc_alloc = cached_alloc(sc->ctx, &d, bytes);
+    if (rc_alloc) return rc_alloc;
     HIP_TRY(hipMemset(d, 0, bytes));
     sc->allocs.push_back(d);
     if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
@@ -608,10 +654,10 @@ extern "C" void rsx_scene_free(rsx_scene *scene) {
     // nothing of the scene is freed while a pass may still read it: the private lanes first, then the context stream
     for (TraceLane &ln : scene->ctx->lanes) if (ln.stream) (void)hipStreamSynchronize(ln.stream);
     (void)hipStreamSynchronize(scene->ctx->stream);
-    if (scene->rel) (void)hipFree(scene->rel);
-    if (scene->rel_info) (void)hipFree(scene->rel_info);
-    if (scene->rel_jobs_dev) (void)hipFree(scene->rel_jobs_dev);
-    for (void *p : scene->allocs) (void)hipFree(p);
+    cached_release(scene->ctx, scene->rel);
+    cached_release(scene->ctx, scene->rel_info);
+    cached_release(scene->ctx, scene->rel_jobs_dev);
+    for (void *p : scene->allocs) cached_release(scene->ctx, p);
     delete scene;
 }
 
@@ -1233,9 +1279,10 @@ int ensure_camera_relative(rsx_scene *scene, const rsx_camera &cam, hipStream_t 
     if (!scene->rel) {
         const size_t bytes = (size_t)scene->rel_records * 48;
         if ((double)bytes > max_gb * 1073741824.0 || scene->rel_jobs.size() > 65535) { scene->rel_refused = true; return RSX_OK; }
-        if (hipMalloc(&scene->rel, bytes) != hipSuccess) { (void)hipGetLastError(); scene->rel = nullptr; scene->rel_refused = true; return RSX_OK; }
-        HIP_TRY(hipMalloc(&scene->rel_info, (size_t)scene->d.n_prims * sizeof(RelInfo)));
-        HIP_TRY(hipMalloc(&scene->rel_jobs_dev, scene->rel_jobs.size() * sizeof(RelJob)));
+        if (cached_alloc(scene->ctx, &scene->rel, bytes) != RSX_OK) { (void)hipGetLastError(); scene->rel = nullptr; scene->rel_refused = true; return RSX_OK; }
+        int rc_a;
+        if ((rc_a = cached_alloc(scene->ctx, &scene->rel_info, (size_t)scene->d.n_prims * sizeof(RelInfo)))) return rc_a;
+        if ((rc_a = cached_alloc(scene->ctx, &scene->rel_jobs_dev, scene->rel_jobs.size() * sizeof(RelJob)))) return rc_a;
         static_assert(sizeof(RelJobHost) == sizeof(RelJob), "same layout");
         HIP_TRY(hipMemcpy(scene->rel_jobs_dev, scene->rel_jobs.data(), scene->rel_jobs.size() * sizeof(RelJob), hipMemcpyHostToDevice));
         std::vector<RelInfo> none((size_t)scene->d.n_prims);
@@ -1286,15 +1333,17 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (!fmean || h_mean || h_xyz) return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 accumulates into a device frame (rsx_render_pinhole_frame)");
         if (desc->rng_mode != RSX_RNG_PHILOX) return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 needs RSX_RNG_PHILOX (a serial stream is consumed pass by pass)");
         if ((long long)desc->spp * passes > (1 << 20)) return rsx_fail(RSX_EINVAL, "render: spp * passes out of range");
+        // (path-traced scenes too: the path kernel sees one pass of K * spp samples per pixel, whose term arena grows and is traced again
+        // like any pass's before anything is merged; k_accumulate replays the lists pass by pass)
+        bool path_terms = false;
         for (int32_t i = 0; i < desc->n_materials; ++i) {
             const int32_t mt = desc->materials[i].type;
-            if (mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC)
-                return rsx_fail(RSX_EUNSUPPORTED, "render: passes > 1 is for scenes without path terms (a path pass that runs out of term blocks is rendered again by itself)");
+            path_terms = path_terms || mt == RSX_MAT_NULL || mt == RSX_MAT_UNIFORM_VOLUME_EMITTER || mt == RSX_MAT_LAMBERT || mt == RSX_MAT_DIELECTRIC;
         }
         // K x spp that does not divide the 64 rays of a unit (or exceeds them) would cut pixels across units and keep the recurrence out of the
         // packet kernel: such a call is served as several — the largest power-of-two groups that fit, then the rest (24 passes of 1 spp
         // = 16 + 8) — passes are merged in their order either way
-        if (desc->spp < WAVE && WAVE % desc->spp == 0 && (WAVE % (desc->spp * passes) != 0 || desc->spp * passes > WAVE)) {
+        if (!path_terms && desc->spp < WAVE && WAVE % desc->spp == 0 && (WAVE % (desc->spp * passes) != 0 || desc->spp * passes > WAVE)) {
             uint64_t rays = 0;
             int32_t done = 0;
             while (done < passes) {
@@ -1358,6 +1407,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // merge, so its passes run one after the other on the context stream)
     const bool one_at_a_time = scene->d.csg_arena != nullptr;
     const bool deferred = !one_at_a_time && has_vol && ctx->defer_path && fmean && !h_mean && !h_xyz && ctx->pipeline_depth > 1 && n_units_all <= (long long)RSX_LPT_MAX_UNITS;
+    // (a call of several path passes may be deferred like any other: a failed call is left out of the frame as a whole and issued again)
     // Fused form (dev_render.hpp, "Welford in the trace kernel"): a pass that runs alone on the context stream, merges into a frame,
     // has closed-form materials only and whole pixels per 64-ray unit keeps its sample records in per-wave rings
     // — round 2, per-lane walk: measured on configs[2], 2048^2 x 64 spp: two kernels 34.9 + 5.8 = 40.8 ms per pass, fused 41.9 ms. That
@@ -1614,8 +1664,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         // units, so slice k + 1 starts the units that held slice k's longest paths first.
         static const int path_lpt = [] { const char *e = std::getenv("RSX_PATH_LPT"); return e ? std::atoi(e) : 2; }();
         // (a call of several passes — batched small passes — is as many times the units of one and balances by itself; the one-workgroup sort
-        // behind it cost a 16-pass batch of configs[1] 0.25 - 0.8 ms next to a 1.3 ms kernel: profiles/r05a_c2_kernel_stats.csv)
-        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && passes == 1 && (has_vol ? path_lpt > 0 && !use_wf : !two_pass_csg);
+        // behind it cost a 16-pass batch of configs[1] 0.25 - 0.8 ms next to a 1.3 ms kernel: profiles/r05a_c2_kernel_stats.csv. Path passes stay
+        // tail-bound however many a call carries: they keep the ordering — 96^2 x 16 spp Cornell passes, two per call: 3.7 ms per pass without)
+        want_order = RSX_LPT_SCHEDULE != 0 && n_units <= (long long)RSX_LPT_MAX_UNITS && (passes == 1 || has_vol) && (has_vol ? path_lpt > 0 && !use_wf : !two_pass_csg);
         rp.measure_cost = want_order ? 1 : 0;
         if (has_vol && path_lpt == 1) want_order = false;           // (measure, do not re-order: tuning aid)
         // Primary-ray passes over the same units cost the same from pass to pass (the rays differ only by their jitter): the list
@@ -1881,6 +1932,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
             HIP_TRY(hipStreamSynchronize(lane.stream));
             const bool grow = (flags & 1u) && has_scatter && !std::getenv("RSX_PATH_ARENA"), again = (flags & 4u) && !rewalk, refile = (flags & 8u) && !wf_off;
+            static const bool path_debug = std::getenv("RSX_PATH_DEBUG") != nullptr;
+            if (path_debug) std::fprintf(stderr, "rsx path pass: attempt %d flags %u S %zu arena %zu passes %d\n", attempt, flags, S, arena_blocks, (int)passes);
             if (!grow && !again && !refile) break;
             if (refile) wf_off = true;
             if (again) rewalk = true;
@@ -2007,9 +2060,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         const bool staged = ap.spp >= 4, in_lds = ap.tables_in_lds != 0;
 #define ACC(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V>) \
                                                                                            : reinterpret_cast<const void *>(k_accumulate<true, V, false>))
-#define ACC_MULTI (!staged ? reinterpret_cast<const void *>(k_accumulate<false, 0, false, true>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, 0, true, true>) \
-                                                                                                  : reinterpret_cast<const void *>(k_accumulate<true, 0, false, true>))
-        const void *kernel = passes > 1 ? ACC_MULTI : vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);     // (passes > 1: scenes without path terms)
+#define ACC_MULTI(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V, false, true>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V, true, true>) \
+                                                                                                     : reinterpret_cast<const void *>(k_accumulate<true, V, false, true>))
+        const void *kernel = passes > 1 ? (vol == 0 ? ACC_MULTI(0) : vol == 1 ? ACC_MULTI(1) : ACC_MULTI(2)) : vol == 0 ? ACC(0) : vol == 1 ? ACC(1) : ACC(2);
 #undef ACC_MULTI
 #undef ACC
         void *args[] = {(void *)&ap};

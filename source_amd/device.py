@@ -31,6 +31,7 @@ class DeviceContext:
     def __init__(self, ordinal):
         self.ordinal = ordinal
         self._h = C.c_void_p()
+        self._pid = os.getpid()
         _lib.check(_lib.lib().rsx_init(int(ordinal), C.byref(self._h)))
 
     @property
@@ -43,7 +44,8 @@ class DeviceContext:
         return p
 
     def free(self, p):
-        _lib.lib().rsx_dev_free(self._h, p)
+        if os.getpid() == self._pid:                        # (never from a forked material worker: the device belongs to the parent)
+            _lib.lib().rsx_dev_free(self._h, p)
 
     def upload(self, p, array):
         a = np.ascontiguousarray(array)
@@ -126,6 +128,7 @@ class DeviceScene:
         self.flat = flat
         self.context = context or get_context()
         self._h = C.c_void_p()
+        self._pid = os.getpid()
         _lib.check(_lib.lib().rsx_scene_create(self.context.handle, C.byref(flat.desc), C.byref(self._h)))
 
     @property
@@ -134,7 +137,8 @@ class DeviceScene:
 
     def close(self):
         if self._h:
-            _lib.lib().rsx_scene_free(self._h)
+            if os.getpid() == self._pid:                    # (a forked material worker inherits the object, not the device: hybrid.run_block)
+                _lib.lib().rsx_scene_free(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):

@@ -1172,16 +1172,24 @@ def run_block(world, scene, key, template, per_node, origin, direction, pixel, s
     flat = scene.flat
     host = scene.host_scene() if hasattr(scene, "host_scene") else None
     conns, procs, slot = [], [], {}
-    for w in range(workers):
-        a, b = int(bounds[w]), int(bounds[w + 1])
-        mine, theirs = ctx.Pipe()
-        proc = ctx.Process(target=_worker, args=(theirs, world, flat, key, template, per_node, origin[a:b], direction[a:b], pixel[a:b], sample[a:b]),
-                           daemon=True)
-        proc.start()
-        theirs.close()
-        conns.append(mine)
-        procs.append(proc)
-        slot[mine] = (a, b)
+    # (the workers start with the cyclic collector off: a collection in a child would run the finalisers of whatever device-owning
+    # garbage the parent had not collected yet — scenes and frames of earlier renders — against a device the child does not have)
+    collecting = gc.isenabled()
+    gc.disable()
+    try:
+        for w in range(workers):
+            a, b = int(bounds[w]), int(bounds[w + 1])
+            mine, theirs = ctx.Pipe()
+            proc = ctx.Process(target=_worker, args=(theirs, world, flat, key, template, per_node, origin[a:b], direction[a:b], pixel[a:b], sample[a:b]),
+                               daemon=True)
+            proc.start()
+            theirs.close()
+            conns.append(mine)
+            procs.append(proc)
+            slot[mine] = (a, b)
+    finally:
+        if collecting:
+            gc.enable()
     out, rays, failure = np.zeros((n, template.bins)), 0, None
     t_start = time.perf_counter()
     stats = dict(workers=workers, primary_rays=n, fork_s=t_start - t_fork, serve_s=0.0, trace_s=0.0, requests=0, request_rays=0, worker_s=[], worker_wait_s=[])

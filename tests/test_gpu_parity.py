@@ -1082,6 +1082,50 @@ def test_host_callback_path_equals_device_path(ns):
         assert frames[0][3] == frames[1][3] and (frames[0][0] > 0).mean() > 0.2
 
 
+def test_python_materials_in_forked_workers_with_the_device_in_the_loop(ns, monkeypatch):
+    """A scene with a user-written material splits its primary rays over forked worker processes (hybrid.run_block) while THIS process —
+    HIP initialised, scene resident — answers their ray waves on the device: the frame equals the all-device render and the
+    one-process host render bit for bit, per_node_materials=True (every material through the plugin API) included; the parent's
+    device stays usable afterwards (a second device render of another scene)."""
+    from source_amd.optical import hybrid
+    from source_amd.optical.material import hemisphere_cosine_pdf
+
+    class MyLambert(ns.Lambert):
+        def evaluate_shading(self, world, ray, s_in, s_out, w_refl, w_trans, back_face, w2s, s2w, intersection):
+            pdf = hemisphere_cosine_pdf(s_out)
+            if pdf == 0.0:
+                return ray.new_spectrum()
+            spectrum = ray.spawn_daughter(w_refl, s_out.transform(s2w)).trace(world)
+            spectrum.mul_array(self.reflectivity.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins))
+            spectrum.mul_scalar(pdf)
+            return spectrum
+
+    monkeypatch.setattr(hybrid, "MIN_RAYS_PER_WORKER", 256)
+
+    def render(user, **engine):
+        world, prims = scenes.build_cornell(ns)
+        if user:
+            for p in prims:
+                if isinstance(p.material, ns.Lambert):
+                    p.material = MyLambert(p.material.reflectivity)
+        cam, pipe = scenes.cornell_camera(ns, world, (40, 36), 2, 5)
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=17, **engine)
+        del hybrid.last_stats[:]
+        cam.observe()
+        return pipe.frame.mean.copy(), pipe.frame.variance.copy(), cam.stats["rays"], [st["workers"] for st in hybrid.last_stats]
+
+    device = render(False)
+    workers = render(True, host_workers=4)
+    alone = render(True, host_workers=1)
+    per_node = render(True, host_workers=3, per_node_materials=True)
+    assert workers[3] == [4] and alone[3] == [] and per_node[3] == [3]
+    for other in (workers, alone, per_node):
+        assert eq(device[0], other[0]) and eq(device[1], other[1]) and device[2] == other[2]
+    again = render(False)
+    assert eq(device[0], again[0]) and (device[0] > 0).mean() > 0.3
+
+
 def test_user_written_material_through_observe(orc, ns):
     """A Material subclass the library has never seen renders through observe() (SURVEY.md §8b plug-point #3: the material plugin API
     stays untouched). (1) A user re-implementation of Lambert's shading goes through the host-callback path and reproduces the
@@ -1652,6 +1696,58 @@ def test_auto_batched_passes_equal_separate_passes(orc, ns):
     assert eq(n, on) and eq(m, om) and eq(v, ov)              # (combine_arrays is the reference's merge law element by element: the same bits)
 
 
+def test_several_path_passes_per_call_equal_separate_passes(orc, ns):
+    """HipEngine(passes_per_call=K) on path-traced scenes: the path kernel traces the K passes' paths in one launch (Philox counters of K
+    consecutive passes), k_accumulate replays every pixel's term lists pass by pass — per pass the recurrence from its first sample and
+    the frame merge. The frame must be that of K separate observe() calls bit for bit: Cornell box (importance sampling, glass; 4 spp per
+    pass: the chunked replay; 1 spp: the plain one), the diffuse room with its CSG solid, volume emitter and null shell (two-pass CSG
+    path kernels, volume terms), several spectral slices (deferred end-of-pass checks) — and one call is checked against the oracle
+    merged pass by pass with combine_samples (power.pyx:424-437)."""
+    from source_amd import distributed as D
+    cases = ((lambda: scenes.build_cornell(ns), lambda w, spp: scenes.cornell_camera(ns, w, (56, 40), spp, 5), 4, 3, 1),
+             (lambda: scenes.build_cornell(ns), lambda w, spp: scenes.cornell_camera(ns, w, (56, 40), spp, 5), 1, 5, 1),
+             (lambda: scenes.build_lambert(ns), lambda w, spp: scenes.lambert_camera(ns, w, (40, 32), spp=spp, bins=4, extinction=(0.2, 2, 9)), 2, 4, 1),
+             (lambda: scenes.build_cornell(ns), lambda w, spp: scenes.cornell_camera(ns, w, (40, 32), spp, 6), 4, 2, 3))
+    for build, camera, spp, K, slices in cases:
+        frames = []
+        for per_call in (K, 1):
+            world, prims = build()
+            cam, pipe = camera(world, spp)
+            cam.spectral_rays = slices
+            cam.frame_sampler = ns.RectFrameSampler2D()
+            cam.render_engine = ns.HipEngine(rng="philox", seed=23, passes_per_call=per_call, auto_batch=False)
+            rays = 0
+            for _ in range(2 * K // per_call):                                   # two calls of K passes / 2 K separate passes
+                cam.observe()
+                rays += cam.stats["rays"]
+            f = pipe.frame
+            frames.append((np.array(f.mean), np.array(f.variance), np.array(f.samples), rays, world, cam))
+        a, b = frames
+        assert eq(a[0], b[0]) and eq(a[1], b[1]) and eq(a[2], b[2]) and a[3] == b[3], (spp, K, slices)
+        assert (a[2] == 2 * K * spp).all() and (a[0] > 0).mean() > 0.2
+    # the first case's first call against the oracle: K = 3 passes of 4 spp, merged pass by pass
+    build, camera, spp, K, _ = cases[0]
+    world, prims = build()
+    cam, pipe = camera(world, spp)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.render_engine = ns.HipEngine(rng="philox", seed=23, passes_per_call=K, auto_batch=False)
+    cam.observe()
+    nx, ny = cam.pixels
+    flat = world.flatten()
+    om = ov = on = None
+    for p in range(K):
+        keep = []
+        desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, nx, ny), sample_offset=spp * p)
+        pm, pv, _ = orc.render_pinhole(flat, desc, threads=orc.max_threads())
+        pm, pv = pm.reshape(ny, nx, 5).transpose(1, 0, 2), pv.reshape(ny, nx, 5).transpose(1, 0, 2)
+        if om is None:
+            om, ov, on = pm, pv, np.full(pm.shape, spp, dtype=np.int32)
+        else:
+            om, ov, on = D.combine_arrays(om, ov, on, pm, np.maximum(pv, 0.0), np.full(pm.shape, spp, dtype=np.int32))
+    f = pipe.frame
+    assert eq(np.array(f.samples), on) and eq(np.array(f.mean), om) and eq(np.array(f.variance), ov)
+
+
 def test_toolchain_divergent_loop_exit_workaround(tmp_path):
     """hipcc 7.2 miscompiles per-lane loops that the lanes of a wave leave at different turns through a `return` / `continue` in the
     middle of the body (tests/toolchain/divergent_loop_exit.hip holds both forms of one loop and says so in its output). librsx writes
@@ -1772,9 +1868,9 @@ def test_passes_per_call_equals_separate_passes(ns):
     cam.render_engine = ns.HipEngine(passes_per_call=4)
     with pytest.raises(ValueError):
         cam.observe()
-    world = scenes.build_lambert(ns)[0]
+    world = scenes.build_lambert(ns)[0]                      # (path-traced scenes are covered: test_several_path_passes_per_call_equal_separate_passes)
     cam, _ = scenes.lambert_camera(ns, world)
-    cam.pipelines = [ns.SpectralRadiancePipeline2D()]
+    cam.pipelines = [ns.RGBPipeline2D()]
     cam.render_engine = ns.HipEngine(passes_per_call=4)
     with pytest.raises(Exception, match="passes"):
         cam.observe()
