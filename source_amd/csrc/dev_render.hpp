@@ -137,6 +137,13 @@ __device__ __forceinline__ void camera_ray(const RSX_CONST_AS RenderParams *q, i
 // Welford steps (IntRcp); the quotient is formed by exact_div — bit-identical to `/` (see refine_rcp /
 // rsx_selftest_exact_division). At 64 samples/pixel x 15 bins the accumulate kernel is VALU-bound on this recurrence
 // (4.0e9 updates in 8.7 ms on configs[2]); staging the sample records through LDS was measured and changed nothing.
+// the lanes whose x is +0.0, as a lane mask (written out: through ballot the compiler turns the class test into a value and compares it again)
+__device__ __forceinline__ unsigned long long mask_plus_zero(double x) {
+    unsigned long long m;
+    asm("v_cmp_class_f64_e64 %0, %1, 64" : "=s"(m) : "v"(x));
+    return m;
+}
+
 struct IntRcp {
     double d, y;
     __device__ __forceinline__ explicit IntRcp(int n) : d((double)n), y(refine_rcp((double)n)) {}
@@ -253,7 +260,66 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
             x = x * l_w[base + i];
             return x * scale;
         };
-        if constexpr (!MULTI) {
+        if constexpr (!MULTI && TABLES_IN_LDS) {
+            // The staged form (fused_flush): l_tab holds each sample's BYTE OFFSET of its table row in the wave's LDS copy — absorbers point at
+            // the all-zero row behind the tables and carry a = +0.0, so x = (a * t) * weight * scale is (+0.0 * +0.0) * weight * scale, the
+            // reference's product for an empty spectrum, without a select — and the step is written so that it costs what its arithmetic
+            // costs: round 5 counted ~40 vector instructions per step where the recurrence needs 22 (a 32-bit multiply and a clamp for the
+            // table address, compare + two selects for absorbers, six register moves of the operand rotation, the lane predicate of the range
+            // test turned into a value and back). Two steps per trip: the operands of step i + 1 load into the registers step i - 1 used.
+            const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
+            const uint32_t row0 = (uint32_t)(reinterpret_cast<const char *>(l_tables) - reinterpret_cast<const char *>(smem)) + (uint32_t)b * 8u;
+            auto t_at = [&](int32_t off) { return *reinterpret_cast<const double *>(smem + row0 + (uint32_t)off); };
+            const double *p_a = l_a + base, *p_w = l_w + base;
+            const int32_t *p_o = l_tab + base;
+            const lanemask act = pkt_mask(true);                              // the lanes that hold a chain
+            // the frame cell is asked for now and merged after the chain (its round trip to HBM runs under the recurrence)
+            const size_t f = ((size_t)px.ix * fz.ny + px.iy) * fz.frame_bins + fz.slice_offset + b;
+            const double f_m = fz.fmean[f], f_v = fz.fvar[f];
+            const int f_n = fz.fn[f];
+            double m = ((p_a[0] * t_at(p_o[0])) * p_w[0]) * scale, v = 0;
+            auto step = [&](int i, double a_c, double w_c, double t_c) {      // _add_sample (statsarray.pyx:743-776) for sample i of the chain
+                double x = a_c * t_c;
+                x = x * w_c;
+                x = x * scale;
+                const double dm = consts[2 * i], ym = consts[2 * i + 1], dn = consts[2 * i + 2], yn = consts[2 * i + 3];
+                const double cc = i == 1 ? 1.0 : consts[2 * i - 2];
+                const double pm = m, pv = v;
+                const double n1 = x - pm;
+                const double q1 = __builtin_fma(__builtin_fma(-dn, n1 * yn, n1), yn, n1 * yn);
+                const double m1 = pm + q1;
+                const double n2 = pv * cc + n1 * (x - m1);
+                const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
+                const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
+                // exact_div's operand test as lane masks: their algebra and the branch are scalar
+                const lanemask ok1 = (pkt_mask(a1 >= 0x1p-300) & pkt_mask(a1 <= 0x1p+300)) | mask_plus_zero(n1);
+                const lanemask ok2 = (pkt_mask(a2 >= 0x1p-300) & pkt_mask(a2 <= 0x1p+300)) | mask_plus_zero(n2);
+                if (__builtin_expect((ok1 & ok2) != act, 0)) {
+                    m = pm + exact_div(n1, dn, yn, true);
+                    v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
+                } else { m = m1; v = q2; }
+            };
+            // operands of sample 1 in set A, the offset of sample 2; samples past the chain's end are clamped to its last (read, never used)
+            const int last = spp - 1;
+            auto at = [&](int i) { return i < last ? i : last; };
+            double aA = p_a[at(1)], wA = p_w[at(1)], tA = t_at(p_o[at(1)]);
+            int32_t o_n = p_o[at(2)];
+            int i = 1;
+            for (; i + 1 < spp; i += 2) {
+                const double aB = p_a[at(i + 1)], wB = p_w[at(i + 1)], tB = t_at(o_n);
+                const int32_t o_b = p_o[at(i + 2)];
+                step(i, aA, wA, tA);
+                aA = p_a[at(i + 2)]; wA = p_w[at(i + 2)]; tA = t_at(o_b);
+                o_n = p_o[at(i + 3)];
+                step(i + 1, aB, wB, tB);
+            }
+            if (i < spp) step(i, aA, wA, tA);
+            if (v < 0) v = 0;                                                 // statsarray.pyx:649-650
+            double mt, vt;
+            int nt;
+            combine_samples_uniform(f_m, f_v, f_n, m, v, spp, mt, vt, nt, consts, ACC_CONSTS_ENTRIES);
+            fz.fmean[f] = mt; fz.fvar[f] = vt; fz.fn[f] = nt;
+        } else if constexpr (!MULTI) {
             double m = value(0), v = 0;
             const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)fz.consts;
             // the operands of sample i + 1 (and the table id of sample i + 2, which the table read of i + 1 needs) are requested while the
@@ -280,8 +346,8 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
                 const double n2 = pv * cc + n1 * (x - m1);
                 const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
                 const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
-                const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
-                if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
+                const lanemask okm = ((pkt_mask(a1 >= 0x1p-300) & pkt_mask(a1 <= 0x1p+300)) | mask_plus_zero(n1)) & ((pkt_mask(a2 >= 0x1p-300) & pkt_mask(a2 <= 0x1p+300)) | mask_plus_zero(n2));
+                if (__builtin_expect(okm != pkt_mask(true), 0)) {
                     m = pm + exact_div(n1, dn, yn, true);
                     v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
                 } else { m = m1; v = q2; }
@@ -311,8 +377,8 @@ __device__ __forceinline__ void fused_chains(const RSX_CONST_AS RenderParams *q,
                     const double n2 = pv * cc + n1 * (x - m1);
                     const double q2 = __builtin_fma(__builtin_fma(-dm, n2 * ym, n2), ym, n2 * ym);
                     const double a1 = __builtin_fabs(n1), a2 = __builtin_fabs(n2);
-                    const bool ok = ((a1 >= 0x1p-300 && a1 <= 0x1p+300) || __double_as_longlong(n1) == 0LL) && ((a2 >= 0x1p-300 && a2 <= 0x1p+300) || __double_as_longlong(n2) == 0LL);
-                    if (__builtin_expect(__builtin_amdgcn_ballot_w64(!ok) != 0ULL, 0)) {
+                    const lanemask okm = ((pkt_mask(a1 >= 0x1p-300) & pkt_mask(a1 <= 0x1p+300)) | mask_plus_zero(n1)) & ((pkt_mask(a2 >= 0x1p-300) & pkt_mask(a2 <= 0x1p+300)) | mask_plus_zero(n2));
+                    if (__builtin_expect(okm != pkt_mask(true), 0)) {
                         m = pm + exact_div(n1, dn, yn, true);
                         v = exact_div(pv * cc + n1 * (x - m), dm, ym, true);
                     } else { m = m1; v = q2; }
@@ -340,11 +406,19 @@ __device__ __forceinline__ void fused_flush(const RSX_CONST_AS RenderParams *q, 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    // (one pass per call with the tables in LDS: the chains read row OFFSETS, and absorbers the zero row behind the tables — fused_chains)
+    const bool offsets = !MULTI && fz.tables_in_lds;
+    const int32_t row_bytes = fz.bins * 8, zero_row = fz.n_tables * row_bytes;
     for (int u = 0; u < n_units; ++u) {
         const Sample smp = ring[u * WAVE + lane];
-        l_a[u * WAVE + lane] = smp.a; l_w[u * WAVE + lane] = smp.weight; l_tab[u * WAVE + lane] = smp.table;
+        const bool absorber = smp.table < 0;
+        l_a[u * WAVE + lane] = offsets && absorber ? 0.0 : smp.a; l_w[u * WAVE + lane] = smp.weight;
+        l_tab[u * WAVE + lane] = offsets ? (absorber ? zero_row : smp.table * row_bytes) : smp.table;
     }
-    if (fz.tables_in_lds) for (int e = lane; e < fz.n_tables * fz.bins; e += WAVE) l_tables[e] = fz.tables[e];
+    if (fz.tables_in_lds) {
+        for (int e = lane; e < fz.n_tables * fz.bins; e += WAVE) l_tables[e] = fz.tables[e];
+        if (offsets) for (int e = lane; e < fz.bins; e += WAVE) l_tables[fz.n_tables * fz.bins + e] = 0.0;
+    }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1726,9 +1800,9 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // reference's states), 35 -> 24 vector instructions per sample and bin.
     const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)ap.consts;
     const bool fast_steps = rcp_table && ap.consts != nullptr;
-    auto quotient_ok = [](double n) {
+    auto quotient_ok = [](double n) {                        // (as lane masks: the algebra and the branch run on the scalar unit)
         const double a = __builtin_fabs(n);
-        return (a >= 0x1p-300 && a <= 0x1p+300) || __double_as_longlong(n) == 0LL;
+        return (pkt_mask(a >= 0x1p-300) & pkt_mask(a <= 0x1p+300)) | mask_plus_zero(n);
     };
     auto step = [&](double x, int i) {
         if (fast_steps) {
@@ -1740,7 +1814,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
             const double m1 = pm + q1;
             const double n2 = pv * c + n1 * (x - m1);
             const double q2 = __builtin_fma(__builtin_fma(-dm_u, n2 * ym, n2), ym, n2 * ym);
-            if (__builtin_expect(__builtin_amdgcn_ballot_w64(!(quotient_ok(n1) && quotient_ok(n2))) != 0ULL, 0)) {
+            if (__builtin_expect((quotient_ok(n1) & quotient_ok(n2)) != pkt_mask(true), 0)) {
                 m = pm + exact_div(n1, dn, yn, true);
                 v = exact_div(pv * c + n1 * (x - m), dm_u, ym, true);
             } else { m = m1; v = q2; }

@@ -1739,7 +1739,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         fz.lds_bytes = (int32_t)wave_lds;
         fz.consts = ctx->acc_consts;
         fz.passes = passes; fz.pass_spp = desc->spp / passes;
-        fz.tables_in_lds = fuse_fixed + (size_t)std::max(1, desc->n_tables) * B * 8 <= wave_lds ? 1 : 0;
+        fz.tables_in_lds = fuse_fixed + ((size_t)std::max(1, desc->n_tables) + 1) * B * 8 <= wave_lds ? 1 : 0;   // (+ the zero row of fused_chains)
     }
     const int slot = (int)(ctx->render_calls % RING_SLOTS);
     while (ctx->ring.size() < (size_t)(slot + 1) * 4) { hipEvent_t e; HIP_TRY(hipEventCreate(&e)); ctx->ring.push_back(e); }
