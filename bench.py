@@ -78,9 +78,11 @@ WORKLOADS = {
     "c1": dict(nx=1024, ny=1024, spp=16, counter_rows=8, paths=True,
                name="configs[0]'s scene on the device: Cornell box after demos/cornell_box.py (Lambert walls, ceiling light, glass block and "
                     "sphere, multiple importance sampling, Russian roulette), PinholeCamera 1024x1024, 16 spp/pass, 15 spectral bins, path traced"),
-    "c5": dict(nx=1024, ny=1024, spp=1, counter_rows=8, paths=True, bins=512, slices=512,
+    "c5": dict(nx=1024, ny=1024, spp=1, counter_rows=8, paths=True, bins=512, slices=512, passes_per_call=8,
                name="configs[4]: demos/prism.py scene (SF11 prism, N-BK7 stand: Sellmeier dispersion per spectral slice), PinholeCamera "
-                    "1024x1024, 512 spectral bins as 512 one-bin slices, 1 spp per slice and pass (256 passes = the config's 256 spp), path traced"),
+                    "1024x1024, 512 spectral bins as 512 one-bin slices, a step = one observe() of HipEngine(passes_per_call=8) = 8 passes of "
+                    "1 spp per slice (32 steps = the config's 256 spp; the frame of 8 observe() calls, bit for bit; --passes-per-call 1: "
+                    "one pass per step, 1.43 s), path traced"),
     "c5s": dict(nx=128, ny=128, spp=2, counter_rows=8, paths=True, bins=16, slices=16,
                 name="configs[4] in small (test aid): demos/prism.py scene, 128x128, 16 one-bin spectral slices, 2 spp per slice and pass"),
 }
