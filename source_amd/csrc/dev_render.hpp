@@ -1699,6 +1699,11 @@ __global__ void k_fill_acc_consts(double *consts, int n) {
 #ifndef ACC_BATCH
 #define ACC_BATCH 4                 // sample records whose loads are issued together
 #endif
+#ifndef RSX_ACC_TOUCH
+#define RSX_ACC_TOUCH 0             // path passes: a chunk's term blocks requested together before the walk (k_accumulate) — measured (round 5,
+                                    // Cornell box 1024^2 x 16 spp): the replay 5.13 -> 5.72 ms with the touches; the walk's own loads already overlap across the
+                                    // eight waves of a SIMD, and the touches only add instructions and a full stop per chunk. Off.
+#endif
 #ifndef ACC_PATH_CHUNK
 #define ACC_PATH_CHUNK 8            // path passes: samples whose term lists a lane walks back to back before the wave meets for their Welford steps
                                     // (Cornell box: 4 -> 5.4 ms, 8 -> 5.2 ms, 16 -> 8.8 ms: the values wait in LDS, 2 KB per sample and workgroup)
@@ -1848,6 +1853,19 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         m = 0; v = 0; dm = 1.0;
         for (int chunk0 = 0; chunk0 < ap.spp; chunk0 += ACC_PATH_CHUNK) {
             const int cn = ap.spp - chunk0 < ACC_PATH_CHUNK ? ap.spp - chunk0 : ACC_PATH_CHUNK;     // (wave-uniform)
+#if RSX_ACC_TOUCH
+            // The chunk's lists are asked for TOGETHER before any of them is walked: the lines of every sample's last block (where its walk
+            // begins; a path of up to fifteen terms has no other) — left to the walk, a lane met one miss after the other, three lines per
+            // block and sample, each a round trip to HBM with nothing else of the lane in flight.
+            {
+                float sink = 0.0f;
+                for (int qi = 0; qi < cn; ++qi) {
+                    const char *tb = reinterpret_cast<const char *>(ap.pool + (long long)ap.tail[rec_base + chunk0 + qi] * PATH_BLOCK);
+                    sink += *reinterpret_cast<const float *>(tb) + *reinterpret_cast<const float *>(tb + 128) + *reinterpret_cast<const float *>(tb + 256);
+                }
+                asm volatile("" :: "v"(sink));
+            }
+#endif
             int si = 0;
             Sample cur = sp[chunk0], nxt = cur;
             long long blk = ap.tail[rec_base + chunk0], nblk = blk;
@@ -1920,6 +1938,17 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
         fm = ap.fmean[f]; fv = ap.fvar[f]; fcount = ap.fn[f];
     }
+#if RSX_ACC_TOUCH
+    if constexpr (VOL != 0 && MULTI) {                       // the term blocks of (up to sixteen of) the call's records, requested together
+        const int n_touch = n_pass * ap.spp < 16 ? n_pass * ap.spp : 16;
+        float sink = 0.0f;
+        for (int qi = 0; qi < n_touch; ++qi) {
+            const char *tb = reinterpret_cast<const char *>(ap.pool + (long long)ap.tail[rec0 + qi] * PATH_BLOCK);
+            sink += *reinterpret_cast<const float *>(tb) + *reinterpret_cast<const float *>(tb + 128) + *reinterpret_cast<const float *>(tb + 256);
+        }
+        asm volatile("" :: "v"(sink));
+    }
+#endif
     Sample head = s[0];
     for (int pass = 0; pass < n_pass; ++pass, s += ap.spp, rec0 += ap.spp) {
     // (the first record of the NEXT pass is requested before this pass's merge: K one-sample passes are K dependent merges per thread, and

@@ -192,6 +192,8 @@ struct TraceLane {
     unsigned int *overflow = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
+    hipEvent_t sort_from = nullptr, sorted = nullptr;   // a lone path pass's work-list sort on the context's side stream (render())
+    bool sort_pending = false;
     // deferred path passes (rsx_defer_path_checks): the lane's own copies of the per-call material / table blobs, and the check that
     // is still owed for the pass it ran last
     void *mat_dev = nullptr, *tab_dev = nullptr;
@@ -242,6 +244,7 @@ struct rsx_ctx {
     unsigned int deferred_error_flags = 0;
     unsigned long long deferred_rays = 0;
     double *acc_consts = nullptr;                  // {(double)i, refine_rcp(i)} for the accumulate kernel's steps (k_fill_acc_consts)
+    hipStream_t sort_stream = nullptr;             // k_order_units of lone path passes: beside the replay instead of in front of it
 };
 
 // the check a deferred path pass still owes: wait for its merge, read its flags and ray count
@@ -364,6 +367,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->sort_stream) { (void)hipStreamSynchronize(ctx->sort_stream); (void)hipStreamDestroy(ctx->sort_stream); }
     std::vector<TraceLane *> all_lanes{&ctx->main};
     for (TraceLane &l8 : ctx->lanes) all_lanes.push_back(&l8);
     for (TraceLane *ln : all_lanes) {
@@ -372,6 +376,8 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
+        if (ln->sort_from) (void)hipEventDestroy(ln->sort_from);
+        if (ln->sorted) (void)hipEventDestroy(ln->sorted);
     }
     for (int i = 0; i < POOL_SLOTS; ++i) if (ctx->pool[i]) (void)hipFree(ctx->pool[i]);
     for (auto &e : ctx->cache_free) (void)hipFree(e.second);
@@ -415,6 +421,7 @@ extern "C" int rsx_synchronize(rsx_ctx *ctx) {
     HIP_TRY(hipSetDevice(ctx->device));
     for (TraceLane &ln : ctx->lanes) if (ln.in_flight) { HIP_TRY(hipStreamSynchronize(ln.stream)); ln.in_flight = false; }
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->sort_stream) HIP_TRY(hipStreamSynchronize(ctx->sort_stream));
     return RSX_OK;
 }
 
@@ -1479,6 +1486,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // partial batches of small passes eagerly, tools/r5_eager_repro.py.)
     if (!pipelined) for (TraceLane &ln : ctx->lanes) if (ln.in_flight) HIP_TRY(hipStreamSynchronize(ln.stream));
     if ((rc = settle_lane(ctx, lane))) return rc;          // (a deferred pass this lane ran before: its buffers are about to be reused)
+    // (the work lists of this lane's previous lone path pass were sorted on the side stream: everything this pass puts on the lane's stream comes after)
+    if (lane.sort_pending) { HIP_TRY(hipStreamWaitEvent(lane.stream, lane.sorted, 0)); lane.sort_pending = false; }
 
     // materials and the importance manager's spheres share one small buffer: [materials][spheres]
     const int n_important = has_scatter && desc->important ? std::max(0, desc->n_important) : 0;
@@ -1990,8 +1999,20 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (pipelined) HIP_TRY(hipEventRecord(lane.traced, lane.stream));
     if (want_order) {
         // longest-first work list for this lane's NEXT pass over the same units, sorted while this pass's waves drain
-        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, lane.stream, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
+        // (a path pass that runs alone: the one-workgroup sort — 0.54 ms for the 262 144 units of a Cornell-box pass — goes to a side stream
+        // and runs beside the replay of the term lists instead of in front of it; the lane's next pass waits for it. RSX_SIDE_SORT=0: in line)
+        static const bool side_sort = [] { const char *e = std::getenv("RSX_SIDE_SORT"); return !e || std::atoi(e) != 0; }();
+        hipStream_t sort_on = lane.stream;
+        if (side_sort && has_vol && !pipelined && !deferred && !use_wf) {
+            if (!ctx->sort_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->sort_stream, hipStreamNonBlocking));
+            if (!lane.sort_from) { HIP_TRY(hipEventCreateWithFlags(&lane.sort_from, hipEventDisableTiming)); HIP_TRY(hipEventCreateWithFlags(&lane.sorted, hipEventDisableTiming)); }
+            HIP_TRY(hipEventRecord(lane.sort_from, lane.stream));
+            HIP_TRY(hipStreamWaitEvent(ctx->sort_stream, lane.sort_from, 0));
+            sort_on = ctx->sort_stream;
+        }
+        hipLaunchKernelGGL(k_order_units, dim3(1), dim3(1024), 0, sort_on, lane.unit_cost, lane.unit_order, lane.n_work, order_n, order_tiles_x, (int)desc->spp, has_vol ? 1 : 0);
         HIP_TRY(hipGetLastError());
+        if (sort_on != lane.stream) { HIP_TRY(hipEventRecord(lane.sorted, sort_on)); lane.sort_pending = true; }
         lane.order_units = order_n;
         if (has_vol) lane.cost_zeroed = order_n;
     }
