@@ -1082,48 +1082,18 @@ def test_host_callback_path_equals_device_path(ns):
         assert frames[0][3] == frames[1][3] and (frames[0][0] > 0).mean() > 0.2
 
 
-def test_python_materials_in_forked_workers_with_the_device_in_the_loop(ns, monkeypatch):
-    """A scene with a user-written material splits its primary rays over forked worker processes (hybrid.run_block) while THIS process —
+def test_python_materials_in_forked_workers_with_the_device_in_the_loop():
+    """A scene with a user-written material splits its primary rays over forked worker processes (hybrid.run_block) while the parent —
     HIP initialised, scene resident — answers their ray waves on the device: the frame equals the all-device render and the
     one-process host render bit for bit, per_node_materials=True (every material through the plugin API) included; the parent's
-    device stays usable afterwards (a second device render of another scene)."""
-    from source_amd.optical import hybrid
-    from source_amd.optical.material import hemisphere_cosine_pdf
-
-    class MyLambert(ns.Lambert):
-        def evaluate_shading(self, world, ray, s_in, s_out, w_refl, w_trans, back_face, w2s, s2w, intersection):
-            pdf = hemisphere_cosine_pdf(s_out)
-            if pdf == 0.0:
-                return ray.new_spectrum()
-            spectrum = ray.spawn_daughter(w_refl, s_out.transform(s2w)).trace(world)
-            spectrum.mul_array(self.reflectivity.sample(spectrum.min_wavelength, spectrum.max_wavelength, spectrum.bins))
-            spectrum.mul_scalar(pdf)
-            return spectrum
-
-    monkeypatch.setattr(hybrid, "MIN_RAYS_PER_WORKER", 256)
-
-    def render(user, **engine):
-        world, prims = scenes.build_cornell(ns)
-        if user:
-            for p in prims:
-                if isinstance(p.material, ns.Lambert):
-                    p.material = MyLambert(p.material.reflectivity)
-        cam, pipe = scenes.cornell_camera(ns, world, (40, 36), 2, 5)
-        cam.frame_sampler = ns.RectFrameSampler2D()
-        cam.render_engine = ns.HipEngine(rng="philox", seed=17, **engine)
-        del hybrid.last_stats[:]
-        cam.observe()
-        return pipe.frame.mean.copy(), pipe.frame.variance.copy(), cam.stats["rays"], [st["workers"] for st in hybrid.last_stats]
-
-    device = render(False)
-    workers = render(True, host_workers=4)
-    alone = render(True, host_workers=1)
-    per_node = render(True, host_workers=3, per_node_materials=True)
-    assert workers[3] == [4] and alone[3] == [] and per_node[3] == [3]
-    for other in (workers, alone, per_node):
-        assert eq(device[0], other[0]) and eq(device[1], other[1]) and device[2] == other[2]
-    again = render(False)
-    assert eq(device[0], again[0]) and (device[0] > 0).mean() > 0.3
+    device stays usable afterwards (a second device render of another scene). The case (tests/forked_workers_case.py) runs in a process
+    of its own: forked children of THIS process inherit whatever the suite has mapped by then — after the full-size frames of the tests
+    above, every fork and every copy-on-write fault of 4 busy children cost so much that the case took 510 s of the suite's 690
+    (round 5) against seconds alone; what is tested is the scheme, not fork() of a 20 GB test runner."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "forked_workers_case.py")], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0 and "forked workers OK" in r.stdout, (r.stdout[-2000:], r.stderr[-4000:])
 
 
 def test_user_written_material_through_observe(orc, ns):
