@@ -2072,6 +2072,93 @@ __global__ __launch_bounds__(256) void k_accumulate_xyz(AccumParams ap, int xyz_
     ap.mean[k * 3 + c] = m; ap.variance[k * 3 + c] = v;
 }
 
+// Several ONE-SAMPLE passes of a path-traced call (rsx_render_desc.passes = K with spp = 1: the step of configs[4], 512 one-bin slices x K
+// passes), in two kernels. k_accumulate's multi-pass form gives a (pixel, bin) thread the K records of its pixel to replay one after the
+// other — K dependent pointer walks per thread, every lane of a wave in a different list (one bin per slice: no two lanes share a
+// load): at K = 8 it ran 18 ms per slice against 1.25 ms for one pass, a fifth of the GPU time of a configs[4] step
+// (profiles/r05c_c5_kernel_stats.csv). Here every (pixel, bin, record) gets a thread of its own for the replay — K times the lists in
+// flight, records and tail ids read as contiguous runs — and leaves its value x in `xs`; k_merge_passes then merges a pixel's K values
+// into the frame cell in pass order. Per (pixel, bin) the same operations on the same values in the same order as k_accumulate<false, VOL,
+// false, true> with spp = 1 (m = x, v = 0, combine_samples per pass): frames are equal bit for bit
+// (test_several_path_passes_per_call_equal_separate_passes).
+template <int VOL>
+__global__ __launch_bounds__(256) void k_path_values(AccumParams ap, double *xs) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long R = ap.passes, total = ap.n_tasks * ap.bins * R;
+    if (gid >= total) return;
+    if (ap.abort_flags && (*ap.abort_flags & 7u)) return;
+    long long pb;
+    int r;
+    if (total < (1LL << 31)) { pb = (uint32_t)gid / (uint32_t)R; r = (int)((uint32_t)gid % (uint32_t)R); }
+    else { pb = gid / R; r = (int)(gid % R); }
+    const long long p = pb / ap.bins;
+    const int b = (int)(pb % ap.bins);
+    const long long record = p * R + r;
+    const Sample smp = ap.samples[record];
+    // x = (a * table[bin]) * weight [* sensitivity] with the path's terms applied newest first — value() / apply_term of k_accumulate, tables from global
+    const double tab = ap.tables[(smp.table < 0 ? 0 : smp.table) * ap.bins + b];
+    double x = smp.table < 0 ? 0.0 : smp.a * tab;
+    long long blk = ap.tail[record];
+    int n = smp.pad;
+    for (;;) {
+        const PathTerm *t = ap.pool + blk * PATH_BLOCK;
+        const int first = blk < ap.n_records ? 0 : 1;
+        for (int j = n - 1; j >= first; --j) {
+            const PathTerm tm = t[j];
+            const double tv = ap.tables[tm.table * ap.bins + b];
+            static_assert(TERM_LAMBERT == 1 && TERM_LAMBERT_NORM == 2 && TERM_NORM == 4 && TERM_ATTEN == 5, "kind tests below");
+            const bool has_norm = ((0x14u >> (unsigned)tm.kind) & 1u) != 0u;
+            const double emission = 0.0 + tv * tm.b;
+            const double with_emission = x + emission * tm.a;
+            double y = x * (has_norm ? ap.roulette_norm : 1.0);
+            y = y * (tm.kind == TERM_NORM ? 1.0 : tv);
+            y = y * tm.a;
+            y = y * tm.b;
+            y = tm.kind == TERM_VOL ? with_emission : y;
+            if constexpr (VOL == 2) {                          // dielectric.pyx:325-326; pow(1, length) = 1 exactly
+                if (tm.kind == TERM_ATTEN) y = tv != 1.0 ? x * portable_pow(tv, tm.a) : x;
+            }
+            x = y;
+        }
+        if (first == 0) break;
+        blk = t[0].table;
+        n = PATH_BLOCK;
+    }
+    x = x * smp.weight;
+    if (ap.power) x = x * ap.sensitivity;
+    xs[gid] = x;
+}
+
+__global__ __launch_bounds__(256) void k_merge_passes(AccumParams ap, const double *xs) {
+    const long long gid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = ap.n_tasks * ap.bins;
+    accumulate_rearm(ap, gid);
+    if (gid >= total) return;
+    if (ap.abort_flags && (*ap.abort_flags & 7u)) return;
+    long long p;
+    int b;
+    if (total < (1LL << 31)) { p = (uint32_t)gid / (uint32_t)ap.bins; b = (int)((uint32_t)gid % (uint32_t)ap.bins); }
+    else { p = gid / ap.bins; b = (int)(gid % ap.bins); }
+    int ix, iy;
+    if (ap.tasks) { ix = ap.tasks[2 * p]; iy = ap.tasks[2 * p + 1]; }
+    else {
+        const int h = ap.rect[3] - ap.rect[1];
+        ix = ap.rect[0] + (int)((uint32_t)p / (uint32_t)h); iy = ap.rect[1] + (int)((uint32_t)p % (uint32_t)h);
+    }
+    const RSX_CONST_AS double *consts = (const RSX_CONST_AS double *)(unsigned long long)ap.consts;
+    const size_t f = ((size_t)ix * ap.ny + iy) * ap.frame_bins + ap.slice_offset + b;
+    double fm = ap.fmean[f], fv = ap.fvar[f];
+    int fcount = ap.fn[f];
+    const double *mine = xs + gid * ap.passes;
+    for (int r = 0; r < ap.passes; ++r) {                       // one pass = one sample: (m, v, n) = (x, 0, 1), merged like Pipeline2D.update
+        double mt, vt;
+        int nt;
+        combine_samples_uniform(fm, fv, fcount, mine[r], 0.0, 1, mt, vt, nt, consts, ACC_CONSTS_ENTRIES);
+        fm = mt; fv = vt; fcount = nt;
+    }
+    ap.fmean[f] = fm; ap.fvar[f] = fv; ap.fn[f] = fcount;
+}
+
 __global__ __launch_bounds__(256) void k_frame_combine(long long n, double *ma, double *va, int32_t *na, const double *mb,
                                                        const double *vb, const int32_t *nb) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;

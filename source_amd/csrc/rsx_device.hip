@@ -183,6 +183,8 @@ struct TraceLane {
     size_t samples_bytes = 0, uniforms_bytes = 0, terms_bytes = 0, tail_bytes = 0;
     void *order_counts = nullptr;      // k_order_natural_*: per-block list counts / offsets
     size_t order_counts_bytes = 0;
+    void *xs = nullptr;                // k_path_values -> k_merge_passes: one value per (pixel, bin, record) of a call of several one-sample path passes
+    size_t xs_bytes = 0;
     void *ring = nullptr;              // fused passes: FUSE_UNITS x 64 sample records per wave of the grid
     size_t ring_bytes = 0;
     void *path_queue = nullptr;        // path passes: PathState records handed from the first launch's retiring waves to the drain launch
@@ -372,7 +374,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
     for (TraceLane &l8 : ctx->lanes) all_lanes.push_back(&l8);
     for (TraceLane *ln : all_lanes) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
-        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, ln->wf_paths, ln->wf_hits, ln->wf_lists, ln->wf_counts, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts})
+        for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, ln->wf_paths, ln->wf_hits, ln->wf_lists, ln->wf_counts, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts, ln->xs})
             if (q) (void)hipFree(q);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
@@ -2079,6 +2081,18 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     } else {
         const int vol = !has_vol ? 0 : has_dielectric ? 2 : 1;
         const bool staged = ap.spp >= 4, in_lds = ap.tables_in_lds != 0;
+        // several one-sample path passes per call: the replay with a thread per record, then the merge (k_path_values / k_merge_passes;
+        // RSX_RECORD_REPLAY=0: k_accumulate's multi-pass form)
+        static const bool record_replay = [] { const char *e = std::getenv("RSX_RECORD_REPLAY"); return !e || std::atoi(e) != 0; }();
+        const size_t xs_need = (size_t)total * (size_t)passes * 8;
+        if (record_replay && passes > 1 && has_vol && ap.spp == 1 && fmean && xs_need <= ((size_t)8 << 30)) {
+            if ((rc = lane_buffer(lane.xs, lane.xs_bytes, xs_need))) return rc;
+            const dim3 val_grid((unsigned)(((long long)total * passes + 255) / 256));
+            double *xs = static_cast<double *>(lane.xs);
+            if (vol == 2) hipLaunchKernelGGL((k_path_values<2>), val_grid, dim3(256), 0, ctx->stream, ap, xs);
+            else hipLaunchKernelGGL((k_path_values<1>), val_grid, dim3(256), 0, ctx->stream, ap, xs);
+            hipLaunchKernelGGL(k_merge_passes, acc_grid, dim3(256), 0, ctx->stream, ap, static_cast<const double *>(xs));
+        } else {
 #define ACC(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V>) \
                                                                                            : reinterpret_cast<const void *>(k_accumulate<true, V, false>))
 #define ACC_MULTI(V) (!staged ? reinterpret_cast<const void *>(k_accumulate<false, V, false, true>) : in_lds ? reinterpret_cast<const void *>(k_accumulate<true, V, true, true>) \
@@ -2088,6 +2102,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
 #undef ACC
         void *args[] = {(void *)&ap};
         HIP_TRY(hipLaunchKernel(kernel, acc_grid, dim3(256), args, staged ? acc_lds : 0, ctx->stream));
+        }
     }
     HIP_TRY(hipGetLastError());
     if (timed) HIP_TRY(hipEventRecord(re[2], ctx->stream));
