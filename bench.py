@@ -222,8 +222,12 @@ def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cp
         timed(spread_desc(1)[0], t)                             # (the thread team of this size exists before the clock starts)
         dt = min(timed(desc_t, t), timed(desc_t, t)) if n_t / rate1 / t < 0.5 else timed(desc_t, t)
         sweep.append({"threads": t, "rays_s": round(n_t / dt, 1), "rows": rows_t, "seconds": round(dt, 3)})
-    best = max(sweep, key=lambda e: e["rays_s"])                # the baseline is the best configuration measured, nothing less
-    fewest = min((e for e in sweep if e["rays_s"] >= 0.90 * best["rays_s"]), key=lambda e: e["threads"])
+    # the baseline is the best configuration measured — among thread counts the cgroup quota can SUSTAIN: a 0.8 s sample on twice the quota's
+    # threads runs on burst credit (round 5: 32 threads 4.8e7 rays/s in the sweep under a 16-core quota, 2.5e7 over the 32 s sample that
+    # became `value`, against 4.5e7 on 16); the points above the quota stay in `scaling` for what they are
+    sustained = [e for e in sweep if e["threads"] <= host["usable"]] or sweep
+    best = max(sustained, key=lambda e: e["rays_s"])
+    fewest = min((e for e in sustained if e["rays_s"] >= 0.90 * best["rays_s"]), key=lambda e: e["threads"])
     best_threads, rate = best["threads"], best["rays_s"]
     desc, n_primary, rows_final = spread_desc(rate * cpu_seconds / (NX * CAM_SPP))
     what = ("%d full %dx%d passes of %d spp" % (rows_final // NY, NX, NY, CAM_SPP)) if rows_final >= NY else \
@@ -234,7 +238,7 @@ def cpu_baseline_port(orc, flat, world, cam, engine, NX, NY, CAM_SPP, SLICES, cp
     one = next(e for e in sweep if e["threads"] == 1)
     cpu = {"value": round(n_primary / tcpu, 1), "unit": "primary rays/s", "cores": best_threads, "kind": "port",
            "sample": "%s of the same workload (%d primary rays), oracle/rsx_oracle.c (C restatement of the reference algorithm) "
-                     "with OpenMP on %d host threads (the best of the thread sweep, whose samples are cut the same way), %.1f s" % (what, n_primary, best_threads, tcpu),
+                     "with OpenMP on %d host threads (the best of the thread sweep within the cgroup quota, whose samples are cut the same way), %.1f s" % (what, n_primary, best_threads, tcpu),
            "host": host, "scaling": sweep, "fewest_threads_within_10_percent": fewest["threads"],
            "speedup_over_one_thread": round(n_primary / tcpu / one["rays_s"], 2),
            "one_thread": {"value": one["rays_s"], "unit": "primary rays/s", "cores": 1,
