@@ -483,7 +483,15 @@ void k_render_trace(DScene sc, RenderParams rp, Sample *samples, unsigned long l
         int unit;
         if constexpr (MODE == 2) {
             const long long n_units = q->seg[9];
-            while (redo_unit < n_units && q->redo_mask[redo_unit] == 0ULL) redo_unit += (long long)gridDim.x * (WG_THREADS / WAVE);
+            // (the wave looks at the masks of its next 64 units at once, one per lane: nearly every mask is zero — a grazing ray here and
+            // there — and one dependent scalar load per unit made the launch 0.12 ms of a 4.5 ms configs[3] pass with nothing to do)
+            const long long stride = (long long)gridDim.x * (WG_THREADS / WAVE);
+            while (redo_unit < n_units) {
+                const long long mine = redo_unit + (long long)lane * stride;
+                const unsigned long long found = __ballot(mine < n_units && q->redo_mask[mine] != 0ULL);
+                if (found) { redo_unit += (long long)(__ffsll((long long)found) - 1) * stride; break; }
+                redo_unit += (long long)WAVE * stride;
+            }
             if (redo_unit >= n_units) break;
             unit = __builtin_amdgcn_readfirstlane((int)redo_unit);
             redo_lanes = q->redo_mask[unit];
