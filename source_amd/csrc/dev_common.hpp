@@ -29,6 +29,7 @@ struct DScene {
     char *spill;               // per-wave global spill regions
     const struct CsgInfo *csg; // per primitive: parent CSG node, per-lane state slot, operand side (null without CSG)
     const struct CsgFast *csgfast;   // per primitive: flattened operand tree of a top-level CSG node whose leaves are all analytic (n_leaves = 0: none)
+    const struct CsgFast *csgfast_uniform;   // the same table, never redirected to a kernel's LDS copy: what the scalar data path reads (csg_fast_hit_uniform)
     int32_t n_wnodes, n_witems;   // sizes of the world tree (the path kernel stages a small one in LDS)
     int32_t wide[8];           // analytic world primitives that sit in several world leaves (floors, walls, enclosing emitters), most leaves
                                // first, -1 = none: world_trace_wave computes their first root once per ray instead of once per leaf

@@ -361,7 +361,32 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
                     }
                 }
             }
-            if (gate && !is_mesh) {
+            // The prefill round asks every lane about the SAME solid (sc.wide_csg[k]): the wave-wide evaluator answers it — the flattened tree,
+            // every node's and leaf's box, matrix and parameters over the scalar data path instead of a 376-byte record per lane and operand —
+            // with the lanes' own rays; same operations on the same values per lane as csg_fast_hit. Round 5's phase profile of a prism
+            // pass (tools/path_prof.py prism): 0.77 of the path kernel's time is world_trace_wave and 0.88 of that this round's evaluations.
+            bool prefilled = false;
+            if constexpr (CSG && FASTONLY && RSX_PREFILL_UNIFORM) {
+                if (prefill) {
+                    const int32_t uidx = __builtin_amdgcn_readfirstlane(idx);
+                    const RSX_CONST_AS CsgFast *flat = sc.csgfast_uniform ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast_uniform + uidx) : nullptr;
+                    if (flat != nullptr && flat->n_leaves > 0 && mesh_stack.lds_levels >= 2 * flat->n_leaves) {      // (wave-uniform)
+                        prefilled = true;
+                        const bool ask = gate && !is_mesh;
+                        if (__any(ask)) {
+                            Hit found;
+                            found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;
+                            found.u = found.v = found.w = 0.0f; found.hx = found.hy = found.hz = 0.0;
+                            const int fast = csg_fast_hit_uniform(sc.csgfast_uniform, sc.prims_uniform, sc.prims, uidx, ask, r, mesh_stack, found);
+                            if (ask) {
+                                if (fast == 1) cand = found;
+                                if (fast < 0) work |= 0x80000000u;                    // (as below: the redo pass traces this ray again)
+                            }
+                        }
+                    }
+                }
+            }
+            if (gate && !is_mesh && !prefilled) {
                 bool needs_stream = false;
                 primitive_first_hit<CSG, FASTONLY>(sc, idx, p, r, mesh_stack, csg_state, cand, needs_stream);
                 if (FASTONLY && needs_stream) work |= 0x80000000u;            // top bit of the cost counter: trace this ray again with the stream merge

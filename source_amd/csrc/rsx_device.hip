@@ -75,6 +75,9 @@
                                     // three waves with ~30 cold spills, 72 ms. Four waves still spill hot values and lose.
 #endif
 
+#ifndef RSX_PREFILL_UNIFORM
+#define RSX_PREFILL_UNIFORM 1       // the CSG prefill round of the path kernels through the wave-wide evaluator (dev_world.hpp)
+#endif
 #ifndef RSX_PACKET_MIN_WAVES
 #define RSX_PACKET_MIN_WAVES 4      // launch-bounds waves per SIMD of the packet instantiation of k_render_trace (128 registers)
 #endif
@@ -324,8 +327,12 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         ctx->render_wg_override = env ? std::atoi(env) : 0;
         // path passes whose checks are deferred (the spectral slices of one observe()): each is a bulk of a few milliseconds and a
         // drain launch of ten and more (a few paths trapped in glass), so many of them are kept in flight — one lane, one stream each
+        // (six by default: a configs[4] step takes the same time on four, six or eight lanes — round 5: 9.81 / 9.72 / 9.75 s — and every stream is an
+        // HSA queue whose scratch the runtime reserves for the largest kernel it has run (the CSG redo form: 7 KB per lane): with eight
+        // lanes a process that had rendered three other path-traced scenes before the prism aborted with HSA_STATUS_ERROR_OUT_OF_RESOURCES
+        // at the eighth queue, with seven it did not (tools/r5_handed_case.py). Two queues of margin.)
         env = std::getenv("RSX_PATH_LANES");
-        ctx->path_lanes = env ? std::atoi(env) : 8;
+        ctx->path_lanes = env ? std::atoi(env) : 6;
         if (ctx->path_lanes < 1) ctx->path_lanes = 1;
         if (ctx->path_lanes > RSX_MAX_LANES) ctx->path_lanes = RSX_MAX_LANES;
         const char *env2 = std::getenv("RSX_MAX_IN_FLIGHT");
@@ -808,6 +815,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         d.csg_arena = static_cast<NodeSt *>(arena); d.csg_arena_slots = max_slots; d.csg_arena_lanes = (int32_t)lanes;
     }
     if (any_fast) UP(upload(sc, fast.data(), fast.size(), &d.csgfast));
+    d.csgfast_uniform = d.csgfast;
     // (the world nodes are uploaded below, after the wide primitives are known: wide-only leaves are tagged in the device copy)
     UP(upload(sc, desc->world_kd.items, (size_t)desc->world_kd.n_items, &d.witems));
     std::memcpy(d.wlower, desc->world_kd.lower, 24);
