@@ -1044,6 +1044,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     (void)rp;
     const int my_xcd = xcc_id();
     int victim = -1;
+    unsigned long long redo_batch = 0ULL;                  // MODE 2: the entries of the wave's current 64-entry ticket whose units have rays to redo,
+    long long redo_base = 0;                               // and the ticket's first list position (wave-uniform)
     long long unit = -1;                                   // wave-uniform: the unit rays are being taken from, and how many are gone
     int cursor = WAVE;
     bool exhausted = false;
@@ -1121,6 +1123,32 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         while (idle && !exhausted) {
             if (cursor >= WAVE) {
                 long long tk = -1;
+                if constexpr (MODE == 2) {
+                    // The redo pass visits the units whose mask is not zero — a few in a thousand. One ticket per unit made every wave pay a
+                    // returned atomic on one of nine contended addresses (~17 ns each, serialised: 131 072 units of an 8-pass slice = 2.2 ms
+                    // in which the launch's workgroups hold their 256-register places) plus two dependent loads, to learn "nothing to do".
+                    // A ticket is 64 list entries here: the wave reads their 64 masks at once, one per lane, and walks the set bits.
+                    for (;;) {
+                        if (redo_batch) { tk = redo_base + (__ffsll((long long)redo_batch) - 1); redo_batch &= redo_batch - 1ULL; break; }
+                        bool refilled = false;
+                        while (victim < 8) {
+                            const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
+                            const long long begin = q->seg[list], end = q->seg[list + 1];
+                            unsigned long long mine = 0;
+                            if (lane == 0) mine = atomicAdd(ticket + 16 * list, (unsigned long long)WAVE);
+                            const long long got = begin + (long long)(((unsigned long long)(uint32_t)__builtin_amdgcn_readfirstlane((int)(mine >> 32)) << 32) |
+                                                                      (uint32_t)__builtin_amdgcn_readfirstlane((int)mine));
+                            if (got < end) {
+                                unsigned long long m = 0ULL;
+                                if (got + lane < end) m = q->redo_mask[q->unit_order[got + lane] & 0x3ffffffu];
+                                redo_batch = __ballot(m != 0ULL); redo_base = got; refilled = true;
+                                break;
+                            }
+                            ++victim;
+                        }
+                        if (!refilled) break;
+                    }
+                } else
                 while (victim < 8) {
                     const int list = victim < 0 ? 0 : 1 + ((my_xcd + victim) & 7);
                     const long long begin = q->seg[list], end = q->seg[list + 1];
