@@ -381,12 +381,32 @@ __device__ int csg_fast_hit_uniform(const CsgFast *csgfast, const rsx_primitive 
     double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
     int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
     const int n_leaves = P->n_leaves, top_a_leaves = P->top_a_leaves, top_type = P->top_type;
-    Ray l0 = to_local_uniform(uniform_prim(prims_uniform, uidx), r);
+    // A record whose to_local keeps directions (rsx_scene_create: bit 0 of the device copy's `pad` — translate() and default transforms,
+    // most nodes of a CSG tree) hands a direction without a zero or non-finite component on bit for bit ((1 * d + 0 * e) + 0 * f = d; a zero
+    // could change its sign, a non-finite component turns the zeros into NaN), and with it its reciprocals: the nine multiply-adds and
+    // the three divisions of such a step are skipped when every asking lane's CURRENT direction is of that kind (`dir_ok`, re-established
+    // by three class tests whenever the direction has changed).
+    auto dirs_plain = [&](const Ray &q) {                    // wave-uniform: every component of every asking lane's direction is finite and not zero
+        const bool ok = __builtin_amdgcn_class(q.dx, 0x198) && __builtin_amdgcn_class(q.dy, 0x198) && __builtin_amdgcn_class(q.dz, 0x198);   // -normal | -denormal | +denormal | +normal
+        return RSX_CSG_KEEP_DIRECTION != 0 && __builtin_amdgcn_ballot_w64(want && !ok) == 0ULL;
+    };
+    auto origin_only = [](UPrim p, const Ray &q, double &ox, double &oy, double &oz) {   // to_local_uniform's origin for an affine matrix (w = 1.0, x * 1.0 = x)
+        const RSX_CONST_AS double *m = p->to_local;
+        ox = (m[0] * q.ox + m[1] * q.oy + m[2] * q.oz + m[3]) * 1.0;
+        oy = (m[4] * q.ox + m[5] * q.oy + m[6] * q.oz + m[7]) * 1.0;
+        oz = (m[8] * q.ox + m[9] * q.oy + m[10] * q.oz + m[11]) * 1.0;
+    };
+    const UPrim top = uniform_prim(prims_uniform, uidx);
+    Ray l0;
+    bool l0_ok;
+    if (dirs_plain(r) && (top->pad & 1) != 0) { l0 = r; origin_only(top, r, l0.ox, l0.oy, l0.oz); l0_ok = true; }
+    else { l0 = to_local_uniform(top, r); l0_ok = dirs_plain(l0); }
     l0.maxd = INFINITY;
     int result = 0;
     bool on = want;                                          // this lane is still being answered
     uint32_t nroots = 0, lone_exit = 0;
     const double l0rx = 1.0 / l0.dx, l0ry = 1.0 / l0.dy, l0rz = 1.0 / l0.dz;
+    bool dir_ok = l0_ok;
     Ray cur = l0;
     double crx = l0rx, cry = l0ry, crz = l0rz;
     bool prefix_alive = true;
@@ -399,17 +419,25 @@ __device__ int csg_fast_hit_uniform(const CsgFast *csgfast, const rsx_primitive 
         if (!sibling) {
             cur = l0; crx = l0rx; cry = l0ry; crz = l0rz;
             prefix_alive = true;
+            dir_ok = l0_ok;
             for (int j = 0; j + 1 < len; ++j) {              // BoundPrimitive gates on the way down (boundprimitive.pyx:42-51)
                 const UPrim node = uniform_prim(prims_uniform, P->chain[k][j]);
                 const double lo[3] = {node->box_lower[0], node->box_lower[1], node->box_lower[2]}, hi[3] = {node->box_upper[0], node->box_upper[1], node->box_upper[2]};
                 double f, b;
                 const bool through = aabb_rcp(lo, hi, cur, crx, cry, crz, f, b);
                 // (a lane whose gate failed keeps its ray where it stopped; it is not looked at again before the next reset)
-                const Ray down = to_local_uniform(node, cur);
                 const bool go = prefix_alive && through;
-                cur.ox = go ? down.ox : cur.ox; cur.oy = go ? down.oy : cur.oy; cur.oz = go ? down.oz : cur.oz;
-                cur.dx = go ? down.dx : cur.dx; cur.dy = go ? down.dy : cur.dy; cur.dz = go ? down.dz : cur.dz;
-                crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz;
+                if (dir_ok && (node->pad & 1) != 0) {                        // (wave-uniform) the node keeps directions: only the origin moves
+                    double dox, doy, doz;
+                    origin_only(node, cur, dox, doy, doz);
+                    cur.ox = go ? dox : cur.ox; cur.oy = go ? doy : cur.oy; cur.oz = go ? doz : cur.oz;
+                } else {
+                    const Ray down = to_local_uniform(node, cur);
+                    cur.ox = go ? down.ox : cur.ox; cur.oy = go ? down.oy : cur.oy; cur.oz = go ? down.oz : cur.oz;
+                    cur.dx = go ? down.dx : cur.dx; cur.dy = go ? down.dy : cur.dy; cur.dz = go ? down.dz : cur.dz;
+                    crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz;
+                    dir_ok = dirs_plain(cur);
+                }
                 prefix_alive = go;
             }
         }
@@ -426,17 +454,18 @@ __device__ int csg_fast_hit_uniform(const CsgFast *csgfast, const rsx_primitive 
             meets = aabb_rcp(lo, hi, cur, crx, cry, crz, f, b) && meets;
         }
         if (__builtin_amdgcn_ballot_w64(meets) != 0ULL) {
-            const Ray ll = to_local_uniform(leaf, cur);
+            // (a leaf that keeps directions: the ray's direction and its reciprocals are the parent space's)
+            const bool leaf_keeps = dir_ok && (leaf->pad & 1) != 0;
+            Ray ll;
+            if (leaf_keeps) { ll = cur; origin_only(leaf, cur, ll.ox, ll.oy, ll.oz); }
+            else ll = to_local_uniform(leaf, cur);
             const int32_t type = leaf->type;
             Roots roots;
             roots.n = 0;
             if (type == RSX_PRIM_SPHERE) sphere_roots_uniform(leaf->params[0], ll, roots);
             else if (type == RSX_PRIM_BOX) {
-                const RSX_CONST_AS double *m = leaf->to_local;
-                const bool identity = m[0] == 1.0 && m[1] == 0.0 && m[2] == 0.0 && m[4] == 0.0 && m[5] == 1.0 && m[6] == 0.0 &&
-                                      m[8] == 0.0 && m[9] == 0.0 && m[10] == 1.0;
                 const double prm[6] = {leaf->params[0], leaf->params[1], leaf->params[2], leaf->params[3], leaf->params[4], leaf->params[5]};
-                box_roots_uniform(prm, ll, identity, crx, cry, crz, roots);
+                box_roots_uniform(prm, ll, leaf_keeps, crx, cry, crz, roots);
             } else cylinder_roots(prims[leaf_id], ll, roots);
             const int n = meets ? roots.n : 0;
 #pragma unroll

@@ -75,6 +75,9 @@
                                     // three waves with ~30 cold spills, 72 ms. Four waves still spill hot values and lose.
 #endif
 
+#ifndef RSX_CSG_KEEP_DIRECTION
+#define RSX_CSG_KEEP_DIRECTION 1    // csg_fast_hit_uniform: steps into spaces whose to_local keeps directions skip the direction's arithmetic and reciprocals
+#endif
 #ifndef RSX_PREFILL_UNIFORM
 #define RSX_PREFILL_UNIFORM 1       // the CSG prefill round of the path kernels through the wave-wide evaluator (dev_world.hpp)
 #endif
@@ -795,7 +798,21 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         }
     }
 #define UP(expr) do { rc = (expr); if (rc) { rsx_scene_free(sc); return rc; } } while (0)
-    UP(upload(sc, desc->primitives, (size_t)desc->n_primitives, &d.prims));
+    {
+        // the device copy's `pad` carries what the host can say about a record once and for all. Bit 0 (PRIM_KEEPS_DIRECTION): to_local is
+        // affine with the rotation part exactly the identity (+1.0 on the diagonal, +0.0 elsewhere: translate() and the default transform) —
+        // a direction without a zero or non-finite component then comes out of Vector3D.transform bit for bit as it went in
+        // ((1 * dx + 0 * dy) + 0 * dz = dx), and so do its reciprocals: csg_fast_hit_uniform keeps both (dev_csg.hpp)
+        std::vector<rsx_primitive> dev_prims(desc->primitives, desc->primitives + desc->n_primitives);
+        for (rsx_primitive &pr : dev_prims) {
+            const double *m = pr.to_local;
+            auto is = [](double v, double want) { return std::memcmp(&v, &want, sizeof(double)) == 0; };     // (bitwise: -0.0 is not +0.0)
+            const bool keeps = is(m[0], 1.0) && is(m[1], 0.0) && is(m[2], 0.0) && is(m[4], 0.0) && is(m[5], 1.0) && is(m[6], 0.0) &&
+                               is(m[8], 0.0) && is(m[9], 0.0) && is(m[10], 1.0) && is(m[12], 0.0) && is(m[13], 0.0) && is(m[14], 0.0) && is(m[15], 1.0);
+            pr.pad = keeps ? 1 : 0;
+        }
+        UP(upload(sc, dev_prims.data(), dev_prims.size(), &d.prims));
+    }
     d.prims_uniform = d.prims;
     if (sc->has_csg) UP(upload(sc, info.data(), info.size(), &d.csg));
     d.csg_arena = nullptr; d.csg_arena_slots = 0; d.csg_arena_lanes = 0;
