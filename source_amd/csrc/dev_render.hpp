@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     uint32_t work = 0;
     r.ox = r.oy = r.oz = 0; r.dx = r.dy = 0; r.dz = 1; r.maxd = INFINITY;
 #if RSX_PHASE_PROF == 3
-    unsigned long long pp_acc[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
+    unsigned long long pp_acc[24] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pp_mark = clock64(), pp_t2 = 0, pp_t3 = 0;
 #endif
     auto push = [&](double a, double b, int32_t table, int32_t kind) {
         const bool full = pos == PATH_BLOCK;
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
         }
     }
 #if RSX_PHASE_PROF == 3
-    if (lane == 0 && q->unit_times) for (int k = 0; k < 20; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
+    if (lane == 0 && q->unit_times) for (int k = 0; k < 24; ++k) atomicAdd(q->unit_times + k, pp_acc[k]);
 #endif
     // ray statistics (Ray.ray_count, ray.pyx:536-547: the primary ray and every daughter spawned)
     // (a lane of the drain launch that abandons a handed-on path takes off rays other lanes counted: the lane's count is signed)

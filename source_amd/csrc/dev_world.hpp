@@ -225,6 +225,9 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
     double t_cull = INFINITY;
 #pragma unroll
     for (int j = 0; j < WIDE_N; ++j) if (wide.t[j] >= 0.0 && wide.t[j] < t_cull) t_cull = wide.t[j];
+    // (the prefill round below leaves out a solid whose padded box the ray enters BEYOND that answer: every hit of the solid lies inside its
+    // box, hence farther than a hit the traversal is certain to meet — Primitive.hit is not asked, the mailbox records a miss)
+    const double t_wide_near = RSX_PREFILL_CULL ? t_cull : INFINITY;
 #if RSX_WORLD_CULL == 0
     t_cull = -INFINITY;
 #endif
@@ -251,6 +254,97 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
     int32_t last_leaf = 0;
     uint32_t last_meta = 0;                                  // bits 0..7 a0, 8..15 a1, 16..23 flags, 28..29: 0 not asked, 1 hit, 2 no hit, 3 stream merge
     int32_t node = 0, sp = 0;
+    // The prefill round, packed. Asked solid by solid the wave ran the evaluator 3.3 times per segment round of a prism pass for 21 asking
+    // lanes of 38 live ones each (tools/path_prof.py prism, round 5) — 67 (ray, solid) questions, one wave's worth, in three turns.
+    // Here the questions are dealt out 64 to a turn: lane L of turn i answers question 64 i + L (questions in solid order, then lane order:
+    // the source lane is the rank-th set bit of that solid's gate mask), fetches the asking lane's ray through the cross-lane network,
+    // evaluates it with the per-lane evaluator — the same function on the same bits as before — and the asking lane fetches the answer
+    // back into its mailbox. Same answers, same mailbox order (solid 0 .. 3); the in-loop prefill round below is then skipped.
+    if constexpr (CSG && FASTONLY && CSG_MAILBOX >= 4 && !UNIFORM_ITEMS && RSX_PREFILL_PACK != 0) {
+        if (prefill) {
+            const int lane = threadIdx.x % WAVE;
+            const int n_solids = (sc.wide_csg[1] < 0) ? 1 : (sc.wide_csg[2] < 0) ? 2 : (sc.wide_csg[3] < 0) ? 3 : 4;      // (wave-uniform)
+            unsigned long long gmask[4] = {0ULL, 0ULL, 0ULL, 0ULL};
+            bool asks[4] = {false, false, false, false};
+            int base[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if (k < n_solids) {
+                    const UPrim up = uniform_prim(sc.prims_uniform, sc.wide_csg[k]);
+                    const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
+                    double f, b;
+                    asks[k] = aabb_rcp(lo, hi, r, rx, ry, rz, f, b) && active;          // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                }
+                gmask[k] = __ballot(asks[k]);
+                base[k + 1] = base[k] + __popcll(gmask[k]);
+            }
+            const int n_questions = base[4];
+            const unsigned long long below = (1ULL << lane) - 1ULL;
+            auto pull = [&](int from, double v) {                           // the value lane `from` holds (every lane takes part)
+                const long long bits = __double_as_longlong(v);
+                const int lo32 = __builtin_amdgcn_ds_bpermute(from << 2, (int)(bits & 0xffffffffLL)), hi32 = __builtin_amdgcn_ds_bpermute(from << 2, (int)(bits >> 32));
+                return __longlong_as_double(((long long)hi32 << 32) | (long long)(uint32_t)lo32);
+            };
+            for (int turn = 0; turn * WAVE < n_questions; ++turn) {
+                const int q_mine = turn * WAVE + lane;
+                const bool answering = q_mine < n_questions;
+                const int kq = q_mine >= base[3] ? 3 : q_mine >= base[2] ? 2 : q_mine >= base[1] ? 1 : 0;
+                int rank = q_mine - (kq == 3 ? base[3] : kq == 2 ? base[2] : kq == 1 ? base[1] : 0);
+                unsigned long long m = kq == 3 ? gmask[3] : kq == 2 ? gmask[2] : kq == 1 ? gmask[1] : gmask[0];
+                int src = 0;                                                 // the rank-th set bit of m (binary search on popcounts)
+#pragma unroll
+                for (int width = 32; width >= 1; width >>= 1) {
+                    const unsigned long long low = m & ((1ULL << width) - 1ULL);
+                    const int c = __popcll(low);
+                    const bool upper = rank >= c;
+                    rank = upper ? rank - c : rank;
+                    src = upper ? src + width : src;
+                    m = upper ? m >> width : low;
+                }
+                if (!answering) src = lane;
+                Ray rq;
+                rq.ox = pull(src, r.ox); rq.oy = pull(src, r.oy); rq.oz = pull(src, r.oz);
+                rq.dx = pull(src, r.dx); rq.dy = pull(src, r.dy); rq.dz = pull(src, r.dz); rq.maxd = pull(src, r.maxd);
+                Hit ans;
+                ans.prim = -1; ans.t = 0; ans.a0 = ans.a1 = 0; ans.leaf = 0; ans.flags = 0; ans.u = ans.v = ans.w = 0.0f; ans.hx = ans.hy = ans.hz = 0.0;
+                int code = 0;                                                // 1 hit, 0 miss, 2 the redo pass
+                if (answering) {
+                    const int32_t qidx = kq == 3 ? sc.wide_csg[3] : kq == 2 ? sc.wide_csg[2] : kq == 1 ? sc.wide_csg[1] : sc.wide_csg[0];
+                    bool needs_stream = false;
+                    primitive_first_hit<CSG, FASTONLY>(sc, qidx, sc.prims[qidx], rq, mesh_stack, csg_state, ans, needs_stream);
+                    code = needs_stream ? 2 : ans.prim >= 0 ? 1 : 0;
+                }
+                const uint32_t ans_meta = ((uint32_t)ans.a0 & 0xffu) | (((uint32_t)ans.a1 & 0xffu) << 8) | (ans.flags << 16);
+                // the asking lanes take their answers home: solid k's question of lane L is number base[k] + (set bits of gmask[k] below L)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int q_k = base[k] + __popcll(gmask[k] & below);
+                    const bool here = asks[k] && (q_k >> 6) == turn;
+                    const int from = here ? (q_k & (WAVE - 1)) : lane;
+                    const double t_k = pull(from, ans.t);
+                    const int meta_k = __builtin_amdgcn_ds_bpermute(from << 2, (int)ans_meta), leaf_k = __builtin_amdgcn_ds_bpermute(from << 2, ans.leaf),
+                              code_k = __builtin_amdgcn_ds_bpermute(from << 2, code);
+                    if (here) {
+                        mb_t[k] = code_k == 1 ? t_k : -1.0; mb_leaf[k] = code_k == 1 ? leaf_k : 0; mb_meta[k] = code_k == 1 ? (uint32_t)meta_k : 0u;
+                        if (code_k == 2) work |= 0x80000000u;                  // top bit of the cost counter: trace this ray again with the stream merge
+                    }
+                }
+            }
+            // every live lane's mailbox now names the solids in their order, asked or not (a failed gate is an answer too)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k < n_solids && active) { mb_idx[k] = sc.wide_csg[k]; }
+            if (active) mb_next = n_solids == CSG_MAILBOX ? 0 : n_solids;
+            work += 16u * (uint32_t)n_solids;
+            prefill = false;
+            if constexpr (CSG_ANSWERED) {                    // the nearest answer now includes those of the CSG primitives
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (mb_idx[j] >= 0 && mb_t[j] >= 0.0 && mb_t[j] < t_cull) t_cull = mb_t[j];
+#if RSX_WORLD_CULL == 0
+                t_cull = -INFINITY;
+#endif
+            }
+        }
+    }
     while (__any(active)) {
         double distance = 0;
         int32_t count = 0;
@@ -338,7 +432,8 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
                 }
             }
             double f, b;
-            const bool gate = have && !is_wide && !cached && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            bool gate = have && !is_wide && !cached && aabb_rcp(p.box_lower, p.box_upper, r, rx, ry, rz, f, b);   // BoundPrimitive.hit gate
+            if (prefill && f > t_wide_near) gate = false;
             const bool is_mesh = MESHES && gate && p.type == RSX_PRIM_MESH;
             // Mesh primitives are traced one primitive at a time with everything about the primitive wave-uniform (matrix, mesh
             // descriptor, array bases: scalar loads, SGPRs): a wave that straddles several instances takes one turn per instance.
@@ -366,13 +461,16 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
             // with the lanes' own rays; same operations on the same values per lane as csg_fast_hit. Round 5's phase profile of a prism
             // pass (tools/path_prof.py prism): 0.77 of the path kernel's time is world_trace_wave and 0.88 of that this round's evaluations.
             bool prefilled = false;
-            if constexpr (CSG && FASTONLY && RSX_PREFILL_UNIFORM) {
+            if constexpr (CSG && FASTONLY && RSX_PREFILL_UNIFORM && !(CSG_MAILBOX >= 4 && !UNIFORM_ITEMS && RSX_PREFILL_PACK != 0)) {
                 if (prefill) {
                     const int32_t uidx = __builtin_amdgcn_readfirstlane(idx);
                     const RSX_CONST_AS CsgFast *flat = sc.csgfast_uniform ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast_uniform + uidx) : nullptr;
                     if (flat != nullptr && flat->n_leaves > 0 && mesh_stack.lds_levels >= 2 * flat->n_leaves) {      // (wave-uniform)
                         prefilled = true;
                         const bool ask = gate && !is_mesh;
+#if RSX_PHASE_PROF == 3
+                        if (phase_acc) { phase_acc[20] += 1; phase_acc[21] += __popcll(__ballot(ask)); phase_acc[22] += __any(ask) ? 1 : 0; phase_acc[23] += __popcll(__ballot(active)); }
+#endif
                         if (__any(ask)) {
                             Hit found;
                             found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;

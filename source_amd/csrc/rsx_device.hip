@@ -78,6 +78,14 @@
 #ifndef RSX_CSG_KEEP_DIRECTION
 #define RSX_CSG_KEEP_DIRECTION 1    // csg_fast_hit_uniform: steps into spaces whose to_local keeps directions skip the direction's arithmetic and reciprocals
 #endif
+#ifndef RSX_PREFILL_CULL
+#define RSX_PREFILL_CULL 0          // the CSG prefill round skips solids whose box lies beyond the nearest answer of the wide analytic primitives:
+                                    // exact (boxes are padded by 1e-9, csg.pyx:39) and without effect — configs[4] 8.90 s per step without, 8.95 with: a wave
+                                    // evaluates a solid when ANY lane asks, and among 38 incoherent rays one nearly always does. Off.
+#endif
+#ifndef RSX_PREFILL_PACK
+#define RSX_PREFILL_PACK 1          // the CSG prefill round of the path kernels deals its (ray, solid) questions out 64 to a turn (dev_world.hpp)
+#endif
 #ifndef RSX_PREFILL_UNIFORM
 #define RSX_PREFILL_UNIFORM 1       // the CSG prefill round of the path kernels through the wave-wide evaluator (dev_world.hpp)
 #endif
