@@ -267,14 +267,43 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
             unsigned long long gmask[4] = {0ULL, 0ULL, 0ULL, 0ULL};
             bool asks[4] = {false, false, false, false};
             int base[5] = {0, 0, 0, 0, 0};
+            uint32_t askbits = 0;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 if (k < n_solids) {
                     const UPrim up = uniform_prim(sc.prims_uniform, sc.wide_csg[k]);
                     const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                     double f, b;
-                    asks[k] = aabb_rcp(lo, hi, r, rx, ry, rz, f, b) && active;          // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                    if (aabb_rcp(lo, hi, r, rx, ry, rz, f, b) && active) askbits |= 1u << k;      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
                 }
+            }
+            // A solid that half the wave asks about (the coherent first segments of the camera's rays) is cheaper answered for all its lanes at
+            // once by the wave-wide evaluator — tree and operand records over the scalar data path — than as questions of a packed turn, which
+            // costs about twice a wave-wide run: such solids are answered here, one loop trip each, and leave the packing.
+            if constexpr (RSX_PREFILL_UNIFORM_MIN <= WAVE) {
+                for (int k = 0; k < n_solids; ++k) {                         // (wave-uniform trip count; one copy of the evaluator)
+                    const bool ask = ((askbits >> k) & 1u) != 0u;
+                    if (__popcll(__ballot(ask)) < RSX_PREFILL_UNIFORM_MIN) continue;
+                    const int32_t uidx = k == 0 ? sc.wide_csg[0] : k == 1 ? sc.wide_csg[1] : k == 2 ? sc.wide_csg[2] : sc.wide_csg[3];
+                    const RSX_CONST_AS CsgFast *flat = sc.csgfast_uniform ? (const RSX_CONST_AS CsgFast *)(unsigned long long)(sc.csgfast_uniform + uidx) : nullptr;
+                    if (flat == nullptr || flat->n_leaves <= 0 || mesh_stack.lds_levels < 2 * flat->n_leaves) continue;   // (left to the packed turns: the redo pass)
+                    Hit found;
+                    found.prim = -1; found.t = 0; found.a0 = found.a1 = 0; found.leaf = 0; found.flags = 0;
+                    found.u = found.v = found.w = 0.0f; found.hx = found.hy = found.hz = 0.0;
+                    const int fast = csg_fast_hit_uniform(sc.csgfast_uniform, sc.prims_uniform, sc.prims, uidx, ask, r, mesh_stack, found);
+                    if (ask) {
+                        const bool got = fast == 1;
+                        const uint32_t meta = ((uint32_t)found.a0 & 0xffu) | (((uint32_t)found.a1 & 0xffu) << 8) | (found.flags << 16);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) if (j == k) { mb_t[j] = got ? found.t : -1.0; mb_leaf[j] = got ? found.leaf : 0; mb_meta[j] = got ? meta : 0u; }
+                        if (fast < 0) work |= 0x80000000u;                    // the redo pass traces this ray again
+                        askbits &= ~(1u << k);
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                asks[k] = ((askbits >> k) & 1u) != 0u;
                 gmask[k] = __ballot(asks[k]);
                 base[k + 1] = base[k] + __popcll(gmask[k]);
             }

@@ -83,6 +83,11 @@
                                     // exact (boxes are padded by 1e-9, csg.pyx:39) and without effect — configs[4] 8.90 s per step without, 8.95 with: a wave
                                     // evaluates a solid when ANY lane asks, and among 38 incoherent rays one nearly always does. Off.
 #endif
+#ifndef RSX_PREFILL_UNIFORM_MIN
+#define RSX_PREFILL_UNIFORM_MIN 65  // packed prefill: a solid at least this many lanes ask about is answered by the wave-wide evaluator instead (65: never, the
+                                    // block is not compiled). Measured at 32 (round 5): configs[4] 7.95 -> 12.0 s per step, frames equal — two inlined
+                                    // evaluators in one kernel of 256 registers; the packed turns alone are the better form.
+#endif
 #ifndef RSX_PREFILL_PACK
 #define RSX_PREFILL_PACK 1          // the CSG prefill round of the path kernels deals its (ray, solid) questions out 64 to a turn (dev_world.hpp)
 #endif
