@@ -265,12 +265,46 @@ __device__ unsigned long long g_csgf_why[4];    // diagnostic builds: why csg_fa
 #else
 #define CSGF_WHY(k)
 #endif
+// to_local for the per-lane evaluator, with what the host has noted about the record (rsx_scene_create, bits of the device copy's `pad`):
+// bit 1 — the matrix is affine: for a finite point Point3D.transform's w is (0 * x + 0 * y) + 0 * z + 1 = 1 exactly and x * (1.0 / 1.0) = x,
+// so the w row, its division and the three multiplications go; bit 0 — the rotation part is the identity: a direction without a zero or
+// non-finite component comes out as it went in (`kept`: the caller then keeps its reciprocals too). Same bits as to_local() either way.
+#ifndef RSX_CSG_LANE_FLAGS
+#define RSX_CSG_LANE_FLAGS 0             // measured (round 5, configs[4]): 7.94 -> 11.0 s per step with the flags read per lane — the per-lane tests and the second
+#endif                                  // copy of every transform cost the 256-register kernel more than the arithmetic they skip; 0: to_local() as before
+
+__device__ __forceinline__ Ray to_local_flagged(const rsx_primitive &p, const Ray &q, bool &kept) {
+    const double *m = p.to_local;
+    const int flags = RSX_CSG_LANE_FLAGS ? p.pad : 0;
+    Ray l;
+    if ((flags & 2) && __builtin_amdgcn_class(q.ox, 0x1f8) && __builtin_amdgcn_class(q.oy, 0x1f8) && __builtin_amdgcn_class(q.oz, 0x1f8)) {   // finite
+        l.ox = m[0] * q.ox + m[1] * q.oy + m[2] * q.oz + m[3];
+        l.oy = m[4] * q.ox + m[5] * q.oy + m[6] * q.oz + m[7];
+        l.oz = m[8] * q.ox + m[9] * q.oy + m[10] * q.oz + m[11];
+    } else xform_point(m, q.ox, q.oy, q.oz, l.ox, l.oy, l.oz);
+    kept = (flags & 1) && __builtin_amdgcn_class(q.dx, 0x198) && __builtin_amdgcn_class(q.dy, 0x198) && __builtin_amdgcn_class(q.dz, 0x198);   // finite, not zero
+    if (kept) { l.dx = q.dx; l.dy = q.dy; l.dz = q.dz; }
+    else xform_vector(m, q.dx, q.dy, q.dz, l.dx, l.dy, l.dz);
+    l.maxd = q.maxd;
+    return l;
+}
+// box_roots with the reciprocals of the ray's direction components given (box_slab forms 1.0 / d itself and multiplies by it: the same quotients)
+__device__ __forceinline__ void box_roots_rcp(const rsx_primitive &p, const Ray &l, double rx, double ry, double rz, Roots &out) {
+    double near_t = -INFINITY, far_t = INFINITY;
+    int nf = NO_FACE, ff = NO_FACE, na = -1, fa = -1;
+    box_slab_rcp(0, l.ox, l.dx, rx, p.params[0], p.params[3], near_t, far_t, nf, ff, na, fa);
+    box_slab_rcp(1, l.oy, l.dy, ry, p.params[1], p.params[4], near_t, far_t, nf, ff, na, fa);
+    box_slab_rcp(2, l.oz, l.dz, rz, p.params[2], p.params[5], near_t, far_t, nf, ff, na, fa);
+    pick_roots(near_t, far_t, nf, na, ff, fa, l.maxd, out);
+}
+
 __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const Stack &ms, Hit &cand) {
     const CsgFast &P = sc.csgfast[idx];
     const int lane = threadIdx.x % WAVE;
     double *lds_t = reinterpret_cast<double *>(smem + ms.lds_t);
     int32_t *lds_m = reinterpret_cast<int32_t *>(smem + ms.lds_id);
-    Ray l0 = to_local(sc.prims[idx], r);
+    bool kept;
+    Ray l0 = to_local_flagged(sc.prims[idx], r, kept);
     l0.maxd = INFINITY;
     uint32_t nroots = 0;                                     // 2 bits per leaf
     uint32_t lone_exit = 0;                                  // bit k: leaf k has one root, an exit (the ray starts inside it)
@@ -295,8 +329,8 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
                 const rsx_primitive &node = sc.prims[P.chain[k][j]];
                 double f, b;
                 if (!aabb_rcp(node.box_lower, node.box_upper, cur, crx, cry, crz, f, b)) { prefix_alive = false; break; }
-                cur = to_local(node, cur);                   // csg_first: the operands see the ray in the node's space
-                crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz;
+                cur = to_local_flagged(node, cur, kept);     // csg_first: the operands see the ray in the node's space
+                if (!kept) { crx = 1.0 / cur.dx; cry = 1.0 / cur.dy; crz = 1.0 / cur.dz; }
             }
         }
         if (!prefix_alive) continue;
@@ -309,11 +343,11 @@ __device__ int csg_fast_hit(const DScene &sc, int32_t idx, const Ray &r, const S
             double f, b;
             if (!aabb_rcp(leaf.box_lower, leaf.box_upper, cur, crx, cry, crz, f, b)) continue;
         }
-        const Ray ll = to_local(leaf, cur);
+        const Ray ll = to_local_flagged(leaf, cur, kept);
         Roots roots;
         roots.n = 0;
         if (leaf.type == RSX_PRIM_SPHERE) sphere_roots(leaf, ll, roots);
-        else if (leaf.type == RSX_PRIM_BOX) box_roots(leaf, ll, roots);
+        else if (leaf.type == RSX_PRIM_BOX) { if (kept) box_roots_rcp(leaf, ll, crx, cry, crz, roots); else box_roots(leaf, ll, roots); }
         else cylinder_roots(leaf, ll, roots);
         for (int j = 0; j < roots.n; ++j) {
             const bool exiting = analytic_exiting(leaf, ll, roots.t[j], roots.a0[j], roots.a1[j]);

@@ -822,7 +822,8 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             auto is = [](double v, double want) { return std::memcmp(&v, &want, sizeof(double)) == 0; };     // (bitwise: -0.0 is not +0.0)
             const bool keeps = is(m[0], 1.0) && is(m[1], 0.0) && is(m[2], 0.0) && is(m[4], 0.0) && is(m[5], 1.0) && is(m[6], 0.0) &&
                                is(m[8], 0.0) && is(m[9], 0.0) && is(m[10], 1.0) && is(m[12], 0.0) && is(m[13], 0.0) && is(m[14], 0.0) && is(m[15], 1.0);
-            pr.pad = keeps ? 1 : 0;
+            const bool affine = is(m[12], 0.0) && is(m[13], 0.0) && is(m[14], 0.0) && is(m[15], 1.0);   // bit 1: Point3D.transform's w is exactly 1 for a finite point
+            pr.pad = (keeps ? 1 : 0) | (affine ? 2 : 0);
         }
         UP(upload(sc, dev_prims.data(), dev_prims.size(), &d.prims));
     }
