@@ -109,7 +109,7 @@ typedef struct rsx_primitive {
     int32_t mesh;         /* RSX_PRIM_MESH: index into meshes[] */
     int32_t child_a;      /* CSG: primitive indices of operands A and B */
     int32_t child_b;
-    int32_t pad;          /* ignored on input (the library's device copy keeps per-record flags here: bit 0 = to_local keeps directions) */
+    int32_t pad;          /* ignored on input (the library's device copy keeps per-record flags here: bit 0 = to_local keeps directions, bit 1 = affine) */
     double params[6];
     double to_local[16];  /* Node.to_local(): root -> primitive space, row-major 4x4 */
     double to_root[16];   /* Node.to_root()  */
