@@ -66,18 +66,28 @@ __device__ __forceinline__ int lane_here() {
     asm volatile("" : "+v"(l));
     return l;
 }
-__device__ __forceinline__ void pstack_push(const Stack &st, int32_t sp, int32_t id, double t) {
+// The node ids of the pending entries live in ONE vector register of the wave — lane L holds the id of stack level L (world levels first,
+// the mesh walk's behind them: `base`) — written with v_writelane and read with v_readlane: one instruction each where an LDS word cost
+// two moves, the address arithmetic, the write and, on the way back, a read, a wait and a readfirstlane. (wdepth + mdepth <= 64: render()
+// takes the packet kernel only then.)
+#ifndef RSX_PKT_ASM
+#define RSX_PKT_ASM 1              // the descent (branch steps down to a leaf) as hand-written wave-level code: packet_descend
+#endif
+struct IdStack { int v; int base; };
+__device__ __forceinline__ void pstack_push(const Stack &st, IdStack &ids, int32_t sp, int32_t id, double t) {
     const int lane = (int)(threadIdx.x % WAVE);
-    *reinterpret_cast<int32_t *>(smem + st.lds_id + sp * 4) = id;
+    {   // (lane select through m0: a VOP3 may name one scalar register, the id is the other)
+        const int at = sp + ids.base;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(ids.v) : "s"(id), "s"(at) : "m0");
+    }
     if (__builtin_expect(sp < st.lds_levels, 1)) *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;    // (scalar branch)
     else reinterpret_cast<double *>(st.gt)[(sp - st.lds_levels) * WAVE + lane_here()] = t;
 }
-__device__ __forceinline__ void pstack_pop(const Stack &st, int32_t sp, int32_t &id, double &t) {
+__device__ __forceinline__ void pstack_pop(const Stack &st, const IdStack &ids, int32_t sp, int32_t &id, double &t) {
     const int lane = (int)(threadIdx.x % WAVE);
-    const int32_t v = *reinterpret_cast<const int32_t *>(smem + st.lds_id + sp * 4);
     if (__builtin_expect(sp < st.lds_levels, 1)) t = *reinterpret_cast<const double *>(smem + st.lds_t + (sp * WAVE + lane) * 8);
     else t = __builtin_nontemporal_load(reinterpret_cast<const double *>(st.gt) + (sp - st.lds_levels) * WAVE + lane_here());
-    id = __builtin_amdgcn_readfirstlane(v);
+    id = __builtin_amdgcn_readlane(ids.v, sp + ids.base);
 }
 
 __host__ __device__ __forceinline__ int packet_world_levels(int wdepth) { return wdepth < PKT_WORLD_LDS_LEVELS ? wdepth : PKT_WORLD_LDS_LEVELS; }
@@ -188,7 +198,7 @@ __device__ __forceinline__ bool pkt_lanes(lanemask m) { return __builtin_amdgcn_
 
 template <bool WORLD>
 __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t node, double o, double d, double y, bool fast, lanemask m_neg, lanemask &m_in,
-                                                    double &tmin, double &tmax, const Stack &st, int32_t &sp, double t_cull PKT_ARG) {
+                                                    double &tmin, double &tmax, const Stack &st, IdStack &ids, int32_t &sp, double t_cull PKT_ARG) {
     const double split = unode_split(nd);
     const int32_t lower = node + 1, upper = nd.count;
     const double num = split - o;
@@ -228,7 +238,7 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
         }
         const lanemask m_want_near = m_in & ~m_far;
         if (m_want_near) {
-            if (m_cross) { pstack_push(st, sp, far_id, pkt_lanes(m_cross) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
+            if (m_cross) { pstack_push(st, ids, sp, far_id, pkt_lanes(m_cross) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
             const double keep = pkt_lanes(m_cross) ? plane : tmax;         // (near-side lanes that cross go on to the plane, the others keep their range)
             tmax = pkt_lanes(m_want_near) ? keep : PKT_EMPTY;
             m_in = m_want_near;
@@ -254,7 +264,7 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
     if (b_up != 0ULL && (m_both & m_lower_near) != 0ULL) {
         // both-crossing lanes disagree on the near child: the upper-first lanes come back to this node alone, after the others are
         // through with it
-        pstack_push(st, sp, node, pkt_lanes(b_up) ? tmax : PKT_EMPTY);
+        pstack_push(st, ids, sp, node, pkt_lanes(b_up) ? tmax : PKT_EMPTY);
         ++sp;
         tmax = pkt_lanes(b_up) ? PKT_EMPTY : tmax;
         m_in &= ~b_up; m_both &= ~b_up;
@@ -267,7 +277,7 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
     const int32_t first = upper_first ? upper : lower, second = upper_first ? lower : upper;
     const lanemask m_want_f = upper_first ? m_want_upper : m_want_lower, m_want_s = upper_first ? m_want_lower : m_want_upper;
     if (m_want_f) {
-        if (m_want_s) { pstack_push(st, sp, second, pkt_lanes(m_want_s) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
+        if (m_want_s) { pstack_push(st, ids, sp, second, pkt_lanes(m_want_s) ? tmax : PKT_EMPTY); ++sp; PKT_COUNT(PKC_PUSHES, 1) }
         const double keep = pkt_lanes(m_both) ? plane : tmax;              // (a both-crossing lane's near child is `first` by construction)
         tmax = pkt_lanes(m_want_f) ? keep : PKT_EMPTY;
         m_in = m_want_f;
@@ -280,7 +290,7 @@ __device__ __forceinline__ int32_t packet_step_axis(const UNode &nd, int32_t nod
 
 template <bool WORLD>
 __device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, const Ray &r, const AxisDiv &ad, const PacketSpace &ps, double &tmin, double &tmax,
-                                               const Stack &st, int32_t &sp, double t_cull, lanemask &m_carry PKT_ARG) {
+                                               const Stack &st, IdStack &ids, int32_t &sp, double t_cull, lanemask &m_carry PKT_ARG) {
     const int axis = nd.type & 3;                                          // (wave-uniform: a scalar branch)
 #if RSX_STEP_CARRY_IN
     lanemask &m_in = m_carry;                                              // the lanes with a range: what the last step (or pop) left, not a compare per step
@@ -288,17 +298,171 @@ __device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, co
     lanemask m_in = pkt_mask(tmax != PKT_EMPTY);
     (void)m_carry;
 #endif
-    if (axis == 0) return packet_step_axis<WORLD>(nd, node, r.ox, r.dx, ad.yx, (ps.fast & 1) != 0, ps.neg[0], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
-    if (axis == 1) return packet_step_axis<WORLD>(nd, node, r.oy, r.dy, ad.yy, (ps.fast & 2) != 0, ps.neg[1], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
-    return packet_step_axis<WORLD>(nd, node, r.oz, r.dz, ad.yz, (ps.fast & 4) != 0, ps.neg[2], m_in, tmin, tmax, st, sp, t_cull PKT_PASS);
+    if (axis == 0) return packet_step_axis<WORLD>(nd, node, r.ox, r.dx, ad.yx, (ps.fast & 1) != 0, ps.neg[0], m_in, tmin, tmax, st, ids, sp, t_cull PKT_PASS);
+    if (axis == 1) return packet_step_axis<WORLD>(nd, node, r.oy, r.dy, ad.yy, (ps.fast & 2) != 0, ps.neg[1], m_in, tmin, tmax, st, ids, sp, t_cull PKT_PASS);
+    return packet_step_axis<WORLD>(nd, node, r.oz, r.dz, ad.yz, (ps.fast & 4) != 0, ps.neg[2], m_in, tmin, tmax, st, ids, sp, t_cull PKT_PASS);
 }
 
+#if RSX_PKT_ASM
+// ---------------------------------------------------------------------------------------------------
+// The descent by hand: every branch step from `node` down to the next leaf in ONE block of wave-level code. It is packet_step_axis's short
+// form (every lane has the same near child; the hoisted-reciprocal quotient needs no range test) operation for operation — the same
+// quotient (v_mul, v_fma, v_fma = exact_div), the same three range compares, the same child order, pushes and ranges per lane — and it
+// hands the one step it does not cover back to packet_step: an origin exactly on the split plane, or a push beyond the LDS levels
+// (`return true`: node / nd / masks untouched for that step). Compiled from C++ the same step cost 23 vector + 48 scalar instructions:
+// the backend structurizes the whole unit loop, so the three-way axis dispatch and every early return became flag registers and
+// flag branches, the node record was copied between register quads, the push went through two LDS words with their address moves.
+// Here: 17 vector / LDS + ~30 scalar with a push, and nothing spilled inside.
+//  * lane predicates are 64-bit masks in scalar registers; a select is a move under exec = mask (whole 64-bit operands);
+//  * a lane without a range is a lane outside `m_in` — its tmax is whatever it was — and PKT_EMPTY is written once on the way out;
+//  * near child: num = split - origin is the same number in every lane, `num > 0` (origin < split) fills vcc or leaves it empty;
+//  * the node record sits in s[52:55] by name (an asm operand's halves cannot be named otherwise).
+// WORLD: world_step's cull (node type bits 2 / 3, t_cull) as in packet_step_axis.
+typedef int pkt_i4 __attribute__((ext_vector_type(4)));
+#define PKT_ASM_STEP(TAG, O, D, Y, CULL) \
+    "Lax" TAG "%=:\n" \
+    "v_mov_b64 %[num], " O "\n" \
+    "v_add_f64 %[num], s[54:55], -%[num]\n" \
+    "v_mul_f64 %[q], %[num], " Y "\n" \
+    "v_fma_f64 %[pl], -" D ", %[q], %[num]\n" \
+    "v_fma_f64 %[pl], %[pl], " Y ", %[q]\n" \
+    "v_cmp_eq_f64 vcc, 0, %[num]\n" \
+    "s_cbranch_vccnz Lslow%=\n" \
+    "v_cmp_lt_f64 vcc, 0, %[num]\n" \
+    "v_cmp_lt_f64 %[gt0], 0, %[pl]\n" \
+    "v_cmp_le_f64 %[le], %[pl], %[tmax]\n" \
+    "v_cmp_lt_f64 %[far], %[pl], %[tmin]\n" \
+    "s_and_b64 %[cross], %[gt0], %[le]\n" \
+    "s_and_b64 %[cross], %[cross], %[min]\n" \
+    "s_and_b64 %[far], %[far], %[cross]\n" \
+    "s_add_i32 %[lower], %[node], 1\n" \
+    "s_cmp_lg_u64 vcc, 0\n" \
+    "s_cselect_b32 %[nearid], %[lower], s53\n" \
+    "s_cselect_b32 %[farid], s53, %[lower]\n" \
+    CULL(TAG) \
+    "s_andn2_b64 %[want], %[min], %[far]\n" \
+    "s_cbranch_scc0 Lfaronly" TAG "%=\n" \
+    "s_cmp_lg_u64 %[cross], 0\n" \
+    "s_cbranch_scc0 Lnopush" TAG "%=\n" \
+    "s_cmp_ge_i32 %[sp], %[levels]\n" \
+    "s_cbranch_scc1 Lslow%=\n" \
+    "v_mov_b64 %[p], %[ninf]\n" \
+    "s_mov_b64 exec, %[cross]\n" \
+    "v_mov_b64 %[p], %[tmax]\n" \
+    "s_mov_b64 exec, %[ex]\n" \
+    "v_lshl_add_u32 %[addr], %[sp], 9, %[lds]\n" \
+    "ds_write_b64 %[addr], %[p]\n" \
+    "s_add_i32 m0, %[sp], %[idbase]\n" \
+    "s_nop 0\n" \
+    "v_writelane_b32 %[ids], %[farid], m0\n" \
+    "s_add_i32 %[sp], %[sp], 1\n" \
+    "Lnopush" TAG "%=:\n" \
+    "s_mov_b64 exec, %[cross]\n" \
+    "v_mov_b64 %[tmax], %[pl]\n" \
+    "s_mov_b64 exec, %[ex]\n" \
+    "s_mov_b64 %[min], %[want]\n" \
+    "s_mov_b32 %[node], %[nearid]\n" \
+    "s_branch Lnext%=\n" \
+    "Lfaronly" TAG "%=:\n" \
+    "s_mov_b64 %[min], %[cross]\n" \
+    "s_mov_b32 %[node], %[farid]\n" \
+    "s_branch Lnext%=\n"
+#define PKT_ASM_NOCULL(TAG)
+#define PKT_ASM_CULL(TAG) \
+    "s_cselect_b32 %[t0], 4, 8\n" \
+    "s_and_b32 %[t0], %[t0], s52\n" \
+    "s_cbranch_scc0 Lnocull" TAG "%=\n" \
+    "v_cmp_lt_f64 %[gt0], %[pl], %[tcull]\n" \
+    "s_andn2_b64 %[le], %[cross], %[far]\n" \
+    "s_and_b64 %[gt0], %[gt0], %[le]\n" \
+    "s_mov_b64 exec, %[gt0]\n" \
+    "v_mov_b64 %[tmin], %[pl]\n" \
+    "s_mov_b64 exec, %[ex]\n" \
+    "s_or_b64 %[far], %[far], %[gt0]\n" \
+    "Lnocull" TAG "%=:\n"
+#define PKT_ASM_HEAD \
+    "s_mov_b64 %[ex], exec\n" \
+    "s_mov_b32 %[m0save], m0\n" \
+    "s_mov_b32 %[steps], 0\n" \
+    "Ltop%=:\n" \
+    "s_and_b32 %[t0], s52, 3\n" \
+    "s_cmp_eq_u32 %[t0], 0\n" \
+    "s_cbranch_scc1 Laxx%=\n" \
+    "s_cmp_eq_u32 %[t0], 1\n" \
+    "s_cbranch_scc1 Laxy%=\n"
+#define PKT_ASM_TAIL \
+    "Lnext%=:\n" \
+    "s_lshl_b32 %[t0], %[node], 4\n" \
+    "s_load_dwordx4 s[52:55], %[nodes], %[t0]\n" \
+    "s_add_i32 %[steps], %[steps], 1\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "s_cmp_lt_i32 s52, 0\n" \
+    "s_cbranch_scc0 Ltop%=\n" \
+    "s_mov_b32 %[flag], 0\n" \
+    "s_branch Lend%=\n" \
+    "Lslow%=:\n" \
+    "s_mov_b32 %[flag], 1\n" \
+    "Lend%=:\n" \
+    "s_andn2_b64 exec, %[ex], %[min]\n" \
+    "v_mov_b64 %[tmax], %[ninf]\n" \
+    "s_mov_b64 exec, %[ex]\n" \
+    "s_mov_b32 m0, %[m0save]\n"
+
+// In: node (a branch), nd = its record, the lanes with a range `m_in` (tmax == PKT_EMPTY elsewhere). Out: false — `node` is a leaf, nd its
+// record; true — the step at `node` is one for packet_step. `steps`: branch steps taken.
+template <bool WORLD>
+__device__ __forceinline__ bool packet_descend(const rsx_kdnode *nodes, int32_t &node, UNode &nd, const Ray &r, const AxisDiv &ad, lanemask &m_in, double &tmin, double &tmax,
+                                               const Stack &st, IdStack &ids, int32_t &sp, double t_cull, int32_t &steps_out) {
+    pkt_i4 rec;
+    rec.x = nd.type; rec.y = nd.count; rec.z = (int)nd.lo; rec.w = (int)nd.hi;
+    const unsigned long long base = (unsigned long long)nodes;
+    const unsigned long long ninf = 0xfff0000000000000ULL;
+    const uint32_t lds = st.lds_t + (uint32_t)(threadIdx.x % WAVE) * 8u;
+    const int levels = st.lds_levels, idbase = ids.base;
+    double num, q, pl, p;
+    int addr, flag, lower, nearid, farid, t0, m0save, steps;
+    unsigned long long gt0, le, cross, far, want, ex;
+    if constexpr (WORLD) {
+        asm volatile(PKT_ASM_HEAD
+                     PKT_ASM_STEP("z", "%[oz]", "%[dz]", "%[yz]", PKT_ASM_CULL)
+                     PKT_ASM_STEP("x", "%[ox]", "%[dx]", "%[yx]", PKT_ASM_CULL)
+                     PKT_ASM_STEP("y", "%[oy]", "%[dy]", "%[yy]", PKT_ASM_CULL)
+                     PKT_ASM_TAIL
+                     : [node] "+s"(node), [rec] "+{s[52:55]}"(rec), [min] "+s"(m_in), [tmax] "+v"(tmax), [tmin] "+v"(tmin), [sp] "+s"(sp), [ids] "+v"(ids.v),
+                       [flag] "=&s"(flag), [steps] "=&s"(steps), [num] "=&v"(num), [q] "=&v"(q), [pl] "=&v"(pl), [p] "=&v"(p), [addr] "=&v"(addr),
+                       [gt0] "=&s"(gt0), [le] "=&s"(le), [cross] "=&s"(cross), [far] "=&s"(far), [want] "=&s"(want), [ex] "=&s"(ex),
+                       [lower] "=&s"(lower), [nearid] "=&s"(nearid), [farid] "=&s"(farid), [t0] "=&s"(t0), [m0save] "=&s"(m0save)
+                     : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+                       [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
+                       [tcull] "v"(t_cull)
+                     : "vcc", "scc", "memory");
+    } else {
+        asm volatile(PKT_ASM_HEAD
+                     PKT_ASM_STEP("z", "%[oz]", "%[dz]", "%[yz]", PKT_ASM_NOCULL)
+                     PKT_ASM_STEP("x", "%[ox]", "%[dx]", "%[yx]", PKT_ASM_NOCULL)
+                     PKT_ASM_STEP("y", "%[oy]", "%[dy]", "%[yy]", PKT_ASM_NOCULL)
+                     PKT_ASM_TAIL
+                     : [node] "+s"(node), [rec] "+{s[52:55]}"(rec), [min] "+s"(m_in), [tmax] "+v"(tmax), [sp] "+s"(sp), [ids] "+v"(ids.v),
+                       [flag] "=&s"(flag), [steps] "=&s"(steps), [num] "=&v"(num), [q] "=&v"(q), [pl] "=&v"(pl), [p] "=&v"(p), [addr] "=&v"(addr),
+                       [gt0] "=&s"(gt0), [le] "=&s"(le), [cross] "=&s"(cross), [far] "=&s"(far), [want] "=&s"(want), [ex] "=&s"(ex),
+                       [lower] "=&s"(lower), [nearid] "=&s"(nearid), [farid] "=&s"(farid), [t0] "=&s"(t0), [m0save] "=&s"(m0save)
+                     : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
+                       [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
+                       [tmin] "v"(tmin)
+                     : "vcc", "scc", "memory");
+    }
+    nd.type = rec.x; nd.count = rec.y; nd.lo = (uint32_t)rec.z; nd.hi = (uint32_t)rec.w;
+    steps_out = steps;
+    return flag != 0;
+}
+#endif
+
 // Pops until some lane has a range again. `done` lanes (their ray found its hit) discard theirs. False: the stack is empty.
-__device__ __forceinline__ bool packet_pop(const Stack &st, int32_t &sp, int32_t &node, double &tmax, bool done PKT_ARG) {
+__device__ __forceinline__ bool packet_pop(const Stack &st, const IdStack &ids, int32_t &sp, int32_t &node, double &tmax, bool done PKT_ARG) {
     while (sp > 0) {
         --sp;
         double t;
-        pstack_pop(st, sp, node, t);
+        pstack_pop(st, ids, sp, node, t);
         PKT_COUNT(PKC_POPS, 1)
         tmax = done ? PKT_EMPTY : t;
         if (pkt_any(tmax != PKT_EMPTY)) return true;
@@ -399,7 +563,7 @@ __device__ __forceinline__ bool aabb_rcp_signed(bool uniform, bool neg_x, bool n
 // (Measured and not adopted — the mesh walk as a real call, `noinline`, so that the world walk's state would sit in callee-saved
 // registers across a visit instead of being spilled piecemeal: configs[2] 27.4 -> 33.3 ms. The call's own traffic — arguments through
 // vector registers and memory, uniform values re-established with readfirstlane, the callee's saves — cost more than the spills.)
-__device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, MeshHit &out, int32_t &work PKT_ARG) {
+__device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool want, UMesh m, const Ray &r, const Stack &st, IdStack &ids, MeshHit &out, int32_t &work PKT_ARG) {
     const rsx_kdnode *nodes = m->nodes;
     const float4 *leaf = m->leaf;
     const AxisDiv ad = axis_div(r);
@@ -446,19 +610,17 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
         asm volatile("; MARK mesh steps begin");
 #endif
         while (nd.type >= 0) {
-#if RSX_STEP_PREFETCH
-            // both children are asked for before the step: the next node's record is a dependent scalar load (the constant cache answers in
-            // ~100 cycles, L2 in several hundred) at the end of every step otherwise — here it travels under the step's own arithmetic
-            const int32_t lower_id = node + 1;
-            const UNode nl = load_node_u(nodes, lower_id), nu = load_node_u(nodes, nd.count);
-            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0, m_have PKT_PASS);
-            const bool took_lower = node == lower_id;
-            nd.type = took_lower ? nl.type : nu.type; nd.count = took_lower ? nl.count : nu.count;
-            nd.lo = took_lower ? nl.lo : nu.lo; nd.hi = took_lower ? nl.hi : nu.hi;
-#else
-            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, sp, 0.0, m_have PKT_PASS);
-            nd = load_node_u(nodes, node);
+#if RSX_PKT_ASM
+            if (__builtin_expect(ps.fast == 7, 1)) {
+                int32_t steps;
+                const bool slow = packet_descend<false>(nodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, 0.0, steps);
+                work += steps;
+                PKT_COUNT(PKC_MSTEPS, steps)
+                if (!slow) break;
+            }
 #endif
+            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, ids, sp, 0.0, m_have PKT_PASS);
+            nd = load_node_u(nodes, node);
             work += 1;
             PKT_COUNT(PKC_MSTEPS, 1)
         }
@@ -498,7 +660,7 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; }
         }
         if (tmax != PKT_EMPTY) tmin = tmax;                                    // the next range of this ray begins where this one ended
-        if (!packet_pop(st, sp, node, tmax, hit PKT_PASS)) break;
+        if (!packet_pop(st, ids, sp, node, tmax, hit PKT_PASS)) break;
     }
     return hit;
 }
@@ -636,21 +798,23 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
 #endif
     int32_t node = 0, sp = 0;
     lanemask m_have = 0ULL;
+    IdStack ids;
+    ids.v = 0; ids.base = 0;                               // (world levels: lanes 0 .. wdepth - 1, a mesh walk's behind them)
     for (;;) {
         m_have = pkt_mask(tmax != PKT_EMPTY);
         UNode nd = load_node_u(wnodes, node);
         while (nd.type >= 0) {
-#if RSX_STEP_PREFETCH >= 2
-            const int32_t lower_id = node + 1;
-            const UNode nl = load_node_u(wnodes, lower_id), nu = load_node_u(wnodes, nd.count);
-            node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, sp, t_cull, m_have PKT_PASS);
-            const bool took_lower = node == lower_id;
-            nd.type = took_lower ? nl.type : nu.type; nd.count = took_lower ? nl.count : nu.count;
-            nd.lo = took_lower ? nl.lo : nu.lo; nd.hi = took_lower ? nl.hi : nu.hi;
-#else
-            node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, sp, t_cull, m_have PKT_PASS);
-            nd = load_node_u(wnodes, node);
+#if RSX_PKT_ASM
+            if (__builtin_expect(ps.fast == 7, 1)) {
+                int32_t steps;
+                const bool slow = packet_descend<true>(wnodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, t_cull, steps);
+                work += steps;
+                PKT_COUNT(PKC_WSTEPS, steps)
+                if (!slow) break;
+            }
 #endif
+            node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, ids, sp, t_cull, m_have PKT_PASS);
+            nd = load_node_u(wnodes, node);
             work += 1;
             PKT_COUNT(PKC_WSTEPS, 1)
         }
@@ -706,9 +870,11 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                             l.ox = readlane_f64(l.ox, 0); l.oy = readlane_f64(l.oy, 0); l.oz = readlane_f64(l.oz, 0);   // ... which then lives in scalar registers)
                             const UMesh um = (UMesh)(unsigned long long)(sc->meshes + up->mesh);
                             MeshHit mh;
-                            if (mesh_trace_packet(sc, idx, gate, um, l, mesh_stack, mh, work PKT_PASS)) {
+                            ids.base = sc->wdepth;                             // (the mesh walk's ids lie behind the world's in the same register)
+                            if (mesh_trace_packet(sc, idx, gate, um, l, mesh_stack, ids, mh, work PKT_PASS)) {
                                 cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w;
                             }
+                            ids.base = 0;
                         }
                     } else if (CSG && is_csg(type)) {
                         const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
@@ -753,7 +919,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
         }
         if (tmax != PKT_EMPTY) tmin = tmax;
         work = __builtin_amdgcn_readfirstlane(work);
-        if (!packet_pop(st, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
+        if (!packet_pop(st, ids, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
     }
     work_out = (uint32_t)work;
     return best.prim >= 0;

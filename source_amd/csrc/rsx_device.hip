@@ -1472,8 +1472,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     // unit must be ONE pixel's samples for its rays to share their way through the trees)
     // (CSG scenes: the fast pass of the two — state-free evaluator — may be the packet kernel; RSX_PACKET_CSG=0 keeps the per-lane one)
     static const bool packet_csg = [] { const char *e = std::getenv("RSX_PACKET_CSG"); return !e || std::atoi(e) != 0; }();
+    // (the packet walk keeps the node ids of its pending entries in the lanes of one vector register: world levels + mesh levels <= 64)
     const bool use_packet = !has_vol && (!scene->has_csg || (two_pass_csg && packet_csg && !h_xyz)) && packet_min_spp > 0 && desc->spp >= (desc->tasks ? std::max(packet_min_spp, WAVE) : packet_min_spp) &&
-                            !ctx->unit_times;
+                            !ctx->unit_times && scene->d.wdepth + scene->d.mdepth <= WAVE;
     const size_t wave_lds = use_packet ? packet_lds_bytes(scene->d.wdepth, scene->d.mdepth, scene->d.csg_fast_rows) : (size_t)(scene->d.wlds + scene->d.mlds) * WAVE * 12 + STAGE_BYTES;
     const size_t fuse_fixed = (size_t)FUSE_UNITS * WAVE * 20 + ((size_t)desc->spp + 2) * 8;
     // (default: on for packet passes — round 3: their trace kernel waits on latency, not on instruction issue, and hides the recurrence:

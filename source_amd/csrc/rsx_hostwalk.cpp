@@ -5,8 +5,9 @@
 // on the device path — 69 us against the reference's ~1.2 us (world.pyx:125-146 from Python). This file answers those calls on the
 // host: an explicit-stack walk over the SAME flattened arrays the device scene is built from (rsx_scene_desc), operation for operation
 // what the kernels do (and therefore what the reference does: every function cites it). It is product code for the single-ray API
-// only: observe(), the batch queries and bench.py never come here, nothing under oracle/ is used, and a scene with CSG primitives is
-// refused (RSX_EUNSUPPORTED: the caller takes the device path).
+// only: observe(), the batch queries and bench.py never come here, nothing under oracle/ is used. CSG solids are answered by the
+// reference's own stream merge (csg.pyx:132-234): hit() / next_intersection() of the operands, each with the cached state the reference
+// keeps on its primitive objects (one record per primitive, per calling thread).
 //
 // Compiled with -ffp-contract=off like the device side; IEEE `/` and sqrt; the mesh test keeps the reference's mixed precision.
 #include <cmath>
@@ -376,7 +377,169 @@ void mesh_geom(const HostMesh &m, const HRay &l, double t, int32_t tri, float u,
     g.exiting = (l.dx * fx + l.dy * fy + l.dz * fz) > 0.0;
 }
 
-struct HHit { int32_t prim; double t; int32_t a0, a1; float u, v, w; };
+// ---- CSG: raysect/primitive/csg.pyx:132-234 (hit / next_intersection / _identify_intersection / _closest_intersection), the operators'
+// _valid_intersection tables (:326-348 Union, :424-446 Intersect, :526-548 Subtract) and Subtract._modify_intersection (:550-568) ----
+// An Intersection as an operand hands it up: the record in the operand's own space (points, normal, exiting), lifted one level at a time.
+struct Isect {
+    bool valid = false;
+    double t = 0;
+    int32_t prim = -1;         // the primitive whose space the record is in (a CSG node once lifted)
+    int32_t leaf = -1;         // the operand leaf that produced the root
+    int32_t tri = -1;
+    float u = 0, v = 0, w = 0;
+    Geom g;
+};
+// What the reference keeps on the primitive objects between hit() and next_intersection(): the cached second root of a sphere / box /
+// cylinder (sphere.pyx:150-157 ...), a mesh's continuation ray (mesh.pyx:1240-1275), a CSG node's stream heads (csg.pyx:150-155) and
+// BoundPrimitive's "was the primitive reached" (boundprimitive.pyx:38-60).
+struct PState {
+    bool further = false; double next_t = 0; HRay c_local{}; int32_t c_a0 = 0, c_a1 = 0;
+    bool seek_next = false; HRay next_local{}; double ray_distance = 0;
+    HRay cache_ray{}; Isect cache_a, cache_b; bool cache_last_is_a = false, cache_invalid = true;
+    bool tested = false;
+};
+struct CsgEval { const rsx_host_scene &sc; std::vector<PState> &st; };
+
+void prim_first(CsgEval &e, int32_t idx, const HRay &ray, Isect &out);
+void prim_next(CsgEval &e, int32_t idx, Isect &out);
+bool bound_contains(const rsx_host_scene &sc, int32_t idx, double px, double py, double pz);
+
+inline void analytic_record(const rsx_primitive &p, int32_t idx, const HRay &l, double t, int32_t a0, int32_t a1, Isect &out) {
+    out.valid = true; out.t = t; out.prim = idx; out.leaf = idx; out.tri = -1; out.u = out.v = out.w = 0.0f;
+    analytic_geom(p, l, t, a0, a1, out.g);
+}
+inline void mesh_record(CsgEval &e, int32_t idx, const HostMesh &m, const HRay &local, const MeshHit &mh, Isect &out) {   // Mesh._process_intersection, mesh.pyx:1240-1275
+    PState &s = e.st[(size_t)idx];
+    out.valid = true; out.prim = idx; out.leaf = idx; out.tri = mh.tri; out.u = mh.u; out.v = mh.v; out.w = mh.w;
+    out.t = (double)mh.t;
+    mesh_geom(m, local, out.t, mh.tri, mh.u, mh.v, mh.w, out.g);
+    s.seek_next = true;
+    s.next_local.ox = out.g.hit[0] + local.dx * MESH_EPS; s.next_local.oy = out.g.hit[1] + local.dy * MESH_EPS; s.next_local.oz = out.g.hit[2] + local.dz * MESH_EPS;
+    s.next_local.dx = local.dx; s.next_local.dy = local.dy; s.next_local.dz = local.dz;
+    s.next_local.maxd = local.maxd - out.t - MESH_EPS;
+    out.t += s.ray_distance;
+    s.ray_distance = out.t + MESH_EPS;
+}
+// BoundPrimitive.hit / next_intersection (boundprimitive.pyx:42-60)
+inline void bound_first(CsgEval &e, int32_t idx, const HRay &ray, Isect &out) {
+    const rsx_primitive &p = e.sc.prims[(size_t)idx];
+    double f, b;
+    out.valid = false;
+    if (aabb(p.box_lower, p.box_upper, ray, f, b)) { e.st[(size_t)idx].tested = true; prim_first(e, idx, ray, out); return; }
+    e.st[(size_t)idx].tested = false;
+}
+inline void bound_next(CsgEval &e, int32_t idx, Isect &out) {
+    out.valid = false;
+    if (e.st[(size_t)idx].tested) prim_next(e, idx, out);
+}
+inline bool csg_accepts(int32_t type, const Isect &a, const Isect &b, bool closest_is_a) {
+    const bool inside_a = a.valid && a.g.exiting, inside_b = b.valid && b.g.exiting;
+    if (type == RSX_PRIM_UNION) return (!inside_a && !inside_b) || (inside_a && !inside_b && closest_is_a) || (!inside_a && inside_b && !closest_is_a);
+    if (type == RSX_PRIM_INTERSECT) return (inside_a && inside_b) || (inside_a && !inside_b && !closest_is_a) || (!inside_a && inside_b && closest_is_a);
+    return (!inside_a && !inside_b && closest_is_a) || (inside_a && !inside_b) || (inside_a && inside_b && !closest_is_a);
+}
+inline int csg_nearer(const Isect &a, const Isect &b) {       // _closest_intersection, csg.pyx:226-234: 1 = a, 0 = b (b wins a tie), -1 = neither
+    if (!a.valid) return b.valid ? 0 : -1;
+    if (!b.valid || a.t < b.t) return 1;
+    return 0;
+}
+void csg_merge(CsgEval &e, int32_t idx, const HRay &ray, Isect &a, Isect &b, Isect &out) {     // _identify_intersection, csg.pyx:181-224
+    const rsx_primitive &p = e.sc.prims[(size_t)idx];
+    PState &s = e.st[(size_t)idx];
+    out.valid = false;
+    for (int closest = csg_nearer(a, b); closest >= 0; closest = csg_nearer(a, b)) {
+        const Isect &c = closest ? a : b;
+        if (csg_accepts(p.type, a, b, closest != 0)) {
+            if (!(c.t <= ray.maxd)) return;
+            s.cache_ray = ray; s.cache_a = a; s.cache_b = b; s.cache_last_is_a = closest != 0; s.cache_invalid = false;
+            Isect r = c;
+            if (p.type == RSX_PRIM_SUBTRACT && !closest) {                    // the surface of the subtracted solid, seen from the other side
+                for (int k = 0; k < 3; ++k) { const double tmp = r.g.inside[k]; r.g.inside[k] = r.g.outside[k]; r.g.outside[k] = tmp; r.g.normal[k] = -r.g.normal[k]; }
+                r.g.exiting = !r.g.exiting;
+            }
+            const rsx_primitive &src = e.sc.prims[(size_t)r.prim];            // from the operand's space into this node's (csg.pyx:198-208)
+            double x, y, z;
+            xform_point(src.to_root, r.g.hit[0], r.g.hit[1], r.g.hit[2], x, y, z); r.g.hit[0] = x; r.g.hit[1] = y; r.g.hit[2] = z;
+            xform_point(src.to_root, r.g.inside[0], r.g.inside[1], r.g.inside[2], x, y, z); r.g.inside[0] = x; r.g.inside[1] = y; r.g.inside[2] = z;
+            xform_point(src.to_root, r.g.outside[0], r.g.outside[1], r.g.outside[2], x, y, z); r.g.outside[0] = x; r.g.outside[1] = y; r.g.outside[2] = z;
+            const double *mi = src.to_local;                                  // Normal3D.transform_with_inverse: the inverse's transpose
+            x = mi[0] * r.g.normal[0] + mi[4] * r.g.normal[1] + mi[8] * r.g.normal[2];
+            y = mi[1] * r.g.normal[0] + mi[5] * r.g.normal[1] + mi[9] * r.g.normal[2];
+            z = mi[2] * r.g.normal[0] + mi[6] * r.g.normal[1] + mi[10] * r.g.normal[2];
+            r.g.normal[0] = x; r.g.normal[1] = y; r.g.normal[2] = z;
+            r.prim = idx;
+            out = r;
+            return;
+        }
+        if (closest) bound_next(e, p.child_a, a); else bound_next(e, p.child_b, b);
+    }
+}
+void prim_first(CsgEval &e, int32_t idx, const HRay &ray, Isect &out) {
+    const rsx_primitive &p = e.sc.prims[(size_t)idx];
+    PState &s = e.st[(size_t)idx];
+    out.valid = false;
+    if (is_csg_type(p.type)) {                                                // CSGPrimitive.hit, csg.pyx:132-155
+        s.cache_invalid = true;
+        HRay local = to_local(p, ray);
+        local.maxd = INFINITY;
+        Isect a, b;
+        bound_first(e, p.child_a, local, a);
+        if (p.type != RSX_PRIM_UNION && !a.valid) return;                     // Intersect / Subtract: nothing without a root of A (:421, :523)
+        bound_first(e, p.child_b, local, b);
+        csg_merge(e, idx, ray, a, b, out);
+        return;
+    }
+    const HRay l = to_local(p, ray);
+    if (p.type == RSX_PRIM_MESH) {                                            // Mesh.hit, mesh.pyx:1178-1211
+        s.ray_distance = 0;
+        MeshHit mh;
+        const HostMesh &m = e.sc.meshes[(size_t)p.mesh];
+        if (mesh_trace(m, l, mh)) { mesh_record(e, idx, m, l, mh, out); return; }
+        s.seek_next = false;
+        return;
+    }
+    Roots roots;
+    roots.n = 0;
+    s.further = false;
+    if (p.type == RSX_PRIM_SPHERE) sphere_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_BOX) box_roots(p, l, roots);
+    else if (p.type == RSX_PRIM_CYLINDER) cylinder_roots(p, l, roots);
+    if (roots.n == 0) return;
+    if (roots.n == 2) { s.further = true; s.next_t = roots.t[1]; s.c_local = l; s.c_a0 = roots.a0[1]; s.c_a1 = roots.a1[1]; }
+    analytic_record(p, idx, l, roots.t[0], roots.a0[0], roots.a1[0], out);
+}
+void prim_next(CsgEval &e, int32_t idx, Isect &out) {
+    const rsx_primitive &p = e.sc.prims[(size_t)idx];
+    PState &s = e.st[(size_t)idx];
+    out.valid = false;
+    if (is_csg_type(p.type)) {                                                // CSGPrimitive.next_intersection, csg.pyx:160-179
+        if (s.cache_invalid) return;
+        Isect a = s.cache_a, b = s.cache_b;
+        const HRay ray = s.cache_ray;
+        if (s.cache_last_is_a) bound_next(e, p.child_a, a); else bound_next(e, p.child_b, b);
+        csg_merge(e, idx, ray, a, b, out);
+        return;
+    }
+    if (p.type == RSX_PRIM_MESH) {                                            // Mesh.next_intersection, mesh.pyx:1213-1238
+        if (!s.seek_next) return;
+        const HostMesh &m = e.sc.meshes[(size_t)p.mesh];
+        const HRay local = s.next_local;
+        MeshHit mh;
+        if (mesh_trace(m, local, mh)) { mesh_record(e, idx, m, local, mh, out); return; }
+        s.seek_next = false;
+        return;
+    }
+    if (!s.further) return;
+    s.further = false;
+    analytic_record(p, idx, s.c_local, s.next_t, s.c_a0, s.c_a1, out);
+}
+std::vector<PState> &csg_states(const rsx_host_scene &sc) {   // one set of records per calling thread, as large as the biggest scene it has seen
+    thread_local std::vector<PState> st;
+    if (st.size() < sc.prims.size()) st.resize(sc.prims.size());
+    return st;
+}
+
+struct HHit { int32_t prim; double t; int32_t a0, a1; float u, v, w; Isect csg; };
 
 // World.hit — core/scenegraph/world.pyx:125-146, core/acceleration/kdtree.pyx:73-122, boundprimitive.pyx:42-51
 bool world_hit(const rsx_host_scene &sc, const HRay &r, HHit &best) {
@@ -392,7 +555,12 @@ bool world_hit(const rsx_host_scene &sc, const HRay &r, HHit &best) {
             const HRay l = to_local(p, r);
             HHit cand;
             cand.prim = -1;
-            if (p.type == RSX_PRIM_MESH) {
+            if (is_csg_type(p.type)) {
+                CsgEval e{sc, csg_states(sc)};
+                e.st[(size_t)idx].tested = true;
+                prim_first(e, idx, r, cand.csg);
+                if (cand.csg.valid) { cand.prim = idx; cand.t = cand.csg.t; cand.a0 = cand.csg.tri; cand.a1 = 0; cand.u = cand.csg.u; cand.v = cand.csg.v; cand.w = cand.csg.w; }
+            } else if (p.type == RSX_PRIM_MESH) {
                 MeshHit mh;
                 if (mesh_trace(sc.meshes[(size_t)p.mesh], l, mh)) { cand.prim = idx; cand.t = (double)mh.t; cand.a0 = mh.tri; cand.a1 = 0; cand.u = mh.u; cand.v = mh.v; cand.w = mh.w; }
             } else {
@@ -414,6 +582,12 @@ bool world_hit(const rsx_host_scene &sc, const HRay &r, HHit &best) {
 bool leaf_contains(const rsx_host_scene &sc, const rsx_primitive &p, double px, double py, double pz) {
     double qx, qy, qz;
     xform_point(p.to_local, px, py, pz, qx, qy, qz);
+    if (is_csg_type(p.type)) {                                                // Union / Intersect / Subtract.contains, csg.pyx:350-353, 448-451, 570-573
+        const bool a = bound_contains(sc, p.child_a, qx, qy, qz);
+        if (p.type == RSX_PRIM_UNION) return a || bound_contains(sc, p.child_b, qx, qy, qz);
+        if (p.type == RSX_PRIM_INTERSECT) return a && bound_contains(sc, p.child_b, qx, qy, qz);
+        return a && !bound_contains(sc, p.child_b, qx, qy, qz);
+    }
     if (p.type == RSX_PRIM_SPHERE) return (qx * qx + qy * qy + qz * qz) <= p.params[0] * p.params[0];
     if (p.type == RSX_PRIM_BOX) return aabb_contains(p.params, p.params + 3, qx, qy, qz);
     if (p.type == RSX_PRIM_CYLINDER) return (0.0 <= qz && qz <= p.params[1]) && ((qx * qx + qy * qy) <= (p.params[0] * p.params[0]));
@@ -426,6 +600,11 @@ bool leaf_contains(const rsx_host_scene &sc, const rsx_primitive &p, double px, 
         if (mesh_trace(m, zr, mh)) return m.fnormals[3 * (size_t)mh.tri + 2] > 0.0f;
     }
     return false;
+}
+
+bool bound_contains(const rsx_host_scene &sc, int32_t idx, double px, double py, double pz) {   // BoundPrimitive.contains, boundprimitive.pyx:62-66
+    const rsx_primitive &p = sc.prims[(size_t)idx];
+    return aabb_contains(p.box_lower, p.box_upper, px, py, pz) && leaf_contains(sc, p, px, py, pz);
 }
 
 int kd_depth(const rsx_kdtree &kd) {                          // deepest leaf of the pre-order array (bounds the stack)
@@ -485,7 +664,6 @@ extern "C" void rsx_host_scene_free(rsx_host_scene *scene) { delete scene; }
 extern "C" int rsx_hit_host(const rsx_host_scene *scene, int64_t n, const double *origin, const double *direction, const double *max_distance,
                             int32_t *prim, double *t, uint8_t *exiting, int32_t *tri, float *uvw, double *geom) {
     if (!scene || n < 0 || (n > 0 && (!origin || !direction || !prim))) return rsx_fail(RSX_EINVAL, "rsx_hit_host: bad arguments");
-    if (scene->has_csg) return rsx_fail(RSX_EUNSUPPORTED, "rsx_hit_host: scenes with CSG primitives are answered by the device (rsx_hit_batch)");
     for (int64_t i = 0; i < n; ++i) {
         HRay r;
         r.ox = origin[3 * i]; r.oy = origin[3 * i + 1]; r.oz = origin[3 * i + 2];
@@ -495,7 +673,8 @@ extern "C" int rsx_hit_host(const rsx_host_scene *scene, int64_t n, const double
         const bool hit = world_hit(*scene, r, h);
         prim[i] = hit ? h.prim : -1;
         if (t) t[i] = hit ? h.t : NAN;
-        const bool mesh = hit && scene->prims[(size_t)h.prim].type == RSX_PRIM_MESH;
+        const bool csg = hit && is_csg_type(scene->prims[(size_t)h.prim].type);
+        const bool mesh = hit && (csg ? h.csg.tri >= 0 : scene->prims[(size_t)h.prim].type == RSX_PRIM_MESH);   // (a CSG node hands its operand's MeshIntersection on)
         if (tri) tri[i] = mesh ? h.a0 : -1;
         if (uvw) { uvw[3 * i] = mesh ? h.u : 0.0f; uvw[3 * i + 1] = mesh ? h.v : 0.0f; uvw[3 * i + 2] = mesh ? h.w : 0.0f; }
         if (exiting || geom) {
@@ -504,7 +683,8 @@ extern "C" int rsx_hit_host(const rsx_host_scene *scene, int64_t n, const double
             if (hit) {
                 const rsx_primitive &p = scene->prims[(size_t)h.prim];
                 const HRay l = to_local(p, r);
-                if (mesh) mesh_geom(scene->meshes[(size_t)p.mesh], l, h.t, h.a0, h.u, h.v, h.w, g);
+                if (csg) g = h.csg.g;
+                else if (mesh) mesh_geom(scene->meshes[(size_t)p.mesh], l, h.t, h.a0, h.u, h.v, h.w, g);
                 else analytic_geom(p, l, h.t, h.a0, h.a1, g);
             }
             if (exiting) exiting[i] = hit && g.exiting ? 1 : 0;
@@ -537,7 +717,6 @@ extern "C" int rsx_hit_host_one(const rsx_host_scene *scene, const double *in, d
 // World.contains — kdtree3d.pyx:736-792, kdtree.pyx:126-162; inside[i, j] = primitive j of World.primitives contains point i
 extern "C" int rsx_contains_host(const rsx_host_scene *scene, int64_t n, const double *points, uint8_t *inside) {
     if (!scene || n < 0 || (n > 0 && (!points || !inside))) return rsx_fail(RSX_EINVAL, "rsx_contains_host: bad arguments");
-    if (scene->has_csg) return rsx_fail(RSX_EUNSUPPORTED, "rsx_contains_host: scenes with CSG primitives are answered by the device (rsx_contains_batch)");
     const int32_t nw = scene->n_world;
     for (int64_t i = 0; i < n; ++i) {
         const double px = points[3 * i], py = points[3 * i + 1], pz = points[3 * i + 2];
