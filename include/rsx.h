@@ -291,8 +291,8 @@ int rsx_contains_batch(rsx_scene *scene, int64_t n, const double *points, uint8_
  * core/acceleration/kdtree.pyx:73-162): a device round trip per ray costs ~70 us, the reference answers in ~1 us. These entry points
  * answer such calls on the host from the same flattened arrays the device scene is created from — the same operations in the same
  * order as the kernels (hit ids, distances, barycentrics and geometry are the device's, bit for bit). They exist for the single-ray
- * API only: render calls, batch queries and the bench never use them; a scene with CSG primitives is refused (RSX_EUNSUPPORTED: the
- * caller goes to rsx_hit_batch / rsx_contains_batch). No device is needed. Arguments as rsx_hit_batch / rsx_contains_batch (host
+ * API only: render calls, batch queries and the bench never use them. CSG solids are answered by the reference's stream merge
+ * (csg.pyx:132-234, 326-599) with per-thread operand state. No device is needed. Arguments as rsx_hit_batch / rsx_contains_batch (host
  * pointers; max_distance, t, exiting, tri, uvw, geom may be NULL). */
 typedef struct rsx_host_scene rsx_host_scene;
 int rsx_host_scene_create(const rsx_scene_desc *desc, rsx_host_scene **out);   /* copies what it needs from desc */

@@ -78,7 +78,8 @@ __device__ __forceinline__ void pstack_push(const Stack &st, IdStack &ids, int32
     const int lane = (int)(threadIdx.x % WAVE);
     {   // (lane select through m0: a VOP3 may name one scalar register, the id is the other)
         const int at = sp + ids.base;
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(ids.v) : "s"(id), "s"(at) : "m0");
+        int keep;
+        asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1" : "+v"(ids.v), "=&s"(keep) : "s"(id), "s"(at));
     }
     if (__builtin_expect(sp < st.lds_levels, 1)) *reinterpret_cast<double *>(smem + st.lds_t + (sp * WAVE + lane) * 8) = t;    // (scalar branch)
     else reinterpret_cast<double *>(st.gt)[(sp - st.lds_levels) * WAVE + lane_here()] = t;
@@ -380,11 +381,40 @@ typedef int pkt_i4 __attribute__((ext_vector_type(4)));
     "s_mov_b64 exec, %[ex]\n" \
     "s_or_b64 %[far], %[far], %[gt0]\n" \
     "Lnocull" TAG "%=:\n"
+#ifndef RSX_PKT_PREFETCH
+#define RSX_PKT_PREFETCH 1         // both children's records are asked for before the step's arithmetic (s[56:59] lower, s[60:63] upper)
+#endif
+#if RSX_PKT_PREFETCH
+#define PKT_ASM_FETCH \
+    "s_lshl_b32 %[t0], %[node], 4\n" \
+    "s_add_i32 %[t0], %[t0], 16\n" \
+    "s_load_dwordx4 s[56:59], %[nodes], %[t0]\n" \
+    "s_lshl_b32 %[t0], s53, 4\n" \
+    "s_load_dwordx4 s[60:63], %[nodes], %[t0]\n"
+#define PKT_ASM_ARRIVE \
+    "s_add_i32 %[steps], %[steps], 1\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "s_cmp_eq_u32 %[node], %[lower]\n" \
+    "s_cselect_b64 s[52:53], s[56:57], s[60:61]\n" \
+    "s_cselect_b64 s[54:55], s[58:59], s[62:63]\n"
+#define PKT_ASM_DRAIN "s_waitcnt lgkmcnt(0)\n"
+#define PKT_ASM_CLOBBERS "vcc", "scc", "memory", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
+#else
+#define PKT_ASM_FETCH
+#define PKT_ASM_ARRIVE \
+    "s_lshl_b32 %[t0], %[node], 4\n" \
+    "s_load_dwordx4 s[52:55], %[nodes], %[t0]\n" \
+    "s_add_i32 %[steps], %[steps], 1\n" \
+    "s_waitcnt lgkmcnt(0)\n"
+#define PKT_ASM_DRAIN
+#define PKT_ASM_CLOBBERS "vcc", "scc", "memory"
+#endif
 #define PKT_ASM_HEAD \
     "s_mov_b64 %[ex], exec\n" \
     "s_mov_b32 %[m0save], m0\n" \
     "s_mov_b32 %[steps], 0\n" \
     "Ltop%=:\n" \
+    PKT_ASM_FETCH \
     "s_and_b32 %[t0], s52, 3\n" \
     "s_cmp_eq_u32 %[t0], 0\n" \
     "s_cbranch_scc1 Laxx%=\n" \
@@ -392,15 +422,13 @@ typedef int pkt_i4 __attribute__((ext_vector_type(4)));
     "s_cbranch_scc1 Laxy%=\n"
 #define PKT_ASM_TAIL \
     "Lnext%=:\n" \
-    "s_lshl_b32 %[t0], %[node], 4\n" \
-    "s_load_dwordx4 s[52:55], %[nodes], %[t0]\n" \
-    "s_add_i32 %[steps], %[steps], 1\n" \
-    "s_waitcnt lgkmcnt(0)\n" \
+    PKT_ASM_ARRIVE \
     "s_cmp_lt_i32 s52, 0\n" \
     "s_cbranch_scc0 Ltop%=\n" \
     "s_mov_b32 %[flag], 0\n" \
     "s_branch Lend%=\n" \
     "Lslow%=:\n" \
+    PKT_ASM_DRAIN \
     "s_mov_b32 %[flag], 1\n" \
     "Lend%=:\n" \
     "s_andn2_b64 exec, %[ex], %[min]\n" \
@@ -435,7 +463,7 @@ __device__ __forceinline__ bool packet_descend(const rsx_kdnode *nodes, int32_t 
                      : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
                        [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
                        [tcull] "v"(t_cull)
-                     : "vcc", "scc", "memory");
+                     : PKT_ASM_CLOBBERS);
     } else {
         asm volatile(PKT_ASM_HEAD
                      PKT_ASM_STEP("z", "%[oz]", "%[dz]", "%[yz]", PKT_ASM_NOCULL)
@@ -449,7 +477,7 @@ __device__ __forceinline__ bool packet_descend(const rsx_kdnode *nodes, int32_t 
                      : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
                        [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
                        [tmin] "v"(tmin)
-                     : "vcc", "scc", "memory");
+                     : PKT_ASM_CLOBBERS);
     }
     nd.type = rec.x; nd.count = rec.y; nd.lo = (uint32_t)rec.z; nd.hi = (uint32_t)rec.w;
     steps_out = steps;

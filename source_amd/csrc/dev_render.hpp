@@ -57,7 +57,19 @@ struct RenderParams {
     const uint32_t *seg;              // [10] begin offsets of the shared heavy list and the 8 per-XCD lists in unit_order (+ end)
     int32_t measure_cost;             // 1: record unit costs (small, tail-bound passes); 0: large passes keep the natural order
     unsigned long long *unit_times;   // optional [n_units,12]: wall_clock64 start, end, (xcc<<16 | cu) per 64-ray unit (tuning aid)
+    double origin[3];                 // the pinhole in world space: camera_origin(cam) formed once on the host (the same IEEE operations every ray made for itself)
 };
+
+// Point3D(0, 0, 0).transform(camera.to_root) — point.pyx:253-284 with the reference's products by zero kept (a non-finite matrix entry
+// makes the same NaN). Host and device form it with the same correctly rounded operations (-ffp-contract=off on both sides).
+__host__ __device__ inline void camera_origin(const rsx_camera &cam, double *o) {
+    const double *m = cam.to_root;
+    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
+    wq = 1.0 / wq;
+    o[0] = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
+    o[1] = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
+    o[2] = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+}
 
 // per-sample record consumed by k_accumulate: x[bin] = (a * table[bin]) * weight
 struct Sample {
@@ -121,11 +133,7 @@ __device__ __forceinline__ void camera_ray(const RSX_CONST_AS RenderParams *q, i
     normalise3(dx, dy, dz);
     weight = dz;
     const RSX_CONST_AS double *m = q->cam.to_root;
-    double wq = m[12] * 0.0 + m[13] * 0.0 + m[14] * 0.0 + m[15];
-    wq = 1.0 / wq;
-    r.ox = (m[0] * 0.0 + m[1] * 0.0 + m[2] * 0.0 + m[3]) * wq;
-    r.oy = (m[4] * 0.0 + m[5] * 0.0 + m[6] * 0.0 + m[7]) * wq;
-    r.oz = (m[8] * 0.0 + m[9] * 0.0 + m[10] * 0.0 + m[11]) * wq;
+    r.ox = q->origin[0]; r.oy = q->origin[1]; r.oz = q->origin[2];           // (camera_origin, once per pass on the host)
     r.dx = m[0] * dx + m[1] * dy + m[2] * dz;
     r.dy = m[4] * dx + m[5] * dy + m[6] * dz;
     r.dz = m[8] * dx + m[9] * dy + m[10] * dz;

@@ -1646,6 +1646,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     int order_tiles_x = 0;
     RenderParams rp;
     rp.cam = desc->camera;
+    camera_origin(rp.cam, rp.origin);
     rp.materials = static_cast<const rsx_material *>(d_mat);
     rp.tasks = desc->tasks ? static_cast<const int32_t *>(d_tasks) : nullptr;
     rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? static_cast<const double *>(lane.uniforms) : nullptr;
@@ -2294,6 +2295,7 @@ extern "C" int rsx_selftest_camera_rays(rsx_ctx *ctx, const rsx_render_desc *des
     RenderParams rp;
     std::memset(&rp, 0, sizeof(rp));
     rp.cam = desc->camera;
+    camera_origin(rp.cam, rp.origin);
     rp.tasks = tasks.as<int32_t>();
     rp.uniforms = desc->rng_mode == RSX_RNG_STREAM ? uni.as<double>() : nullptr;
     rp.n_tasks = desc->n_tasks;

@@ -4,6 +4,7 @@ ctypes (include/rsx.h); if the library or a gfx950 device is missing these calls
 """
 import ctypes as C
 import os
+import threading
 import weakref
 
 import numpy as np
@@ -169,11 +170,10 @@ class DeviceScene:
         return Intersection(*args)
 
     def host_scene(self):
-        """The host-side twin for single rays and points (HostScene), or None for a scene the host side refuses (CSG primitives)."""
+        """The host-side twin for single rays and points (HostScene; CSG solids included: the stream merge runs on the host too)."""
         h = getattr(self, "_host", None)
         if h is None:
-            has_csg = any(r["type"] in (_lib.PRIM_UNION, _lib.PRIM_INTERSECT, _lib.PRIM_SUBTRACT) for r in self.flat.records)
-            h = self._host = HostScene(self.flat) if (not has_csg and _lib.has("rsx_hit_host")) else False
+            h = self._host = HostScene(self.flat) if _lib.has("rsx_hit_host") else False
         return h or None
 
     def hit_single(self, ray):
@@ -236,12 +236,13 @@ _private_scenes = weakref.WeakKeyDictionary()
 
 class HostScene:
     """rsx_host_scene wrapper: World.hit / World.contains for single rays and points on the host (include/rsx.h, "one ray, one point").
-    Built from the same FlatScene the device scene is; needs no GPU. Scenes with CSG primitives are refused by the library
-    (RsxError): the callers then take the device path."""
+    Built from the same FlatScene the device scene is; needs no GPU. The call buffers of hit_one are per thread (ctypes releases the
+    GIL during the call: two threads probing one world must not share them)."""
 
     def __init__(self, flat):
         self.flat = flat
         self._h = C.c_void_p()
+        self._tls = threading.local()
         _lib.check(_lib.lib().rsx_host_scene_create(C.byref(flat.desc), C.byref(self._h)))
 
     def close(self):
@@ -274,9 +275,9 @@ class HostScene:
 
     def hit_one(self, ox, oy, oz, dx, dy, dz, max_distance):
         """One ray through two preallocated ctypes buffers (no numpy on the way): (prim, t, exiting, tri, (u, v, w), geom[12]) or None."""
-        b = getattr(self, "_one", None)
+        b = getattr(self._tls, "one", None)
         if b is None:
-            b = self._one = ((C.c_double * 7)(), (C.c_double * 19)(), _lib.lib().rsx_hit_host_one)
+            b = self._tls.one = ((C.c_double * 7)(), (C.c_double * 19)(), _lib.lib().rsx_hit_host_one)
         i, o, call = b
         i[0], i[1], i[2], i[3], i[4], i[5], i[6] = ox, oy, oz, dx, dy, dz, max_distance
         rc = call(self._h, i, o)

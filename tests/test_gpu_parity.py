@@ -612,6 +612,8 @@ def test_csg_demo_world(orc, ns, golden):
     dev = sc.hit_batch(o, d, m, geometry=True)
     _check_world(dev, g["world_idx"], g["world_rec"])
     assert_hits_equal(dev, orc.hit_batch(flat, o, d, m, geometry=True), geometry=True)
+    from source_amd.device import HostScene                  # the single-ray host walk (csrc/rsx_hostwalk.cpp) answers CSG worlds with the device's bits
+    assert_hits_equal(HostScene(flat).hit_batch(o, d, m, geometry=True), dev, geometry=True)
     for name, index in (("obj0", 0), ("lens", 4)):
         counts, t, ex = sc.roots_batch(index, o[:4000], d[:4000], None, max_roots=64)
         assert eq(counts, g[name + "_counts"]), name

@@ -517,8 +517,8 @@ def test_host_walk_single_rays_against_golden_vectors(orc, ns, golden, m70k):
     "n = 1 -> CPU lib") against the reference's own vectors, no GPU involved: the mesh ray classes of F04 (ids, t, u, v, w, exiting,
     geometry; vertex / edge rays, origins on the surface, max_distance short / exact / long), the analytic primitives of F05 (first
     root, full geometry, contains), the edge worlds of F11 (empty world, coincident primitives, t == max_distance, axis-parallel
-    grazing rays) — and against the pinned oracle on a mixed world of instanced meshes and analytic primitives. Scenes with CSG
-    primitives (F06 / F07's worlds) are refused loudly: their single rays go to the device."""
+    grazing rays), the CSG worlds of F06 / F07 — and against the pinned oracle on a mixed world of instanced meshes and analytic
+    primitives, on CSG solids with mesh operands and on the prism scene."""
     import raysets
     from source_amd import scenes, _lib
     from source_amd._flatten import FlatScene
@@ -585,10 +585,37 @@ def test_host_walk_single_rays_against_golden_vectors(orc, ns, golden, m70k):
     # single-ray form through preallocated buffers = the batch form
     one = host.hit_one(*o[0], *d[0], float(m[0]))
     assert (one is None) == (a["prim"][0] < 0) and (one is None or (one[0] == a["prim"][0] and one[1] == a["t"][0] and eq(one[5], a["geom"][0])))
-    # CSG worlds are the device's: loud refusal, no silent substitute
-    for build in (scenes.build_csg_demo, scenes.build_mixed):
-        host = HostScene(build(ns)[0].flatten())
-        with pytest.raises(_lib.RsxError):
-            host.hit_batch([[0, 0, -4]], [[0, 0, 1]])
-        with pytest.raises(_lib.RsxError):
-            host.contains_batch([[0, 0, 0]])
+    # CSG worlds: the host walk runs the reference's stream merge (csg.pyx:132-234) — the demos/csg.py tree (F06) and the mixed world with CSG
+    # solids and instances (F07) against the reference's own vectors, ids / t / exiting / geometry and contains()
+    g = golden("f06_csg")
+    world, prims = scenes.build_csg_demo(ns)
+    host = HostScene(world.flatten())
+    o, d, m = raysets.scene_rays(12000, 101, 9.0, 4.5)
+    og, dg, mg = raysets.pinhole_grid(64, (0.0, 0.0, -4.0), 75.0)
+    o, d, m = np.concatenate([o, og]), np.concatenate([d, dg]), np.concatenate([m, mg])
+    T._check_world(host.hit_batch(o, d, m, geometry=True), g["world_idx"], g["world_rec"])
+    assert eq(host.contains_batch(raysets.points(4000, 102, 4.5)), g["contains"])
+    g = golden("f07_world")
+    world, prims = scenes.build_mixed(ns)
+    host = HostScene(world.flatten())
+    o, d, m = raysets.scene_rays(20000, 111, 6.0, 2.2)
+    r = host.hit_batch(o, d, m, geometry=True)
+    T._check_world(r, g["idx"], g["rec"])
+    assert eq(host.contains_batch(raysets.points(6000, 112, 2.0)), g["contains"])
+    # ... the prism scene (configs[4]: nested Intersect / Subtract of boxes) and mesh operands (the mesh's next_intersection stream inside
+    # the merge, MeshIntersection extras handed up) against the pinned oracle
+    v24, t24 = scenes.displaced_sphere(24, radius=0.5)
+    world = ns.World()
+    ns.Subtract(ns.Mesh(v24, t24, smoothing=False, transform=ns.translate(0.1, 0, 0)), ns.Box(ns.Point3D(-0.3, -1, -1), ns.Point3D(0.25, 1, 1)), world,
+                ns.translate(0, 0.1, 0.2) * ns.rotate(10, 20, 30), ns.AbsorbingSurface())
+    ns.Intersect(ns.Sphere(0.45, transform=ns.translate(0.2, 0, 0)), ns.Mesh(v24, t24, smoothing=False), world, ns.translate(1.5, 0, 0), ns.AbsorbingSurface())
+    for w, rays, pts in ((world, raysets.scene_rays(20000, 301, 4.0, 1.2), raysets.points(3000, 302, 1.5)),
+                         (scenes.build_prism(ns)[0], raysets.scene_rays(20000, 303, 3.0, 1.0), raysets.points(3000, 304, 1.0))):
+        flat = w.flatten()
+        host = HostScene(flat)
+        a, b = host.hit_batch(*rays, geometry=True), orc.hit_batch(flat, *rays, geometry=True)
+        assert eq(a["prim"], b["prim"]) and (a["prim"] >= 0).mean() > 0.05
+        hit = b["prim"] >= 0
+        for key in ("t", "exiting", "tri", "uvw", "geom"):
+            assert eq(a[key][hit], b[key][hit]), key
+        assert eq(host.contains_batch(pts), orc.contains_batch(flat, pts))
