@@ -68,8 +68,10 @@ void k_hit_batch(DScene sc, long long n, const double *origin, const double *dir
         if (!valid) continue;
         if constexpr (MODE == 1) { if (work >> 31) { out.prim[i] = HIT_REDO; continue; } }
         out.prim[i] = hit ? h.prim : -1;
-        if (out.t) out.t[i] = hit ? h.t : NAN;
         bool mesh = hit && sc.prims[h.prim].type == RSX_PRIM_MESH;
+        // (a mesh reports `t + Mesh._ray_distance`, mesh.pyx:1240-1275 — + 0.0 for a first hit: a root at -0.0, an origin ON the surface, leaves as
+        // +0.0 while the geometry below is formed with the root as found)
+        if (out.t) out.t[i] = hit ? (mesh ? h.t + 0.0 : h.t) : NAN;
         if constexpr (CSG) {   // a CSG node hands back its operand's MeshIntersection (triangle, u, v, w survive the lift)
             if (hit && is_csg(sc.prims[h.prim].type)) mesh = sc.prims[h.leaf].type == RSX_PRIM_MESH;
         }

@@ -672,9 +672,10 @@ extern "C" int rsx_hit_host(const rsx_host_scene *scene, int64_t n, const double
         HHit h;
         const bool hit = world_hit(*scene, r, h);
         prim[i] = hit ? h.prim : -1;
-        if (t) t[i] = hit ? h.t : NAN;
         const bool csg = hit && is_csg_type(scene->prims[(size_t)h.prim].type);
         const bool mesh = hit && (csg ? h.csg.tri >= 0 : scene->prims[(size_t)h.prim].type == RSX_PRIM_MESH);   // (a CSG node hands its operand's MeshIntersection on)
+        // (a mesh reports `t + Mesh._ray_distance`, mesh.pyx:1240-1275 — + 0.0 for a first hit: a root at -0.0 leaves as +0.0, the geometry keeps the root as found)
+        if (t) t[i] = hit ? (mesh && !csg ? h.t + 0.0 : h.t) : NAN;
         if (tri) tri[i] = mesh ? h.a0 : -1;
         if (uvw) { uvw[3 * i] = mesh ? h.u : 0.0f; uvw[3 * i + 1] = mesh ? h.v : 0.0f; uvw[3 * i + 2] = mesh ? h.w : 0.0f; }
         if (exiting || geom) {

@@ -619,3 +619,51 @@ def test_host_walk_single_rays_against_golden_vectors(orc, ns, golden, m70k):
         for key in ("t", "exiting", "tri", "uvw", "geom"):
             assert eq(a[key][hit], b[key][hit]), key
         assert eq(host.contains_batch(pts), orc.contains_batch(flat, pts))
+
+
+def test_binding_under_stock_raysect_fixture(ns, golden, m70k):
+    """F19: tests/golden/bind_reference.py ran integration/raysect_hip.py — `HipAccelerator(raysect.core.acceleration.Accelerator)` over
+    rsx_host_scene_create / rsx_hit_host_one / rsx_contains_host — under the COMPILED reference in the build container: every World.hit /
+    World.contains of the F04 / F05 / F06 / F07 / F11 ray sets asked through stock `World` objects, once with Raysect's KDTree accelerator and
+    once with librsx behind `world.accelerator`, all Intersection fields equal bit for bit (0 differences recorded). The fixture keeps a
+    SHA-256 of what both accelerators answered; here the same rays go through this repository's own API mirror and host walk and must
+    reproduce it — sign of zero included."""
+    import hashlib
+    import raysets
+    from source_amd import scenes
+    from source_amd._flatten import FlatScene
+    from source_amd.device import HostScene
+    import test_oracle_golden as T
+    g = golden("f19_binding")
+
+    def check(name, flat, o, d, m, pts):
+        host = HostScene(flat)
+        r = host.hit_batch(o, d, m, geometry=True)
+        inside = host.contains_batch(pts)
+        table = np.zeros((len(pts), max(1, flat.n_world)), dtype=np.uint8)
+        table[:, :flat.n_world] = inside
+        hit = r["prim"] >= 0
+        rec = np.column_stack([r["t"], r["exiting"].astype(np.float64), r["geom"]])
+        h = hashlib.sha256()
+        h.update(r["prim"].astype(np.int32).tobytes())
+        h.update(np.ascontiguousarray(rec[hit]).tobytes())
+        h.update(table.tobytes())
+        n_rays, n_hits, hit_diff, cont_diff, n_pts = (int(x) for x in g[name])
+        assert (hit_diff, cont_diff) == (0, 0), name                               # what the container run recorded
+        assert (n_rays, n_hits, n_pts) == (len(o), int(hit.sum()), len(pts)), name
+        assert h.digest() == g[name + "_sha"].tobytes(), name
+
+    mesh, v, t = m70k
+    sets = [raysets.random_outside(3000, 41), raysets.through_vertices(v, 1500, 44), raysets.along_edges(v, t, 1000, 45), raysets.axis_aligned(1000, 46, 0.1, v)]
+    check("f04_mesh_world", FlatScene([mesh]), *(np.concatenate([s[k] for s in sets]) for k in range(3)), raysets.points(1500, 49, 0.1))
+    for k, (name, prim) in enumerate(T._prims(ns).items()):
+        world = ns.World()
+        prim.parent = world                                                        # (in a world, as the container run had them: to_local() is then the transform's inverse)
+        check("f05_" + name, world.flatten(), *raysets.primitive_rays(3000, 70 + k), raysets.points(1500, 90 + k, 1.2))
+    o, d, m = raysets.scene_rays(6000, 101, 9.0, 4.5)
+    og, dg, mg = raysets.pinhole_grid(48, (0.0, 0.0, -4.0), 75.0)
+    check("f06_csg_demo", scenes.build_csg_demo(ns)[0].flatten(), np.concatenate([o, og]), np.concatenate([d, dg]), np.concatenate([m, mg]), raysets.points(3000, 102, 4.5))
+    check("f07_mixed_world", scenes.build_mixed(ns)[0].flatten(), *raysets.scene_rays(12000, 111, 6.0, 2.2), raysets.points(4000, 112, 2.0))
+    for name, (world, prims) in scenes.build_edge_worlds(ns).items():
+        o, d, m = scenes.edge_rays(name)
+        check("f11_" + name, world.flatten(), o, d, m, np.concatenate([o, o + 0.25 * d]))
