@@ -569,7 +569,9 @@ class _ObserverBase(Observer):
         self.stats = {"rays": 0, "kernel_ms": 0.0}
         self._check_counter_layout(self.render_engine)
         self._pass_offset = self.pass_sample_offset(self.render_engine)
-        if self._lazy_pass(tasks, templates):                # a small pass: accepted, submitted with its successors (HipEngine.auto_batch)
+        self._initialise_statistics(tasks)
+        # (an observer that reports — quiet False — renders its pass now: the closing line states this pass's time and rays)
+        if self.quiet and self._lazy_pass(tasks, templates):  # a small pass: accepted, submitted with its successors (HipEngine.auto_batch)
             self._auto_offset += self._samples_per_pass()
             self._finalise_pipelines()
             return
@@ -585,6 +587,7 @@ class _ObserverBase(Observer):
                     continue
                 self.render_engine.run(tasks, self._render_pixel, self._update_state,
                                        render_args=(slice_id, template), update_args=(slice_id,))
+                self._update_statistics(len(tasks))
         finally:
             if deferring:
                 self._end_deferred_slices()
@@ -592,6 +595,44 @@ class _ObserverBase(Observer):
         self._auto_offset += (self._samples_per_pass() * max(1, int(getattr(self.render_engine, "sample_stride", 1)))
                               * max(1, int(getattr(self.render_engine, "passes_per_call", 1))))
         self._finalise_pipelines()                           # render_complete stays False: only a pass without tasks completes a render
+        self._finalise_statistics()
+
+    # The observer's own report (observer.pyx:463-511): the reference counts a task per pixel and spectral ray as its workers hand them
+    # back and prints a progress line at most once a second and a closing line. Here a slice comes back whole, so progress moves a slice
+    # at a time; the closing line waits for the device (passes are asynchronous) so that its time is the render's and its rays are all
+    # of them. `quiet` switches both off, as there.
+    def _initialise_statistics(self, tasks):
+        if self.quiet:
+            return
+        import time
+        self._stats_ray_count = 0
+        self._stats_start_time = self._stats_progress_timer = time.time()
+        self._stats_total_tasks = len(tasks) * self.spectral_rays
+        self._stats_completed_tasks = 0
+
+    def _update_statistics(self, n_tasks):
+        if self.quiet:
+            return
+        import time
+        self._stats_completed_tasks += n_tasks
+        if (time.time() - self._stats_progress_timer) > 1.0:
+            rays = self.stats.get("rays", 0)
+            print("Render time: {:0.3f}s ({:0.2f}% complete, {:0.1f}k rays)".format(
+                time.time() - self._stats_start_time, 100 * (self._stats_completed_tasks / self._stats_total_tasks), (rays - self._stats_ray_count) / 1000))
+            self._stats_ray_count = rays
+            self._stats_progress_timer = time.time()
+
+    def _finalise_statistics(self):
+        if self.quiet:
+            return
+        import time
+        from ..device import get_context
+        try:
+            get_context().synchronize()
+        except Exception:
+            pass
+        elapsed_time = max(time.time() - self._stats_start_time, 1e-9)
+        print("Render complete - time elapsed {:0.3f}s - {:0.1f}k rays/s".format(elapsed_time, self.stats.get("rays", 0) / elapsed_time / 1000))
 
     def _lazy_pass(self, tasks, templates):
         """Observers that can batch small passes override this (PinholeCamera); False: render the pass now."""

@@ -40,6 +40,14 @@ def orc():
 
 
 @pytest.fixture(scope="session")
+def m1m(ns):
+    """The bench's `flat` workload: ONE mesh of 1 048 576 triangles (scenes.build_flat; host build ~4 s, shared by the session)."""
+    from source_amd import scenes
+    v, t = scenes.displaced_sphere(512)
+    return ns.Mesh(v, t, smoothing=False, closed=True), v, t
+
+
+@pytest.fixture(scope="session")
 def m70k(ns):
     """The ~70k-triangle stand-in mesh (host build only; no GPU involved)."""
     from source_amd import scenes

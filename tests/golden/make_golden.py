@@ -582,6 +582,30 @@ def f17_scenes():
     save("f17_scenes", **out)
 
 
+# ------------------------------------------------------------------ F18 the `flat` workload: ONE mesh of 1 048 576 triangles
+def f18_flat():
+    """SURVEY.md 8(d) "M1M-flat" (scenes.build_flat: the bench's `flat` workload, the one tree that leaves the caches): the reference's own
+    SAH tree over 1 048 576 triangles as the SHA-256 of MeshData.save()'s bytes (kdtree3d.pyx:126-486, mesh.pyx:864-931), and one million
+    Mesh.hit() answers as a digest of (triangle, t, u, v, w, exiting), the form of F04's."""
+    import time
+    v, t = scenes.displaced_sphere(512)
+    t0 = time.time()
+    mesh = Mesh(v, t, smoothing=False, closed=True)
+    print("    reference built the 1M-triangle tree in %.1f s" % (time.time() - t0))
+    b = rsm_bytes(mesh)
+    out = {"flat_sha256": np.frombuffer(hashlib.sha256(b).digest(), dtype=np.uint8), "flat_len": np.array([len(b)]),
+           "flat_ntri": np.array([mesh.data.face_normals.shape[0]]),
+           "flat_face_normals_sha256": np.frombuffer(hashlib.sha256(mesh.data.face_normals.tobytes()).digest(), dtype=np.uint8)}
+    o, d, m = raysets.random_outside(1000000, 51)
+    tri, tt, uvw, ex, _ = mesh_hit_arrays(mesh, o, d, m)
+    h = hashlib.sha256(); h.update(tri.tobytes()); h.update(tt.tobytes()); h.update(uvw.tobytes()); h.update(ex.tobytes())
+    out["digest_1m"] = np.frombuffer(h.digest(), dtype=np.uint8)
+    out["digest_1m_hits"] = np.array([(tri >= 0).sum()])
+    # a few hundred answers in full, so that a mismatch can be located
+    out["first_tri"] = tri[:512]; out["first_t"] = tt[:512]; out["first_uvw"] = uvw[:512]; out["first_ex"] = ex[:512]
+    save("f18_flat", **out)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["all"]
     run = lambda k: "all" in which or k in which  # noqa: E731
@@ -606,3 +630,4 @@ if __name__ == "__main__":
     if run("f15"): f15_importance()
     if run("f16"): f16_rgb()
     if run("f17"): f17_scenes()
+    if run("f18"): f18_flat()

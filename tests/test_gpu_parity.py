@@ -449,6 +449,47 @@ def test_c3_full_size_instanced_1m_triangles(orc, ns):
     _full_size_properties(orc, ns, world, cam, pipe, make, strip_rows=2048, spp=64, seed=11)     # the WHOLE 268 M-ray frame against the oracle
 
 
+def test_flat_1m_triangle_mesh_against_reference_digest_and_oracle(orc, ns, golden, m1m):
+    """SURVEY.md 8(d) "M1M-flat" — the bench's `flat` workload, ONE mesh of 1 048 576 triangles: the tree that leaves the caches (66 MB of
+    nodes + items on the host, 0.45 GB of node and leaf records on the device). F18 pins it to the compiled reference: (1) the device's
+    answers to one million rays = the reference's SHA-256 of (triangle, t, u, v, w, exiting) — Mesh.hit of the reference's own tree over
+    the same triangles (the tree bytes themselves are pinned on the CPU side, tests/test_oracle_golden.py); (2) the 2048 x 2048 x 64 spp
+    frame of scenes.build_flat through the packet kernel: every element holds 64 samples and a strip of 64 rows (8.4 M rays) equals the
+    oracle's mean and variance bit for bit."""
+    g = golden("f18_flat")
+    mesh, v, t = m1m
+    sc = dev_scene(FlatScene([mesh]))
+    o, d, m = raysets.random_outside(1000000, 51)
+    r = sc.hit_batch(o, d, m)
+    tri = np.where(r["prim"] >= 0, r["tri"], -1).astype(np.int32)
+    tt = np.where(tri >= 0, r["t"], np.nan)
+    uvw = np.where((tri >= 0)[:, None], r["uvw"], 0).astype(np.float32)
+    ex = np.where(tri >= 0, r["exiting"], 0).astype(np.uint8)
+    assert eq(tri[:512], g["first_tri"]) and eq(tt[:512], g["first_t"]) and eq(uvw[:512], g["first_uvw"]) and eq(ex[:512], g["first_ex"])
+    h = hashlib.sha256()
+    for a in (tri, tt, uvw, ex):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert int((tri >= 0).sum()) == int(g["digest_1m_hits"][0])
+    assert h.digest() == bytes(g["digest_1m"])
+    del sc
+    world = scenes.build_flat(ns, n=512)[0]
+    cam, pipe = scenes.c2_camera(ns, world, (2048, 2048), spp=64, bins=15)
+    cam.render_engine = ns.HipEngine(rng="philox", seed=19)
+    cam.frame_sampler = ns.RectFrameSampler2D()
+    cam.observe()
+    f = pipe.frame
+    mean, var, n = f.mean, f.variance, f.samples
+    assert (n == 64).all() and np.isfinite(mean).all() and (var >= 0).all() and mean.max() > 0
+    strip_rows, nx, ny = 64, 2048, 2048
+    y0 = ny // 2 - strip_rows // 2
+    keep = []
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, y0, nx, y0 + strip_rows))
+    mo, vo, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    assert rays == nx * strip_rows * 64
+    assert eq(mean[:, y0:y0 + strip_rows, :], mo.reshape(strip_rows, nx, 15).transpose(1, 0, 2))
+    assert eq(var[:, y0:y0 + strip_rows, :], vo.reshape(strip_rows, nx, 15).transpose(1, 0, 2))
+
+
 def test_c4_full_size_csg_demo(orc, ns):
     """BASELINE configs[3] at full size: the demos/csg.py Boolean tree, 1024x1024, 16 samples/pixel."""
     world = scenes.build_csg_demo(ns)[0]

@@ -172,6 +172,32 @@ def test_mesh_1m_ray_digest(orc, golden, m70k):
     assert h.digest() == bytes(g["digest_1m"])
 
 
+def test_flat_1m_triangle_tree_and_digest(orc, golden, m1m):
+    """F18, the bench's `flat` workload (ONE mesh of 1 048 576 triangles, SURVEY.md 8d "M1M-flat"): librsx's host builder writes the
+    reference's own 66.7 MB of MeshData.save() — vertices, triangles and the SAH tree of kdtree3d.pyx:126-486, node for node — and the
+    pinned oracle answers one million rays with the reference's (triangle, t, u, v, w, exiting)."""
+    import io
+    g = golden("f18_flat")
+    mesh, v, t = m1m
+    f = io.BytesIO()
+    mesh.save(f)
+    b = f.getvalue()
+    assert len(b) == int(g["flat_len"][0]) and mesh.data._triangles.shape[0] == int(g["flat_ntri"][0]) == 1047536    # (1 048 576 less the degenerate ones at the poles, _filter_triangles mesh.pyx:363-399)
+    assert hashlib.sha256(b).digest() == bytes(g["flat_sha256"])
+    assert hashlib.sha256(mesh.data.face_normals.tobytes()).digest() == bytes(g["flat_face_normals_sha256"])
+    flat = FlatScene([mesh])
+    o, d, m = raysets.random_outside(1000000, 51)
+    r = orc.prim_hit_batch(flat, 0, o, d, m, threads=orc.max_threads())
+    tri = np.where(r["prim"] >= 0, r["tri"], -1).astype(np.int32)
+    tt = np.where(tri >= 0, r["t"], np.nan)
+    assert eq(tri[:512], g["first_tri"]) and eq(tt[:512], g["first_t"]) and eq(r["uvw"][:512], g["first_uvw"]) and eq(r["exiting"][:512], g["first_ex"])
+    h = hashlib.sha256()
+    for a in (tri, tt, r["uvw"], r["exiting"]):
+        h.update(np.ascontiguousarray(a).tobytes())
+    assert int((tri >= 0).sum()) == int(g["digest_1m_hits"][0])
+    assert h.digest() == bytes(g["digest_1m"])
+
+
 @pytest.mark.parametrize("name", ["cube", "sphere8", "blob24", "fan500"])
 def test_small_mesh_hits(orc, ns, golden, name):
     g = golden("f04b_small_meshes")
