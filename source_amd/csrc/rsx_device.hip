@@ -282,11 +282,26 @@ static int settle_lane(rsx_ctx *ctx, TraceLane &ln) {
     return RSX_OK;
 }
 
+// hipMalloc for the library's own working buffers (pools, lane buffers, spill regions, work lists): when the device is full, the blocks
+// the cache holds back for the next scene / frame (cached_release: up to 8 GB) are returned to the runtime and the request is made
+// once more — they are free memory as far as any caller can tell.
+static hipError_t malloc_or_flush(rsx_ctx *ctx, void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->cache_free.empty()) {
+        (void)hipGetLastError();
+        for (auto &b : ctx->cache_free) { ctx->cache_size.erase(b.second); (void)hipFree(b.second); }
+        ctx->cache_free.clear(); ctx->cache_bytes = 0;
+        e = hipMalloc(out, bytes);
+    }
+    return e;
+}
+template <typename T> static hipError_t malloc_or_flush(rsx_ctx *ctx, T **out, size_t bytes) { return malloc_or_flush(ctx, reinterpret_cast<void **>(out), bytes); }
+
 static int pool_get(rsx_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes > ctx->pool_bytes[slot]) {
         if (ctx->pool[slot]) { HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(ctx->pool[slot])); ctx->pool[slot] = nullptr; ctx->pool_bytes[slot] = 0; }
         const size_t want = bytes + bytes / 8 + 256;
-        HIP_TRY(hipMalloc(&ctx->pool[slot], want));
+        HIP_TRY(malloc_or_flush(ctx, &ctx->pool[slot], want));
         ctx->pool_bytes[slot] = want;
         if (slot <= POOL_TASKS) ctx->shadow[slot].clear();   // new storage holds nothing yet
     }
@@ -463,6 +478,11 @@ extern "C" int rsx_idle(rsx_ctx *ctx, int32_t *idle) {
     const hipError_t e = hipStreamQuery(ctx->stream);
     if (e == hipErrorNotReady) *idle = 0;
     else if (e != hipSuccess) return rsx_fail(RSX_EHIP, "hipStreamQuery: %s", hipGetErrorString(e));
+    if (*idle && ctx->sort_stream) {                        // (the work-list sort of a lone path pass runs beside its replay)
+        const hipError_t es = hipStreamQuery(ctx->sort_stream);
+        if (es == hipErrorNotReady) *idle = 0;
+        else if (es != hipSuccess) return rsx_fail(RSX_EHIP, "hipStreamQuery: %s", hipGetErrorString(es));
+    }
     return RSX_OK;
 }
 
@@ -551,12 +571,7 @@ int cached_alloc(rsx_ctx *ctx, void **out, size_t bytes) {
         ctx->cache_free.erase(it);
         return RSX_OK;
     }
-    if (hipMalloc(out, bytes) != hipSuccess) {                 // out of memory: give the cache back and try once more
-        (void)hipGetLastError();
-        for (auto &e : ctx->cache_free) { ctx->cache_size.erase(e.second); (void)hipFree(e.second); }
-        ctx->cache_free.clear(); ctx->cache_bytes = 0;
-        HIP_TRY(hipMalloc(out, bytes));
-    }
+    HIP_TRY(malloc_or_flush(ctx, out, bytes));                 // (out of memory: the cache is given back and the request made once more)
     ctx->cache_size[*out] = bytes;
     return RSX_OK;
 }
@@ -585,7 +600,11 @@ extern "C" int rsx_dev_alloc(rsx_ctx *ctx, size_t bytes, void **dptr) {
 extern "C" int rsx_dev_free(rsx_ctx *ctx, void *dptr) {
     if (!ctx) return rsx_fail(RSX_EINVAL, "null ctx");
     HIP_TRY(hipSetDevice(ctx->device));
+    // the block may go straight to the next rsx_dev_alloc / scene upload: everything that could still touch it must be over — the
+    // context stream, passes in flight on the private lanes and the side stream of the work-list sort (what hipFree waited for by itself)
+    for (TraceLane &ln : ctx->lanes) if (ln.in_flight) HIP_TRY(hipStreamSynchronize(ln.stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->sort_stream) HIP_TRY(hipStreamSynchronize(ctx->sort_stream));
     cached_release(ctx, dptr);
     return RSX_OK;
 }
@@ -837,7 +856,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         const size_t lanes = (size_t)ctx->n_cus * RSX_CSG_ARENA_WG_PER_CU * WG_THREADS;
         const size_t bytes = lanes * (size_t)max_slots * sizeof(NodeSt);
         void *arena = nullptr;
-        if (hipMalloc(&arena, bytes) != hipSuccess) {
+        if (malloc_or_flush(ctx, &arena, bytes) != hipSuccess) {
             (void)hipGetLastError();
             rsx_scene_free(sc);
             return rsx_fail(RSX_ENOMEM, "CSG tree with %d nodes: %zu bytes of stream-merge state could not be allocated", max_slots, bytes);
@@ -1083,7 +1102,7 @@ int plan(rsx_scene *sc, long long work_items, TraceLane &lane, Launch &l, int wg
     const size_t need = (size_t)sc->ctx->n_cus * RSX_MAX_WG_PER_CU * WG_WAVES * spill_wave_bytes(sc->d.wdepth, sc->d.wlds, sc->d.mdepth, sc->d.mlds);
     if (need > lane.spill_bytes) {
         if (lane.spill) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipFree(lane.spill)); lane.spill = nullptr; lane.spill_bytes = 0; }
-        HIP_TRY(hipMalloc(&lane.spill, need));
+        HIP_TRY(malloc_or_flush(sc->ctx, &lane.spill, need));
         lane.spill_bytes = need;
     }
     sc->d.spill = static_cast<char *>(lane.spill);
@@ -1574,7 +1593,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     auto lane_upload = [&](void *&dev, size_t &dev_bytes, std::vector<unsigned char> &host, const void *src, size_t bytes) -> int {
         if (bytes > dev_bytes) {
             if (dev) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(dev)); dev = nullptr; dev_bytes = 0; }
-            HIP_TRY(hipMalloc(&dev, bytes + 256));
+            HIP_TRY(malloc_or_flush(ctx, &dev, bytes + 256));
             dev_bytes = bytes + 256;
         }
         host.assign(static_cast<const unsigned char *>(src), static_cast<const unsigned char *>(src) + bytes);   // (lives until the lane's next pass)
@@ -1607,7 +1626,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
         if (bytes > have) {
             if (buf) { HIP_TRY(hipStreamSynchronize(lane.stream)); HIP_TRY(hipStreamSynchronize(ctx->stream)); HIP_TRY(hipFree(buf)); buf = nullptr; have = 0; }
             const size_t want = bytes + bytes / 8 + 256;
-            HIP_TRY(hipMalloc(&buf, want));
+            HIP_TRY(malloc_or_flush(ctx, &buf, want));
             have = want;
         }
         return RSX_OK;
@@ -1680,8 +1699,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             if (lane.unit_order) HIP_TRY(hipFree(lane.unit_order));
             lane.unit_capacity = (size_t)n_units + (size_t)n_units / 8 + 64;
             lane.cost_zeroed = 0;
-            HIP_TRY(hipMalloc(&lane.unit_cost, lane.unit_capacity * 4));
-            HIP_TRY(hipMalloc(&lane.unit_order, lane.unit_capacity * 4));
+            HIP_TRY(malloc_or_flush(ctx, &lane.unit_cost, lane.unit_capacity * 4));
+            HIP_TRY(malloc_or_flush(ctx, &lane.unit_order, lane.unit_capacity * 4));
             if (!lane.n_work) HIP_TRY(hipMalloc(&lane.n_work, 64));
             lane.cost_units = 0;
             lane.order_units = 0;

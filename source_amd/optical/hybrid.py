@@ -55,6 +55,7 @@ HOST_WALK_BELOW = 24            # waves smaller than this are answered by the ho
 
 
 MIN_RAYS_PER_WORKER = 2048     # primary rays a worker process must get to be worth its fork
+WORKER_SILENCE_S = float(os.environ.get("RSX_WORKER_SILENCE_S", "600"))   # run_block gives up on forked material workers that say nothing for this long
 
 
 def trace_wave(scene, host, o, d, m):
@@ -1195,8 +1196,26 @@ def run_block(world, scene, key, template, per_node, origin, direction, pixel, s
     stats = dict(workers=workers, primary_rays=n, fork_s=t_start - t_fork, serve_s=0.0, trace_s=0.0, requests=0, request_rays=0, worker_s=[], worker_wait_s=[])
     try:
         live = list(conns)
+        owner = dict(zip(conns, procs))
+        quiet_since = time.perf_counter()
         while live:
-            for conn in multiprocessing.connection.wait(live):
+            # A worker forked while another thread of this process held a runtime or allocator lock can hang before its first message
+            # (the parent has live HIP / OpenMP threads): the wait is bounded, workers that died are reported, and a block in which no
+            # live worker has said anything for WORKER_SILENCE_S seconds is abandoned with an error instead of hanging the render.
+            ready = multiprocessing.connection.wait(live, timeout=1.0)
+            if not ready:
+                dead = [c for c in live if not owner[c].is_alive() and not c.poll()]
+                for c in dead:
+                    live.remove(c)
+                    failure = failure or "a material worker process (pid %s) ended without an answer (exit code %s)" % (owner[c].pid, owner[c].exitcode)
+                if live and time.perf_counter() - quiet_since > WORKER_SILENCE_S:
+                    failure = failure or ("no material worker has answered for %.0f s (%d of %d still running): forked workers can deadlock on a lock "
+                                          "another thread of the parent held at fork time; HipEngine(host_workers=1) evaluates in this process"
+                                          % (WORKER_SILENCE_S, len(live), workers))
+                    break
+                continue
+            quiet_since = time.perf_counter()
+            for conn in ready:
                 t0 = time.perf_counter()
                 try:
                     msg = conn.recv()
