@@ -347,6 +347,47 @@ def ceilings(c, kernel_ms, algorithmic_gbs):
     return out, binding
 
 
+# Vector wave-instructions a 64-ray unit of a fused packet pass cannot do without — an instruction FLOOR for the design's own operations
+# (f64 arithmetic of the reference kept bit for bit, one wave instruction per 64 lanes), priced per operation below and multiplied by the
+# oracle's per-unit event counts (orc_packet_counters: the distinct nodes / items / records a unit's rays touch). What the compiled
+# kernel issues beyond it is addressing, lane-mask bookkeeping, register moves, spill traffic and re-formed values.
+VALU_FLOOR_COSTS = {
+    "ray": 130,              # two Philox-4x32-10 draws (10 rounds x 2 wide multiplies + 4 adds/xors, two u64 -> f64), pixel coordinates (6), normalise (3 products, sqrt ~10, division ~10, 3 products), direction through the camera matrix (9), pixel bookkeeping (10)
+    "walk_setup": 41,        # three refined reciprocals (rcp + two Newton steps = 5 each) and their range tests (6), the tree's bounds (12 products, 8 compares)
+    "branch_step": 10,       # quotient (3), three range compares, two selected moves, and a push on 0.6 of the steps (4: two moves, address, write)
+    "leaf_item": 20,         # BoundPrimitive gate: 6 differences x 6 products, 8 compares / selects
+    "wide_primitive": 36,    # gate + Box.hit of an untransformed box with wave-uniform signs: 12 products, 24 compares / selects
+    "mesh_visit": 65,        # ray into the instance's space (12), reciprocals (21), the mesh's bounds (20), the triangle test's ray constants (12)
+    "triangle_record": 30,   # watertight test against camera-relative vertices: shear (6), three edge functions (6), sign tests (3), determinant and distance (8), range tests (4), reciprocal (3)
+    "shade_hit": 30,         # intersection record of a hit that is shaded (debug Light: hit point, normal through the instance's matrix, dot product)
+    "welford_step": 18,      # per (sample, bin) chain step: 12 arithmetic + two exact quotients (3 each)
+    "frame_merge": 30,       # combine_samples of a pixel's bins with the frame cell, per unit
+}
+
+
+def valu_floor(per_unit, spp, bins, pixels_per_unit, units_per_launch, kernel_ms, simd_cycles=None, issued=None):
+    """{achieved: floor SIMD-cycles per launch, peak: SIMD-cycles the launch had, frac} + the per-unit breakdown."""
+    K = VALU_FLOOR_COSTS
+    steps_w = max(0.0, per_unit["world_nodes"] - per_unit["world_leaves"])
+    steps_m = max(0.0, per_unit["mesh_nodes"] - per_unit["mesh_leaves"])
+    parts = {"ray": K["ray"], "walk_setup": K["walk_setup"], "world_steps": K["branch_step"] * steps_w, "world_items": K["leaf_item"] * per_unit["world_items"],
+             "wide_primitives": 2 * K["wide_primitive"], "mesh_visits": K["mesh_visit"] * per_unit["mesh_visits"], "mesh_steps": K["branch_step"] * steps_m,
+             "triangles": K["triangle_record"] * per_unit["triangle_records"], "shading": K["shade_hit"] * min(1.0, per_unit["mesh_visits"]),
+             "welford": K["welford_step"] * spp * bins * pixels_per_unit / 64.0, "frame_merge": K["frame_merge"]}
+    per = float(sum(parts.values()))
+    floor_cycles = per * VALU_CYCLES_PER_WAVE_INSTR * units_per_launch
+    have = simd_cycles if simd_cycles else kernel_ms * 1e-3 * 2.4e9 * N_CUS * SIMDS_PER_CU
+    out = {"achieved": int(floor_cycles), "peak": int(have), "unit": "SIMD-cycles per launch (necessary vector wave-instructions x 4 / available)",
+           "frac": round(floor_cycles / have, 4), "wave_instructions_per_unit": round(per, 1), "per_unit": {k: round(float(v), 1) for k, v in parts.items()},
+           "costs": K, "floor_ms_at_full_issue": round(floor_cycles / (2.4e9 * N_CUS * SIMDS_PER_CU) * 1e3, 3),
+           "note": "instruction floor of the packet design: oracle event counts per 64-ray unit x a stated vector-instruction cost per operation (bench.py: VALU_FLOOR_COSTS); "
+                   "frac = floor cycles / SIMD cycles the launch had, i.e. the distance from done if nothing but necessary vector work were issued at full rate"}
+    if issued:
+        out["issued_wave_instructions_per_unit"] = round(issued / units_per_launch, 1)
+        out["floor_over_issued"] = round(per * units_per_launch / issued, 4)
+    return out
+
+
 class stdout_to_stderr:
     """RCCL prints a version banner on stdout when a communicator is created; the bench's stdout carries ONE JSON line."""
 
@@ -815,6 +856,10 @@ def main():
                     bytes_acc = (24.0 * SPP + 40.0 * BINS) * NX * NY
                     ceil_a, bind_a = ceilings(ac[1], accum_avg, bytes_acc / (accum_avg * 1e-3) / 1e9)
                     roofline["accumulate"] = dict(ceil_a, kernel=ac[0], bound=bind_a)
+        if hbm_per_wave is not None:
+            vi = roofline.get("valu_issue")
+            roofline["valu_floor"] = valu_floor(hbm_per_wave["per_unit"], SPP, BINS, WAVE_RAYS // SPP, hbm_per_wave["units_per_launch"], trace_avg,
+                                                simd_cycles=vi["peak"] if vi else None, issued=vi["wave_instructions"] if vi else None)
         if roofline["bound"] is None and hbm_contract is not None:
             # no counters in this run (--no-pmc, N > 1): only the contract's line can be given
             roofline.update({"bound": "hbm", "achieved": hbm_contract["achieved"], "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": hbm_contract["frac"],

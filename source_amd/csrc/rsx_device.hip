@@ -211,6 +211,11 @@ struct TraceLane {
     void *wf_paths = nullptr, *wf_hits = nullptr, *wf_lists = nullptr, *wf_counts = nullptr;   // path passes in stages (dev_wavefront.hpp)
     size_t wf_paths_bytes = 0, wf_hits_bytes = 0, wf_lists_bytes = 0, wf_counts_bytes = 0;
     unsigned int *overflow = nullptr;
+    // pinned host words the lane's small read-backs land in (flags, ray counts, list counts): a device-to-host copy into pageable memory
+    // — a stack variable — goes through the runtime's pin / staging path, and that path is where a process that had made a second device
+    // scene lost 60 - 90 ms, two or three times in the following 300 ms (tools/r6_world_stalls.py, profiles/r06_world_stalls.txt: the time
+    // sits inside hipMemcpyAsync, the device idle behind the copy kernel)
+    unsigned long long *host_words = nullptr;
     hipEvent_t traced = nullptr, merged = nullptr;
     bool in_flight = false;
     hipEvent_t sort_from = nullptr, sorted = nullptr;   // a lone path pass's work-list sort on the context's side stream (render())
@@ -272,8 +277,9 @@ struct rsx_ctx {
 static int settle_lane(rsx_ctx *ctx, TraceLane &ln) {
     if (!ln.check_pending) return RSX_OK;
     HIP_TRY(hipEventSynchronize(ln.merged));
-    unsigned long long words[2] = {0, 0};
-    HIP_TRY(hipMemcpy(words, ln.overflow, sizeof(words), hipMemcpyDeviceToHost));
+    unsigned long long *words = ln.host_words;              // (pinned: see TraceLane::host_words)
+    HIP_TRY(hipMemcpyAsync(words, ln.overflow, 16, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
     const unsigned int flags = (unsigned int)(words[0] & 0xffffffffu);
     if (!(flags & 7u)) ctx->deferred_rays += words[1];    // (a pass that is rendered again reports its rays then)
     if (flags & 2u) ctx->deferred_error_flags |= 2u;
@@ -387,6 +393,7 @@ extern "C" int rsx_init(int device_ordinal, rsx_ctx **out) {
         if (ln != &ctx->main && ++lane_no >= std::max(ctx->pipeline_depth, ctx->path_lanes)) continue;      // only the lanes in use get a stream (= an HSA queue)
         if (ln != &ctx->main && ctx->pipeline_depth < 2) continue;
         if (ln != &ctx->main) HIP_TRY(hipStreamCreateWithFlags(&ln->stream, hipStreamNonBlocking));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void **>(&ln->host_words), 4096, hipHostMallocDefault));
         HIP_TRY(hipMalloc(&ln->ticket, 2 * 9 * 16 * sizeof(unsigned long long)));   // one ticket per XCD list, a cache line apart; two sets (the second: the redo pass of a CSG path pass)
         HIP_TRY(hipEventCreateWithFlags(&ln->traced, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ln->merged, hipEventDisableTiming));
@@ -414,6 +421,7 @@ extern "C" void rsx_free(rsx_ctx *ctx) {
         if (ln != &ctx->main && ln->stream) { (void)hipStreamSynchronize(ln->stream); (void)hipStreamDestroy(ln->stream); }
         for (void *q : {(void *)ln->ticket, ln->spill, (void *)ln->unit_cost, (void *)ln->unit_order, (void *)ln->n_work, ln->samples, ln->uniforms, ln->terms, ln->tail, ln->redo, ln->ring, ln->path_queue, ln->wf_paths, ln->wf_hits, ln->wf_lists, ln->wf_counts, (void *)ln->overflow, ln->mat_dev, ln->tab_dev, ln->order_counts, ln->xs})
             if (q) (void)hipFree(q);
+        if (ln->host_words) (void)hipHostFree(ln->host_words);
         if (ln->traced) (void)hipEventDestroy(ln->traced);
         if (ln->merged) (void)hipEventDestroy(ln->merged);
         if (ln->sort_from) (void)hipEventDestroy(ln->sort_from);
@@ -641,9 +649,17 @@ int upload(rsx_scene *sc, const T *host, size_t count, const T **dev) {
     const size_t bytes = std::max<size_t>(count * sizeof(T), 16) + 64;   // slack: traversal reads node pairs (id, id+1)
     const int rc_alloc = cached_alloc(sc->ctx, &d, bytes);
     if (rc_alloc) return rc_alloc;
-    HIP_TRY(hipMemset(d, 0, bytes));
+    // (on the context's own stream: the legacy null stream is a queue of its own, see rsx_scene_create)
+    static const bool null_stream = [] { const char *e = std::getenv("RSX_UPLOAD_NULL_STREAM"); return e && std::atoi(e) != 0; }();
     sc->allocs.push_back(d);
-    if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    if (null_stream) {
+        HIP_TRY(hipMemset(d, 0, bytes));
+        if (count) HIP_TRY(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+    } else {
+        HIP_TRY(hipMemsetAsync(d, 0, bytes, sc->ctx->stream));
+        if (count) HIP_TRY(hipMemcpyAsync(d, host, count * sizeof(T), hipMemcpyHostToDevice, sc->ctx->stream));
+        HIP_TRY(hipStreamSynchronize(sc->ctx->stream));             // (the host array may go away after the call)
+    }
     *dev = static_cast<const T *>(d);
     return RSX_OK;
 }
@@ -1924,8 +1940,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
                             void *args[] = {(void *)&scene->d, (void *)&rp, (void *)&lane.samples, (void *)&wf, (void *)&ps};
                             HIP_TRY(hipLaunchKernel(level_kernel, dim3((unsigned)std::max<long long>(1, std::min(level_wgs, need_wgs))), dim3(WG_THREADS), args, l.lds, lane.stream));
                         }
-                        HIP_TRY(hipMemcpyAsync(row.data(), counts + (size_t)((level - 1) % rows) * WF_SEGS, WF_SEGS * 4, hipMemcpyDeviceToHost, lane.stream));
+                        static_assert(64 + WF_SEGS * 4 <= 4096, "the lane's pinned read-back words hold a row of list counts");
+                        HIP_TRY(hipMemcpyAsync(lane.host_words + 8, counts + (size_t)((level - 1) % rows) * WF_SEGS, WF_SEGS * 4, hipMemcpyDeviceToHost, lane.stream));
                         HIP_TRY(hipStreamSynchronize(lane.stream));
+                        std::memcpy(row.data(), lane.host_words + 8, WF_SEGS * 4);
                         live = 0;
                         for (uint32_t v : row) live += v;
                         if (live == 0) break;
@@ -1999,9 +2017,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
             // has_scatter: the arena can run out; volumes: a point can lie in more of them than the fast form keeps
             if (deferred) break;                             // (the flags are read when the caller collects; k_accumulate leaves a failed pass out of the frame)
             if (!(has_scatter && !std::getenv("RSX_PATH_ARENA")) && !(rp.n_vol_emitters > PATH_VOL_OVERLAP && !rewalk)) break;
-            unsigned int flags = 0;
-            HIP_TRY(hipMemcpyAsync(&flags, lane.overflow, sizeof(flags), hipMemcpyDeviceToHost, lane.stream));
+            HIP_TRY(hipMemcpyAsync(lane.host_words, lane.overflow, sizeof(unsigned int), hipMemcpyDeviceToHost, lane.stream));   // (pinned words)
             HIP_TRY(hipStreamSynchronize(lane.stream));
+            const unsigned int flags = *reinterpret_cast<const unsigned int *>(lane.host_words);
             const bool grow = (flags & 1u) && has_scatter && !std::getenv("RSX_PATH_ARENA"), again = (flags & 4u) && !rewalk, refile = (flags & 8u) && !wf_off;
             static const bool path_debug = std::getenv("RSX_PATH_DEBUG") != nullptr;
             if (path_debug) std::fprintf(stderr, "rsx path pass: attempt %d flags %u S %zu arena %zu passes %d\n", attempt, flags, S, arena_blocks, (int)passes);
@@ -2184,8 +2202,8 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     } else
     if (has_vol) {                                          // a ray that ran out of term slots or segments must not go unnoticed
         const hipStream_t check = solo_path ? lane.stream : ctx->stream;      // (solo_path: the merge on the ctx stream is not waited for)
-        unsigned long long words[2] = {0, 0};                                 // [0] low half: flags, [1]: rays spawned
-        HIP_TRY(hipMemcpyAsync(words, lane.overflow, sizeof(words), hipMemcpyDeviceToHost, check));
+        unsigned long long *words = lane.host_words;                          // [0] low half: flags, [1]: rays spawned (pinned words)
+        HIP_TRY(hipMemcpyAsync(words, lane.overflow, 16, hipMemcpyDeviceToHost, check));
         HIP_TRY(hipStreamSynchronize(check));
         const unsigned int flags = (unsigned int)(words[0] & 0xFFFFFFFFull);
         if (ray_count) *ray_count = words[1];

@@ -13,8 +13,46 @@
 #include <limits>
 #include <vector>
 
+#include <cstdio>
+#include <sched.h>
+
 #include "../../include/rsx.h"
 #include "rsx_internal.h"
+
+// The host builders' OpenMP team. Two facts of the machines this runs on shape it (tools/r6_world_stalls.py, profiles/r06_world_stalls.txt):
+// a container sees every hardware thread of the node (256) but may only USE its cgroup's CPU quota (cpu.max: 16 cores per 100 ms period),
+// and LLVM's OpenMP runtime keeps the workers of a finished parallel region spinning for KMP_BLOCKTIME = 200 ms. A KD build on 256 threads
+// therefore left 255 spinning threads that burnt the quota of the next two or three 100-ms periods in a few milliseconds each — and the
+// kernel's bandwidth control froze the WHOLE process for the rest of every such period: 60 - 90 ms stalls of a render loop, the device
+// idle, two or three times after every new scene (DESIGN 8.7 of round 5). So: no more threads than the process can run, and workers
+// that go to sleep when their region ends.
+extern "C" void kmp_set_blocktime(int) __attribute__((weak));     // (LLVM libomp; absent from other runtimes)
+namespace {
+int host_team_size() {
+    static const int team = [] {
+        int n = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+        if (n <= 0) n = 1;
+        long long quota = -1, period = 100000;
+        if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota|max> <period>"
+            char q[32] = {0};
+            if (std::fscanf(f, "%31s %lld", q, &period) >= 1 && q[0] != 'm') quota = std::atoll(q);
+            std::fclose(f);
+        } else if (FILE *g = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {   // cgroup v1
+            if (std::fscanf(g, "%lld", &quota) != 1) quota = -1;
+            std::fclose(g);
+            if (FILE *h = std::fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (std::fscanf(h, "%lld", &period) != 1) period = 100000; std::fclose(h); }
+        }
+        if (quota > 0 && period > 0) n = (int)std::min<long long>(n, std::max<long long>(1, quota / period));
+        if (const char *e = std::getenv("RSX_HOST_THREADS")) { const int v = std::atoi(e); if (v > 0) n = v; }
+        return n;
+    }();
+    static const bool spin = [] { const char *e = std::getenv("RSX_HOST_SPIN"); return e && std::atoi(e) != 0; }();   // (1: the runtime's own waiting policy — reproduces the fault)
+    if (kmp_set_blocktime && !spin) kmp_set_blocktime(0);                                // (per calling thread in libomp)
+    return team;
+}
+}  // namespace
 
 namespace {
 
@@ -192,7 +230,7 @@ extern "C" int rsx_kd_build(const double *aabbs, int32_t n, int32_t max_depth, i
             kd->upper[k] = std::max(kd->upper[k], items[i].hi[k]);
         }
     }
-#pragma omp parallel
+#pragma omp parallel num_threads(host_team_size())
 #pragma omp single
     build_node(kd->tree, items, kd->lower, kd->upper, 0, bp);
     *out = kd;
@@ -267,7 +305,7 @@ extern "C" int32_t rsx_mesh_filter_triangles(const float *vertices, int32_t *tri
 
 extern "C" int rsx_mesh_face_normals(const float *vertices, const int32_t *triangles, int32_t n, int32_t stride, float *out) {
     if (!vertices || !triangles || !out || n < 0 || stride < 3) return rsx_fail(RSX_EINVAL, "rsx_mesh_face_normals: bad arguments");
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_team_size())
     for (int32_t i = 0; i < n; ++i) {
         V3 c = edge_cross(vertices, triangles + (size_t)i * stride);
         const double s = 1.0 / std::sqrt(c.x * c.x + c.y * c.y + c.z * c.z);
@@ -281,7 +319,7 @@ extern "C" int rsx_mesh_face_normals(const float *vertices, const int32_t *trian
 extern "C" int rsx_mesh_triangle_aabbs(const float *vertices, const int32_t *triangles, int32_t n, int32_t stride, double *out) {
     if (!vertices || !triangles || !out || n < 0 || stride < 3) return rsx_fail(RSX_EINVAL, "rsx_mesh_triangle_aabbs: bad arguments");
     const double padding = 1e-6;                                            // BOX_PADDING, mesh.pyx:42
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for schedule(static) num_threads(host_team_size())
     for (int32_t i = 0; i < n; ++i) {
         const int32_t *tri = triangles + (size_t)i * stride;
         double lo[3], hi[3], widest = 0.0;
