@@ -310,7 +310,7 @@ __device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, co
 // form (every lane has the same near child; the hoisted-reciprocal quotient needs no range test) operation for operation — the same
 // quotient (v_mul, v_fma, v_fma = exact_div), the same three range compares, the same child order, pushes and ranges per lane — and it
 // hands the one step it does not cover back to packet_step: an origin exactly on the split plane, or a push beyond the LDS levels
-// (`return true`: node / nd / masks untouched for that step). Compiled from C++ the same step cost 23 vector + 48 scalar instructions:
+// (flag 1: node / nd / masks untouched for that step). Compiled from C++ the same step cost 23 vector + 48 scalar instructions:
 // the backend structurizes the whole unit loop, so the three-way axis dispatch and every early return became flag registers and
 // flag branches, the node record was copied between register quads, the push went through two LDS words with their address moves.
 // Here: 17 vector / LDS + ~30 scalar with a push, and nothing spilled inside.
@@ -319,6 +319,8 @@ __device__ __forceinline__ int32_t packet_step(const UNode &nd, int32_t node, co
 //  * near child: num = split - origin is the same number in every lane, `num > 0` (origin < split) fills vcc or leaves it empty;
 //  * the node record sits in s[52:55] by name (an asm operand's halves cannot be named otherwise).
 // WORLD: world_step's cull (node type bits 2 / 3, t_cull) as in packet_step_axis.
+// (Measured and taken out again: both children's records asked for before the step's arithmetic — two s_load_dwordx4 at the top, a scalar
+// select at the bottom: configs[2] 21.68 ms against 21.57 without. The walk waits for issue slots, not for its node records.)
 typedef int pkt_i4 __attribute__((ext_vector_type(4)));
 #define PKT_ASM_STEP(TAG, O, D, Y, CULL) \
     "Lax" TAG "%=:\n" \
@@ -381,107 +383,129 @@ typedef int pkt_i4 __attribute__((ext_vector_type(4)));
     "s_mov_b64 exec, %[ex]\n" \
     "s_or_b64 %[far], %[far], %[gt0]\n" \
     "Lnocull" TAG "%=:\n"
-#ifndef RSX_PKT_PREFETCH
-#define RSX_PKT_PREFETCH 0         // (1: measured, configs[2] 21.68 ms against 21.57 without — the walk waits for issue slots, not for its node records) both children's records are asked for before the step's arithmetic (s[56:59] lower, s[60:63] upper)
-#endif
-#if RSX_PKT_PREFETCH
-#define PKT_ASM_FETCH \
-    "s_lshl_b32 %[t0], %[node], 4\n" \
-    "s_add_i32 %[t0], %[t0], 16\n" \
-    "s_load_dwordx4 s[56:59], %[nodes], %[t0]\n" \
-    "s_lshl_b32 %[t0], s53, 4\n" \
-    "s_load_dwordx4 s[60:63], %[nodes], %[t0]\n"
-#define PKT_ASM_ARRIVE \
-    "s_add_i32 %[steps], %[steps], 1\n" \
-    "s_waitcnt lgkmcnt(0)\n" \
-    "s_cmp_eq_u32 %[node], %[lower]\n" \
-    "s_cselect_b64 s[52:53], s[56:57], s[60:61]\n" \
-    "s_cselect_b64 s[54:55], s[58:59], s[62:63]\n"
-#define PKT_ASM_DRAIN "s_waitcnt lgkmcnt(0)\n"
-#define PKT_ASM_CLOBBERS "vcc", "scc", "memory", "s56", "s57", "s58", "s59", "s60", "s61", "s62", "s63"
-#else
-#define PKT_ASM_FETCH
-#define PKT_ASM_ARRIVE \
-    "s_lshl_b32 %[t0], %[node], 4\n" \
-    "s_load_dwordx4 s[52:55], %[nodes], %[t0]\n" \
-    "s_add_i32 %[steps], %[steps], 1\n" \
-    "s_waitcnt lgkmcnt(0)\n"
-#define PKT_ASM_DRAIN
-#define PKT_ASM_CLOBBERS "vcc", "scc", "memory"
-#endif
+// Around the steps: the walk between two leaves that have work. A mesh leaf without triangles (most leaves a packet meets) and every
+// "leave this leaf, pop until some lane has a range again" are transitions of a few instructions each; compiled, each cost ~45 vector and
+// ~80 scalar instructions of flags, register moves, an LDS word for the id with its wait and readfirstlane, a vector compare + ballot per
+// popped entry — per mesh visit about as much as the forty steps themselves. So the block below runs from "at a node" (or, `enter` set,
+// "done with the leaf the walk is at") to the next leaf with work, the end of the walk, or a transition it hands back:
+//   flag 0: at a leaf with work (a world leaf; a mesh leaf with triangles) — node / nd are the leaf's
+//   flag 1: the branch step at `node` is one for packet_step (origin on the plane, push beyond the LDS levels)
+//   flag 2: the stack is empty: the walk is over
+//   flag 3: the next entry lies beyond the LDS levels: packet_pop fetches it (the leaf has been left: tmin is up to date)
+// Leaving a leaf: tmin = tmax for the lanes that had a range in it (the next range of a ray begins where this one ended); a popped entry
+// gives its lanes a range unless they are `done` (their ray found its hit) or the entry holds PKT_EMPTY for them (v_cmp_class: -inf).
 #define PKT_ASM_HEAD \
     "s_mov_b64 %[ex], exec\n" \
     "s_mov_b32 %[m0save], m0\n" \
     "s_mov_b32 %[steps], 0\n" \
+    "s_cmp_lg_u32 %[enter], 0\n" \
+    "s_cbranch_scc1 Lpop%=\n" \
+    "s_cmp_lt_i32 s52, 0\n" \
+    "s_cbranch_scc1 Lleaf%=\n" \
     "Ltop%=:\n" \
-    PKT_ASM_FETCH \
     "s_and_b32 %[t0], s52, 3\n" \
     "s_cmp_eq_u32 %[t0], 0\n" \
     "s_cbranch_scc1 Laxx%=\n" \
     "s_cmp_eq_u32 %[t0], 1\n" \
     "s_cbranch_scc1 Laxy%=\n"
-#define PKT_ASM_TAIL \
+#define PKT_ASM_LEAF_WORLD "s_branch Lwork%=\n"
+#define PKT_ASM_LEAF_MESH \
+    "s_cmp_eq_u32 s53, 0\n" \
+    "s_cbranch_scc0 Lwork%=\n"
+#define PKT_ASM_TAIL(LEAF) \
     "Lnext%=:\n" \
-    PKT_ASM_ARRIVE \
+    "s_add_i32 %[steps], %[steps], 1\n" \
+    "Lload%=:\n" \
+    "s_lshl_b32 %[t0], %[node], 4\n" \
+    "s_load_dwordx4 s[52:55], %[nodes], %[t0]\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
     "s_cmp_lt_i32 s52, 0\n" \
     "s_cbranch_scc0 Ltop%=\n" \
+    "Lleaf%=:\n" \
+    LEAF \
+    "Lpop%=:\n" \
+    "s_mov_b64 exec, %[min]\n" \
+    "v_mov_b64 %[tmin], %[tmax]\n" \
+    "s_mov_b64 exec, %[ex]\n" \
+    "Lpop2%=:\n" \
+    "s_cmp_eq_u32 %[sp], 0\n" \
+    "s_cbranch_scc1 Ldone%=\n" \
+    "s_sub_i32 %[t0], %[sp], 1\n" \
+    "s_cmp_ge_i32 %[t0], %[levels]\n" \
+    "s_cbranch_scc1 Lslowpop%=\n" \
+    "s_mov_b32 %[sp], %[t0]\n" \
+    "v_lshl_add_u32 %[addr], %[sp], 9, %[lds]\n" \
+    "ds_read_b64 %[p], %[addr]\n" \
+    "s_add_i32 m0, %[sp], %[idbase]\n" \
+    "s_nop 0\n" \
+    "v_readlane_b32 %[node], %[ids], m0\n" \
+    "s_waitcnt lgkmcnt(0)\n" \
+    "v_cmp_class_f64 %[gt0], %[p], 4\n" \
+    "v_mov_b64 %[tmax], %[p]\n" \
+    "s_andn2_b64 %[min], %[notdone], %[gt0]\n" \
+    "s_cbranch_scc0 Lpop2%=\n" \
+    "s_branch Lload%=\n" \
+    "Lwork%=:\n" \
     "s_mov_b32 %[flag], 0\n" \
     "s_branch Lend%=\n" \
     "Lslow%=:\n" \
-    PKT_ASM_DRAIN \
     "s_mov_b32 %[flag], 1\n" \
+    "s_branch Lend%=\n" \
+    "Ldone%=:\n" \
+    "s_mov_b32 %[flag], 2\n" \
+    "s_mov_b64 %[min], 0\n" \
+    "s_branch Lend%=\n" \
+    "Lslowpop%=:\n" \
+    "s_mov_b32 %[flag], 3\n" \
     "Lend%=:\n" \
     "s_andn2_b64 exec, %[ex], %[min]\n" \
     "v_mov_b64 %[tmax], %[ninf]\n" \
     "s_mov_b64 exec, %[ex]\n" \
     "s_mov_b32 m0, %[m0save]\n"
 
-// In: node (a branch), nd = its record, the lanes with a range `m_in` (tmax == PKT_EMPTY elsewhere). Out: false — `node` is a leaf, nd its
-// record; true — the step at `node` is one for packet_step. `steps`: branch steps taken.
+// In: node, nd = its record (a branch or a leaf), the lanes with a range `m_in` (tmax == PKT_EMPTY elsewhere), the lanes still looking for a
+// hit `m_notdone`, `enter` (see above). Out: the flag; node / nd / m_in / tmin / tmax / sp / ids as the walk left them. `steps`: branch steps.
 template <bool WORLD>
-__device__ __forceinline__ bool packet_descend(const rsx_kdnode *nodes, int32_t &node, UNode &nd, const Ray &r, const AxisDiv &ad, lanemask &m_in, double &tmin, double &tmax,
-                                               const Stack &st, IdStack &ids, int32_t &sp, double t_cull, int32_t &steps_out) {
+__device__ __forceinline__ int packet_descend(const rsx_kdnode *nodes, int32_t &node, UNode &nd, const Ray &r, const AxisDiv &ad, lanemask &m_in, double &tmin, double &tmax,
+                                              const Stack &st, IdStack &ids, int32_t &sp, double t_cull, lanemask m_notdone, int enter, int32_t &steps_out) {
     pkt_i4 rec;
     rec.x = nd.type; rec.y = nd.count; rec.z = (int)nd.lo; rec.w = (int)nd.hi;
     const unsigned long long base = (unsigned long long)nodes;
     const unsigned long long ninf = 0xfff0000000000000ULL;
     const uint32_t lds = st.lds_t + (uint32_t)(threadIdx.x % WAVE) * 8u;
     const int levels = st.lds_levels, idbase = ids.base;
+    enter = __builtin_amdgcn_readfirstlane(enter);                              // (wave-uniform by construction: say so)
     double num, q, pl, p;
     int addr, flag, lower, nearid, farid, t0, m0save, steps;
     unsigned long long gt0, le, cross, far, want, ex;
+#define PKT_ASM_OPERANDS \
+                     : [node] "+s"(node), [rec] "+{s[52:55]}"(rec), [min] "+s"(m_in), [tmax] "+v"(tmax), [tmin] "+v"(tmin), [sp] "+s"(sp), [ids] "+v"(ids.v), \
+                       [flag] "=&s"(flag), [steps] "=&s"(steps), [num] "=&v"(num), [q] "=&v"(q), [pl] "=&v"(pl), [p] "=&v"(p), [addr] "=&v"(addr), \
+                       [gt0] "=&s"(gt0), [le] "=&s"(le), [cross] "=&s"(cross), [far] "=&s"(far), [want] "=&s"(want), [ex] "=&s"(ex), \
+                       [lower] "=&s"(lower), [nearid] "=&s"(nearid), [farid] "=&s"(farid), [t0] "=&s"(t0), [m0save] "=&s"(m0save) \
+                     : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz), \
+                       [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf), \
+                       [tcull] "v"(t_cull), [notdone] "s"(m_notdone), [enter] "s"(enter) \
+                     : "vcc", "scc", "memory"
     if constexpr (WORLD) {
         asm volatile(PKT_ASM_HEAD
                      PKT_ASM_STEP("z", "%[oz]", "%[dz]", "%[yz]", PKT_ASM_CULL)
                      PKT_ASM_STEP("x", "%[ox]", "%[dx]", "%[yx]", PKT_ASM_CULL)
                      PKT_ASM_STEP("y", "%[oy]", "%[dy]", "%[yy]", PKT_ASM_CULL)
-                     PKT_ASM_TAIL
-                     : [node] "+s"(node), [rec] "+{s[52:55]}"(rec), [min] "+s"(m_in), [tmax] "+v"(tmax), [tmin] "+v"(tmin), [sp] "+s"(sp), [ids] "+v"(ids.v),
-                       [flag] "=&s"(flag), [steps] "=&s"(steps), [num] "=&v"(num), [q] "=&v"(q), [pl] "=&v"(pl), [p] "=&v"(p), [addr] "=&v"(addr),
-                       [gt0] "=&s"(gt0), [le] "=&s"(le), [cross] "=&s"(cross), [far] "=&s"(far), [want] "=&s"(want), [ex] "=&s"(ex),
-                       [lower] "=&s"(lower), [nearid] "=&s"(nearid), [farid] "=&s"(farid), [t0] "=&s"(t0), [m0save] "=&s"(m0save)
-                     : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-                       [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
-                       [tcull] "v"(t_cull)
-                     : PKT_ASM_CLOBBERS);
+                     PKT_ASM_TAIL(PKT_ASM_LEAF_WORLD)
+                     PKT_ASM_OPERANDS);
     } else {
         asm volatile(PKT_ASM_HEAD
                      PKT_ASM_STEP("z", "%[oz]", "%[dz]", "%[yz]", PKT_ASM_NOCULL)
                      PKT_ASM_STEP("x", "%[ox]", "%[dx]", "%[yx]", PKT_ASM_NOCULL)
                      PKT_ASM_STEP("y", "%[oy]", "%[dy]", "%[yy]", PKT_ASM_NOCULL)
-                     PKT_ASM_TAIL
-                     : [node] "+s"(node), [rec] "+{s[52:55]}"(rec), [min] "+s"(m_in), [tmax] "+v"(tmax), [sp] "+s"(sp), [ids] "+v"(ids.v),
-                       [flag] "=&s"(flag), [steps] "=&s"(steps), [num] "=&v"(num), [q] "=&v"(q), [pl] "=&v"(pl), [p] "=&v"(p), [addr] "=&v"(addr),
-                       [gt0] "=&s"(gt0), [le] "=&s"(le), [cross] "=&s"(cross), [far] "=&s"(far), [want] "=&s"(want), [ex] "=&s"(ex),
-                       [lower] "=&s"(lower), [nearid] "=&s"(nearid), [farid] "=&s"(farid), [t0] "=&s"(t0), [m0save] "=&s"(m0save)
-                     : [nodes] "s"(base), [ox] "s"(r.ox), [oy] "s"(r.oy), [oz] "s"(r.oz), [dx] "v"(r.dx), [dy] "v"(r.dy), [dz] "v"(r.dz),
-                       [yx] "v"(ad.yx), [yy] "v"(ad.yy), [yz] "v"(ad.yz), [levels] "s"(levels), [idbase] "s"(idbase), [lds] "v"(lds), [ninf] "s"(ninf),
-                       [tmin] "v"(tmin)
-                     : PKT_ASM_CLOBBERS);
+                     PKT_ASM_TAIL(PKT_ASM_LEAF_MESH)
+                     PKT_ASM_OPERANDS);
     }
+#undef PKT_ASM_OPERANDS
     nd.type = rec.x; nd.count = rec.y; nd.lo = (uint32_t)rec.z; nd.hi = (uint32_t)rec.w;
     steps_out = steps;
-    return flag != 0;
+    return flag;
 }
 #endif
 
@@ -630,31 +654,51 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
     }
     bool hit = false;
     int32_t node = 0, sp = 0;
-    lanemask m_have = 0ULL;
+    lanemask m_have = pkt_mask(tmax != PKT_EMPTY);                             // (the steps and the pops hand it on)
+    UNode nd = load_node_u(nodes, node);
+    int enter = 0;                                                             // 1: the leaf the walk is at has been dealt with
+#if RSX_PKT_ASM
+    const bool by_hand = ps.fast == 7;                                         // (wave-uniform)
+#else
+    const bool by_hand = false;
+#endif
     for (;;) {
-        m_have = pkt_mask(tmax != PKT_EMPTY);                                  // (once per descent: the steps hand it on)
-        UNode nd = load_node_u(nodes, node);
+        // to the next leaf with triangles (packet_descend's contract; the compiled form of the same transitions serves ray spaces whose
+        // quotients need the per-node range test)
+        int flag;
 #ifdef RSX_ASM_MARKS
         asm volatile("; MARK mesh steps begin");
 #endif
-        while (nd.type >= 0) {
 #if RSX_PKT_ASM
-            if (__builtin_expect(ps.fast == 7, 1)) {
-                int32_t steps;
-                const bool slow = packet_descend<false>(nodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, 0.0, steps);
-                work += steps;
-                PKT_COUNT(PKC_MSTEPS, steps)
-                if (!slow) break;
-            }
+        if (__builtin_expect(by_hand, 1)) {
+            int32_t steps;
+            flag = packet_descend<false>(nodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, 0.0, ~pkt_mask(hit), enter, steps);
+            work += steps;
+            PKT_COUNT(PKC_MSTEPS, steps)
+        } else
 #endif
-            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, ids, sp, 0.0, m_have PKT_PASS);
-            nd = load_node_u(nodes, node);
-            work += 1;
-            PKT_COUNT(PKC_MSTEPS, 1)
+        {
+            if (enter || (nd.type < 0 && nd.count <= 0)) { if (tmax != PKT_EMPTY) tmin = tmax; flag = 3; }   // the next range of a ray begins where this one ended
+            else flag = nd.type >= 0 ? 1 : 0;
         }
 #ifdef RSX_ASM_MARKS
         asm volatile("; MARK mesh steps end");
 #endif
+        enter = 0;
+        if (flag == 1) {
+            node = packet_step<false>(nd, node, r, ad, ps, tmin, tmax, st, ids, sp, 0.0, m_have PKT_PASS);
+            nd = load_node_u(nodes, node);
+            work += 1;
+            PKT_COUNT(PKC_MSTEPS, 1)
+            continue;
+        }
+        if (flag == 3) {
+            if (!packet_pop(st, ids, sp, node, tmax, hit PKT_PASS)) break;
+            m_have = pkt_mask(tmax != PKT_EMPTY);
+            nd = load_node_u(nodes, node);
+            continue;
+        }
+        if (flag == 2) break;
 #ifdef PKT_ABLATE_TRIS
         const int32_t count = 0;                                               // (timing ablation: results are wrong)
 #else
@@ -687,8 +731,7 @@ __device__ __forceinline__ bool mesh_trace_packet(PScene sc, int32_t prim, bool 
             }
             if (closest >= 0) { out.u = bu; out.v = bv; out.w = bw; out.t = (float)distance; out.tri = closest; hit = true; }
         }
-        if (tmax != PKT_EMPTY) tmin = tmax;                                    // the next range of this ray begins where this one ended
-        if (!packet_pop(st, ids, sp, node, tmax, hit PKT_PASS)) break;
+        enter = 1;
     }
     return hit;
 }
@@ -825,27 +868,46 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     t_cull = -INFINITY;
 #endif
     int32_t node = 0, sp = 0;
-    lanemask m_have = 0ULL;
     IdStack ids;
     ids.v = 0; ids.base = 0;                               // (world levels: lanes 0 .. wdepth - 1, a mesh walk's behind them)
-    for (;;) {
-        m_have = pkt_mask(tmax != PKT_EMPTY);
-        UNode nd = load_node_u(wnodes, node);
-        while (nd.type >= 0) {
+    lanemask m_have = pkt_mask(tmax != PKT_EMPTY);
+    UNode nd = load_node_u(wnodes, node);
+    int enter = 0;
 #if RSX_PKT_ASM
-            if (__builtin_expect(ps.fast == 7, 1)) {
-                int32_t steps;
-                const bool slow = packet_descend<true>(wnodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, t_cull, steps);
-                work += steps;
-                PKT_COUNT(PKC_WSTEPS, steps)
-                if (!slow) break;
-            }
+    const bool by_hand = ps.fast == 7;
+#else
+    const bool by_hand = false;
 #endif
+    for (;;) {
+        int flag;                                          // (packet_descend's contract; every world leaf has work)
+#if RSX_PKT_ASM
+        if (__builtin_expect(by_hand, 1)) {
+            int32_t steps;
+            flag = packet_descend<true>(wnodes, node, nd, r, ad, m_have, tmin, tmax, st, ids, sp, t_cull, ~pkt_mask(best.prim >= 0), enter, steps);
+            work += steps;
+            PKT_COUNT(PKC_WSTEPS, steps)
+        } else
+#endif
+        {
+            if (enter) { if (tmax != PKT_EMPTY) tmin = tmax; flag = 3; }
+            else flag = nd.type >= 0 ? 1 : 0;
+        }
+        enter = 0;
+        if (flag == 1) {
             node = packet_step<true>(nd, node, r, ad, ps, tmin, tmax, st, ids, sp, t_cull, m_have PKT_PASS);
             nd = load_node_u(wnodes, node);
             work += 1;
             PKT_COUNT(PKC_WSTEPS, 1)
+            continue;
         }
+        if (flag == 3) {
+            work = __builtin_amdgcn_readfirstlane(work);
+            if (!packet_pop(st, ids, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
+            m_have = pkt_mask(tmax != PKT_EMPTY);
+            nd = load_node_u(wnodes, node);
+            continue;
+        }
+        if (flag == 2) break;
         double distance = r.maxd < tmax ? r.maxd : tmax;                       // (no range: -inf, `t <= distance` fails)
         PKT_COUNT(PKC_WLEAVES, 1)
         const int32_t tag = (int32_t)nd.hi;
@@ -945,9 +1007,8 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
                 if (cand.prim >= 0 && cand.t <= distance) { distance = cand.t; best = cand; }   // `<=`: later item wins ties (kdtree.pyx:113)
             }
         }
-        if (tmax != PKT_EMPTY) tmin = tmax;
         work = __builtin_amdgcn_readfirstlane(work);
-        if (!packet_pop(st, ids, sp, node, tmax, best.prim >= 0 PKT_PASS)) break;
+        enter = 1;
     }
     work_out = (uint32_t)work;
     return best.prim >= 0;

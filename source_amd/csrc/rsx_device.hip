@@ -277,9 +277,10 @@ struct rsx_ctx {
 static int settle_lane(rsx_ctx *ctx, TraceLane &ln) {
     if (!ln.check_pending) return RSX_OK;
     HIP_TRY(hipEventSynchronize(ln.merged));
-    unsigned long long *words = ln.host_words;              // (pinned: see TraceLane::host_words)
-    HIP_TRY(hipMemcpyAsync(words, ln.overflow, 16, hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    // (pinned words, see TraceLane::host_words; a blocking copy that waits for nothing but itself: the lane's merge is over — the event —
+    // and the context stream holds the merges of every OTHER lane in flight, which this read-back must not wait for)
+    unsigned long long *words = ln.host_words;
+    HIP_TRY(hipMemcpy(words, ln.overflow, 16, hipMemcpyDeviceToHost));
     const unsigned int flags = (unsigned int)(words[0] & 0xffffffffu);
     if (!(flags & 7u)) ctx->deferred_rays += words[1];    // (a pass that is rendered again reports its rays then)
     if (flags & 2u) ctx->deferred_error_flags |= 2u;

@@ -960,9 +960,14 @@ class PinholeCamera(Observer2D):
         first, last = getattr(engine, "slice_range", None) or (0, n_slices)
         parts = []
         for slice_id in range(first, last):
-            keep = []
-            probe = self.render_desc(world, None, self._slices[slice_id], engine, keep, rect=(0, 0, 1, 1), sample_offset=0)
-            parts.append(self._material_bytes(probe, keep))
+            # (what render_desc sends of the materials, without the rest of a render description — camera, important spheres with their
+            # bounding boxes, Philox keys: this probe runs in every observe() of a lazy batch)
+            sl = self._slices[slice_id]
+            tables = []
+            mats = [p.material.device_material(tables, sl.min_wavelength, sl.max_wavelength, sl.bins) for p in world._primitives]
+            parts.append(bytes((_lib.Material * max(1, len(mats)))(*mats)))
+            if tables:
+                parts.append(np.ascontiguousarray(np.array(tables, dtype=np.float64).reshape(len(tables), sl.bins)).tobytes())
         return b"".join(parts)
 
     @staticmethod
