@@ -2034,3 +2034,27 @@ def test_three_worlds_in_one_process_render_without_stalls(ns):
             times.append((time.perf_counter() - t0) * 1e3)
         worst.append(max(times[1:]))
     assert max(worst) < 25.0, worst
+
+
+@pytest.mark.gpu
+def test_packet_walk_takes_the_compiled_transitions_where_the_quotient_needs_its_range_test(orc, ns):
+    """The hand-written descent (dev_packet.hpp: packet_descend) serves ray spaces in which the hoisted-reciprocal quotient needs no
+    per-node range test (PacketSpace::fast == 7); any other space takes the compiled form of the same transitions. Such a space, made
+    on purpose: a camera whose origin has an x coordinate of exactly 0 in a world whose tree holds splits closer to zero than 2^-240
+    (a sphere of radius 1e-80 at the origin: numerators `split - origin` then leave the shortcut's operand range). A 64-spp packet pass
+    over an instanced mesh world must equal the oracle bit for bit on that path too."""
+    world = scenes.build_c3(ns, n=24)[0]
+    ns.Sphere(1e-80, world, material=ns.AbsorbingSurface())
+    pipe = ns.SpectralRadiancePipeline2D()
+    cam = ns.PinholeCamera((40, 24), fov=60, parent=world, pipelines=[pipe], frame_sampler=ns.RectFrameSampler2D(),
+                           transform=ns.translate(0, 0.35, -0.9))
+    cam.pixel_samples, cam.spectral_bins, cam.spectral_rays, cam.quiet = 64, 5, 1, True
+    cam.render_engine = ns.HipEngine(rng="philox", seed=23)
+    cam.observe()
+    mean, var = pipe.frame.mean.copy(), pipe.frame.variance.copy()
+    assert (pipe.frame.samples == 64).all() and mean.max() > 0
+    keep = []
+    desc = cam.render_desc(world, None, cam._slice_spectrum()[0], cam.render_engine, keep, rect=(0, 0, 40, 24))
+    m, v, rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+    assert rays == 40 * 24 * 64
+    assert eq(mean, m.reshape(24, 40, 5).transpose(1, 0, 2)) and eq(var, v.reshape(24, 40, 5).transpose(1, 0, 2))
