@@ -856,7 +856,7 @@ def main():
                     bytes_acc = (24.0 * SPP + 40.0 * BINS) * NX * NY
                     ceil_a, bind_a = ceilings(ac[1], accum_avg, bytes_acc / (accum_avg * 1e-3) / 1e9)
                     roofline["accumulate"] = dict(ceil_a, kernel=ac[0], bound=bind_a)
-        if hbm_per_wave is not None:
+        if hbm_per_wave is not None and steps_per_launch <= 1:   # (batched small passes widen the unit: the sampled units above are not the kernel's)
             vi = roofline.get("valu_issue")
             roofline["valu_floor"] = valu_floor(hbm_per_wave["per_unit"], SPP, BINS, WAVE_RAYS // SPP, hbm_per_wave["units_per_launch"], trace_avg,
                                                 simd_cycles=vi["peak"] if vi else None, issued=vi["wave_instructions"] if vi else None)
