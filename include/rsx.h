@@ -235,6 +235,11 @@ int rsx_dev_memset(rsx_ctx *ctx, void *dptr, int value, size_t bytes);
 int rsx_kd_build(const double *aabbs, int32_t n, int32_t max_depth, int32_t min_items,
                  double hit_cost, double empty_bonus, rsx_kd **out);
 int rsx_kd_info(const rsx_kd *kd, rsx_kdtree *view);   /* view points into kd-owned memory */
+/* Threads the host builders (rsx_kd_build, the mesh preprocessing) start: the smaller of the process's CPU affinity and its cgroup CPU
+ * quota (cpu.max), RSX_HOST_THREADS overrides; their OpenMP workers sleep when a region ends. The reference builds on one thread
+ * (kdtree3d.pyx:126-486); what this replaces is the OpenMP default — every hardware thread a container can see, spinning — which got
+ * a process with a 16-core quota on a 256-thread node throttled for 60 - 90 ms at a time after every build. */
+int rsx_host_team_size(void);
 void rsx_kd_free(rsx_kd *kd);
 /* Serialise exactly like KDTree3DCore.save() (kdtree3d.pyx:864-912); returns bytes written or needed. */
 int64_t rsx_kd_serialise(const rsx_kd *kd, int32_t min_items, double hit_cost, double empty_bonus,

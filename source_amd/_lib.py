@@ -111,6 +111,7 @@ SYMBOLS = [
     ("rsx_dev_memset", C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     ("rsx_kd_build", C.c_int, [_vp, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double, C.POINTER(_vp)]),
     ("rsx_kd_info", C.c_int, [_vp, C.POINTER(KDTree)]),
+    ("rsx_host_team_size", C.c_int, []),
     ("rsx_kd_free", None, [_vp]),
     ("rsx_kd_serialise", C.c_int64, [_vp, C.c_int32, C.c_double, C.c_double, _vp, C.c_int64]),
     ("rsx_mesh_filter_triangles", C.c_int32, [_vp, _vp, C.c_int32, C.c_int32]),

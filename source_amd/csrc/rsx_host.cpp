@@ -54,6 +54,8 @@ int host_team_size() {
 }
 }  // namespace
 
+extern "C" int rsx_host_team_size(void) { return host_team_size(); }
+
 namespace {
 
 struct Item {

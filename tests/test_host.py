@@ -667,3 +667,26 @@ def test_binding_under_stock_raysect_fixture(ns, golden, m70k):
     for name, (world, prims) in scenes.build_edge_worlds(ns).items():
         o, d, m = scenes.edge_rays(name)
         check("f11_" + name, world.flatten(), o, d, m, np.concatenate([o, o + 0.25 * d]))
+
+
+def test_host_builders_team_is_sized_to_what_the_process_may_use(tmp_path):
+    """rsx_host_team_size (csrc/rsx_host.cpp): the OpenMP team of the host KD / mesh builders is the smaller of the CPU affinity and the cgroup
+    CPU quota — not every hardware thread the container sees (the cause of round 5's "80 ms stalls after a second world": 256 spinning
+    workers on a 16-core quota got the process throttled) — and RSX_HOST_THREADS overrides it. Checked in fresh processes (the value is
+    read once)."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from source_amd import _lib; print(_lib.lib().rsx_host_team_size())" % os.path.dirname(_lib._HERE)
+    plain = int(subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120).stdout.strip().splitlines()[-1])
+    quota = None
+    try:
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        quota = None if q == "max" else max(1, int(q) // int(period))
+    except OSError:
+        pass
+    assert 1 <= plain <= len(os.sched_getaffinity(0))
+    if quota is not None:
+        assert plain <= quota
+    forced = int(subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_HOST_THREADS="3"), capture_output=True, text=True,
+                                timeout=120).stdout.strip().splitlines()[-1])
+    assert forced == 3
