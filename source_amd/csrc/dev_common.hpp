@@ -45,6 +45,11 @@ struct DScene {
                                           // LDS rows the state-free CSG evaluator needs: two per leaf of the scene's biggest flattened tree (0: none)
     const float4 *rel;                    // camera-relative leaf records of the mesh instances (dev_packet.hpp: RelInfo), or null
     const struct RelInfo *rel_info;       // per primitive
+    // The packet walk's short cut (dev_packet.hpp: world_trace_packet): up to four boxes that together hold the bounding box of every world
+    // primitive the packet kernel does not answer before its walk (everything but wide[0] and wide[1]). A unit none of whose rays enters any of
+    // them meets those two answers only. pkt_clusters: number of boxes, -1 = no short cut (coordinates too large for its margin argument).
+    int32_t pkt_clusters, pkt_pad;
+    double cluster_lo[4][3], cluster_hi[4][3];
     const rsx_kdnode *wnodes_scatter;   // the world nodes annotated for the kernels of scattered rays: leaf tags and cull bits for the eight-slot set, or — CSG
                                         // scenes — two slots plus the CSG primitives answered before the traversal (wnodes: for the first two slots)
 };

@@ -70,6 +70,9 @@ __device__ __forceinline__ int lane_here() {
 // the mesh walk's behind them: `base`) — written with v_writelane and read with v_readlane: one instruction each where an LDS word cost
 // two moves, the address arithmetic, the write and, on the way back, a read, a wait and a readfirstlane. (wdepth + mdepth <= 64: render()
 // takes the packet kernel only then.)
+#ifndef RSX_PKT_CLUSTERS
+#define RSX_PKT_CLUSTERS 1         // units none of whose rays comes near a primitive that is not answered up front skip the world walk (world_trace_packet)
+#endif
 #ifndef RSX_PKT_ASM
 #define RSX_PKT_ASM 1              // the descent (branch steps down to a leaf) as hand-written wave-level code: packet_descend
 #endif
@@ -866,6 +869,48 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     for (int j = 0; j < 2; ++j) if (wide.t[j] >= 0.0 && wide.t[j] < t_cull) t_cull = wide.t[j];
 #if RSX_WORLD_CULL == 0
     t_cull = -INFINITY;
+#endif
+#if RSX_PKT_CLUSTERS
+    if constexpr (!CSG) {
+    // The short cut. The two wide slots are answered; every other world primitive lies inside one of up to four cluster boxes
+    // (DScene::cluster_lo / hi: unions of the primitives' own bounding boxes). A ray that enters none of them fails the BoundPrimitive gate
+    // of every such primitive — the gate's slab products are monotone in the bounds, so a box inside a box the ray misses is missed — and
+    // its walk would meet the two answers only: kdtree.pyx:99-116 accepts wide answer t_j in the first leaf on the ray that lists j and
+    // whose range reaches t_j (`t_j <= min(max_distance, tmax)`; the last leaf's tmax is the world box's `back`), the nearer answer first:
+    // the point at t_j lies in j's bounding box with BOX_PADDING = 1e-9 to spare on every side (box.pyx:37, sphere.pyx:38 ...), so the leaf
+    // whose range holds t_j overlaps that box and lists j — rounding moves positions by ~1e-12 at the coordinates this is enabled for
+    // (|world bounds| <= 1e4, rsx_scene_create) — and a leaf that holds the farther answer but not the nearer one lies behind a leaf that
+    // held the nearer. When NO ray of the unit enters a cluster box the unit is finished here: the nearer eligible answer per ray. Equal
+    // answers (the leaf's item order would decide) send the unit through the walk. configs[2]: 0.4 - 0.6 of the units.
+    // (scenes without CSG solids only: the CSG packet kernel sits at 212 registers / two waves, and in such scenes the solids' boxes are most of the view)
+    if (!CSG && sc->pkt_clusters >= 0) {
+        bool near_something = false;
+        RCP3
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            if (c < sc->pkt_clusters) {
+                const double lo[3] = {sc->cluster_lo[c][0], sc->cluster_lo[c][1], sc->cluster_lo[c][2]}, hi[3] = {sc->cluster_hi[c][0], sc->cluster_hi[c][1], sc->cluster_hi[c][2]};
+                double f, b;
+                near_something = near_something || (enters && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, lo, hi, r, rx, ry, rz, f, b));
+            }
+        }
+        if (!pkt_any(near_something)) {
+            const double reach = r.maxd < tmax ? r.maxd : tmax;                // (no range: -inf)
+            const bool c0 = wide.t[0] >= 0.0 && wide.t[0] <= reach, c1 = wide.t[1] >= 0.0 && wide.t[1] <= reach;
+            if (!pkt_any(c0 && c1 && wide.t[0] == wide.t[1])) {
+                const bool second = c1 && (!c0 || wide.t[1] < wide.t[0]);
+                if (c0 || c1) {
+                    const int32_t faces = (int32_t)((wide.faces[0] >> (second ? 8 : 0)) & 255u);
+                    best.prim = second ? sc->wide[1] : sc->wide[0]; best.t = second ? wide.t[1] : wide.t[0];
+                    best.a0 = (faces & 15) - 1; best.a1 = (faces >> 4) - 1;
+                    best.u = best.v = best.w = 0.0f;
+                }
+                work_out = 1;
+                return best.prim >= 0;
+            }
+        }
+    }
+    }
 #endif
     int32_t node = 0, sp = 0;
     IdStack ids;

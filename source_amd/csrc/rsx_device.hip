@@ -954,6 +954,50 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             for (int c = 0; plain && c < 12; ++c) plain = wp.to_local[c] == ident[c];      // (numerically: -0.0 entries leave x * 1 + y * 0 + z * 0 + 0 = x as well)
             if (plain) d.wide_plain |= 1 << k;
         }
+        // cluster boxes of everything the packet kernel does not answer up front (DScene::pkt_clusters): the primitives' own (padded)
+        // bounding boxes, grouped by two median cuts of their centres along the widest spread
+        {
+            d.pkt_clusters = -1; d.pkt_pad = 0;
+            std::memset(d.cluster_lo, 0, sizeof(d.cluster_lo)); std::memset(d.cluster_hi, 0, sizeof(d.cluster_hi));
+            // (a world tree of a handful of nodes — one mesh, a floor and a sky — has no walk worth skipping: the boxes' tests cost the `flat`
+            // workload 3 % for nothing)
+            bool tame = !std::getenv("RSX_NO_PKT_CLUSTERS") && desc->world_kd.n_nodes >= 8;
+            // the short cut's argument needs rounding errors of positions far below BOX_PADDING = 1e-9 (box.pyx:37 ...): coordinates below 1e4
+            for (int k = 0; k < 3; ++k) tame = tame && std::isfinite(desc->world_kd.lower[k]) && std::isfinite(desc->world_kd.upper[k]) &&
+                                              std::fabs(desc->world_kd.lower[k]) <= 1e4 && std::fabs(desc->world_kd.upper[k]) <= 1e4;
+            if (tame) {
+                std::vector<int32_t> rest;
+                for (int32_t i = 0; i < desc->n_world; ++i) if (i != d.wide[0] && i != d.wide[1] && desc->primitives[i].type != RSX_PRIM_NULL) rest.push_back(i);
+                std::vector<std::vector<int32_t>> groups;
+                if (!rest.empty()) groups.push_back(rest);
+                auto centre = [&](int32_t i, int k) { return 0.5 * (desc->primitives[i].box_lower[k] + desc->primitives[i].box_upper[k]); };
+                while (groups.size() < 4) {
+                    int best = -1, axis = 0;
+                    double spread = 0.0;
+                    for (size_t g = 0; g < groups.size(); ++g) {
+                        if (groups[g].size() < 2) continue;
+                        for (int k = 0; k < 3; ++k) {
+                            double lo = INFINITY, hi = -INFINITY;
+                            for (int32_t i : groups[g]) { lo = std::min(lo, centre(i, k)); hi = std::max(hi, centre(i, k)); }
+                            if (hi - lo > spread) { spread = hi - lo; best = (int)g; axis = k; }
+                        }
+                    }
+                    if (best < 0) break;
+                    std::vector<int32_t> all = groups[(size_t)best];
+                    std::sort(all.begin(), all.end(), [&](int32_t a, int32_t b) { return centre(a, axis) < centre(b, axis); });
+                    const size_t half = all.size() / 2;
+                    groups[(size_t)best].assign(all.begin(), all.begin() + (long)half);
+                    groups.emplace_back(all.begin() + (long)half, all.end());
+                }
+                d.pkt_clusters = (int32_t)groups.size();
+                for (size_t g = 0; g < groups.size(); ++g)
+                    for (int k = 0; k < 3; ++k) {
+                        double lo = INFINITY, hi = -INFINITY;
+                        for (int32_t i : groups[g]) { lo = std::min(lo, desc->primitives[i].box_lower[k]); hi = std::max(hi, desc->primitives[i].box_upper[k]); }
+                        d.cluster_lo[g][k] = lo; d.cluster_hi[g][k] = hi;
+                    }
+            }
+        }
         for (int32_t &w : d.wide_csg) w = -1;
         if (any_fast && !std::getenv("RSX_NO_WIDE_CSG")) {
             std::vector<int32_t> cand;
