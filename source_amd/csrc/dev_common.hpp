@@ -50,6 +50,10 @@ struct DScene {
     // them meets those two answers only. pkt_clusters: number of boxes, -1 = no short cut (coordinates too large for its margin argument).
     int32_t pkt_clusters, pkt_pad;
     double cluster_lo[4][3], cluster_hi[4][3];
+    // ... and, for a cluster of at most four primitives, their own bounding boxes: a unit that enters the cluster's box is asked the
+    // BoundPrimitive gates themselves (0 members: the cluster's box decides)
+    int32_t cluster_members[4];
+    double member_lo[4][4][3], member_hi[4][4][3];
     const rsx_kdnode *wnodes_scatter;   // the world nodes annotated for the kernels of scattered rays: leaf tags and cull bits for the eight-slot set, or — CSG
                                         // scenes — two slots plus the CSG primitives answered before the traversal (wnodes: for the first two slots)
 };

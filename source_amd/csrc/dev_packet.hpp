@@ -71,7 +71,7 @@ __device__ __forceinline__ int lane_here() {
 // two moves, the address arithmetic, the write and, on the way back, a read, a wait and a readfirstlane. (wdepth + mdepth <= 64: render()
 // takes the packet kernel only then.)
 #ifndef RSX_PKT_CLUSTERS
-#define RSX_PKT_CLUSTERS 1         // units none of whose rays comes near a primitive that is not answered up front skip the world walk (world_trace_packet)
+#define RSX_PKT_CLUSTERS 1         // (2: a second level, the members' own boxes for clusters of at most four — measured: 20.93 against 20.99 ms, not worth its code) units none of whose rays comes near a primitive that is not answered up front skip the world walk (world_trace_packet)
 #endif
 #ifndef RSX_PKT_ASM
 #define RSX_PKT_ASM 1              // the descent (branch steps down to a leaf) as hand-written wave-level code: packet_descend
@@ -835,7 +835,6 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     { RCP3 enters = valid && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, wlo, whi, r, rx, ry, rz, tmin, tmax); }
     if (!enters) tmax = PKT_EMPTY;
     if (!pkt_any(enters)) { work_out = 0; return false; }
-    const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);
     const rsx_kdnode *wnodes = sc->wnodes;
     WideSet8 wide;
 #pragma unroll
@@ -891,7 +890,20 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
             if (c < sc->pkt_clusters) {
                 const double lo[3] = {sc->cluster_lo[c][0], sc->cluster_lo[c][1], sc->cluster_lo[c][2]}, hi[3] = {sc->cluster_hi[c][0], sc->cluster_hi[c][1], sc->cluster_hi[c][2]};
                 double f, b;
-                near_something = near_something || (enters && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, lo, hi, r, rx, ry, rz, f, b));
+                const bool in_cluster = enters && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, lo, hi, r, rx, ry, rz, f, b);
+#if RSX_PKT_CLUSTERS >= 2
+                // (second level: the gates themselves, for the lanes inside a cluster of at most four primitives)
+                const int n_members = sc->cluster_members[c];
+                if (n_members == 0) near_something = near_something || in_cluster;
+                else if (pkt_any(in_cluster)) {
+                    for (int m = 0; m < n_members; ++m) {
+                        const double mlo[3] = {sc->member_lo[c][m][0], sc->member_lo[c][m][1], sc->member_lo[c][m][2]}, mhi[3] = {sc->member_hi[c][m][0], sc->member_hi[c][m][1], sc->member_hi[c][m][2]};
+                        near_something = near_something || (in_cluster && aabb_rcp_signed(signs_uniform, neg_x, neg_y, neg_z, mlo, mhi, r, rx, ry, rz, f, b));
+                    }
+                }
+#else
+                near_something = near_something || in_cluster;
+#endif
             }
         }
         if (!pkt_any(near_something)) {
@@ -912,6 +924,7 @@ __device__ __forceinline__ bool world_trace_packet(bool valid, PScene sc, const 
     }
     }
 #endif
+    const PacketSpace ps = packet_space(r, ad, wlo, whi, valid, sc->wsplits_bounded);      // (for the walk only: behind the short cut)
     int32_t node = 0, sp = 0;
     IdStack ids;
     ids.v = 0; ids.base = 0;                               // (world levels: lanes 0 .. wdepth - 1, a mesh walk's behind them)

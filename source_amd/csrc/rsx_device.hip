@@ -959,6 +959,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         {
             d.pkt_clusters = -1; d.pkt_pad = 0;
             std::memset(d.cluster_lo, 0, sizeof(d.cluster_lo)); std::memset(d.cluster_hi, 0, sizeof(d.cluster_hi));
+            std::memset(d.cluster_members, 0, sizeof(d.cluster_members)); std::memset(d.member_lo, 0, sizeof(d.member_lo)); std::memset(d.member_hi, 0, sizeof(d.member_hi));
             // (a world tree of a handful of nodes — one mesh, a floor and a sky — has no walk worth skipping: the boxes' tests cost the `flat`
             // workload 3 % for nothing)
             bool tame = !std::getenv("RSX_NO_PKT_CLUSTERS") && desc->world_kd.n_nodes >= 8;
@@ -996,6 +997,14 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                         for (int32_t i : groups[g]) { lo = std::min(lo, desc->primitives[i].box_lower[k]); hi = std::max(hi, desc->primitives[i].box_upper[k]); }
                         d.cluster_lo[g][k] = lo; d.cluster_hi[g][k] = hi;
                     }
+                for (size_t g = 0; g < groups.size(); ++g) {
+                    d.cluster_members[g] = groups[g].size() <= 4 ? (int32_t)groups[g].size() : 0;
+                    for (int32_t m = 0; m < d.cluster_members[g]; ++m)
+                        for (int k = 0; k < 3; ++k) {
+                            d.member_lo[g][m][k] = desc->primitives[groups[g][(size_t)m]].box_lower[k];
+                            d.member_hi[g][m][k] = desc->primitives[groups[g][(size_t)m]].box_upper[k];
+                        }
+                }
             }
         }
         for (int32_t &w : d.wide_csg) w = -1;
