@@ -48,7 +48,8 @@ struct DScene {
     // The packet walk's short cut (dev_packet.hpp: world_trace_packet): up to four boxes that together hold the bounding box of every world
     // primitive the packet kernel does not answer before its walk (everything but wide[0] and wide[1]). A unit none of whose rays enters any of
     // them meets those two answers only. pkt_clusters: number of boxes, -1 = no short cut (coordinates too large for its margin argument).
-    int32_t pkt_clusters, pkt_pad;
+    int32_t pkt_clusters;
+    int32_t all_wide8;         // 1: every world primitive is one of wide[0 .. 7] (and the coordinates are tame): world_trace_wave's eight-slot form has answered them all before its walk
     double cluster_lo[4][3], cluster_hi[4][3];
     // ... and, for a cluster of at most four primitives, their own bounding boxes: a unit that enters the cluster's box is asked the
     // BoundPrimitive gates themselves (0 members: the cluster's box decides)

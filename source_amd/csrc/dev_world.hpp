@@ -113,6 +113,9 @@ __device__ __forceinline__ int wide_slot(const DScene &sc, int32_t idx) {     //
     return slot;
 }
 
+#ifndef RSX_WIDE_ALL_SHORTCUT
+#define RSX_WIDE_ALL_SHORTCUT 1      // worlds whose every primitive is answered before the walk (eight slots) skip the walk: world_trace_wave
+#endif
 #ifndef RSX_WORLD_CULL
 #define RSX_WORLD_CULL 1
 #endif
@@ -253,6 +256,39 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
     double last_t = 0.0;
     int32_t last_leaf = 0;
     uint32_t last_meta = 0;                                  // bits 0..7 a0, 8..15 a1, 16..23 flags, 28..29: 0 not asked, 1 hit, 2 no hit, 3 stream merge
+#if RSX_WIDE_ALL_SHORTCUT
+    // A world all of whose primitives sit in the eight slots (DScene::all_wide8: a Cornell box, a furnace) has been answered completely
+    // before the walk; what the walk would add is WHICH answer a ray takes: kdtree.pyx:99-116 accepts answer t_j in the first leaf on the ray
+    // that lists j and whose range reaches t_j (`t_j <= min(max_distance, tmax)`, the last leaf's tmax being the world box's `back`), the
+    // nearer answer before the farther — the point at t_j lies inside j's bounding box with BOX_PADDING = 1e-9 to spare on every side, so the
+    // leaf whose range holds t_j overlaps that box and lists j (positions move by ~1e-12 of rounding at the coordinates this is enabled for,
+    // |world bounds| <= 1e4), and a leaf that holds the farther answer but not the nearer lies behind one that held the nearer. So a ray takes
+    // its nearest eligible answer; only when the nearest is shared by two primitives (the leaf's item order decides) does it walk.
+    if constexpr (!CSG && WIDE_N == 8) {
+        if (sc.all_wide8) {                                  // (wave-uniform)
+            const double reach = r.maxd < tmax ? r.maxd : tmax;
+            double bt = INFINITY;
+            int slot = -1;
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = wide.t[j] >= 0.0 && wide.t[j] <= reach;
+                if (ok && wide.t[j] == bt) tie = true;
+                if (ok && wide.t[j] < bt) { bt = wide.t[j]; slot = j; tie = false; }
+            }
+            if (active && !tie && slot >= 0) {
+                int32_t idx = sc.wide[0];
+#pragma unroll
+                for (int q = 1; q < 8; ++q) if (slot == q) idx = sc.wide[q];
+                const uint32_t f = (slot < 4 ? wide.faces[0] >> (8 * slot) : wide.faces[1] >> (8 * (slot - 4))) & 255u;
+                best.prim = idx; best.t = bt; best.a0 = (int32_t)(f & 15u) - 1; best.a1 = (int32_t)(f >> 4) - 1;
+                best.u = best.v = best.w = 0.0f;
+            }
+            active = active && tie;                          // (the decided rays are done; a tied ray walks)
+            if (!__any(active)) return best.prim >= 0;
+        }
+    }
+#endif
     int32_t node = 0, sp = 0;
     // The prefill round, packed. Asked solid by solid the wave ran the evaluator 3.3 times per segment round of a prism pass for 21 asking
     // lanes of 38 live ones each (tools/path_prof.py prism, round 5) — 67 (ray, solid) questions, one wave's worth, in three turns.

@@ -957,7 +957,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         // cluster boxes of everything the packet kernel does not answer up front (DScene::pkt_clusters): the primitives' own (padded)
         // bounding boxes, grouped by two median cuts of their centres along the widest spread
         {
-            d.pkt_clusters = -1; d.pkt_pad = 0;
+            d.pkt_clusters = -1; d.all_wide8 = 0;
             std::memset(d.cluster_lo, 0, sizeof(d.cluster_lo)); std::memset(d.cluster_hi, 0, sizeof(d.cluster_hi));
             std::memset(d.cluster_members, 0, sizeof(d.cluster_members)); std::memset(d.member_lo, 0, sizeof(d.member_lo)); std::memset(d.member_hi, 0, sizeof(d.member_hi));
             // (a world tree of a handful of nodes — one mesh, a floor and a sky — has no walk worth skipping: the boxes' tests cost the `flat`
@@ -966,6 +966,18 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
             // the short cut's argument needs rounding errors of positions far below BOX_PADDING = 1e-9 (box.pyx:37 ...): coordinates below 1e4
             for (int k = 0; k < 3; ++k) tame = tame && std::isfinite(desc->world_kd.lower[k]) && std::isfinite(desc->world_kd.upper[k]) &&
                                               std::fabs(desc->world_kd.lower[k]) <= 1e4 && std::fabs(desc->world_kd.upper[k]) <= 1e4;
+            {   // (the eight-slot kernels' form of the same argument: a world all of whose primitives are answered before the walk)
+                bool coords = !std::getenv("RSX_NO_PKT_CLUSTERS");
+                for (int k = 0; k < 3; ++k) coords = coords && std::isfinite(desc->world_kd.lower[k]) && std::isfinite(desc->world_kd.upper[k]) &&
+                                                     std::fabs(desc->world_kd.lower[k]) <= 1e4 && std::fabs(desc->world_kd.upper[k]) <= 1e4;
+                bool all = coords && !sc->has_csg && desc->n_world > 0;
+                for (int32_t i = 0; all && i < desc->n_world; ++i) {
+                    bool found = desc->primitives[i].type == RSX_PRIM_NULL;
+                    for (int q = 0; q < 8; ++q) found = found || d.wide[q] == i;
+                    all = found;
+                }
+                d.all_wide8 = all ? 1 : 0;
+            }
             if (tame) {
                 std::vector<int32_t> rest;
                 for (int32_t i = 0; i < desc->n_world; ++i) if (i != d.wide[0] && i != d.wide[1] && desc->primitives[i].type != RSX_PRIM_NULL) rest.push_back(i);
