@@ -51,6 +51,7 @@ struct RenderParams {
     int32_t prims_lds;                         // > 0: byte offset of the LDS copy of the primitive records (+ CSG programs) in the path kernel
     int32_t n_vol_emitters, world_lds;         // materials with a volume contribution (0: the per-segment world.contains() pass is skipped);
                                                // world_lds > 0: byte offset in the workgroup's LDS where the path kernel stages the world tree
+    int32_t bank_lds;                          // path kernel: byte offset in the workgroup's LDS of its waves' ray banks (RAY_BANK_BYTES each; k_render_trace_path)
     unsigned long long *redo_mask;    // [n_units] CSG scenes: lanes of each unit the fast pass could not finish (ties -> stream merge), or null
     uint32_t *unit_cost;              // [n_units] measured duration of each unit in this launch (100 MHz ticks), feeds the next launch's order
     const uint32_t *unit_order;       // work list: ticket k of a list processes unit unit_order[k]
@@ -1010,6 +1011,11 @@ __device__ __forceinline__ unsigned int arena_block(const PathStore &ps, bool ne
 #ifndef RSX_PATH_NOMESH_MIN_WAVES
 #define RSX_PATH_NOMESH_MIN_WAVES 3
 #endif
+// The ray bank. A path wave refills the lanes whose paths ended from the unit it holds a ticket for — seven lanes of 64 in a Cornell box
+// round — and ran the whole of a camera ray for them every round (pixel of the ray's number, its Philox draw, PinholeCamera._generate_rays,
+// the transform to world space: ~350 vector instructions for a tenth of the lanes, 0.16 of the kernel). Here the wave makes the 64 rays of a
+// unit at once when it takes the unit, all lanes busy, and leaves them in LDS; a refill is a handful of loads. Same arithmetic per ray.
+#define RAY_BANK_BYTES (WAVE * (4 * 8 + 3 * 4))      // per wave: direction[3][64], weight[64] (f64); record[64] (-1: no ray), pixel key[64], sample[64] (i32)
 template <bool CSG, int MODE = 0, bool VOLS = true, bool REWALK = false, bool STAGED = false, bool QUEUE = false, bool MESHES = true>
 __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES : CSG && MODE != 1 ? 1 : !CSG && !MESHES ? RSX_PATH_NOMESH_MIN_WAVES : RSX_PATH_MIN_WAVES) void k_render_trace_path(DScene sc_arg, RenderParams rp, Sample *samples, unsigned long long *ticket, PathStore ps) {
     __shared__ uint32_t arena_res[2 * WG_WAVES];           // arena_block: the blocks each wave has reserved
@@ -1044,6 +1050,8 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
     Stack st, ms;
     wave_stacks(sc, st, ms);
     const int lane = threadIdx.x % WAVE;
+    double *const bank_d = reinterpret_cast<double *>(smem + rp.bank_lds + __builtin_amdgcn_readfirstlane((int)(threadIdx.x / WAVE)) * RAY_BANK_BYTES);   // [4][WAVE]
+    int32_t *const bank_i = reinterpret_cast<int32_t *>(bank_d + 4 * WAVE);                                                                              // [3][WAVE]
     NodeSt csg_state[CSG && MODE != 1 ? CSG_MAX_SLOTS : 1];
     int ray_unit = 0, ray_slot = 0;                        // where the lane's current ray came from (MODE 1: to flag it for the redo pass)
     unsigned long long path_spawned = 0;
@@ -1171,24 +1179,37 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 unit = __builtin_amdgcn_readfirstlane((int)(q->unit_order[tk] & 0x3ffffffu));
                 cursor = 0;
                 if constexpr (MODE == 2) { if (q->redo_mask[unit] == 0ULL) { cursor = WAVE; continue; } }
+                {   // the unit's 64 rays into the wave's bank, ray `lane` by lane `lane`
+                    const UnitPixel px = unit_pixel(q, unit, lane);
+                    const uint32_t key = (uint32_t)px.ix * (uint32_t)q->cam.ny + (uint32_t)px.iy;
+                    double u1, u2;
+                    if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
+                    else philox2(q->seed, (uint64_t)key, q->sample_offset + (uint64_t)px.s, u1, u2);
+                    Ray cr;
+                    double weight;
+                    camera_ray(q, px.ix, px.iy, u1, u2, cr, weight);
+                    bank_d[lane] = cr.dx; bank_d[WAVE + lane] = cr.dy; bank_d[2 * WAVE + lane] = cr.dz; bank_d[3 * WAVE + lane] = weight;
+                    bank_i[lane] = px.valid ? (int32_t)(px.slot * q->spp + px.s) : -1; bank_i[WAVE + lane] = (int32_t)key; bank_i[2 * WAVE + lane] = px.s;
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                }
             }
             const int n_idle = __popcll(idle);
             const int take = n_idle < WAVE - cursor ? n_idle : WAVE - cursor;
             const int rank = __popcll(idle & ((1ULL << lane) - 1ULL));
             if (!active && rank < take) {
-                const UnitPixel px = unit_pixel(q, unit, cursor + rank);
-                bool wanted = px.valid;
-                if constexpr (MODE == 2) wanted = wanted && ((q->redo_mask[unit] >> (cursor + rank)) & 1ULL);
+                const int e = cursor + rank;
+                const int32_t rec = bank_i[e];
+                bool wanted = rec >= 0;
+                if constexpr (MODE == 2) wanted = wanted && ((q->redo_mask[unit] >> e) & 1ULL);
                 if (wanted) {
-                    ray_unit = (int)unit; ray_slot = cursor + rank; path_spawned = 0;
-                    rng_pixel_lo = (uint32_t)px.ix * (uint32_t)q->cam.ny + (uint32_t)px.iy; rng_sample = q->sample_offset + (uint64_t)px.s;
-                    double u1, u2;
-                    if (q->rng_mode == RSX_RNG_STREAM) { u1 = q->uniforms[2 * (px.k * q->spp + px.s)]; u2 = q->uniforms[2 * (px.k * q->spp + px.s) + 1]; }
-                    else philox2(q->seed, (uint64_t)rng_pixel_lo, rng_sample, u1, u2);
-                    double weight;
-                    camera_ray(q, px.ix, px.iy, u1, u2, r, weight);
-                    smp_weight = weight;
-                    record = (int32_t)(px.slot * q->spp + px.s);
+                    ray_unit = (int)unit; ray_slot = e; path_spawned = 0;
+                    rng_pixel_lo = (uint32_t)bank_i[WAVE + e]; rng_sample = q->sample_offset + (uint64_t)bank_i[2 * WAVE + e];
+                    r.ox = q->origin[0]; r.oy = q->origin[1]; r.oz = q->origin[2];      // (camera_ray's)
+                    r.dx = bank_d[e]; r.dy = bank_d[WAVE + e]; r.dz = bank_d[2 * WAVE + e]; r.maxd = INFINITY;
+                    smp_weight = bank_d[3 * WAVE + e];
+                    record = rec;
                     blk = record; pos = 0; depth = 0; segments = 0;
                     ++spawned; ++path_spawned;
                     active = true;

@@ -1760,7 +1760,7 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     rp.sample_offset = desc->sample_offset;
     rp.important = reinterpret_cast<const rsx_important_sphere *>(static_cast<const unsigned char *>(d_mat) + mat_bytes);
     rp.n_important = n_important; rp.passes = 1; rp.important_path_weight = desc->important_path_weight;
-    rp.n_vol_emitters = 0; rp.world_lds = 0; rp.prims_lds = 0;
+    rp.n_vol_emitters = 0; rp.world_lds = 0; rp.prims_lds = 0; rp.bank_lds = 0;
     rp.n_vol_emitters = n_vol_contributors;
     rp.ray_max_depth = desc->ray_max_depth; rp.ray_min_depth = desc->ray_extinction_min_depth; rp.ray_extinction_prob = desc->ray_extinction_prob;
     rp.unit_times = ctx->unit_times;
@@ -1852,8 +1852,9 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (deferred) wg_cap = path_wg_env > 0 ? std::min(path_wg_env, RSX_PATH_MIN_WAVES) : 1;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
-    rp.world_lds = 0; rp.prims_lds = 0;
+    rp.world_lds = 0; rp.prims_lds = 0; rp.bank_lds = 0;
     if (has_vol) {
+        rp.bank_lds = (int32_t)l.lds; l.lds += (size_t)WG_WAVES * RAY_BANK_BYTES;      // the path waves' ray banks (k_render_trace_path)
         // The path kernel runs two workgroups per CU (256 registers per lane), so 80 KB of LDS per workgroup are there for the taking:
         // a world tree that fits behind the traversal stacks is staged there. Scattered rays walk it with a dependent load per step
         // at two waves per SIMD — latency, not issue, is their bound, and LDS answers in a fraction of an L2 round trip.
