@@ -1383,96 +1383,6 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 const double *from = g.exiting ? g.outside : g.inside;
                 xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
                 ++spawned; ++path_spawned;
-            } else if (mat.type == RSX_MAT_LAMBERT) {
-#if RSX_PHASE_PROF == 3
-                const unsigned long long ppl0 = clock64();
-#endif
-                // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
-                // normal.pyx:346-370); the normal faces the incident side
-                const double *from = g.exiting ? g.inside : g.outside;
-                double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
-                if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
-                double ux = nx, uy = ny, uz = nz;
-                normalise3(ux, uy, uz);
-                double vx = 1, vy = 0, vz = 0;
-                if (fabs(ux * vx + uy * vy + uz * vz) > 0.5) { vx = 0; vy = 1; }
-                const double m = ux * vx + uy * vy + uz * vz;
-                double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
-                normalise3(tx, ty, tz);
-                const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
-                // surface_to_world = primitive_to_world.mul(surface_to_primitive) (affinematrix.pyx:255-273), rotation part
-                const double *a = p.to_root;
-                double stw[9];
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
-                    stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
-                    stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
-                }
-                // outgoing direction: HemisphereCosineSampler.sample (solidangle.pyx:228-233) or, in a world with important primitives,
-                // the important-path / BSDF mixture of ContinuousBSDF.evaluate_surface (material.pyx:327-352)
-                const bool mis = q->n_important > 0;
-                double h1, h2, sx, sy, sz, pdf_important = 0.0;
-                bool from_important = false;
-                if (mis) {
-                    const double choose = scatter1, pick = scatter2;
-                    philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
-                    from_important = choose < q->important_path_weight;
-                    double wx, wy, wz;
-                    ImportantPick picked;
-                    picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
-                    if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
-                    double sn, cs;                                            // one azimuth for every lane: 2 pi h1 (a cone) or 2 pi h2 (inside a sphere; the cosine lobe)
-                    portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
-                    if (from_important) {
-                        important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
-                        // s_outgoing = w_outgoing.transform(primitive_to_surface.mul(world_to_primitive))
-                        const double *wtp = p.to_local;
-                        double wts[9];
-#pragma unroll
-                        for (int j = 0; j < 3; ++j) {
-                            wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                            wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                            wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                        }
-                        sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
-                        sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
-                        sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
-                    }
-                    if (!from_important) {
-                        const double rad = sqrt(h1);
-                        sx = rad * cs; sy = rad * sn;
-                        const double sz2 = 1.0 - sx * sx - sy * sy;
-                        sz = sqrt(sz2 > 0 ? sz2 : 0);
-                        wx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                        wy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                        wz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                    }
-                    pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
-                } else {
-                    double sn, cs;
-                    h1 = scatter1; h2 = scatter2;
-                    const double rad = sqrt(h1);
-                    portable_sincos(2.0 * M_PI * h2, sn, cs);
-                    sx = rad * cs; sy = rad * sn;
-                    const double sz2 = 1.0 - sx * sx - sy * sy;
-                    sz = sqrt(sz2 > 0 ? sz2 : 0);
-                }
-                const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;             // HemisphereCosineSampler.pdf
-                const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
-                const double rcp = 1.0 / pdf_all;                             // div_scalar (spectrum.pyx:459-467)
-                if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }   // zero spectrum, then * (1 / 0)
-                else {
-                    // direction = s_outgoing.transform(surface_to_world)
-                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
-                    r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                    r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                    r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                    daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
-                }
-#if RSX_PHASE_PROF == 3
-                pp_acc[13] += clock64() - ppl0; pp_acc[14] += 1;
-#endif
             } else if (mat.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:159-262
 #if RSX_PHASE_PROF == 3
                 const unsigned long long ppd0 = clock64();
@@ -1514,6 +1424,103 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 }
 #if RSX_PHASE_PROF == 3
                 pp_acc[15] += clock64() - ppd0; pp_acc[16] += 1;
+#endif
+            } else if (mat.type == RSX_MAT_LAMBERT) {                         // (behind the Dielectric arm: see the daughter's origin below)
+#if RSX_PHASE_PROF == 3
+                const unsigned long long ppl0 = clock64();
+#endif
+                // (the daughter's origin before anything else — w_reflection_origin: the Dielectric arm has run, nothing else reads the
+                // intersection's two points or this lane's old ray)
+                {
+                    const double *from = g.exiting ? g.inside : g.outside;
+                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                }
+                // The draw first, the surface frame behind it (the order of independent operations is free: the sampling arithmetic — two
+                // Philox draws, portable_sincos, the cone's portable_asin, the CDF walk — holds the kernel's register peak, and the frame's
+                // three vectors and its matrix are not needed before the direction is carried into it).
+                // Outgoing direction: HemisphereCosineSampler.sample (solidangle.pyx:228-233) or, in a world with important primitives,
+                // the important-path / BSDF mixture of ContinuousBSDF.evaluate_surface (material.pyx:327-352)
+                const bool mis = q->n_important > 0;
+                double h1, h2, sx = 0.0, sy = 0.0, sz = 0.0, wx = 0.0, wy = 0.0, wz = 0.0, pdf_important = 0.0;
+                bool from_important = false;
+                if (mis) {
+                    const double choose = scatter1, pick = scatter2;
+                    philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                    from_important = choose < q->important_path_weight;
+                    ImportantPick picked;
+                    picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
+                    if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
+                    double sn, cs;                                            // one azimuth for every lane: 2 pi h1 (a cone) or 2 pi h2 (inside a sphere; the cosine lobe)
+                    portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
+                    if (from_important) important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
+                    else {
+                        const double rad = sqrt(h1);
+                        sx = rad * cs; sy = rad * sn;
+                        const double sz2 = 1.0 - sx * sx - sy * sy;
+                        sz = sqrt(sz2 > 0 ? sz2 : 0);
+                    }
+                } else {
+                    double sn, cs;
+                    h1 = scatter1; h2 = scatter2;
+                    const double rad = sqrt(h1);
+                    portable_sincos(2.0 * M_PI * h2, sn, cs);
+                    sx = rad * cs; sy = rad * sn;
+                    const double sz2 = 1.0 - sx * sx - sy * sy;
+                    sz = sqrt(sz2 > 0 ? sz2 : 0);
+                }
+                // w_reflection_origin and the surface frame (_generate_surface_transforms, material.pyx:393-422; Normal3D.orthogonal,
+                // normal.pyx:346-370); the normal faces the incident side
+                double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
+                if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
+                double ux = nx, uy = ny, uz = nz;
+                normalise3(ux, uy, uz);
+                double vx = 1, vy = 0, vz = 0;
+                if (fabs(ux * vx + uy * vy + uz * vz) > 0.5) { vx = 0; vy = 1; }
+                const double m = ux * vx + uy * vy + uz * vz;
+                double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
+                normalise3(tx, ty, tz);
+                const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
+                if (mis && from_important) {
+                    // s_outgoing = w_outgoing.transform(primitive_to_surface.mul(world_to_primitive))
+                    const double *wtp = p.to_local;
+                    double wts[9];
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) {
+                        wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                        wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                        wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                    }
+                    sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
+                    sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
+                    sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
+                }
+                // surface_to_world = primitive_to_world.mul(surface_to_primitive) (affinematrix.pyx:255-273), rotation part, and
+                // direction = s_outgoing.transform(surface_to_world) — for a direction drawn from the cosine lobe the same operations as the
+                // w_outgoing the important pdf is asked about (material.pyx:343), so that is this vector
+                {
+                    const double *a = p.to_root;
+                    double stw[9];
+#pragma unroll
+                    for (int i = 0; i < 3; ++i) {
+                        stw[3 * i + 0] = a[4 * i] * tx + a[4 * i + 1] * ty + a[4 * i + 2] * tz + a[4 * i + 3] * 0.0;
+                        stw[3 * i + 1] = a[4 * i] * bx + a[4 * i + 1] * by + a[4 * i + 2] * bz + a[4 * i + 3] * 0.0;
+                        stw[3 * i + 2] = a[4 * i] * nx + a[4 * i + 1] * ny + a[4 * i + 2] * nz + a[4 * i + 3] * 0.0;
+                    }
+                    r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                    r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                    r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                }
+                if (mis) {
+                    if (!from_important) { wx = r.dx; wy = r.dy; wz = r.dz; }
+                    pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
+                }
+                const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;             // HemisphereCosineSampler.pdf
+                const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
+                const double rcp = 1.0 / pdf_all;                             // div_scalar (spectrum.pyx:459-467)
+                if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }   // zero spectrum, then * (1 / 0)
+                else { daughter = true; lambert_term = true; term_a = pdf; term_b = rcp; }
+#if RSX_PHASE_PROF == 3
+                pp_acc[13] += clock64() - ppl0; pp_acc[14] += 1;
 #endif
             } else {
                 if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
