@@ -1377,11 +1377,22 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
 #endif
             bool daughter = false, lambert_term = false;
             double term_a = 1.0, term_b = 1.0;                                // (a = b = 1: the replay multiplies every term's a and b in)
+            // The intersection's inside and outside points wait in LDS for the arm that takes one of them: twelve registers through every arm
+            // otherwise — what the compiler spilled to scratch. The wave's leaf staging area is free here: the walk is over, the volume pass too.
+            double *const park = reinterpret_cast<double *>(st.stage) + lane;          // [6][WAVE]
+            static_assert(STAGE_BYTES >= 6 * WAVE * 8, "the parked points fit the staging area");
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { park[k * WAVE] = g.inside[k]; park[(3 + k) * WAVE] = g.outside[k]; }
+            auto parked_point = [&](bool outside, double &x, double &y, double &z) {
+                const double *at = park + (outside ? 3 * WAVE : 0);
+                x = at[0]; y = at[WAVE]; z = at[2 * WAVE];
+            };
             if (abandoned) {}
             else if (segments >= PATH_MAX_SEGMENTS) { atomicOr(ps.flags, 2u); active = false; }
             else if (mat.type == RSX_MAT_NULL || mat.type == RSX_MAT_UNIFORM_VOLUME_EMITTER) {      // null surface: carry on from the far side
-                const double *from = g.exiting ? g.outside : g.inside;
-                xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                double fx, fy, fz;
+                parked_point(g.exiting, fx, fy, fz);
+                xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
                 ++spawned; ++path_spawned;
             } else if (mat.type == RSX_MAT_DIELECTRIC) {                      // dielectric.pyx:159-262
 #if RSX_PHASE_PROF == 3
@@ -1412,28 +1423,39 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 }
                 if (reflect && transmission_only) active = false;             // total internal reflection without a reflected ray: zero spectrum
                 else {
-                    const double *from;
                     if (reflect) {
                         const double temp = 2 * c1;
                         ox = ix + temp * nx; oy = iy + temp * ny; oz = iz + temp * nz;
-                        from = inside ? g.inside : g.outside;
-                    } else from = inside ? g.outside : g.inside;
-                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                    }
+                    double fx, fy, fz;
+                    parked_point(reflect ? !inside : inside, fx, fy, fz);         // reflected: from the side the ray came from; transmitted: the far side
+                    xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
                     xform_vector(p.to_root, ox, oy, oz, r.dx, r.dy, r.dz);
                     daughter = true;
                 }
 #if RSX_PHASE_PROF == 3
                 pp_acc[15] += clock64() - ppd0; pp_acc[16] += 1;
 #endif
-            } else if (mat.type == RSX_MAT_LAMBERT) {                         // (behind the Dielectric arm: see the daughter's origin below)
+            } else if (mat.type != RSX_MAT_LAMBERT) {                         // emitters and absorbers end the path
+                if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
+                else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
+                    double lx, ly, lz;
+                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
+                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
+                    end_a = mat.scale * (dot > 0 ? dot : 0.0);
+                    end_table = mat.table;
+                }
+                active = false;
+            } else {                                                          // RSX_MAT_LAMBERT (the last arm: nothing behind it reads the intersection record)
 #if RSX_PHASE_PROF == 3
                 const unsigned long long ppl0 = clock64();
 #endif
                 // (the daughter's origin before anything else — w_reflection_origin: the Dielectric arm has run, nothing else reads the
                 // intersection's two points or this lane's old ray)
                 {
-                    const double *from = g.exiting ? g.inside : g.outside;
-                    xform_point(p.to_root, from[0], from[1], from[2], r.ox, r.oy, r.oz);
+                    double fx, fy, fz;
+                    parked_point(!g.exiting, fx, fy, fz);
+                    xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
                 }
                 // The draw first, the surface frame behind it (the order of independent operations is free: the sampling arithmetic — two
                 // Philox draws, portable_sincos, the cone's portable_asin, the CDF walk — holds the kernel's register peak, and the frame's
@@ -1522,16 +1544,6 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
 #if RSX_PHASE_PROF == 3
                 pp_acc[13] += clock64() - ppl0; pp_acc[14] += 1;
 #endif
-            } else {
-                if (mat.type == RSX_MAT_UNIFORM_EMITTER) { end_a = mat.scale; end_table = mat.table; }
-                else if (mat.type == RSX_MAT_DEBUG_LIGHT && mat.scale != 0.0) {
-                    double lx, ly, lz;
-                    xform_vector(p.to_local, -mat.light_dir[0], -mat.light_dir[1], -mat.light_dir[2], lx, ly, lz);
-                    const double dot = lx * g.normal[0] + ly * g.normal[1] + lz * g.normal[2];
-                    end_a = mat.scale * (dot > 0 ? dot : 0.0);
-                    end_table = mat.table;
-                }
-                active = false;
             }
 #if RSX_PHASE_PROF == 3
             const unsigned long long ppt0 = clock64();
