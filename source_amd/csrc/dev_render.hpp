@@ -1450,13 +1450,6 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
 #if RSX_PHASE_PROF == 3
                 const unsigned long long ppl0 = clock64();
 #endif
-                // (the daughter's origin before anything else — w_reflection_origin: the Dielectric arm has run, nothing else reads the
-                // intersection's two points or this lane's old ray)
-                {
-                    double fx, fy, fz;
-                    parked_point(!g.exiting, fx, fy, fz);
-                    xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
-                }
                 // The draw first, the surface frame behind it (the order of independent operations is free: the sampling arithmetic — two
                 // Philox draws, portable_sincos, the cone's portable_asin, the CDF walk — holds the kernel's register peak, and the frame's
                 // three vectors and its matrix are not needed before the direction is carried into it).
@@ -1540,7 +1533,12 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
                 const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
                 const double rcp = 1.0 / pdf_all;                             // div_scalar (spectrum.pyx:459-467)
                 if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }   // zero spectrum, then * (1 / 0)
-                else { daughter = true; lambert_term = true; term_a = pdf; term_b = rcp; }
+                else {
+                    double fx, fy, fz;                                        // w_reflection_origin: the point on the incident side, fetched now
+                    parked_point(!g.exiting, fx, fy, fz);
+                    xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
+                    daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
+                }
 #if RSX_PHASE_PROF == 3
                 pp_acc[13] += clock64() - ppl0; pp_acc[14] += 1;
 #endif
