@@ -1285,6 +1285,13 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
 #if RSX_PHASE_PROF == 3
             pp_t2 = clock64();
 #endif
+            double *const park = reinterpret_cast<double *>(st.stage) + lane;          // [6][WAVE]: see parked_point below
+            static_assert(STAGE_BYTES >= 6 * WAVE * 8, "the parked points fit the staging area");
+            auto park_points = [&]() {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { park[k * WAVE] = g.inside[k]; park[(3 + k) * WAVE] = g.outside[k]; }
+            };
+            if constexpr (!MESHES) park_points();                              // (no mesh walk: nothing else uses the staging area, the points leave the registers before the volume pass)
             // volume emitters containing this segment's origin: found in world.contains() order, pushed newest first because the
             // list is replayed backwards
             double v_len[PATH_VOL_OVERLAP] = {0, 0, 0, 0}, v_scale[PATH_VOL_OVERLAP] = {0, 0, 0, 0};     // (initialised: the shift below reads every slot)
@@ -1378,11 +1385,9 @@ __global__ __launch_bounds__(WG_THREADS, CSG && MODE == 2 ? RSX_REDO_MIN_WAVES :
             bool daughter = false, lambert_term = false;
             double term_a = 1.0, term_b = 1.0;                                // (a = b = 1: the replay multiplies every term's a and b in)
             // The intersection's inside and outside points wait in LDS for the arm that takes one of them: twelve registers through every arm
-            // otherwise — what the compiler spilled to scratch. The wave's leaf staging area is free here: the walk is over, the volume pass too.
-            double *const park = reinterpret_cast<double *>(st.stage) + lane;          // [6][WAVE]
-            static_assert(STAGE_BYTES >= 6 * WAVE * 8, "the parked points fit the staging area");
-#pragma unroll
-            for (int k = 0; k < 3; ++k) { park[k * WAVE] = g.inside[k]; park[(3 + k) * WAVE] = g.outside[k]; }
+            // otherwise — what the compiler spilled to scratch. The wave's leaf staging area is free here: the walk is over, the volume pass too
+            // (park_points, above).
+            if constexpr (MESHES) park_points();                               // (forms with the mesh walk: the volume pass above stages leaves there)
             auto parked_point = [&](bool outside, double &x, double &y, double &z) {
                 const double *at = park + (outside ? 3 * WAVE : 0);
                 x = at[0]; y = at[WAVE]; z = at[2 * WAVE];

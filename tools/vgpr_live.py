@@ -44,7 +44,7 @@ for l in lines[start:end]:
     if m:
         cur = (files.get(m.group(1), m.group(1)), int(m.group(2)))
         continue
-    m = re.match(r"^(\.LBB[\w]+):", l)
+    m = re.match(r"^\s*(\.?L[\w$]+):", l)                  # compiler blocks (.LBBn_m) and the labels of inline assembly (Lname<n>)
     if m:
         labels[m.group(1)] = len(insts)
         continue
