@@ -794,6 +794,52 @@ def test_frames_lambert_against_oracle(orc, ns):
         cam.observe()
 
 
+def test_all_wide_worlds_take_their_answers_without_the_walk_and_ties_walk(orc, ns, monkeypatch):
+    """A world of at most eight analytic primitives (no CSG, no mesh) has every primitive answered before the per-lane walk; the path
+    kernel then takes a ray's nearest eligible answer and skips the walk (world_trace_wave, DScene::all_wide8) — except where the
+    nearest answer is shared by two primitives, which the leaf's item order decides (kdtree.pyx:99-116). This world is made of ties:
+    two spheres that are the same sphere with different materials, a slab whose top face lies in the floor's, a box that shares a
+    wall's face plane. Frames equal the oracle's (whose walk is the reference's), and the same frames come out with the short cut off."""
+    P = ns.Point3D
+    red = ns.InterpolatedSF([300, 560, 600, 800], np.array([0.08, 0.1, 0.75, 0.8]))
+    blue = ns.InterpolatedSF([300, 440, 480, 800], np.array([0.7, 0.75, 0.1, 0.08]))
+    white = ns.ConstantSF(0.7)
+
+    def build():
+        world = ns.World()
+        ns.Box(P(-1.0, -1.05, 0.0), P(1.0, -1.0, 2.0), world, material=ns.Lambert(white))                      # floor
+        ns.Box(P(-0.5, -1.04, 0.6), P(0.1, -1.0, 1.2), world, material=ns.Lambert(red))                        # slab: its top face IS the floor's
+        ns.Box(P(-1.0, -1.0, 2.0), P(1.0, 1.0, 2.05), world, material=ns.Lambert(white))                       # back wall
+        ns.Box(P(0.3, -0.2, 1.7), P(0.8, 0.4, 2.0), world, material=ns.Lambert(blue))                          # its far face lies in the wall's near face
+        ns.Sphere(0.3, world, ns.translate(-0.35, -0.4, 1.2), ns.Lambert(red))                                 # the same sphere twice
+        ns.Sphere(0.3, world, ns.translate(-0.35, -0.4, 1.2), ns.Lambert(blue))
+        ns.Box(P(-0.6, 0.98, 0.4), P(0.6, 0.999, 1.6), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 6.0))
+        ns.Cylinder(0.15, 0.5, world, ns.translate(0.5, -1.0, 0.8) * ns.rotate(0, -90, 0), ns.Lambert(white))  # stands on the floor plane
+        return world
+
+    frames = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RSX_NO_PKT_CLUSTERS", "1")
+        world = build()
+        assert len(world.primitives) == 8
+        cam, pipe = scenes.lambert_camera(ns, world, (72, 60), 6, 5, (0.05, 3, 40))
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=123)
+        cam.observe()
+        frames[off] = (pipe.frame.mean.copy(), pipe.frame.variance.copy(), cam.stats["rays"])
+        if not off:
+            w, h = 72, 60
+            keep = []
+            sl = list(cam._slice_spectrum())[0]
+            desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+            om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            assert eq(pipe.frame.mean, om.reshape(h, w, sl.bins).transpose(1, 0, 2)) and eq(pipe.frame.variance, ov.reshape(h, w, sl.bins).transpose(1, 0, 2))
+            assert cam.stats["rays"] == n_rays
+            assert (pipe.frame.mean > 0).mean() > 0.2              # (an open scene: most of the frame looks past it)
+    assert eq(frames[False][0], frames[True][0]) and eq(frames[False][1], frames[True][1]) and frames[False][2] == frames[True][2]
+
+
 def test_frames_dielectric_against_oracle(orc, ns):
     """Dielectric on the device (RSX_MAT_DIELECTRIC): refraction / reflection choice, total internal reflection, transmission_only,
     per-slice Sellmeier index, Beer-Lambert attenuation. The oracle is pinned bit for bit to the reference by fixture F14. Clear and
