@@ -1791,6 +1791,13 @@ __global__ void k_fill_acc_consts(double *consts, int n) {
                                     // Cornell box 1024^2 x 16 spp): the replay 5.13 -> 5.72 ms with the touches; the walk's own loads already overlap across the
                                     // eight waves of a SIMD, and the touches only add instructions and a full stop per chunk. Off.
 #endif
+#ifndef ACC_TERM_BATCH
+#define ACC_TERM_BATCH 1            // path passes: terms of a block requested together in k_accumulate's walk — measured on the Cornell box (replay alone):
+                                    // 1: 5.06 ms (56 registers, eight waves), 2: 5.21, 3: 5.93 (72, seven), 4: 6.62 (78, six). Off.
+#endif
+#ifndef RSX_ACC_SHARE_TOUCH
+#define RSX_ACC_SHARE_TOUCH 0       // (measured: 5.06 -> 5.05 ms on the Cornell box: the walk does not wait for misses but for every round trip) path passes: the bins of a pixel ask for the chunk's term lines between them before the walk (k_accumulate)
+#endif
 #ifndef ACC_PATH_CHUNK
 #define ACC_PATH_CHUNK 8            // path passes: samples whose term lists a lane walks back to back before the wave meets for their Welford steps
                                     // (Cornell box: 4 -> 5.4 ms, 8 -> 5.2 ms, 16 -> 8.8 ms: the values wait in LDS, 2 KB per sample and workgroup)
@@ -1839,8 +1846,8 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
     // every step: as branches each step ran every kind's code in turn (and `||` of two kind tests became branches again: the tests
     // below are arithmetic). A factor a kind does not have is 1.0 — x * 1.0 = x exactly, any x: NORM terms are stored with a = b = 1 —
     // and the emission sum is chosen by a select. 9.2 -> 8.3 ms on the Cornell box.
-    auto apply_term = [&](double x, const PathTerm &tm) {
-        const double tv = tab_lds ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b];
+    auto term_table = [&](const PathTerm &tm) { return tab_lds ? acc_tab[tm.table * ap.bins + b] : ap.tables[tm.table * ap.bins + b]; };
+    auto apply_term_with = [&](double x, const PathTerm &tm, const double tv) {
         static_assert(TERM_LAMBERT == 1 && TERM_LAMBERT_NORM == 2 && TERM_NORM == 4 && TERM_ATTEN == 5, "kind tests below");
         const bool has_norm = ((0x14u >> (unsigned)tm.kind) & 1u) != 0u;
         const double emission = 0.0 + tv * tm.b;
@@ -1855,6 +1862,7 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         }                                                          // (VOL == 1: no dielectric absorbs, and none left a term — render())
         return y;
     };
+    auto apply_term = [&](double x, const PathTerm &tm) { return apply_term_with(x, tm, term_table(tm)); };
     // x = (a * table[bin]) * weight [* sensitivity] — optical/ray.pyx:391-393, observer.pyx:408; absorbers (table < 0) give 0
     auto value = [&](const Sample &smp, long long record) {
         const int e = (smp.table < 0 ? 0 : smp.table) * ap.bins + b;
@@ -1940,6 +1948,25 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
         m = 0; v = 0; dm = 1.0;
         for (int chunk0 = 0; chunk0 < ap.spp; chunk0 += ACC_PATH_CHUNK) {
             const int cn = ap.spp - chunk0 < ACC_PATH_CHUNK ? ap.spp - chunk0 : ACC_PATH_CHUNK;     // (wave-uniform)
+#if RSX_ACC_SHARE_TOUCH
+            // The lanes of a pixel (its bins) walk the same lists, one dependent line after the other: a wave has the lists of four or five
+            // pixels in flight and waits out every miss. Before the walk the pixel's lanes ask for the chunk's lists BETWEEN them: the lane of
+            // bin b < cn for the line in which sample chunk0 + b's walk begins (its newest term), the lanes behind them for the line before
+            // it — one request per lane, the chunk's lists in flight together, one wait; the walk then finds its lines in L2.
+            {
+                const int which = b < cn ? b : b - cn < cn ? b - cn : -1;                  // (bins < 2 cn: some lines are left to the walk)
+                float sink = 0.0f;
+                if (which >= 0) {
+                    const Sample ts = sp[chunk0 + which];
+                    const long long tb = ap.tail[rec_base + chunk0 + which];
+                    const int first_t = tb < ap.n_records ? 0 : 1;
+                    int slot = ts.pad - 1 - (b < cn ? 0 : 5);                              // (a 128-byte line holds five terms and a third)
+                    slot = slot < first_t ? first_t : slot;
+                    sink = *reinterpret_cast<const float *>(ap.pool + tb * PATH_BLOCK + slot);
+                }
+                asm volatile("" :: "v"(sink));
+            }
+#endif
 #if RSX_ACC_TOUCH
             // The chunk's lists are asked for TOGETHER before any of them is walked: the lines of every sample's last block (where its walk
             // begins; a path of up to fifteen terms has no other) — left to the walk, a lane met one miss after the other, three lines per
@@ -1964,6 +1991,21 @@ __global__ __launch_bounds__(256) void k_accumulate(AccumParams ap) {
             double x = cur.table < 0 ? 0.0 : cur.a * (tab_lds ? acc_tab[cur.table * ap.bins + b] : ap.tables[cur.table * ap.bins + b]);
             bool live = true;
             while (live) {
+#if ACC_TERM_BATCH > 1
+                // (an experiment kept for its measurement: where the block still holds ACC_TERM_BATCH terms they are requested together, then
+                // their table entries together, then applied in the list's order — see ACC_TERM_BATCH: slower the wider the batch)
+                if (tp - floor >= ACC_TERM_BATCH) {
+                    PathTerm tb[ACC_TERM_BATCH];
+                    double tvb[ACC_TERM_BATCH];
+#pragma unroll
+                    for (int j = 0; j < ACC_TERM_BATCH; ++j) tb[j] = tp[-j];
+#pragma unroll
+                    for (int j = 0; j < ACC_TERM_BATCH; ++j) tvb[j] = term_table(tb[j]);
+#pragma unroll
+                    for (int j = 0; j < ACC_TERM_BATCH; ++j) x = apply_term_with(x, tb[j], tvb[j]);
+                    tp -= ACC_TERM_BATCH;
+                } else
+#endif
                 if (tp > floor) {
                     x = apply_term(x, *tp);                                    // (term j - 1 requested before term j is applied: 5.2 -> 5.5 ms)
                     --tp;
