@@ -209,7 +209,36 @@ __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS Rend
             xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
             ++spawned; ++path_spawned;
         } else if (arm == WF_LAMBERT) {                               // lambert.pyx:76-104 under ContinuousBSDF.evaluate_surface, material.pyx:286-361
-            const double fx = g.exiting ? g.inside[0] : g.outside[0], fy = g.exiting ? g.inside[1] : g.outside[1], fz = g.exiting ? g.inside[2] : g.outside[2];
+            // (the order of k_render_trace_path's Lambert arm, dev_render.hpp: the draw before the surface frame, world_to_surface formed, used
+            // and dropped before surface_to_world, the daughter's origin last — the same operations on the same values)
+            const bool mis = q->n_important > 0;
+            double h1, h2, sx = 0.0, sy = 0.0, sz = 0.0, wx = 0.0, wy = 0.0, wz = 0.0, pdf_important = 0.0;
+            bool from_important = false;
+            if (mis) {
+                const double choose = scatter1, pick = scatter2;
+                philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
+                from_important = choose < q->important_path_weight;
+                ImportantPick picked;
+                picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
+                if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
+                double sn, cs;
+                portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
+                if (from_important) important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
+                else {
+                    const double rad = sqrt(h1);
+                    sx = rad * cs; sy = rad * sn;
+                    const double sz2 = 1.0 - sx * sx - sy * sy;
+                    sz = sqrt(sz2 > 0 ? sz2 : 0);
+                }
+            } else {
+                double sn, cs;
+                h1 = scatter1; h2 = scatter2;
+                const double rad = sqrt(h1);
+                portable_sincos(2.0 * M_PI * h2, sn, cs);
+                sx = rad * cs; sy = rad * sn;
+                const double sz2 = 1.0 - sx * sx - sy * sy;
+                sz = sqrt(sz2 > 0 ? sz2 : 0);
+            }
             double nx = g.normal[0], ny = g.normal[1], nz = g.normal[2];
             if (g.exiting) { nx = -nx; ny = -ny; nz = -nz; }
             double ux = nx, uy = ny, uz = nz;
@@ -220,69 +249,45 @@ __device__ __forceinline__ void wf_arm(const DScene &sc, const RSX_CONST_AS Rend
             double tx = vx - m * ux, ty = vy - m * uy, tz = vz - m * uz;
             normalise3(tx, ty, tz);
             const double bx = ny * tz - ty * nz, by = nz * tx - tz * nx, bz = nx * ty - tx * ny;    // normal.cross(tangent)
-            const double *a = p.to_root;
-            double stw[9];
+            if (mis && from_important) {
+                const double *wtp = p.to_local;
+                double wts[9];
 #pragma unroll
-            for (int ii = 0; ii < 3; ++ii) {
-                stw[3 * ii + 0] = a[4 * ii] * tx + a[4 * ii + 1] * ty + a[4 * ii + 2] * tz + a[4 * ii + 3] * 0.0;
-                stw[3 * ii + 1] = a[4 * ii] * bx + a[4 * ii + 1] * by + a[4 * ii + 2] * bz + a[4 * ii + 3] * 0.0;
-                stw[3 * ii + 2] = a[4 * ii] * nx + a[4 * ii + 1] * ny + a[4 * ii + 2] * nz + a[4 * ii + 3] * 0.0;
+                for (int j = 0; j < 3; ++j) {
+                    wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                    wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                    wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
+                }
+                sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
+                sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
+                sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
             }
-            const bool mis = q->n_important > 0;
-            double h1, h2, sx, sy, sz, pdf_important = 0.0;
-            bool from_important = false;
-            if (mis) {
-                const double choose = scatter1, pick = scatter2;
-                philox2(q->seed, (uint64_t)rng_pixel_lo | (1ULL << 63), rng_sample | ((uint64_t)(2 * depth + 1) << 48), h1, h2);
-                from_important = choose < q->important_path_weight;
-                double wx, wy, wz;
-                ImportantPick picked;
-                picked.dx = picked.dy = picked.dz = picked.distance = picked.radius = 0.0; picked.cone = false;
-                if (from_important) picked = important_pick(q->important, q->n_important, hx, hy, hz, pick);
-                double sn, cs;
-                portable_sincos(2.0 * M_PI * (from_important && picked.cone ? h1 : h2), sn, cs);
-                if (from_important) {
-                    important_direction(picked, h1, h2, sn, cs, wx, wy, wz);
-                    const double *wtp = p.to_local;
-                    double wts[9];
+            double dirx, diry, dirz;
+            {
+                const double *a = p.to_root;
+                double stw[9];
 #pragma unroll
-                    for (int j = 0; j < 3; ++j) {
-                        wts[0 + j] = tx * wtp[j] + ty * wtp[4 + j] + tz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                        wts[3 + j] = bx * wtp[j] + by * wtp[4 + j] + bz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                        wts[6 + j] = nx * wtp[j] + ny * wtp[4 + j] + nz * wtp[8 + j] + 0.0 * wtp[12 + j];
-                    }
-                    sx = wts[0] * wx + wts[1] * wy + wts[2] * wz;
-                    sy = wts[3] * wx + wts[4] * wy + wts[5] * wz;
-                    sz = wts[6] * wx + wts[7] * wy + wts[8] * wz;
+                for (int ii = 0; ii < 3; ++ii) {
+                    stw[3 * ii + 0] = a[4 * ii] * tx + a[4 * ii + 1] * ty + a[4 * ii + 2] * tz + a[4 * ii + 3] * 0.0;
+                    stw[3 * ii + 1] = a[4 * ii] * bx + a[4 * ii + 1] * by + a[4 * ii + 2] * bz + a[4 * ii + 3] * 0.0;
+                    stw[3 * ii + 2] = a[4 * ii] * nx + a[4 * ii + 1] * ny + a[4 * ii + 2] * nz + a[4 * ii + 3] * 0.0;
                 }
-                if (!from_important) {
-                    const double rad = sqrt(h1);
-                    sx = rad * cs; sy = rad * sn;
-                    const double sz2 = 1.0 - sx * sx - sy * sy;
-                    sz = sqrt(sz2 > 0 ? sz2 : 0);
-                    wx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                    wy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                    wz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
-                }
+                dirx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
+                diry = stw[3] * sx + stw[4] * sy + stw[5] * sz;
+                dirz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+            }
+            if (mis) {
+                if (!from_important) { wx = dirx; wy = diry; wz = dirz; }
                 pdf_important = important_pdf(q->important, q->n_important, hx, hy, hz, wx, wy, wz);
-            } else {
-                double sn, cs;
-                h1 = scatter1; h2 = scatter2;
-                const double rad = sqrt(h1);
-                portable_sincos(2.0 * M_PI * h2, sn, cs);
-                sx = rad * cs; sy = rad * sn;
-                const double sz2 = 1.0 - sx * sx - sy * sy;
-                sz = sqrt(sz2 > 0 ? sz2 : 0);
             }
             const double pdf = sz >= 0.0 ? M_1_PI * sz : 0.0;         // HemisphereCosineSampler.pdf
             const double pdf_all = mis ? q->important_path_weight * pdf_important + (1 - q->important_path_weight) * pdf : pdf;
             const double rcp = 1.0 / pdf_all;                         // div_scalar (spectrum.pyx:459-467)
             if (pdf == 0.0) { push(pdf, rcp, mat.table, TERM_LAMBERT); active = false; }
             else {
+                const double fx = g.exiting ? g.inside[0] : g.outside[0], fy = g.exiting ? g.inside[1] : g.outside[1], fz = g.exiting ? g.inside[2] : g.outside[2];
                 xform_point(p.to_root, fx, fy, fz, r.ox, r.oy, r.oz);
-                r.dx = stw[0] * sx + stw[1] * sy + stw[2] * sz;
-                r.dy = stw[3] * sx + stw[4] * sy + stw[5] * sz;
-                r.dz = stw[6] * sx + stw[7] * sy + stw[8] * sz;
+                r.dx = dirx; r.dy = diry; r.dz = dirz;
                 daughter = true; lambert_term = true; term_a = pdf; term_b = rcp;
             }
         } else if (arm == WF_DIELECTRIC) {                            // dielectric.pyx:159-262
