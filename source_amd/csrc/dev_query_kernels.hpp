@@ -40,7 +40,13 @@ struct HitOut {
 // (prim = HIT_REDO), MODE 2 carries the stream merge and traces exactly those again.
 #define HIT_REDO (-2)
 template <bool CSG, int MODE = 0>
-__global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_MIN_WAVES_PER_SIMD : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
+#ifndef RSX_QUERY_MIN_WAVES
+// The batch query's plain form at TWO waves per SIMD: built for three (168 registers, like the render kernels' per-lane walk) it spills 44
+// registers around every world step, and scattered rays — what a query batch is — pay for them in every step: 2^22 rays in a Cornell box
+// 1.65 -> 1.38 ms, on the configs[2] scene 1.14 -> 1.01 ms (tools/hit_batch_rate.py; the render kernels keep three: configs[1] 0.191 vs 0.197 ms per step).
+#define RSX_QUERY_MIN_WAVES 2
+#endif
+__global__ __launch_bounds__(WG_THREADS, !CSG ? RSX_QUERY_MIN_WAVES : MODE == 1 ? RSX_CSGFAST_MIN_WAVES : RSX_CSG_MIN_WAVES)
 void k_hit_batch(DScene sc, long long n, const double *origin, const double *direction, const double *maxd, HitOut out, unsigned long long *ticket) {
     Stack st, ms;
     wave_stacks(sc, st, ms);
