@@ -690,3 +690,29 @@ def test_host_builders_team_is_sized_to_what_the_process_may_use(tmp_path):
     forced = int(subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RSX_HOST_THREADS="3"), capture_output=True, text=True,
                                 timeout=120).stdout.strip().splitlines()[-1])
     assert forced == 3
+
+
+def test_concurrent_ranks_build_the_library_once(tmp_path):
+    """`bench.py --gpus N` brings every rank through __graft_entry__.build_librsx(): with a stale or missing library they must not write
+    the same file at once. One builds (under a lock, into a temporary name), the others wait and find it fresh."""
+    import shutil
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    fake = tmp_path / "root"
+    (fake / "source_amd" / "csrc").mkdir(parents=True)
+    (fake / "include").mkdir()
+    for f in os.listdir(os.path.join(root, "source_amd", "csrc")):
+        shutil.copy(os.path.join(root, "source_amd", "csrc", f), fake / "source_amd" / "csrc" / f)
+    shutil.copy(os.path.join(root, "include", "rsx.h"), fake / "include" / "rsx.h")
+    cc = tmp_path / "fakecc"
+    cc.write_text('#!/bin/bash\nout="${@: -1}"\necho start >> %s/log\nsleep 1\necho data > "$out"\n' % tmp_path)
+    cc.chmod(0o755)
+    code = "import __graft_entry__ as g; g.ROOT = %r; print(g.build_librsx())" % str(fake)
+    env = dict(os.environ, HIPCC=str(cc), PYTHONPATH=root)
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=env, cwd=root, stdout=subprocess.PIPE) for _ in range(4)]
+    outs = [p.communicate(timeout=60)[0].decode().strip() for p in procs]
+    assert all(p.returncode == 0 for p in procs)
+    assert all(o.endswith("librsx.so") for o in outs)
+    assert (tmp_path / "log").read_text().count("start") == 1
+    assert sorted(f for f in os.listdir(fake / "source_amd" / "lib") if not f.endswith(".lock")) == ["librsx.so"]
