@@ -50,6 +50,8 @@ struct DScene {
     // them meets those two answers only. pkt_clusters: number of boxes, -1 = no short cut (coordinates too large for its margin argument).
     int32_t pkt_clusters;
     int32_t all_wide8;         // 1: every world primitive is one of wide[0 .. 7] (and the coordinates are tame): world_trace_wave's eight-slot form has answered them all before its walk
+    int32_t all_answered_csg;  // 1: a CSG scene all of whose world primitives are answered before the per-lane walk of its fast forms — the analytic ones in
+    int32_t scene_pad;         //    wide[0 .. RSX_CSG_WIDE - 1], the solids in wide_csg[0 .. 3] (and the coordinates are tame): world_trace_wave
     double cluster_lo[4][3], cluster_hi[4][3];
     // ... and, for a cluster of at most four primitives, their own bounding boxes: a unit that enters the cluster's box is asked the
     // BoundPrimitive gates themselves (0 members: the cluster's box decides)

@@ -410,6 +410,54 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
             }
         }
     }
+#if RSX_WIDE_ALL_SHORTCUT
+    // The same short cut for the fast forms of a CSG scene (DScene::all_answered_csg: a prism scene's seven primitives): the analytic
+    // primitives are in the wide slots, the solids were answered in the prefill round above (the mailbox; a solid left out because its
+    // box begins beyond the nearest answer cannot be the nearest either) — a ray takes its nearest eligible answer; a ray whose nearest
+    // is shared walks, and so does one that waits for the redo pass (an answer of it is missing).
+    if constexpr (CSG_ANSWERED && CSG_MAILBOX >= 4) {
+        if (sc.all_answered_csg && !prefill) {               // (wave-uniform)
+            const double reach = r.maxd < tmax ? r.maxd : tmax;
+            double bt = INFINITY;
+            int pick = -1;                                    // 0 .. WIDE_N - 1: a wide slot; 8 + k: mailbox entry k
+            bool tie = false;
+#pragma unroll
+            for (int j = 0; j < WIDE_N; ++j) {
+                const bool ok = sc.wide[j] >= 0 && wide.t[j] >= 0.0 && wide.t[j] <= reach;
+                if (ok && wide.t[j] == bt) tie = true;
+                if (ok && wide.t[j] < bt) { bt = wide.t[j]; pick = j; tie = false; }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const bool ok = mb_idx[k] >= 0 && mb_t[k] >= 0.0 && mb_t[k] <= reach;
+                if (ok && mb_t[k] == bt) tie = true;
+                if (ok && mb_t[k] < bt) { bt = mb_t[k]; pick = 8 + k; tie = false; }
+            }
+            const bool decided = active && !tie && !(work >> 31);
+            if (decided && pick >= 0) {
+                if (pick < 8) {
+                    int32_t idx = sc.wide[0];
+                    uint32_t f = wide.faces[0];
+#pragma unroll
+                    for (int q = 1; q < WIDE_N; ++q) if (pick == q) { idx = sc.wide[q]; f = q < 4 ? wide.faces[0] >> (8 * q) : wide.faces[1] >> (8 * (q - 4)); }
+                    f &= 255u;
+                    best.prim = idx; best.t = bt; best.a0 = (int32_t)(f & 15u) - 1; best.a1 = (int32_t)(f >> 4) - 1;
+                    best.u = best.v = best.w = 0.0f;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        if (pick == 8 + k) {
+                            best.prim = mb_idx[k]; best.t = mb_t[k]; best.leaf = mb_leaf[k];
+                            best.a0 = (int32_t)(int8_t)(mb_meta[k] & 0xff); best.a1 = (int32_t)(int8_t)((mb_meta[k] >> 8) & 0xff);
+                            best.flags = mb_meta[k] >> 16; best.u = best.v = best.w = 0.0f; best.hx = best.hy = best.hz = 0.0;
+                        }
+                    }
+                }
+            }
+            active = active && !decided;
+        }
+    }
+#endif
     while (__any(active)) {
         double distance = 0;
         int32_t count = 0;

@@ -957,7 +957,7 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
         // cluster boxes of everything the packet kernel does not answer up front (DScene::pkt_clusters): the primitives' own (padded)
         // bounding boxes, grouped by two median cuts of their centres along the widest spread
         {
-            d.pkt_clusters = -1; d.all_wide8 = 0;
+            d.pkt_clusters = -1; d.all_wide8 = 0; d.all_answered_csg = 0; d.scene_pad = 0;
             std::memset(d.cluster_lo, 0, sizeof(d.cluster_lo)); std::memset(d.cluster_hi, 0, sizeof(d.cluster_hi));
             std::memset(d.cluster_members, 0, sizeof(d.cluster_members)); std::memset(d.member_lo, 0, sizeof(d.member_lo)); std::memset(d.member_hi, 0, sizeof(d.member_hi));
             // (a world tree of a handful of nodes — one mesh, a floor and a sky — has no walk worth skipping: the boxes' tests cost the `flat`
@@ -1033,6 +1033,18 @@ extern "C" int rsx_scene_create(rsx_ctx *ctx, const rsx_scene_desc *desc, rsx_sc
                 if (!cand.empty() && n_programs <= 4) for (int32_t i = 0; i < desc->n_world; ++i) if (fast[(size_t)i].n_leaves > 0 && leaves[(size_t)i] == 1) cand.push_back(i);
             }
             for (size_t k = 0; k < cand.size() && k < 4; ++k) d.wide_csg[k] = cand[k];
+        }
+        {   // every world primitive answered before the walk of the CSG fast forms? (world_trace_wave's short cut; the argument is DScene::all_wide8's)
+            bool all = sc->has_csg && desc->n_world > 0 && d.wide_csg[0] >= 0 && !std::getenv("RSX_NO_PKT_CLUSTERS");
+            for (int k = 0; k < 3; ++k) all = all && std::isfinite(desc->world_kd.lower[k]) && std::isfinite(desc->world_kd.upper[k]) &&
+                                              std::fabs(desc->world_kd.lower[k]) <= 1e4 && std::fabs(desc->world_kd.upper[k]) <= 1e4;
+            for (int32_t i = 0; all && i < desc->n_world; ++i) {
+                bool found = false;
+                for (int q = 0; q < RSX_CSG_WIDE; ++q) found = found || d.wide[q] == i;
+                for (int q = 0; q < 4; ++q) found = found || d.wide_csg[q] == i;
+                all = found;
+            }
+            d.all_answered_csg = all ? 1 : 0;
         }
         // Device copies of the world nodes. A leaf whose items are ALL wide primitives (most leaves of a scene with a floor and an
         // enclosing emitter; every leaf of a room of boxes) carries its whole item list in the node's spare word — bit 31, the item count
