@@ -310,7 +310,9 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
                     const UPrim up = uniform_prim(sc.prims_uniform, sc.wide_csg[k]);
                     const double lo[3] = {up->box_lower[0], up->box_lower[1], up->box_lower[2]}, hi[3] = {up->box_upper[0], up->box_upper[1], up->box_upper[2]};
                     double f, b;
-                    if (aabb_rcp(lo, hi, r, rx, ry, rz, f, b) && active) askbits |= 1u << k;      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
+                    // (... and not a solid whose padded box the ray enters beyond the nearest analytic answer, RSX_PREFILL_CULL: every hit of it lies
+                    // inside the box, so it is never the nearest — with the questions packed, one question less is work less)
+                    if (aabb_rcp(lo, hi, r, rx, ry, rz, f, b) && active && !(f > t_wide_near)) askbits |= 1u << k;      // BoundPrimitive.hit gate (boundprimitive.pyx:42-51)
                 }
             }
             // A solid that half the wave asks about (the coherent first segments of the camera's rays) is cheaper answered for all its lanes at
@@ -344,6 +346,9 @@ __device__ __forceinline__ bool world_trace_wave(bool valid, const DScene &sc, c
                 base[k + 1] = base[k] + __popcll(gmask[k]);
             }
             const int n_questions = base[4];
+#if RSX_PHASE_PROF == 3
+            if (phase_acc) { phase_acc[20] += 1; phase_acc[21] += n_questions; phase_acc[22] += (n_questions + WAVE - 1) / WAVE; phase_acc[23] += __popcll(__ballot(active)); }
+#endif
             const unsigned long long below = (1ULL << lane) - 1ULL;
             auto pull = [&](int from, double v) {                           // the value lane `from` holds (every lane takes part)
                 const long long bits = __double_as_longlong(v);

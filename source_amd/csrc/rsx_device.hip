@@ -81,7 +81,8 @@
 #ifndef RSX_PREFILL_CULL
 #define RSX_PREFILL_CULL 0          // the CSG prefill round skips solids whose box lies beyond the nearest answer of the wide analytic primitives:
                                     // exact (boxes are padded by 1e-9, csg.pyx:39) and without effect — configs[4] 8.90 s per step without, 8.95 with: a wave
-                                    // evaluates a solid when ANY lane asks, and among 38 incoherent rays one nearly always does. Off.
+                                    // evaluates a solid when ANY lane asks, and among 38 incoherent rays one nearly always does. With the questions packed 64 to a
+                                    // turn (round 6, the gate of the packed round): 7.05 s without, 7.10 with — 92 questions per round are two turns either way. Off.
 #endif
 #ifndef RSX_PREFILL_UNIFORM_MIN
 #define RSX_PREFILL_UNIFORM_MIN 65  // packed prefill: a solid at least this many lanes ask about is answered by the wave-wide evaluator instead (65: never, the

@@ -55,6 +55,8 @@ la, di = c[14] / max(c[7], 1), c[16] / max(c[7], 1)
 print("  inside material + bookkeeping: lane 0 is in the Lambert arm in %.2f of the rounds, in the Dielectric arm in %.2f" % (la, di))
 print("    Lambert arm ~%.2f of it, Dielectric arm ~%.2f, roulette and term ~%.2f, before the arms (scattering draw, first use of the material record) %.2f" % (
     c[13] / max(c[4], 1) / max(la, 1e-9), c[15] / max(c[4], 1) / max(di, 1e-9), c[17] / max(c[4], 1) / max(la + di, 1e-9), c[18] / max(c[4], 1)))
-if c[20] > 0:                                            # CSG prefill round: how many lanes ask about a solid when the wave evaluates it
+if c[20] > 0 and c[8] == 0:                              # packed CSG prefill (no leaf visits: the scene is answered before the walk)
+    print("CSG prefill, packed: %.2f questions per round for %.1f live lanes, %.2f turns of 64" % (c[21] / c[20], c[23] / c[20], c[22] / c[20]))
+elif c[20] > 0:                                          # CSG prefill round: how many lanes ask about a solid when the wave evaluates it
     print("CSG prefill: %.2f solids per segment round offered, %.2f evaluated; asking lanes per evaluation %.1f of %.1f live" % (
         c[20] / max(c[7], 1), c[22] / max(c[7], 1), c[21] / max(c[22], 1), c[23] / max(c[20], 1)))
