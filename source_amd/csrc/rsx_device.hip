@@ -1865,6 +1865,10 @@ int render(rsx_scene *scene, const rsx_render_desc *desc, double *h_mean, double
     if (deferred) wg_cap = path_wg_env > 0 ? std::min(path_wg_env, RSX_PATH_MIN_WAVES) : 1;
     if (pipelined && ctx->render_wg_override > 0) wg_cap = ctx->render_wg_override;
     if ((rc = plan(scene, (long long)S, lane, l, wg_cap))) return rc;
+    // (overlapping slices: RSX_PATH_GRID caps the workgroups one slice's path launch brings — fewer, longer-lived waves have shorter tails per
+    // unit; measured on configs[4]: 256 (one per CU, the default) 7.04 s per step, 128: 7.00, 64: 9.24 — the six streams no longer fill the chip)
+    static const int path_grid_env = [] { const char *e = std::getenv("RSX_PATH_GRID"); return e ? std::atoi(e) : 0; }();
+    if (deferred && has_vol && path_grid_env > 0) l.grid.x = std::min<unsigned>(l.grid.x, (unsigned)path_grid_env);
     rp.world_lds = 0; rp.prims_lds = 0; rp.bank_lds = 0;
     if (has_vol) {
         rp.bank_lds = (int32_t)l.lds; l.lds += (size_t)WG_WAVES * RAY_BANK_BYTES;      // the path waves' ray banks (k_render_trace_path)
