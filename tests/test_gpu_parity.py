@@ -840,6 +840,55 @@ def test_all_wide_worlds_take_their_answers_without_the_walk_and_ties_walk(orc, 
     assert eq(frames[False][0], frames[True][0]) and eq(frames[False][1], frames[True][1]) and frames[False][2] == frames[True][2]
 
 
+def test_csg_worlds_answered_before_the_walk_skip_it_and_ties_walk(orc, ns, monkeypatch):
+    """The same short cut in the fast forms of a CSG scene (DScene::all_answered_csg): at most four analytic primitives in the wide slots,
+    at most four solids answered by the prefill round — nearest eligible answer, ties walk. Here two of the solids are the same solid
+    with different materials (every ray that meets them ties) and a box shares a face plane with a solid's operand. Frames equal the
+    oracle's, and the same frames come out with the short cut off."""
+    P = ns.Point3D
+    red = ns.InterpolatedSF([300, 560, 600, 800], np.array([0.08, 0.1, 0.75, 0.8]))
+    blue = ns.InterpolatedSF([300, 440, 480, 800], np.array([0.7, 0.75, 0.1, 0.08]))
+    white = ns.ConstantSF(0.7)
+
+    def cup(material, world):
+        return ns.Subtract(ns.Box(P(-0.3, -0.3, -0.3), P(0.3, 0.3, 0.3)), ns.Sphere(0.35, transform=ns.translate(0.15, 0.2, -0.2)), world,
+                           ns.translate(-0.4, -0.7, 1.2) * ns.rotate(20, 0, 0), material)
+
+    def build():
+        world = ns.World()
+        ns.Box(P(-1.0, -1.05, 0.0), P(1.0, -1.0, 2.0), world, material=ns.Lambert(white))                      # floor
+        ns.Box(P(-1.0, -1.0, 2.0), P(1.0, 1.0, 2.05), world, material=ns.Lambert(white))                       # back wall
+        ns.Box(P(-0.6, 0.98, 0.4), P(0.6, 0.999, 1.6), world, material=ns.UniformSurfaceEmitter(ns.ConstantSF(1.0), 6.0))
+        cup(ns.Lambert(red), world)                                                                            # the same solid twice
+        cup(ns.Lambert(blue), world)
+        ns.Union(ns.Box(P(0.2, -1.0, 0.7), P(0.7, -0.6, 1.1)), ns.Cylinder(0.15, 0.7, transform=ns.translate(0.45, -1.0, 0.9) * ns.rotate(0, -90, 0)),
+                 world, material=ns.Lambert(white))                                                            # its box stands in the floor's top plane
+        ns.Intersect(ns.Sphere(0.3), ns.Box(P(-0.3, -0.3, 0.0), P(0.3, 0.3, 0.3)), world, ns.translate(0.5, 0.2, 1.5), ns.Lambert(blue))
+        return world
+
+    frames = {}
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("RSX_NO_PKT_CLUSTERS", "1")
+        world = build()
+        assert len(world.primitives) == 7
+        cam, pipe = scenes.lambert_camera(ns, world, (72, 60), 6, 5, (0.05, 3, 40))
+        cam.frame_sampler = ns.RectFrameSampler2D()
+        cam.render_engine = ns.HipEngine(rng="philox", seed=321)
+        cam.observe()
+        frames[off] = (pipe.frame.mean.copy(), pipe.frame.variance.copy(), cam.stats["rays"])
+        if not off:
+            w, h = 72, 60
+            keep = []
+            sl = list(cam._slice_spectrum())[0]
+            desc = cam.render_desc(world, None, sl, cam.render_engine, keep, rect=(0, 0, w, h))
+            om, ov, n_rays = orc.render_pinhole(world.flatten(), desc, threads=orc.max_threads())
+            assert eq(pipe.frame.mean, om.reshape(h, w, sl.bins).transpose(1, 0, 2)) and eq(pipe.frame.variance, ov.reshape(h, w, sl.bins).transpose(1, 0, 2))
+            assert cam.stats["rays"] == n_rays
+            assert (pipe.frame.mean > 0).mean() > 0.2
+    assert eq(frames[False][0], frames[True][0]) and eq(frames[False][1], frames[True][1]) and frames[False][2] == frames[True][2]
+
+
 def test_frames_dielectric_against_oracle(orc, ns):
     """Dielectric on the device (RSX_MAT_DIELECTRIC): refraction / reflection choice, total internal reflection, transmission_only,
     per-slice Sellmeier index, Beer-Lambert attenuation. The oracle is pinned bit for bit to the reference by fixture F14. Clear and
